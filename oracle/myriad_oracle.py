@@ -1,0 +1,525 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+CPU restatement (torch fp64 + SciPy) of the reference's trajectory-optimisation
+hot path, used ONLY by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg as the checker for the HIP kernels in myriad_amd/csrc/.
+Nothing under myriad_amd/ may import this module.
+
+PARITY PINNING STATUS: **parity unpinned at the JAX / IPOPT boundary.**
+The reference (nikihowe/myriad) is pure Python on JAX + cyipopt; neither is
+installed in the build container or on the GPU box, so the reference itself
+cannot be executed to generate vectors.  What IS pinned:
+  * the reference's only numeric test, tests/tests.py:19-43 (RK4 of y'=y over
+    99 steps equals e to 6 decimals) -- see tests/test_oracle.py;
+  * every restated function below follows the cited reference lines one to one
+    (jnp -> torch, jax.jacrev/grad -> torch.func.jacrev/grad, lax.scan -> loop);
+  * the SciPy SLSQP / trust-constr drivers are the reference's own
+    NLPSolverType.SLSQP / TRUST code paths (myriad/nlp_solvers/__init__.py:31-55)
+    called with the same keyword set.
+The IPOPT branch (nlp_solvers/__init__.py:56-58) is not reproducible here.
+
+All citations are relative to /root/reference/.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+torch.set_default_dtype(torch.float64)
+DT = torch.float64
+
+
+def _t(a) -> torch.Tensor:
+  return torch.as_tensor(a, dtype=DT)
+
+
+# --------------------------------------------------------------------------------------
+# L1  systems  (myriad/systems/**)
+# --------------------------------------------------------------------------------------
+class System:
+  """myriad/systems/base.py:12-111 FiniteHorizonControlSystem (fields + method slots)."""
+  name = "BASE"
+  x_0: np.ndarray
+  x_T: Optional[np.ndarray]
+  T: float
+  bounds: np.ndarray
+  terminal_cost: bool = False
+  param_names: Tuple[str, ...] = ()
+
+  # vectorised over leading dims: x[..., ns], u[..., nu] -> [..., ns]
+  def dynamics(self, x, u):
+    raise NotImplementedError
+
+  def cost(self, x, u, t=None):
+    raise NotImplementedError
+
+  def params(self) -> np.ndarray:
+    return np.zeros(0)
+
+  @property
+  def ns(self):
+    return int(self.x_0.shape[0])
+
+  @property
+  def nu(self):
+    return int(self.bounds.shape[0] - self.x_0.shape[0])
+
+
+class CartPole(System):
+  """myriad/systems/classical_control/cartpole.py:50-111."""
+  name = "CARTPOLE"
+  param_names = ("g", "m1", "m2", "length")
+
+  def __init__(self, g=9.81, m1=1., m2=.3, length=0.5):
+    self.g, self.m1, self.m2, self.length = g, m1, m2, length
+    self.u_max, self.d_max, self.d = 20, 2.0, 1.0            # cartpole.py:57-59
+    self.x_0 = np.array([0., 0., 0., 0.])                    # :62
+    self.x_T = np.array([self.d, np.pi, 0., 0.])             # :63
+    self.T = 2.0                                             # :64
+    self.bounds = np.array([[-self.d_max, self.d_max],       # :65-71
+                            [-2 * np.pi, 2 * np.pi],
+                            [-5., 5.],
+                            [-10., 10.],
+                            [-self.u_max, self.u_max]])
+
+  def params(self):
+    return np.array([self.g, self.m1, self.m2, self.length])
+
+  def dynamics(self, x, u):                                  # cartpole.py:76-87
+    theta, dx, dtheta = x[..., 1], x[..., 2], x[..., 3]
+    u0 = u[..., 0]
+    s, c = torch.sin(theta), torch.cos(theta)
+    ddx = ((self.length * self.m2 * s * dtheta ** 2 + u0 + self.m2 * self.g * c * s)
+           / (self.m1 + self.m2 * (1 - c ** 2)))
+    ddtheta = -((self.length * self.m2 * c * dtheta ** 2 + u0 * c + (self.m1 + self.m2) * self.g * s)
+                / (self.length * self.m1 + self.length * self.m2 * (1 - c ** 2)))
+    return torch.stack([dx, dtheta, ddx, ddtheta], dim=-1)
+
+  def cost(self, x, u, t=None):                              # cartpole.py:106-108
+    return u[..., 0] ** 2
+
+
+class VanDerPol(System):
+  """myriad/systems/miscellaneous/van_der_pol.py:29-63."""
+  name = "VANDERPOL"
+  param_names = ("a",)
+
+  def __init__(self, a=1.):
+    self.a = a
+    self.x_0 = np.array([0., 1.])
+    self.x_T = np.zeros(2)
+    self.T = 10.0
+    self.bounds = np.array([[-4., 4.], [-4., 4.], [-0.75, 1.0]])
+
+  def params(self):
+    return np.array([self.a])
+
+  def dynamics(self, x, u):                                  # van_der_pol.py:46-50
+    x0, x1 = x[..., 0], x[..., 1]
+    return torch.stack([self.a * (1. - x1 ** 2) * x0 - x1 + u[..., 0], x0], dim=-1)
+
+  def cost(self, x, u, t=None):                              # van_der_pol.py:59-60
+    return (x * x).sum(-1) + u[..., 0] ** 2
+
+
+class CancerTreatment(System):
+  """myriad/systems/lenhart/cancer_treatment.py:40-91."""
+  name = "CANCERTREATMENT"
+  param_names = ("r", "a", "delta")
+
+  def __init__(self, r=0.3, a=3., delta=0.45, x_0=0.975, T=20):
+    self.r, self.a, self.delta = r, a, delta
+    self.x_0 = np.array([x_0])
+    self.x_T = None
+    self.T = float(T)
+    self.bounds = np.array([[1e-3, 1.], [0., 2.]])
+
+  def params(self):
+    return np.array([self.r, self.a, self.delta])
+
+  def dynamics(self, x, u):                                  # cancer_treatment.py:62-65
+    return self.r * x * torch.log(1 / x) - u * self.delta * x
+
+  def cost(self, x, u, t=None):                              # cancer_treatment.py:75-76
+    return (self.a * x ** 2 + u ** 2)[..., 0]
+
+
+class SimpleCase(System):
+  """myriad/systems/lenhart/simple_case.py:25-62."""
+  name = "SIMPLECASE"
+  param_names = ("A", "B", "C")
+
+  def __init__(self, A=1., B=1., C=4., x_0=1., T=1.):
+    self.A, self.B, self.C = A, B, C
+    self.x_0 = np.array([x_0])
+    self.x_T = None
+    self.T = float(T)
+    self.bounds = np.array([[-np.inf, np.inf], [-np.inf, np.inf]])
+
+  def params(self):
+    return np.array([self.A, self.B, self.C])
+
+  def dynamics(self, x, u):                                  # simple_case.py:46-50
+    return -0.5 * x ** 2 + self.C * u
+
+  def cost(self, x, u, t=None):                              # simple_case.py:52-53
+    return (-self.A * x + self.B * u ** 2)[..., 0]
+
+
+SYSTEMS = {c.name: c for c in (CartPole, VanDerPol, CancerTreatment, SimpleCase)}
+
+
+# --------------------------------------------------------------------------------------
+# L2  integrators  (myriad/utils.py:22-134)
+# --------------------------------------------------------------------------------------
+def _step(dyn, method: str, x, us, idx, h, t=None, ts=None):
+  """One step of utils.py:31-54 / :90-112 (time argument optional)."""
+  def f(xx, uu, tt):
+    return dyn(xx, uu, tt) if ts is not None else dyn(xx, uu)
+  def g(i):  # jnp gather semantics: out-of-range indices clamp (quirk Q6: tests/tests.py:37 relies on it)
+    return us[min(i, us.shape[0] - 1)]
+  tt = ts[idx] if ts is not None else None
+  if method == "EULER":
+    return x + h * f(x, g(idx), tt)
+  if method == "HEUN":
+    k1 = f(x, g(idx), tt)
+    k2 = f(x + h * k1, g(idx + 1), None if tt is None else tt + h)
+    return x + h / 2 * (k1 + k2)
+  if method == "MIDPOINT":
+    x_mid = x + h * f(x, g(idx), tt)
+    u_mid = (g(idx) + g(idx + 1)) / 2
+    return x + h * f(x_mid, u_mid, None if tt is None else tt + h / 2)
+  if method == "RK4":
+    u1, u2, u3 = g(2 * idx), g(2 * idx + 1), g(2 * idx + 2)
+    k1 = f(x, u1, tt)
+    k2 = f(x + h * k1 / 2, u2, None if tt is None else tt + h / 2)
+    k3 = f(x + h * k2 / 2, u2, None if tt is None else tt + h / 2)   # u2 for k2 AND k3 (quirk Q5)
+    k4 = f(x + h * k3, u3, None if tt is None else tt + h)
+    return x + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+  raise KeyError(method)
+
+
+def integrate(dynamics_t, x_0, interval_us, h, N, ts, method: str):
+  """utils.py:22-73 (time-dependent).  Returns (x_T, states[N+1, ...])."""
+  x = x_0
+  out = [x_0]
+  for i in range(N):
+    x = _step(dynamics_t, method, x, interval_us, i, h, ts=ts)
+    out.append(x)
+  return x, torch.stack(out)
+
+
+def integrate_time_independent(dynamics, x_0, interval_us, h, N, method: str):
+  """utils.py:80-131."""
+  x = x_0
+  out = [x_0]
+  for i in range(N):
+    x = _step(dynamics, method, x, interval_us, i, h)
+    out.append(x)
+  return x, torch.stack(out)
+
+
+# --------------------------------------------------------------------------------------
+# L3  transcriptions
+# --------------------------------------------------------------------------------------
+@dataclass
+class Transcription:
+  """What TrajectoryOptimizer (trajectory_optimizers/base.py:28-51) carries."""
+  objective: Callable
+  constraints: Callable
+  bounds: np.ndarray
+  guess: np.ndarray
+  x_rows: int
+  u_rows: int
+  ns: int
+  nu: int
+  x_guess: np.ndarray = None
+  u_guess: np.ndarray = None
+
+  def unravel(self, z):
+    nx = self.x_rows * self.ns
+    return z[:nx].reshape(self.x_rows, self.ns), z[nx:].reshape(self.u_rows, self.nu)
+
+
+def _bounds(system: System, x_rows: int, u_rows: int, trap_quirk=False) -> np.ndarray:
+  """hermite_simpson.py:55-81 / shooting.py:247-275 / trapezoidal.py:55-77."""
+  ns, nu = system.ns, system.nu
+  xb = np.zeros((x_rows, ns, 2))
+  xb[:, :, :] = system.bounds[:-nu]
+  xb[0, :, :] = system.x_0[:, None]
+  if system.x_T is not None:
+    if trap_quirk:                       # trapezoidal.py:71 pins row [-control_shape] (quirk Q2)
+      xb[-nu, :, :] = system.x_T[:, None]
+    else:
+      for i in range(len(system.x_T)):
+        if system.x_T[i] is not None:
+          xb[-1, i, :] = system.x_T[i]
+  xb = xb.reshape(-1, 2)
+  ub = np.empty((u_rows * nu, 2))
+  for i in range(nu, 0, -1):             # control-major blocks (quirk Q1; harmless for nu=1)
+    ub[(nu - i) * u_rows:(nu - i + 1) * u_rows] = system.bounds[-i]
+  return np.vstack((xb, ub))
+
+
+def hermite_simpson(system: System, intervals: int) -> Transcription:
+  """collocation/hermite_simpson.py:16-351."""
+  N = intervals
+  K = 2 * N + 1
+  h = system.T / N                                             # :27 interval_duration
+  ns, nu = system.ns, system.nu
+  u_guess = np.zeros((K, nu))                                  # :37
+  if system.x_T is not None:
+    x_guess = np.linspace(system.x_0, system.x_T, num=K)       # :41
+  else:
+    x_guess = np.ones((K, ns)) * 0.1                           # :43
+  guess = np.concatenate([x_guess.ravel(), u_guess.ravel()])   # ravel_pytree :47
+  bounds = _bounds(system, K, K)
+
+  def split(z):                                                # :84-107
+    xs = z[:K * ns].reshape(K, ns)
+    us = z[K * ns:].reshape(K, nu)
+    return xs[0:-1:2], xs[1::2], xs[2::2], us[0:-1:2], us[1::2], us[2::2]
+
+  def objective(z):                                            # :243-257 with hs_cost :194-214
+    xs_, xm, xe, us_, um, ue = split(z)
+    return ((h / 6) * (system.cost(xs_, us_) + 4 * system.cost(xm, um) + system.cost(xe, ue))).sum()
+
+  def constraints(z):                                          # :325-335
+    xs_, xm, xe, us_, um, ue = split(z)
+    fs, fm, fe = system.dynamics(xs_, us_), system.dynamics(xm, um), system.dynamics(xe, ue)
+    defect = (xe - xs_) - (h / 6) * (fs + 4 * fm + fe)         # hs_defect :110-128
+    interp = xm - 0.5 * (xs_ + xe) - (h / 8) * (fs - fe)       # hs_interpolation :153-170
+    return torch.cat([defect.reshape(-1), interp.reshape(-1)])
+
+  return Transcription(objective, constraints, bounds, guess, K, K, ns, nu, x_guess, u_guess)
+
+
+def trapezoidal(system: System, intervals: int, method: str = "HEUN") -> Transcription:
+  """collocation/trapezoidal.py:16-209."""
+  N = intervals
+  h = system.T / N
+  ns, nu = system.ns, system.nu
+  u_guess = np.zeros((N + 1, nu))                              # :34
+  x_guess = _rollout_guess(system, u_guess, h, N, method, N + 1)   # :36-50
+  guess = np.concatenate([x_guess.ravel(), u_guess.ravel()])
+  bounds = _bounds(system, N + 1, N + 1, trap_quirk=True)
+
+  def split(z):
+    x = z[:(N + 1) * ns].reshape(N + 1, ns)
+    u = z[(N + 1) * ns:].reshape(N + 1, nu)
+    return x, u
+
+  def objective(z):                                            # :115-128
+    x, u = split(z)
+    c = ((h / 2) * (system.cost(x[:-1], u[:-1]) + system.cost(x[1:], u[1:]))).sum()
+    return c
+
+  def constraints(z):                                          # :183-192, trapezoid_defect :151-163
+    x, u = split(z)
+    left = (h / 2) * (system.dynamics(x[:-1], u[:-1]) + system.dynamics(x[1:], u[1:]))
+    right = x[1:] - x[:-1]
+    return (left - right).reshape(-1)                          # sign opposite to HS
+
+  return Transcription(objective, constraints, bounds, guess, N + 1, N + 1, ns, nu, x_guess, u_guess)
+
+
+def _rollout_guess(system, controls_for_guess, interval_size, intervals, method, rows):
+  """shooting.py:56-74 / trapezoidal.py:36-50: linspace where x_T given, else coarse rollout."""
+  ns = system.ns
+  def roll():
+    _, xs = integrate_time_independent(system.dynamics, _t(system.x_0), _t(controls_for_guess),
+                                       interval_size, intervals, method)
+    return xs.numpy()
+  if system.x_T is not None:
+    cols = []
+    rolled = None
+    for i in range(len(system.x_T)):
+      if system.x_T[i] is not None:
+        cols.append(np.linspace(system.x_0[i], system.x_T[i], num=rows).reshape(-1, 1))
+      else:
+        rolled = roll() if rolled is None else rolled
+        cols.append(rolled[:, i].reshape(-1, 1))
+    return np.hstack(cols)
+  return roll()
+
+
+def shooting(system: System, intervals: int, controls_per_interval: int, method: str = "HEUN") -> Transcription:
+  """shooting.py:16-278 (MultipleShootingOptimizer)."""
+  I, cpi = intervals, controls_per_interval
+  S = I * cpi                                                  # :26
+  step = system.T / S                                          # :27
+  interval_size = system.T / I                                 # :28
+  ns, nu = system.ns, system.nu
+  mc = 2 if method == "RK4" else 1                             # :31
+  R_u = mc * S + 1
+  u_guess = np.zeros((R_u, nu))                                # :47
+  x_guess = _rollout_guess(system, u_guess[::mc * cpi], interval_size, I, method, I + 1)  # :56-74
+  guess = np.concatenate([x_guess.ravel(), u_guess.ravel()])
+  bounds = _bounds(system, I + 1, R_u)
+
+  def split(z):
+    return z[:(I + 1) * ns].reshape(I + 1, ns), z[(I + 1) * ns:].reshape(R_u, nu)
+
+  def reorganize_controls(us):                                 # :100-130  -> (I, mc*cpi+1, nu)
+    a = us[:-1].reshape(I, mc * cpi, nu)
+    b = us[::mc * cpi][1:][:, None]
+    return torch.cat([a, b], dim=1)
+
+  def constraints(z):                                          # :230-241
+    xs, us = split(z)
+    ru = reorganize_controls(us).transpose(0, 1)               # (mc*cpi+1, I, nu): batch over I
+    px, _ = integrate_time_independent(system.dynamics, xs[:-1], ru, step, cpi, method)
+    return (px - xs[1:]).reshape(-1)
+
+  def objective(z):                                            # :169-210, augmented_dynamics :80-92
+    xs, us = split(z)
+    ru = reorganize_controls(us).transpose(0, 1)
+    def aug(x_and_c, u):
+      x = x_and_c[..., :-1]
+      return torch.cat([system.dynamics(x, u), system.cost(x, u)[..., None]], dim=-1)
+    start = torch.cat([xs[:-1], torch.zeros(I, 1, dtype=DT)], dim=1)      # :198
+    end, _ = integrate_time_independent(aug, start, ru, step, cpi, method)
+    return end[:, -1].sum()                                    # :205 (no terminal cost in the 4 systems)
+
+  return Transcription(objective, constraints, bounds, guess, I + 1, R_u, ns, nu, x_guess, u_guess)
+
+
+def make_transcription(system: System, optimizer: str, intervals: int, controls_per_interval: int = 1,
+                       quadrature_rule: str = "TRAPEZOIDAL", integration_method: str = "HEUN") -> Transcription:
+  """trajectory_optimizers/__init__.py:12-28 get_optimizer dispatch."""
+  if optimizer == "COLLOCATION":
+    if quadrature_rule == "TRAPEZOIDAL":
+      return trapezoidal(system, intervals, integration_method)
+    if quadrature_rule == "HERMITE_SIMPSON":
+      return hermite_simpson(system, intervals)
+    raise KeyError(quadrature_rule)
+  if optimizer == "SHOOTING":
+    return shooting(system, intervals, controls_per_interval, integration_method)
+  raise KeyError(optimizer)
+
+
+# --------------------------------------------------------------------------------------
+# L4  callbacks + solve  (myriad/nlp_solvers/__init__.py:18-98)
+# --------------------------------------------------------------------------------------
+class Callbacks:
+  """fun / jac / constraints.fun / constraints.jac exactly as nlp_solvers/__init__.py:31-42 builds them
+  (jax.grad -> torch.func.grad, jax.jacrev -> torch.func.jacrev)."""
+
+  def __init__(self, tr: Transcription):
+    self.tr = tr
+    self._grad = torch.func.grad(tr.objective)
+    self._jac = torch.func.jacrev(tr.constraints)
+
+  def fun(self, z):
+    return float(self.tr.objective(_t(z)))
+
+  def grad(self, z):
+    return self._grad(_t(z)).numpy()
+
+  def cons(self, z):
+    return self.tr.constraints(_t(z)).numpy()
+
+  def jac(self, z):
+    return self._jac(_t(z)).numpy()
+
+
+def solve(tr: Transcription, nlpsolver: str = "SLSQP", max_iter: int = 1000, guess=None,
+          extra_options: Optional[dict] = None, cb: Optional[Callbacks] = None):
+  """nlp_solvers/__init__.py:18-98 restricted to the SciPy branches (:50-55).
+  Returns the reference's result dict (+ raw scipy result under 'scipy')."""
+  from scipy.optimize import minimize
+  cb = cb or Callbacks(tr)
+  opts = {"maxiter": max_iter}
+  if extra_options:
+    opts.update(extra_options)
+  method = {"SLSQP": "SLSQP", "TRUST": "trust-constr"}[nlpsolver]
+  sol = minimize(fun=cb.fun, x0=tr.guess if guess is None else guess, method=method, jac=cb.grad,
+                 constraints=({"type": "eq", "fun": cb.cons, "jac": cb.jac}),
+                 bounds=tr.bounds, options=opts)
+  x, u = tr.unravel(sol["x"])
+  res = {"x": x, "u": u, "xs_and_us": sol["x"], "cost": sol["fun"], "scipy": sol}
+  if nlpsolver == "TRUST":
+    res["lambda"] = sol["v"]                                   # :83-84
+  return res
+
+
+# --------------------------------------------------------------------------------------
+# post-solve validation  (myriad/utils.py:258-324)
+# --------------------------------------------------------------------------------------
+def get_state_trajectory_and_cost(system: System, num_steps: int, method: str, start_state, us):
+  """utils.py:258-298: integrate [x; cost] under `us` with hp.integration_method over num_steps."""
+  step = system.T / num_steps
+  us = _t(us)
+  def aug(x_and_c, u, t):
+    x = x_and_c[:-1]
+    return torch.cat([system.dynamics(x, u), system.cost(x, u, t).reshape(1)])
+  times = torch.linspace(0., system.T, num_steps + 1, dtype=DT)
+  start = torch.cat([_t(start_state), torch.zeros(1, dtype=DT)])
+  _, sc = integrate(aug, start, us, step, num_steps, times, method)
+  return sc[:, :-1].numpy(), float(sc[-1, -1])
+
+
+def get_defect(system: System, xs):
+  """utils.py:313-324."""
+  if system.x_T is None:
+    return None
+  return np.array([xs[-1][i] - system.x_T[i] for i in range(len(system.x_T)) if system.x_T[i] is not None])
+
+
+# --------------------------------------------------------------------------------------
+# dense Jacobian <-> stage blocks (the HIP eval kernel's output layout, include/myriad_hip.h)
+# --------------------------------------------------------------------------------------
+def hs_blocks_from_dense(J: np.ndarray, N: int, ns: int, nu: int) -> np.ndarray:
+  """Extract the per-interval stage blocks [N, 5*ns*ns + 5*ns*nu] from a dense HS Jacobian,
+  in the order Dxs,Dxm,Dxe,Dus,Dum,Due,Ixs,Ixe,Ius,Iue (each row-major)."""
+  K = 2 * N + 1
+  out = []
+  for k in range(N):
+    rd = slice(k * ns, (k + 1) * ns)
+    ri = slice(N * ns + k * ns, N * ns + (k + 1) * ns)
+    cx = lambda p: slice(p * ns, (p + 1) * ns)
+    cu = lambda p: slice(K * ns + p * nu, K * ns + (p + 1) * nu)
+    s, m, e = 2 * k, 2 * k + 1, 2 * k + 2
+    blk = [J[rd, cx(s)], J[rd, cx(m)], J[rd, cx(e)], J[rd, cu(s)], J[rd, cu(m)], J[rd, cu(e)],
+           J[ri, cx(s)], J[ri, cx(e)], J[ri, cu(s)], J[ri, cu(e)]]
+    out.append(np.concatenate([b.ravel() for b in blk]))
+  return np.stack(out)
+
+
+def hs_dense_from_blocks(blk: np.ndarray, N: int, ns: int, nu: int) -> np.ndarray:
+  """Inverse of hs_blocks_from_dense (adds the identity d interp / d x_m that the kernel does not store)."""
+  K = 2 * N + 1
+  n, m = K * (ns + nu), 2 * N * ns
+  J = np.zeros((m, n))
+  szs = [ns * ns] * 3 + [ns * nu] * 3 + [ns * ns] * 2 + [ns * nu] * 2
+  for k in range(N):
+    parts = np.split(blk[k], np.cumsum(szs)[:-1])
+    rd = slice(k * ns, (k + 1) * ns)
+    ri = slice(N * ns + k * ns, N * ns + (k + 1) * ns)
+    cx = lambda p: slice(p * ns, (p + 1) * ns)
+    cu = lambda p: slice(K * ns + p * nu, K * ns + (p + 1) * nu)
+    s, mm, e = 2 * k, 2 * k + 1, 2 * k + 2
+    J[rd, cx(s)] += parts[0].reshape(ns, ns); J[rd, cx(mm)] += parts[1].reshape(ns, ns)
+    J[rd, cx(e)] += parts[2].reshape(ns, ns)
+    J[rd, cu(s)] += parts[3].reshape(ns, nu); J[rd, cu(mm)] += parts[4].reshape(ns, nu)
+    J[rd, cu(e)] += parts[5].reshape(ns, nu)
+    J[ri, cx(s)] += parts[6].reshape(ns, ns); J[ri, cx(e)] += parts[7].reshape(ns, ns)
+    J[ri, cx(mm)] += np.eye(ns)
+    J[ri, cu(s)] += parts[8].reshape(ns, nu); J[ri, cu(e)] += parts[9].reshape(ns, nu)
+  return J
+
+
+# --------------------------------------------------------------------------------------
+# workload generators shared by tests and bench
+# --------------------------------------------------------------------------------------
+def random_x0(system: System, B: int, seed: int = 2019, spread: float = 0.1) -> np.ndarray:
+  """x0_b = clip(x_0 + spread * N(0, I), state bounds): the reference's start-state perturbation
+  rule, utils.py:412-419 with hp.start_spread = 0.1 (config.py:80); numpy default_rng(seed)."""
+  rng = np.random.default_rng(seed)
+  x0 = system.x_0[None, :] + spread * rng.standard_normal((B, system.ns))
+  return np.clip(x0, system.bounds[:system.ns, 0], system.bounds[:system.ns, 1])
