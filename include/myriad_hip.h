@@ -1,0 +1,141 @@
+/*
+ * myriad_hip.h -- C-ABI of libmyriad_hip.so, the MI355X (gfx950) batched trajectory-optimisation engine.
+ *
+ * This is the drop-in boundary for the reference's hot path (nikihowe/myriad, citations relative to
+ * /root/reference/).  The reference is pure Python; the interface it would bind through ctypes is:
+ *
+ *   reference interface                                              entry point here
+ *   --------------------------------------------------------------  ---------------------------
+ *   get_optimizer(hp,cfg,system)  trajectory_optimizers/__init__.py:12-28     myr_create / myr_destroy
+ *   jit(objective), jit(grad(objective)), jit(constraints),
+ *   jit(jacrev(constraints))      nlp_solvers/__init__.py:32-40               myr_eval
+ *   solve(hp,cfg,opt_dict) -> minimize_ipopt(...)
+ *                                 nlp_solvers/__init__.py:18-98 (:57-58)      myr_solve
+ *   get_state_trajectory_and_cost / get_defect   utils.py:258-324            myr_rollout
+ *   Python exceptions / solution['success']      nlp_solvers/__init__.py:59-64  return codes, status[], myr_last_error
+ *
+ * Conventions
+ *   - all floating point is IEEE fp64 (the reference sets jax_enable_x64, run.py:15);
+ *   - every array is caller-allocated, C-contiguous; the library never retains or frees caller memory;
+ *   - `mem` says whether ALL array arguments of that call are host pointers (MYR_MEM_HOST: staged through
+ *     the handle's device scratch) or device pointers on the handle's device (MYR_MEM_DEVICE: zero-copy);
+ *   - per-instance arrays are instance-major: z[B][n] uses exactly the reference's ravel_pytree layout
+ *     per instance (states row-major first, then controls);
+ *   - calls block until the result is complete; a handle is not thread-safe;
+ *   - functions return 0 on success, <0 on error (myr_last_error() gives the thread-local message);
+ *     non-convergence is NOT an error (as in the reference): it is reported per instance in status[].
+ */
+#ifndef MYRIAD_HIP_H
+#define MYRIAD_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* system ids: members of myriad.systems.SystemType on the hot path (systems/__init__.py:29-50) */
+enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2, MYR_SYS_SIMPLECASE = 3 };
+/* transcription: OptimizerType x QuadratureRule (config.py:12-57) */
+enum { MYR_TR_HERMITE_SIMPSON = 0, MYR_TR_TRAPEZOIDAL = 1, MYR_TR_SHOOTING = 2 };
+/* IntegrationMethod (config.py:46-50) */
+enum { MYR_INT_EULER = 0, MYR_INT_HEUN = 1, MYR_INT_MIDPOINT = 2, MYR_INT_RK4 = 3 };
+enum { MYR_MEM_HOST = 0, MYR_MEM_DEVICE = 1 };
+/* per-instance solve status */
+enum { MYR_STATUS_CONVERGED = 0, MYR_STATUS_MAXITER = 1, MYR_STATUS_NAN = 2, MYR_STATUS_STALLED = 3 };
+/* kernel ids for myr_kernel_time */
+enum { MYR_K_EVAL = 0, MYR_K_SOLVE = 1, MYR_K_ROLLOUT = 2, MYR_K_RESID = 3, MYR_K_COUNT = 4 };
+/* error codes */
+enum { MYR_OK = 0, MYR_E_ARG = -1, MYR_E_UNSUPPORTED = -2, MYR_E_HIP = -3, MYR_E_CAPACITY = -4 };
+
+typedef struct myr_handle_s* myr_handle;
+
+typedef struct {
+  int32_t system_id;             /* MYR_SYS_*                                         */
+  int32_t transcription;         /* MYR_TR_*                                          */
+  int32_t integration_method;    /* MYR_INT_* (shooting + rollout)                    */
+  int32_t intervals;             /* hp.intervals                                      */
+  int32_t controls_per_interval; /* hp.controls_per_interval (1 for collocation)      */
+  int32_t device;                /* HIP device ordinal                                */
+  int32_t max_batch;             /* capacity B_max the handle sizes its scratch for   */
+  int32_t reserved;
+  double  T;                     /* horizon system.T                                  */
+} myr_problem_desc;
+
+typedef struct {
+  int32_t n;        /* decision variables per instance                                  */
+  int32_t m;        /* equality constraints per instance                                */
+  int32_t ns, nu, np;
+  int32_t x_rows, u_rows;   /* rows of the unravelled (xs, us)                          */
+  int32_t jblk;     /* doubles of stage-block Jacobian per instance (see myr_eval)      */
+  int32_t ngrad;    /* doubles of objective-gradient output per instance (see myr_eval) */
+  int32_t reserved;
+} myr_dims;
+
+typedef struct {
+  int32_t max_iter;     /* hp.max_iter (config.py:70)                                     */
+  int32_t reserved;
+  double  tol_feas;     /* converged: max|c| <= tol_feas                  (default 1e-8)  */
+  double  tol_stat;     /* converged: scaled ||grad f + J^T lam - zL + zU||_inf <= tol_stat (1e-6) */
+  double  tol_compl;    /* converged: complementarity <= tol_compl        (default 1e-7)  */
+  double  mu_init;      /* initial barrier parameter                      (default 0.1)   */
+} myr_solve_opts;
+
+int myr_create(const myr_problem_desc* desc, myr_handle* out);
+int myr_destroy(myr_handle h);
+int myr_get_dims(myr_handle h, myr_dims* out);
+void myr_default_solve_opts(myr_solve_opts* o);
+
+/*
+ * Evaluate the transcription at B decision vectors: replaces the four jitted callbacks of
+ * nlp_solvers/__init__.py:32-40 for B instances at once.
+ *   z      [B][n]      in
+ *   params [B][np] if params_stride==np, or [np] shared if params_stride==0; NULL = system defaults
+ *   f      [B]         out  objective
+ *   gradf  [B][ngrad]  out  d f / d z.  If the system's running cost does not depend on x (CARTPOLE)
+ *                           only the control part is stored (ngrad = u_rows*nu, the non-zeros);
+ *                           otherwise ngrad = n in z layout.
+ *   c      [B][m]      out  constraints, reference row order
+ *   jblk   [B][jblk]   out  constraint Jacobian as stage blocks.  HERMITE_SIMPSON: per interval k,
+ *                           row-major blocks  Dxs,Dxm,Dxe (ns x ns), Dus,Dum,Due (ns x nu)  [defect rows]
+ *                           then              Ixs,Ixe (ns x ns), Ius,Iue (ns x nu)           [interp rows];
+ *                           the identity d interp / d x_m is implied and not stored
+ *                           (jblk = N*(5 ns^2 + 5 ns nu)).
+ * Any output pointer may be NULL to skip it.
+ */
+int myr_eval(myr_handle h, int32_t B, const double* z, const double* params, int32_t params_stride,
+             double* f, double* gradf, double* c, double* jblk, int32_t mem);
+
+/*
+ * Solve B independent NLP instances (replaces the minimize_ipopt call, nlp_solvers/__init__.py:57-58).
+ *   z      [B][n]  in: initial guess (reference rule: linspace(x0,xT) / zeros)   out: solution
+ *   lb,ub  [B][n]  bounds per instance (lb==ub pins a variable, e.g. x[0]=x0, x[-1]=x_T;
+ *                  +-inf allowed)
+ *   lam    [B][m]  out: equality multipliers, sign convention of scipy/ipopt `mult_g`
+ *                  (stationarity: grad f + J^T lam - zL + zU = 0)
+ *   cost   [B]     out: objective at the solution
+ *   status [B], iters [B]  out (int32)
+ *   kkt    [B][3]  out (may be NULL): final {max|c|, stationarity, complementarity}
+ */
+int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, const double* ub,
+              const double* params, int32_t params_stride, const myr_solve_opts* opts,
+              double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt, int32_t mem);
+
+/*
+ * True-dynamics rollout under given controls (utils.py:258-298) + terminal state.
+ *   x0 [B][ns], us [B][u_rows_rollout][nu]  ->  xs [B][num_steps+1][ns] (may be NULL), cost [B]
+ *   u_rows_rollout = (RK4 ? 2 : 1)*num_steps + 1 consumed entries (reference indexing utils.py:57-65).
+ */
+int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u_rows, const double* x0, const double* us,
+                const double* params, int32_t params_stride, double* xs, double* cost, int32_t mem);
+
+/* Average device time (HIP events on the handle's stream) of the launches of one kernel since the last reset. */
+int myr_kernel_time(myr_handle h, int32_t kernel_id, double* avg_ms, int32_t* launches);
+int myr_kernel_time_reset(myr_handle h);
+
+const char* myr_last_error(void);
+const char* myr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

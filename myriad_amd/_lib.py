@@ -1,0 +1,224 @@
+"""ctypes binding of libmyriad_hip.so (C-ABI: include/myriad_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no MI355X is visible, the
+calls raise -- they never route to the oracle or to any host implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmyriad_hip.so")
+
+SYS_IDS = {"CARTPOLE": 0, "VANDERPOL": 1, "CANCERTREATMENT": 2, "SIMPLECASE": 3}
+TR_IDS = {"HERMITE_SIMPSON": 0, "TRAPEZOIDAL": 1, "SHOOTING": 2}
+INT_IDS = {"EULER": 0, "HEUN": 1, "MIDPOINT": 2, "RK4": 3}
+MEM_HOST, MEM_DEVICE = 0, 1
+K_EVAL, K_SOLVE, K_ROLLOUT, K_RESID = 0, 1, 2, 3
+STATUS_NAMES = {0: "CONVERGED", 1: "MAXITER", 2: "NAN", 3: "STALLED"}
+
+EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve",
+           "myr_rollout", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error", "myr_version"]
+
+
+class ProblemDesc(C.Structure):
+  _fields_ = [("system_id", C.c_int32), ("transcription", C.c_int32), ("integration_method", C.c_int32),
+              ("intervals", C.c_int32), ("controls_per_interval", C.c_int32), ("device", C.c_int32),
+              ("max_batch", C.c_int32), ("reserved", C.c_int32), ("T", C.c_double)]
+
+
+class Dims(C.Structure):
+  _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("ns", C.c_int32), ("nu", C.c_int32), ("np", C.c_int32),
+              ("x_rows", C.c_int32), ("u_rows", C.c_int32), ("jblk", C.c_int32), ("ngrad", C.c_int32),
+              ("reserved", C.c_int32)]
+
+
+class SolveOpts(C.Structure):
+  _fields_ = [("max_iter", C.c_int32), ("reserved", C.c_int32), ("tol_feas", C.c_double),
+              ("tol_stat", C.c_double), ("tol_compl", C.c_double), ("mu_init", C.c_double)]
+
+
+class MyriadHipError(RuntimeError):
+  pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+  """Load the HIP library; raise loudly when it has not been built (python __graft_entry__.py build)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise MyriadHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                         "There is no CPU fallback.")
+  lib = C.CDLL(LIB_PATH)
+  vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p   # raw addresses (host numpy or device pointers)
+  lib.myr_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]
+  lib.myr_create.restype = C.c_int
+  lib.myr_destroy.argtypes = [C.c_void_p]
+  lib.myr_destroy.restype = C.c_int
+  lib.myr_get_dims.argtypes = [C.c_void_p, C.POINTER(Dims)]
+  lib.myr_get_dims.restype = C.c_int
+  lib.myr_default_solve_opts.argtypes = [C.POINTER(SolveOpts)]
+  lib.myr_default_solve_opts.restype = None
+  lib.myr_eval.argtypes = [vp, C.c_int32, dp, dp, C.c_int32, dp, dp, dp, dp, C.c_int32]
+  lib.myr_eval.restype = C.c_int
+  lib.myr_solve.argtypes = [vp, C.c_int32, dp, dp, dp, dp, C.c_int32, C.POINTER(SolveOpts), dp, dp, ip, ip, dp, C.c_int32]
+  lib.myr_solve.restype = C.c_int
+  lib.myr_rollout.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, dp, dp, C.c_int32]
+  lib.myr_rollout.restype = C.c_int
+  lib.myr_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+  lib.myr_kernel_time.restype = C.c_int
+  lib.myr_kernel_time_reset.argtypes = [vp]
+  lib.myr_kernel_time_reset.restype = C.c_int
+  lib.myr_last_error.restype = C.c_char_p
+  lib.myr_version.restype = C.c_char_p
+  _lib = lib
+  return lib
+
+
+def _chk(rc: int, what: str):
+  if rc != 0:
+    msg = load().myr_last_error().decode()
+    if rc == -2:
+      raise NotImplementedError(f"{what}: {msg}")
+    if rc == -1:
+      raise ValueError(f"{what}: {msg}")
+    raise MyriadHipError(f"{what} failed ({rc}): {msg}")
+
+
+def _addr(a) -> Optional[int]:
+  """Address of a numpy array (host) or of anything exposing data_ptr() (torch device tensor); None -> NULL."""
+  if a is None:
+    return None
+  if isinstance(a, np.ndarray):
+    return a.ctypes.data
+  if hasattr(a, "data_ptr"):
+    return a.data_ptr()
+  if isinstance(a, int):
+    return a
+  raise TypeError(type(a))
+
+
+def _f64(a, shape=None):
+  a = np.ascontiguousarray(a, dtype=np.float64)
+  if shape is not None and tuple(a.shape) != tuple(shape):
+    raise ValueError(f"expected shape {shape}, got {a.shape}")
+  return a
+
+
+class Engine:
+  """One handle = one (system, transcription, sizes, device) problem family; owns device scratch and a stream."""
+
+  def __init__(self, system: str, transcription: str, intervals: int, T: float, controls_per_interval: int = 1,
+               integration_method: str = "HEUN", device: int = 0, max_batch: int = 4096):
+    self.lib = load()
+    d = ProblemDesc(SYS_IDS[system], TR_IDS[transcription], INT_IDS[integration_method], int(intervals),
+                    int(controls_per_interval), int(device), int(max_batch), 0, float(T))
+    self._h = C.c_void_p()
+    _chk(self.lib.myr_create(C.byref(d), C.byref(self._h)), "myr_create")
+    dm = Dims()
+    _chk(self.lib.myr_get_dims(self._h, C.byref(dm)), "myr_get_dims")
+    self.dims = dm
+    self.desc = d
+    for k in ("n", "m", "ns", "nu", "np", "x_rows", "u_rows", "jblk", "ngrad"):
+      setattr(self, k, int(getattr(dm, k)))
+
+  def close(self):
+    if getattr(self, "_h", None) and self._h.value:
+      self.lib.myr_destroy(self._h)
+      self._h = C.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  # ---- host (numpy) entry points -------------------------------------------------------------
+  def _params(self, params, B):
+    if params is None:
+      return None, 0
+    p = _f64(params)
+    if p.ndim == 1:
+      if p.shape[0] != self.np:
+        raise ValueError("params must have np entries")
+      return p, 0
+    if p.shape != (B, self.np):
+      raise ValueError(f"params must be [B,{self.np}]")
+    return p, self.np
+
+  def eval(self, z, params=None, want=("f", "gradf", "c", "jblk")):
+    z = _f64(z)
+    if z.ndim == 1:
+      z = z[None]
+    B = z.shape[0]
+    if z.shape[1] != self.n:
+      raise ValueError(f"z must be [B,{self.n}]")
+    p, ps = self._params(params, B)
+    out = {"f": np.empty(B) if "f" in want else None,
+           "gradf": np.empty((B, self.ngrad)) if "gradf" in want else None,
+           "c": np.empty((B, self.m)) if "c" in want else None,
+           "jblk": np.empty((B, self.jblk)) if "jblk" in want else None}
+    _chk(self.lib.myr_eval(self._h, B, _addr(z), _addr(p), ps, _addr(out["f"]), _addr(out["gradf"]),
+                           _addr(out["c"]), _addr(out["jblk"]), MEM_HOST), "myr_eval")
+    return {k: v for k, v in out.items() if v is not None}
+
+  def eval_device(self, B, z, params=None, params_stride=0, f=None, gradf=None, c=None, jblk=None):
+    """Zero-copy variant: every argument is a device tensor (anything with data_ptr()) on this handle's device."""
+    _chk(self.lib.myr_eval(self._h, int(B), _addr(z), _addr(params), int(params_stride), _addr(f), _addr(gradf),
+                           _addr(c), _addr(jblk), MEM_DEVICE), "myr_eval")
+
+  def default_opts(self) -> SolveOpts:
+    o = SolveOpts()
+    self.lib.myr_default_solve_opts(C.byref(o))
+    return o
+
+  def solve(self, z0, lb, ub, params=None, opts: Optional[SolveOpts] = None):
+    z = _f64(z0).copy()
+    if z.ndim == 1:
+      z = z[None]
+    B = z.shape[0]
+    lb = np.ascontiguousarray(np.broadcast_to(_f64(lb), z.shape))
+    ub = np.ascontiguousarray(np.broadcast_to(_f64(ub), z.shape))
+    p, ps = self._params(params, B)
+    o = opts or self.default_opts()
+    lam = np.empty((B, self.m)); cost = np.empty(B)
+    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); kkt = np.empty((B, 3))
+    _chk(self.lib.myr_solve(self._h, B, _addr(z), _addr(lb), _addr(ub), _addr(p), ps, C.byref(o), _addr(lam),
+                            _addr(cost), _addr(status), _addr(iters), _addr(kkt), MEM_HOST), "myr_solve")
+    return {"z": z, "lam": lam, "cost": cost, "status": status, "iters": iters, "kkt": kkt}
+
+  def solve_device(self, B, z, lb, ub, params, params_stride, opts, lam, cost, status, iters, kkt=None):
+    _chk(self.lib.myr_solve(self._h, int(B), _addr(z), _addr(lb), _addr(ub), _addr(params), int(params_stride),
+                            C.byref(opts), _addr(lam), _addr(cost), _addr(status), _addr(iters), _addr(kkt),
+                            MEM_DEVICE), "myr_solve")
+
+  def rollout(self, x0, us, num_steps, params=None, want_xs=True):
+    x0 = _f64(x0)
+    us = _f64(us)
+    if x0.ndim == 1:
+      x0 = x0[None]
+    if us.ndim == 2:
+      us = us[None]
+    B = x0.shape[0]
+    p, ps = self._params(params, B)
+    xs = np.empty((B, num_steps + 1, self.ns)) if want_xs else None
+    cost = np.empty(B)
+    _chk(self.lib.myr_rollout(self._h, B, int(num_steps), int(us.shape[1]), _addr(x0), _addr(us), _addr(p), ps,
+                              _addr(xs), _addr(cost), MEM_HOST), "myr_rollout")
+    return xs, cost
+
+  def kernel_time(self, kernel_id: int):
+    ms = C.c_double(); n = C.c_int32()
+    _chk(self.lib.myr_kernel_time(self._h, kernel_id, C.byref(ms), C.byref(n)), "myr_kernel_time")
+    return ms.value, n.value
+
+  def kernel_time_reset(self):
+    _chk(self.lib.myr_kernel_time_reset(self._h), "myr_kernel_time_reset")

@@ -1,0 +1,266 @@
+// myriad_hip.hip -- C-ABI (include/myriad_hip.h) over the gfx950 kernels.  No CPU fallback exists:
+// every entry point either runs the HIP kernels or fails with an error code.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/myriad_hip.h"
+#include "hs_eval.h"
+#include "systems_gen.h"
+
+using namespace myriad;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(MYR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+struct SysInfo { int ns, nu, np; bool cost_dep_x; };
+static bool sys_info(int id, SysInfo* s) {
+  switch (id) {
+    case MYR_SYS_CARTPOLE: *s = {SysCARTPOLE::NS, SysCARTPOLE::NU, SysCARTPOLE::NP, SysCARTPOLE::COST_DEP_X}; return true;
+    case MYR_SYS_VANDERPOL: *s = {SysVANDERPOL::NS, SysVANDERPOL::NU, SysVANDERPOL::NP, SysVANDERPOL::COST_DEP_X}; return true;
+    case MYR_SYS_CANCERTREATMENT: *s = {SysCANCERTREATMENT::NS, SysCANCERTREATMENT::NU, SysCANCERTREATMENT::NP, SysCANCERTREATMENT::COST_DEP_X}; return true;
+    case MYR_SYS_SIMPLECASE: *s = {SysSIMPLECASE::NS, SysSIMPLECASE::NU, SysSIMPLECASE::NP, SysSIMPLECASE::COST_DEP_X}; return true;
+  }
+  return false;
+}
+
+struct KTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  double sum_ms = 0.0;
+  int launches = 0;
+};
+
+struct myr_handle_s {
+  myr_problem_desc d;
+  myr_dims dims;
+  SysInfo si;
+  hipStream_t stream = nullptr;
+  KTimer kt[MYR_K_COUNT];
+  // staging for MYR_MEM_HOST calls
+  void* dbuf = nullptr;
+  size_t dbuf_bytes = 0;
+  int eval_wpt = 4;
+};
+
+static int ensure_dbuf(myr_handle h, size_t bytes) {
+  if (bytes <= h->dbuf_bytes) return 0;
+  if (h->dbuf) HIPCHK(hipFree(h->dbuf));
+  h->dbuf = nullptr; h->dbuf_bytes = 0;
+  HIPCHK(hipMalloc(&h->dbuf, bytes));
+  h->dbuf_bytes = bytes;
+  return 0;
+}
+
+extern "C" const char* myr_last_error(void) { return g_err.c_str(); }
+extern "C" const char* myr_version(void) { return "myriad_hip 0.1 (gfx950)"; }
+
+extern "C" void myr_default_solve_opts(myr_solve_opts* o) {
+  if (!o) return;
+  o->max_iter = 1000;   // config.py:70
+  o->reserved = 0;
+  o->tol_feas = 1e-8;
+  o->tol_stat = 1e-6;
+  o->tol_compl = 1e-7;
+  o->mu_init = 0.1;
+}
+
+extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
+  if (!desc || !out) return fail(MYR_E_ARG, "myr_create: null argument");
+  SysInfo si;
+  if (!sys_info(desc->system_id, &si)) return fail(MYR_E_ARG, "myr_create: unknown system_id");
+  if (desc->intervals < 1 || desc->controls_per_interval < 1 || !(desc->T > 0.0))
+    return fail(MYR_E_ARG, "myr_create: intervals, controls_per_interval and T must be positive");
+  myr_dims dm;
+  memset(&dm, 0, sizeof(dm));
+  dm.ns = si.ns; dm.nu = si.nu; dm.np = si.np;
+  const int N = desc->intervals;
+  switch (desc->transcription) {
+    case MYR_TR_HERMITE_SIMPSON: {
+      const int K = 2 * N + 1;
+      dm.x_rows = K; dm.u_rows = K;
+      dm.n = K * (si.ns + si.nu);
+      dm.m = 2 * N * si.ns;
+      dm.jblk = N * (5 * si.ns * si.ns + 5 * si.ns * si.nu);
+      dm.ngrad = si.cost_dep_x ? dm.n : K * si.nu;
+      break;
+    }
+    case MYR_TR_TRAPEZOIDAL:
+    case MYR_TR_SHOOTING:
+      return fail(MYR_E_UNSUPPORTED, "myr_create: transcription not built yet (HERMITE_SIMPSON only)");
+    default:
+      return fail(MYR_E_ARG, "myr_create: unknown transcription");
+  }
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (desc->device < 0 || desc->device >= ndev) return fail(MYR_E_ARG, "myr_create: bad device ordinal");
+  HIPCHK(hipSetDevice(desc->device));
+  myr_handle h = new myr_handle_s();
+  h->d = *desc;
+  h->dims = dm;
+  h->si = si;
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  for (int i = 0; i < MYR_K_COUNT; ++i) {
+    HIPCHK(hipEventCreate(&h->kt[i].a));
+    HIPCHK(hipEventCreate(&h->kt[i].b));
+  }
+  const char* w = getenv("MYRIAD_EVAL_WPT");
+  if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4) h->eval_wpt = v; }
+  *out = h;
+  return MYR_OK;
+}
+
+extern "C" int myr_destroy(myr_handle h) {
+  if (!h) return MYR_OK;
+  (void)hipSetDevice(h->d.device);
+  if (h->dbuf) (void)hipFree(h->dbuf);
+  for (int i = 0; i < MYR_K_COUNT; ++i) {
+    if (h->kt[i].a) (void)hipEventDestroy(h->kt[i].a);
+    if (h->kt[i].b) (void)hipEventDestroy(h->kt[i].b);
+  }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return MYR_OK;
+}
+
+extern "C" int myr_get_dims(myr_handle h, myr_dims* out) {
+  if (!h || !out) return fail(MYR_E_ARG, "myr_get_dims: null argument");
+  *out = h->dims;
+  return MYR_OK;
+}
+
+extern "C" int myr_kernel_time(myr_handle h, int32_t kernel_id, double* avg_ms, int32_t* launches) {
+  if (!h || kernel_id < 0 || kernel_id >= MYR_K_COUNT) return fail(MYR_E_ARG, "myr_kernel_time: bad argument");
+  const KTimer& k = h->kt[kernel_id];
+  if (avg_ms) *avg_ms = k.launches ? k.sum_ms / k.launches : 0.0;
+  if (launches) *launches = k.launches;
+  return MYR_OK;
+}
+
+extern "C" int myr_kernel_time_reset(myr_handle h) {
+  if (!h) return fail(MYR_E_ARG, "myr_kernel_time_reset: null handle");
+  for (int i = 0; i < MYR_K_COUNT; ++i) { h->kt[i].sum_ms = 0.0; h->kt[i].launches = 0; }
+  return MYR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// eval
+// ------------------------------------------------------------------------------------------------
+template <class Sys>
+static int launch_hs_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
+                          double* f, double* g, double* c, double* j) {
+  const int N = h->d.intervals;
+  const double hstep = h->d.T / N;
+  const int wpt = h->eval_wpt;
+  const size_t lds = hs_eval_lds_bytes<Sys>(N, wpt);
+  if (lds > 160 * 1024) return fail(MYR_E_CAPACITY, "hs_eval: intervals too large for the 160 KiB LDS record");
+  KTimer& kt = h->kt[MYR_K_EVAL];
+  HIPCHK(hipEventRecord(kt.a, h->stream));
+  switch (wpt) {
+    case 1: {
+      auto kern = hs_eval_kernel<Sys, 1>;
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);
+      break;
+    }
+    case 2: {
+      auto kern = hs_eval_kernel<Sys, 2>;
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(B), dim3(128), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);
+      break;
+    }
+    default: {
+      auto kern = hs_eval_kernel<Sys, 4>;
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);
+      break;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(kt.b, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+  kt.sum_ms += ms;
+  kt.launches += 1;
+  return MYR_OK;
+}
+
+static int dispatch_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
+                         double* f, double* g, double* c, double* j) {
+  switch (h->d.system_id) {
+    case MYR_SYS_CARTPOLE: return launch_hs_eval<SysCARTPOLE>(h, B, z, params, pstride, f, g, c, j);
+    case MYR_SYS_VANDERPOL: return launch_hs_eval<SysVANDERPOL>(h, B, z, params, pstride, f, g, c, j);
+    case MYR_SYS_CANCERTREATMENT: return launch_hs_eval<SysCANCERTREATMENT>(h, B, z, params, pstride, f, g, c, j);
+    case MYR_SYS_SIMPLECASE: return launch_hs_eval<SysSIMPLECASE>(h, B, z, params, pstride, f, g, c, j);
+  }
+  return fail(MYR_E_ARG, "eval: unknown system");
+}
+
+extern "C" int myr_eval(myr_handle h, int32_t B, const double* z, const double* params, int32_t params_stride,
+                        double* f, double* gradf, double* c, double* jblk, int32_t mem) {
+  if (!h || !z) return fail(MYR_E_ARG, "myr_eval: null handle or z");
+  if (B < 0) return fail(MYR_E_ARG, "myr_eval: negative batch");
+  if (B == 0) return MYR_OK;
+  if (params && params_stride != 0 && params_stride != h->dims.np)
+    return fail(MYR_E_ARG, "myr_eval: params_stride must be 0 (shared) or np");
+  if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "myr_eval: transcription not built");
+  HIPCHK(hipSetDevice(h->d.device));
+  const myr_dims& dm = h->dims;
+  if (mem == MYR_MEM_DEVICE) return dispatch_eval(h, B, z, params, params_stride, f, gradf, c, jblk);
+  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_eval: bad mem kind");
+  // host pointers: stage through device scratch
+  const size_t nz = (size_t)B * dm.n, npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
+  const size_t nf = f ? (size_t)B : 0, ng = gradf ? (size_t)B * dm.ngrad : 0;
+  const size_t nc = c ? (size_t)B * dm.m : 0, nj = jblk ? (size_t)B * dm.jblk : 0;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };   // keep 16-byte alignment of every carve
+  const size_t total = al(nz) + al(npar) + al(nf) + al(ng) + al(nc) + al(nj);
+  int rc = ensure_dbuf(h, total * 8);
+  if (rc) return rc;
+  double* dz = (double*)h->dbuf;
+  double* dp = dz + al(nz);
+  double* df = dp + al(npar);
+  double* dg = df + al(nf);
+  double* dc = dg + al(ng);
+  double* dj = dc + al(nc);
+  HIPCHK(hipMemcpyAsync(dz, z, nz * 8, hipMemcpyHostToDevice, h->stream));
+  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
+  rc = dispatch_eval(h, B, dz, npar ? dp : nullptr, params_stride, nf ? df : nullptr, ng ? dg : nullptr,
+                     nc ? dc : nullptr, nj ? dj : nullptr);
+  if (rc) return rc;
+  if (nf) HIPCHK(hipMemcpyAsync(f, df, nf * 8, hipMemcpyDeviceToHost, h->stream));
+  if (ng) HIPCHK(hipMemcpyAsync(gradf, dg, ng * 8, hipMemcpyDeviceToHost, h->stream));
+  if (nc) HIPCHK(hipMemcpyAsync(c, dc, nc * 8, hipMemcpyDeviceToHost, h->stream));
+  if (nj) HIPCHK(hipMemcpyAsync(jblk, dj, nj * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MYR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// solve / rollout: kernels land in the next milestones
+// ------------------------------------------------------------------------------------------------
+extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, const double* ub,
+                         const double* params, int32_t params_stride, const myr_solve_opts* opts,
+                         double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt, int32_t mem) {
+  (void)h; (void)B; (void)z; (void)lb; (void)ub; (void)params; (void)params_stride; (void)opts;
+  (void)lam; (void)cost; (void)status; (void)iters; (void)kkt; (void)mem;
+  return fail(MYR_E_UNSUPPORTED, "myr_solve: not built yet");
+}
+
+extern "C" int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u_rows, const double* x0, const double* us,
+                           const double* params, int32_t params_stride, double* xs, double* cost, int32_t mem) {
+  (void)h; (void)B; (void)num_steps; (void)u_rows; (void)x0; (void)us; (void)params; (void)params_stride;
+  (void)xs; (void)cost; (void)mem;
+  return fail(MYR_E_UNSUPPORTED, "myr_rollout: not built yet");
+}

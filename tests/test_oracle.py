@@ -1,0 +1,102 @@
+"""CPU tests of the oracle itself (no GPU): the reference's one known-answer test, the survey's
+App. C numbers, and the committed golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import myriad_oracle as O
+
+
+def test_reference_kat_rk4_integrate():
+  """/root/reference/tests/tests.py:19-43: RK4 `integrate` of y'=y, y(0)=1, 99 steps, equals odeint (=e) to
+  6 decimals.  (The test passes a length-100 control array and relies on index clamping, quirk Q6.)"""
+  from scipy.integrate import odeint
+  res = odeint(lambda t, y: y, np.array([1.]), [0., 1.], tfirst=True)
+  N = 100
+  t = torch.linspace(0., 1., N, dtype=torch.float64)
+  h = t[1]
+  _, states = O.integrate(lambda x, u, tt: x, torch.tensor([1.], dtype=torch.float64), t, h, N - 1, t, "RK4")
+  np.testing.assert_almost_equal(res[-1], states[-1].numpy(), decimal=6)
+
+
+@pytest.mark.parametrize("method,order", [("EULER", 1), ("HEUN", 2), ("MIDPOINT", 1), ("RK4", 4)])
+def test_integrator_orders(method, order):
+  """Convergence order of each step rule in utils.py:31-54 on y'=-y.  The reference's "midpoint" rule takes a
+  FULL Euler step to its "mid" state (utils.py:47-50: x_mid = x + h f(x,u1)), so it is first order (quirk Q11)."""
+  errs = []
+  for n in (20, 40):
+    mc = 2 if method == "RK4" else 1
+    us = torch.zeros(mc * n + 1, 1, dtype=torch.float64)
+    xT, _ = O.integrate_time_independent(lambda x, u: -x, torch.tensor([1.], dtype=torch.float64), us, 1.0 / n, n, method)
+    errs.append(abs(float(xT[0]) - np.exp(-1.0)))
+  assert np.log2(errs[0] / errs[1]) == pytest.approx(order, abs=0.25)
+
+
+def test_shapes_match_survey_appendix_a():
+  """SURVEY.md App. A.5 sizes (n, m, pinned variables) for the BASELINE configs."""
+  cases = [("SIMPLECASE", "SHOOTING", dict(intervals=10, controls_per_interval=100), 1012, 10, 1),
+           ("CARTPOLE", "HS", dict(intervals=100), 1005, 800, 8),
+           ("VANDERPOL", "SHOOTING", dict(intervals=1, controls_per_interval=50), 55, 2, 4),
+           ("CANCERTREATMENT", "SHOOTING", dict(intervals=1, controls_per_interval=100), 103, 1, 1),
+           ("CARTPOLE", "TRAP", dict(intervals=100), 505, 400, 8)]
+  for name, kind, kw, n, m, pinned in cases:
+    s = O.SYSTEMS[name]()
+    tr = {"HS": O.hermite_simpson, "TRAP": O.trapezoidal, "SHOOTING": O.shooting}[kind](s, **kw)
+    assert tr.guess.shape == (n,)
+    assert tr.bounds.shape == (n, 2)
+    assert tr.constraints(torch.as_tensor(tr.guess)).shape == (m,)
+    assert int((tr.bounds[:, 0] == tr.bounds[:, 1]).sum()) == pinned
+
+
+def test_guesses_match_survey_appendix_c():
+  s = O.CancerTreatment(); tr = O.shooting(s, 1, 100)
+  np.testing.assert_allclose(tr.x_guess.ravel(), [0.975, 0.6579], atol=5e-5)       # one Heun step of size 20
+  s = O.SimpleCase(); tr = O.shooting(s, 10, 100)
+  np.testing.assert_allclose(tr.x_guess.ravel()[:3], [1., 0.9524, 0.9092], atol=5e-5)
+  s = O.VanDerPol(); tr = O.shooting(s, 1, 50)
+  np.testing.assert_allclose(tr.x_guess, [[0., 1.], [0., 0.]])
+
+
+def test_slsqp_path_reproduces_survey_costs():
+  """The SciPy SLSQP branch (nlp_solvers/__init__.py:50-52) on the restated callbacks reproduces the
+  independently-measured survey numbers."""
+  s = O.CancerTreatment(); tr = O.shooting(s, 1, 100)
+  r = O.solve(tr, "SLSQP", max_iter=500)
+  assert r["scipy"].success and r["cost"] == pytest.approx(20.5735535185, rel=1e-9)
+  s = O.VanDerPol(); tr = O.shooting(s, 1, 50)
+  r = O.solve(tr, "SLSQP")
+  assert r["scipy"].success and r["cost"] == pytest.approx(2.8731963348, rel=1e-8)
+
+
+def test_golden_eval_vectors_match_oracle(golden_dir):
+  files = sorted(glob.glob(os.path.join(golden_dir, "eval_hs_*.npz")))
+  assert files
+  for path in files:
+    name = os.path.basename(path).split("_")[2].upper()
+    if "N100" in path:
+      continue   # big one is exercised on the GPU side
+    d = np.load(path)
+    s = O.SYSTEMS[name]()
+    N = int(d["N"])
+    tr = O.hermite_simpson(s, N)
+    cb = O.Callbacks(tr)
+    for b in range(d["z"].shape[0]):
+      np.testing.assert_allclose(cb.cons(d["z"][b]), d["c"][b], rtol=0, atol=1e-14)
+      np.testing.assert_allclose(cb.fun(d["z"][b]), d["f"][b], rtol=1e-14)
+      J = O.hs_dense_from_blocks(d["jblk"][b], N, s.ns, s.nu)
+      np.testing.assert_allclose(cb.jac(d["z"][b]), J, rtol=0, atol=1e-14)
+
+
+def test_rollout_and_defect_helpers():
+  """utils.py:258-324 restatement: cost of zero control on SIMPLECASE equals the integral of -x."""
+  s = O.SimpleCase()
+  xs, c = O.get_state_trajectory_and_cost(s, 200, "RK4", s.x_0, np.zeros((401, 1)))
+  # x' = -x^2/2, x(0)=1 -> x(t) = 2/(t+2); integral of -x over [0,1] = -2 ln(3/2)
+  assert xs[-1, 0] == pytest.approx(2.0 / 3.0, rel=1e-9)
+  assert c == pytest.approx(-2.0 * np.log(1.5), rel=1e-9)
+  assert O.get_defect(s, xs) is None
+  cp = O.CartPole()
+  np.testing.assert_allclose(O.get_defect(cp, np.array([[1., np.pi, 0.5, 0.]])), [0., 0., 0.5, 0.])

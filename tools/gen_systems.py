@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""
+Generate myriad_amd/csrc/systems_gen.h: closed-form f, (A,B)=df/d(x,u), cost g, dg, and the
+Lagrangian-Hessian contraction  W = w*d2g + sum_i mu_i * d2f_i  for each control system on the
+hot path, as plain `double` straight-line code usable from both hipcc (device) and g++ (host).
+
+The symbolic definitions below RESTATE the reference's system definitions (citations are relative
+to /root/reference/); derivatives and common-subexpression elimination are done by sympy here, at
+development time.  The generated header is committed; this script is only re-run when a system
+is added.  Run:  python tools/gen_systems.py
+"""
+import os
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+
+OUT = os.path.join(os.path.dirname(__file__), "..", "myriad_amd", "csrc", "systems_gen.h")
+
+
+class Printer(C99CodePrinter):
+  def _print_Pow(self, expr):
+    b, e = expr.as_base_exp()
+    if e == 2:
+      s = self._print(b)
+      return f"(({s})*({s}))"
+    if e == -1:
+      return f"(1.0/({self._print(b)}))"
+    if e == -2:
+      s = self._print(b)
+      return f"(1.0/(({s})*({s})))"
+    if e == 3:
+      s = self._print(b)
+      return f"(({s})*({s})*({s}))"
+    return super()._print_Pow(expr)
+
+
+PR = Printer()
+
+
+def systems():
+  out = []
+  # ---- CARTPOLE: myriad/systems/classical_control/cartpole.py:76-87 (dynamics), :106-108 (cost) ----
+  x = sp.symbols("x0:4", real=True)
+  u = sp.symbols("u0:1", real=True)
+  g, m1, m2, L = p = sp.symbols("p0:4", real=True)   # g, m1, m2, length  (ctor order, cartpole.py:50)
+  th, dx, dth = x[1], x[2], x[3]
+  ddx = (L * m2 * sp.sin(th) * dth ** 2 + u[0] + m2 * g * sp.cos(th) * sp.sin(th)) / (m1 + m2 * (1 - sp.cos(th) ** 2))
+  ddth = -((L * m2 * sp.cos(th) * dth ** 2 + u[0] * sp.cos(th) + (m1 + m2) * g * sp.sin(th))
+           / (L * m1 + L * m2 * (1 - sp.cos(th) ** 2)))
+  out.append(dict(name="CARTPOLE", id=0, x=x, u=u, p=p, f=[dx, dth, ddx, ddth], g=u[0] ** 2,
+                  pdefault=[9.81, 1.0, 0.3, 0.5], pnames=["g", "m1", "m2", "length"]))
+  # ---- VANDERPOL: myriad/systems/miscellaneous/van_der_pol.py:46-50, :59-60 ----
+  x = sp.symbols("x0:2", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:1", real=True)   # a
+  out.append(dict(name="VANDERPOL", id=1, x=x, u=u, p=p,
+                  f=[p[0] * (1 - x[1] ** 2) * x[0] - x[1] + u[0], x[0]],
+                  g=x[0] ** 2 + x[1] ** 2 + u[0] ** 2, pdefault=[1.0], pnames=["a"]))
+  # ---- CANCERTREATMENT: myriad/systems/lenhart/cancer_treatment.py:62-65, :75-76 ----
+  x = sp.symbols("x0:1", positive=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:3", real=True)   # r, a, delta (ctor order, cancer_treatment.py:40)
+  out.append(dict(name="CANCERTREATMENT", id=2, x=x, u=u, p=p,
+                  f=[p[0] * x[0] * sp.log(1 / x[0]) - u[0] * p[2] * x[0]],
+                  g=p[1] * x[0] ** 2 + u[0] ** 2, pdefault=[0.3, 3.0, 0.45], pnames=["r", "a", "delta"]))
+  # ---- SIMPLECASE: myriad/systems/lenhart/simple_case.py:46-53 ----
+  x = sp.symbols("x0:1", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:3", real=True)   # A, B, C
+  out.append(dict(name="SIMPLECASE", id=3, x=x, u=u, p=p,
+                  f=[-sp.Rational(1, 2) * x[0] ** 2 + p[2] * u[0]],
+                  g=-p[0] * x[0] + p[1] * u[0] ** 2, pdefault=[1.0, 1.0, 4.0], pnames=["A", "B", "C"]))
+  return out
+
+
+def emit_block(assigns, indent="  "):
+  """assigns: list of (lhs_string, expr).  CSE over all, emit straight-line code."""
+  exprs = [e for _, e in assigns]
+  repl, red = sp.cse(exprs, symbols=sp.numbered_symbols("t"), optimizations="basic")
+  lines = []
+  for s, e in repl:
+    lines.append(f"{indent}const double {s} = {PR.doprint(e)};")
+  for (lhs, _), e in zip(assigns, red):
+    lines.append(f"{indent}{lhs} = {PR.doprint(e)};")
+  return "\n".join(lines)
+
+
+def gen_system(S):
+  name, x, u, p = S["name"], list(S["x"]), list(S["u"]), list(S["p"])
+  ns, nu, npar = len(x), len(u), len(p)
+  w = x + u
+  nw = ns + nu
+  f = [sp.sympify(e) for e in S["f"]]
+  g = sp.sympify(S["g"])
+  A = [[sp.diff(f[i], x[j]) for j in range(ns)] for i in range(ns)]
+  Bm = [[sp.diff(f[i], u[j]) for j in range(nu)] for i in range(ns)]
+  gw = [sp.diff(g, v) for v in w]
+  mu = sp.symbols(f"mu0:{ns}", real=True)
+  wg = sp.Symbol("wg", real=True)
+  lag = wg * g + sum(mu[i] * f[i] for i in range(ns))
+  H = [[sp.diff(lag, w[i], w[j]) for j in range(nw)] for i in range(nw)]
+  cost_dep_x = any(sp.diff(g, v) != 0 for v in x)
+
+  def unpack(indent="  "):
+    s = []
+    for i, v in enumerate(x):
+      s.append(f"{indent}const double {v} = x[{i}];")
+    for i, v in enumerate(u):
+      s.append(f"{indent}const double {v} = u[{i}];")
+    for i, v in enumerate(p):
+      s.append(f"{indent}const double {v} = p[{i}];")
+    return "\n".join(s) + "\n" + "\n".join(f"{indent}(void){v};" for v in (x + u + p))
+
+  o = []
+  o.append(f"// ===== {name} (id {S['id']}): ns={ns} nu={nu} np={npar} =====")
+  o.append(f"struct Sys{name} {{")
+  o.append(f"  static constexpr int ID = {S['id']}, NS = {ns}, NU = {nu}, NP = {npar}, NW = {nw};")
+  o.append(f"  static constexpr bool COST_DEP_X = {'true' if cost_dep_x else 'false'};")
+  o.append(f"  static constexpr const char* NAME = \"{name}\";")
+  # f
+  o.append("  // dynamics f(x,u)")
+  o.append("  MYR_HD static inline void f(const double* x, const double* u, const double* p, double* fo) {")
+  o.append(unpack("    "))
+  o.append(emit_block([(f"fo[{i}]", f[i]) for i in range(ns)], "    "))
+  o.append("  }")
+  # cost
+  o.append("  // running cost g(x,u)")
+  o.append("  MYR_HD static inline double g(const double* x, const double* u, const double* p) {")
+  o.append(unpack("    "))
+  o.append("    double r;")
+  o.append(emit_block([("r", g)], "    "))
+  o.append("    return r;")
+  o.append("  }")
+  # f, A, B, g, gw
+  o.append("  // f, A=df/dx (row-major ns x ns), B=df/du (ns x nu), g, dg/d(x,u)")
+  o.append("  MYR_HD static inline void lin(const double* x, const double* u, const double* p,")
+  o.append("                                double* fo, double* A, double* B, double* go, double* gw) {")
+  o.append(unpack("    "))
+  ass = [(f"fo[{i}]", f[i]) for i in range(ns)]
+  ass += [(f"A[{i * ns + j}]", A[i][j]) for i in range(ns) for j in range(ns)]
+  ass += [(f"B[{i * nu + j}]", Bm[i][j]) for i in range(ns) for j in range(nu)]
+  ass += [("*go", g)] + [(f"gw[{i}]", gw[i]) for i in range(nw)]
+  o.append(emit_block(ass, "    "))
+  o.append("  }")
+  # everything + Hessian contraction
+  o.append("  // as lin(), plus W (NW x NW row-major, symmetric) = wg*d2g + sum_i mu[i]*d2 f_i wrt (x,u)")
+  o.append("  MYR_HD static inline void lin2(const double* x, const double* u, const double* p,")
+  o.append("                                 const double* mu, double wg,")
+  o.append("                                 double* fo, double* A, double* B, double* go, double* gw, double* W) {")
+  o.append(unpack("    "))
+  for i in range(ns):
+    o.append(f"    const double mu{i} = mu[{i}];")
+  ass2 = list(ass)
+  for i in range(nw):
+    for j in range(nw):
+      if j >= i:
+        ass2.append((f"W[{i * nw + j}]", H[i][j]))
+  o.append(emit_block(ass2, "    "))
+  for i in range(nw):
+    for j in range(i):
+      o.append(f"    W[{i * nw + j}] = W[{j * nw + i}];")
+  o.append("  }")
+  o.append("  MYR_HD static inline void default_params(double* p) {")
+  for i, v in enumerate(S["pdefault"]):
+    o.append(f"    p[{i}] = {v!r};  // {S['pnames'][i]}")
+  o.append("  }")
+  o.append("};")
+  return "\n".join(o)
+
+
+def main():
+  parts = ["// GENERATED by tools/gen_systems.py (sympy) -- do not edit by hand.",
+           "// Closed-form dynamics / cost / derivative code for the control systems on the hot path.",
+           "// Restates /root/reference/myriad/systems/{classical_control/cartpole.py:76-87,106-108,",
+           "//   miscellaneous/van_der_pol.py:46-60, lenhart/cancer_treatment.py:62-76, lenhart/simple_case.py:46-53}.",
+           "#pragma once",
+           "#include <math.h>",
+           "#ifndef MYR_HD",
+           "#if defined(__HIPCC__)",
+           "#define MYR_HD __host__ __device__",
+           "#else",
+           "#define MYR_HD",
+           "#endif",
+           "#endif",
+           "namespace myriad {", ""]
+  for S in systems():
+    parts.append(gen_system(S))
+    parts.append("")
+  parts.append("}  // namespace myriad")
+  with open(OUT, "w") as fh:
+    fh.write("\n".join(parts) + "\n")
+  print("wrote", os.path.abspath(OUT))
+
+
+if __name__ == "__main__":
+  main()
