@@ -1,0 +1,955 @@
+// hs_solver.h -- per-trajectory interior-point SQP for the Hermite-Simpson transcription (K6/K7 in DESIGN.md).
+//
+// This is the new `NLPSolverType.SQP` path that replaces the reference's external NLP call
+// (/root/reference/myriad/nlp_solvers/__init__.py:57-58, cyipopt.minimize_ipopt) for the problem built by
+// /root/reference/myriad/trajectory_optimizers/collocation/hermite_simpson.py:
+//     min f(z)  s.t.  c(z) = 0,  lb <= z <= ub            (objective :243-257, constraints :325-335, bounds :55-81)
+//
+// Algorithm (one trajectory; on the GPU one trajectory per lane, see hs_solve_kernel in myriad_hip.hip):
+//   * bounds by a primal-dual log-barrier (mu -> 0, monotone); variables with lb == ub are pinned;
+//   * each iteration solves ONE equality-constrained QP -- the Newton/SQP step of the barrier problem with
+//     the exact Lagrangian Hessian -- by a stage-wise Riccati recursion over the N intervals:
+//       - the midpoint state is eliminated through the interpolation rows and the end state through the
+//         defect rows (one ns x ns LU per interval),
+//       - the remaining per-stage unknowns q = (du_mid, du_end) are eliminated by a 2nu x 2nu Cholesky,
+//         convexified on the fly when not positive definite (inertia correction),
+//       - pinned terminal states are handled exactly by carrying ns extra right-hand sides (their
+//         multipliers nu enter linearly) and one ns x ns solve; the barrier parameter also enters the
+//         right-hand side linearly, so it is chosen AFTER the backward sweep from the measured KKT error;
+//   * equality multipliers are the discrete adjoint (costate) of the current iterate, obtained in the same
+//     backward sweep; x-row stationarity then holds by construction and optimality is measured on the
+//     control rows;
+//   * globalisation: l1 merit function, backtracking Armijo line search, fraction-to-the-boundary rule.
+//
+// Everything here is plain scalar fp64 code shared between the device build (hipcc, one lane per trajectory,
+// arrays strided by the padded batch so that lanes coalesce) and the host test twin (tests/hostsim, stride 1).
+#pragma once
+#include <math.h>
+#include "systems_gen.h"
+
+namespace myriad {
+
+struct HsSolveOpts {
+  int N;
+  double h;
+  int max_iter;
+  double tol_feas, tol_stat, tol_compl, mu_init;
+  double reg_floor = 1e-3; // smallest pivot accepted in the per-stage Cholesky (inertia correction threshold)
+  double rho_term = 1e4;   // quadratic weight on pinned terminal states inside the QP (does not change its solution)
+};
+
+struct HsSolveResult {
+  int status, iters;
+  double cost, feas, stat, compl_;
+};
+
+// strided per-trajectory view: element i of this trajectory lives at p[i*s]
+struct SV {
+  double* p;
+  long s;
+  MYR_HD inline double& operator[](long i) const { return p[i * s]; }
+};
+
+template <class Sys>
+struct HsSol {
+  static constexpr int NS = Sys::NS, NU = Sys::NU, NW = Sys::NW;
+  static constexpr int NY = NS + 3 * NU;   // stage unknowns: dx_s, du_s, du_m, du_e
+  static constexpr int NQ = 2 * NU;        // eliminated per stage: du_m, du_e
+  static constexpr int NC = 2 + NS;        // right-hand-side columns: base, mu-coefficient, terminal multipliers
+  // per-stage storage for the forward sweep
+  static constexpr int O_K = 0, O_KC = O_K + NQ * NW, O_GE = O_KC + NQ * NC, O_gE = O_GE + NS * NY,
+                       O_GM = O_gE + NS, O_gM = O_GM + NS * NY, STAGE = O_gM + NS;
+  static constexpr int HEAD = NU * NC;     // first-point control gains
+  MYR_HD static constexpr long stage_doubles(int N) { return (long)HEAD + (long)N * STAGE; }
+};
+
+struct HsWork {
+  SV z, lb, ub, zL, zU, lam, dz, st;   // st: stage storage
+};
+
+namespace detail {
+
+MYR_HD inline double dmax(double a, double b) { return a > b ? a : b; }
+MYR_HD inline double dmin(double a, double b) { return a < b ? a : b; }
+MYR_HD inline bool finite_(double v) { return (v - v) == 0.0; }
+
+// In-place LU (no pivoting; the matrices here are I + O(h)) of an n x n row-major matrix.
+template <int n>
+MYR_HD inline void lu_factor(double* a) {
+#pragma unroll
+  for (int k = 0; k < n; ++k) {
+    const double inv = 1.0 / a[k * n + k];
+#pragma unroll
+    for (int i = k + 1; i < n; ++i) {
+      const double l = a[i * n + k] * inv;
+      a[i * n + k] = l;
+#pragma unroll
+      for (int j = k + 1; j < n; ++j) a[i * n + j] -= l * a[k * n + j];
+    }
+  }
+}
+// solve (LU) x = b for `cols` right-hand sides stored row-major b[n][cols]
+template <int n, int cols>
+MYR_HD inline void lu_solve(const double* a, double* b) {
+#pragma unroll
+  for (int c = 0; c < cols; ++c) {
+#pragma unroll
+    for (int i = 1; i < n; ++i) {
+      double s = b[i * cols + c];
+#pragma unroll
+      for (int j = 0; j < i; ++j) s -= a[i * n + j] * b[j * cols + c];
+      b[i * cols + c] = s;
+    }
+#pragma unroll
+    for (int i = n - 1; i >= 0; --i) {
+      double s = b[i * cols + c];
+#pragma unroll
+      for (int j = i + 1; j < n; ++j) s -= a[i * n + j] * b[j * cols + c];
+      b[i * cols + c] = s / a[i * n + i];
+    }
+  }
+}
+// solve (LU)^T x = b for one vector
+template <int n>
+MYR_HD inline void lu_solve_t(const double* a, double* b) {
+  // U^T y = b (forward), then L^T x = y (backward)
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) s -= a[j * n + i] * b[j];
+    b[i] = s / a[i * n + i];
+  }
+#pragma unroll
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+#pragma unroll
+    for (int j = i + 1; j < n; ++j) s -= a[j * n + i] * b[j];
+    b[i] = s;
+  }
+}
+
+// Cholesky a = L L^T in place (lower), convexified on the fly: a pivot below `floor_` is replaced by
+// max(|pivot|, floor_) -- equivalent to adding a PSD diagonal matrix to this block (inertia correction).
+template <int n>
+MYR_HD inline int chol_reg(double* a, double floor_) {
+  int nreg = 0;
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    double d = a[j * n + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= a[j * n + k] * a[j * n + k];
+    if (!(d > floor_)) { d = dmax(fabs(d), floor_); ++nreg; }
+    const double l = sqrt(d);
+    a[j * n + j] = l;
+    const double inv = 1.0 / l;
+#pragma unroll
+    for (int i = j + 1; i < n; ++i) {
+      double s = a[i * n + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= a[i * n + k] * a[j * n + k];
+      a[i * n + j] = s * inv;
+    }
+  }
+  return nreg;
+}
+// solve L L^T x = b, `cols` right-hand sides row-major b[n][cols]
+template <int n, int cols>
+MYR_HD inline void chol_solve(const double* a, double* b) {
+#pragma unroll
+  for (int c = 0; c < cols; ++c) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      double s = b[i * cols + c];
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= a[i * n + k] * b[k * cols + c];
+      b[i * cols + c] = s / a[i * n + i];
+    }
+#pragma unroll
+    for (int i = n - 1; i >= 0; --i) {
+      double s = b[i * cols + c];
+#pragma unroll
+      for (int k = i + 1; k < n; ++k) s -= a[k * n + i] * b[k * cols + c];
+      b[i * cols + c] = s / a[i * n + i];
+    }
+  }
+}
+
+}  // namespace detail
+
+// One collocation point's linearisation.
+template <class Sys>
+struct HsPoint {
+  double x[Sys::NS], u[Sys::NU], f[Sys::NS], A[Sys::NS * Sys::NS], B[Sys::NS * Sys::NU], g, gw[Sys::NW], D2[Sys::NNZ2];
+};
+
+template <class Sys>
+struct HsSolver {
+  using D = HsSol<Sys>;
+  static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC;
+
+  // index of variable (point j, component c of w=(x,u)) in the reference's z layout
+  MYR_HD static inline long zi(int K, int j, int c) { return c < NS ? (long)j * NS + c : (long)K * NS + (long)j * NU + (c - NS); }
+  // Simpson weight of point j in sum_k h/6 (g_s + 4 g_m + g_e)  (hermite_simpson.py:212-214)
+  MYR_HD static inline double wsimp(int K, int j, double h) {
+    return (j & 1) ? 4.0 * h / 6.0 : ((j == 0 || j == K - 1) ? h / 6.0 : 2.0 * h / 6.0);
+  }
+
+  MYR_HD static inline void load_point(const HsWork& w, int K, int j, const double* p, HsPoint<Sys>& P, bool second) {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) P.x[c] = w.z[zi(K, j, c)];
+#pragma unroll
+    for (int c = 0; c < NU; ++c) P.u[c] = w.z[zi(K, j, NS + c)];
+    if (second) Sys::lin_d2(P.x, P.u, p, P.f, P.A, P.B, &P.g, P.gw, P.D2);
+    else Sys::lin(P.x, P.u, p, P.f, P.A, P.B, &P.g, P.gw);
+  }
+
+  // bound data of one variable: barrier Hessian sigma, base gradient part (-zL + zU) for the adjoint,
+  // mu-coefficient g1 = -1/(z-l) + 1/(u-z); also complementarity and pinned flag
+  struct BV { double sigma, g1, zlu; bool pinned; };
+  MYR_HD static inline BV bound_terms(const HsWork& w, long i, double& compl_max, double& compl_min) {
+    BV r;
+    const double zv = w.z[i], l = w.lb[i], u = w.ub[i];
+    r.pinned = !(l < u);
+    r.sigma = 0.0; r.g1 = 0.0; r.zlu = 0.0;
+    if (!r.pinned) {
+      if (l > -INFINITY) {
+        const double sl = zv - l, zl = w.zL[i];
+        r.sigma += zl / sl; r.g1 -= 1.0 / sl; r.zlu -= zl;
+        compl_max = detail::dmax(compl_max, sl * zl); compl_min = detail::dmin(compl_min, sl * zl);
+      }
+      if (u < INFINITY) {
+        const double su = u - zv, zu = w.zU[i];
+        r.sigma += zu / su; r.g1 += 1.0 / su; r.zlu += zu;
+        compl_max = detail::dmax(compl_max, su * zu); compl_min = detail::dmin(compl_min, su * zu);
+      }
+    }
+    return r;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // Backward sweep at the current iterate: constraints, adjoint multipliers, KKT error, Riccati factorisation.
+  // ------------------------------------------------------------------------------------------------
+  struct SweepOut {
+    double f, c1, cinf, stat, compl_max, compl_min, lam_inf, sum_mult;
+    int n_mult;
+    double Tnu[NS * NC];   // d(dual)/d(nu_i) = Tnu[i][0] + mu*Tnu[i][1] + sum_j Tnu[i][2+j] nu_j
+    bool term_pinned[NS];
+    int nreg;
+    bool abort_on_reg;
+  };
+
+  // `delta` is added to the diagonal of every Hessian block (global inertia correction, W + delta I).
+  MYR_HD static void backward(const HsWork& w, const HsSolveOpts& o, const double* p, const double* nuT, double delta, SweepOut& so) {
+    using namespace detail;
+    const int N = o.N, K = 2 * N + 1;
+    const double h = o.h, h6 = h / 6.0, h8 = h / 8.0;
+    so.f = 0; so.c1 = 0; so.cinf = 0; so.stat = 0; so.compl_max = 0; so.compl_min = INFINITY; so.lam_inf = 0; so.sum_mult = 0; so.n_mult = 0; so.nreg = 0;
+#pragma unroll
+    for (int i = 0; i < NS * NC; ++i) so.Tnu[i] = 0.0;
+
+    // value function of everything after the current stage: 1/2 s'^T P s' + s'^T (pc . theta), theta=(1,mu,nu)
+    double P[NW * NW], pc[NW * NC];
+#pragma unroll
+    for (int i = 0; i < NW * NW; ++i) P[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW * NC; ++i) pc[i] = 0.0;
+
+    HsPoint<Sys> Pe, Pm, Ps;
+    load_point(w, K, K - 1, p, Pe, true);
+    // adjoint carries from the later stage: costate on x_e rows, control-row partial residual, Hessian multiplier part
+    double pi_c[NS], ru_c[NU], mu_c[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+      const long i = zi(K, K - 1, c);
+      so.term_pinned[c] = !(w.lb[i] < w.ub[i]);
+      pi_c[c] = so.term_pinned[c] ? nuT[c] : 0.0;
+      mu_c[c] = 0.0;
+      if (so.term_pinned[c]) {
+        pc[c * NC + 2 + c] = 1.0;            // nu_c * dx_N[c]
+        P[c * NW + c] = o.rho_term;          // + rho/2 dx_N[c]^2: vanishes at the solution (dx_N = 0 there), but keeps
+      }                                      //   the nu-parametrised inner problem convex (augmented-Lagrangian form)
+    }
+#pragma unroll
+    for (int c = 0; c < NU; ++c) ru_c[c] = 0.0;
+
+    for (int k = N - 1; k >= 0; --k) {
+      const int je = 2 * k + 2, jm = 2 * k + 1, js = 2 * k;
+      load_point(w, K, jm, p, Pm, true);
+      load_point(w, K, js, p, Ps, true);
+      const double we = wsimp(K, je, h), wm = wsimp(K, jm, h);
+      so.f += we * Pe.g + wm * Pm.g;
+
+      // ---- constraints of interval k (hermite_simpson.py:124-128, :167-170) ----
+      double dk[NS], ik[NS];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        dk[c] = (Pe.x[c] - Ps.x[c]) - h6 * (Ps.f[c] + 4.0 * Pm.f[c] + Pe.f[c]);
+        ik[c] = Pm.x[c] - 0.5 * (Ps.x[c] + Pe.x[c]) - h8 * (Ps.f[c] - Pe.f[c]);
+        so.c1 += fabs(dk[c]) + fabs(ik[c]);
+        so.cinf = dmax(so.cinf, dmax(fabs(dk[c]), fabs(ik[c])));
+      }
+
+      // ---- bound terms of points e and m ----
+      double sig_e[NW], g1_e[NW], zlu_e[NW], sig_m[NW], g1_m[NW], zlu_m[NW];
+      bool pin_e[NW];
+#pragma unroll
+      for (int c = 0; c < NW; ++c) {
+        BV b = bound_terms(w, zi(K, je, c), so.compl_max, so.compl_min);
+        sig_e[c] = b.sigma; g1_e[c] = b.g1; zlu_e[c] = b.zlu; pin_e[c] = b.pinned;
+        BV bm = bound_terms(w, zi(K, jm, c), so.compl_max, so.compl_min);
+        sig_m[c] = bm.sigma; g1_m[c] = bm.g1; zlu_m[c] = bm.zlu;
+      }
+
+      // ---- Cm = 4h/6 A_m, Ne = I/2 - h/8 A_e, Nsm = I/2 + h/8 A_s, E = I - h/6 A_e - Cm Ne ----
+      double Cm[NS * NS], Ne[NS * NS], Nsm[NS * NS], E[NS * NS];
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+          const double id = (r == c) ? 1.0 : 0.0;
+          Cm[r * NS + c] = 4.0 * h6 * Pm.A[r * NS + c];
+          Ne[r * NS + c] = 0.5 * id - h8 * Pe.A[r * NS + c];
+          Nsm[r * NS + c] = 0.5 * id + h8 * Ps.A[r * NS + c];
+        }
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+          double s = ((r == c) ? 1.0 : 0.0) - h6 * Pe.A[r * NS + c];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s -= Cm[r * NS + t] * Ne[t * NS + c];
+          E[r * NS + c] = s;
+        }
+      lu_factor<NS>(E);
+
+      // ---- adjoint multipliers of interval k ----
+      // x_m rows:  r_m - Cm^T lam_d + lam_i = 0 ;  x_e rows:  pi_e + (I - h/6 A_e)^T lam_d - Ne^T lam_i = 0
+      double rm[NS], pie[NS], lamd[NS], lami[NS];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        rm[c] = wm * Pm.gw[c] + zlu_m[c];
+        pie[c] = pi_c[c] + ((k == N - 1 && so.term_pinned[c]) ? 0.0 : (we * Pe.gw[c] + zlu_e[c]));
+      }
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        double s = pie[c];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s += Ne[t * NS + c] * rm[t];
+        lamd[c] = -s;
+      }
+      lu_solve_t<NS>(E, lamd);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        double s = -rm[c];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s += Cm[t * NS + c] * lamd[t];
+        lami[c] = s;
+      }
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        w.lam[(long)k * NS + c] = lamd[c];
+        w.lam[(long)N * NS + (long)k * NS + c] = lami[c];
+        so.lam_inf = dmax(so.lam_inf, dmax(fabs(lamd[c]), fabs(lami[c])));
+        so.sum_mult += fabs(lamd[c]) + fabs(lami[c]);
+      }
+      so.n_mult += 2 * NS;
+
+      // ---- control-row stationarity residuals of points m and e ----
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        double rum = wm * Pm.gw[NS + a] + zlu_m[NS + a];
+        double rue = we * Pe.gw[NS + a] + zlu_e[NS + a] + ru_c[a];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+          rum -= 4.0 * h6 * Pm.B[t * NU + a] * lamd[t];
+          rue += Pe.B[t * NU + a] * (-h6 * lamd[t] + h8 * lami[t]);
+        }
+        so.stat = dmax(so.stat, dmax(fabs(rum), fabs(rue)));
+      }
+
+      // ---- Hessians of the Lagrangian at points e and m ----
+      double mue[NS], mum[NS], We[NW * NW], Wm[NW * NW];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        mue[c] = mu_c[c] - h6 * lamd[c] + h8 * lami[c];
+        mum[c] = -4.0 * h6 * lamd[c];
+      }
+      Sys::contract(Pe.D2, mue, we, We);
+      Sys::contract(Pm.D2, mum, wm, Wm);
+      // value function after adding point e's own terms: P' = P + H_e, pc' = pc + gbar_e
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+        const bool zr = (k == N - 1) && r < NS && so.term_pinned[r];
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+          const bool zc = (k == N - 1) && c < NS && so.term_pinned[c];
+          if (!zr && !zc) P[r * NW + c] += We[r * NW + c] + ((r == c) ? sig_e[r] + delta : 0.0);
+        }
+        if (!zr) { pc[r * NC + 0] += we * Pe.gw[r]; pc[r * NC + 1] += g1_e[r]; }
+        (void)pin_e;
+      }
+#pragma unroll
+      for (int c = 0; c < NW; ++c) Wm[c * NW + c] += sig_m[c] + delta;   // H_m = W_m + Sigma_m (+ delta I)
+
+      // ---- eliminate x_e through the defect rows: E [Ge | ge] = [R | r] ----
+      double Ge[NS * (NY + 1)];   // last column = ge
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {   // dx_s
+          double s = ((r == c) ? 1.0 : 0.0) + h6 * Ps.A[r * NS + c];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Cm[r * NS + t] * Nsm[t * NS + c];
+          Ge[r * (NY + 1) + c] = s;
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          double cb_s = 0.0, cb_e = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) { cb_s += Cm[r * NS + t] * Ps.B[t * NU + a]; cb_e += Cm[r * NS + t] * Pe.B[t * NU + a]; }
+          Ge[r * (NY + 1) + NS + a] = h6 * Ps.B[r * NU + a] + h8 * cb_s;            // du_s
+          Ge[r * (NY + 1) + NS + NU + a] = 4.0 * h6 * Pm.B[r * NU + a];             // du_m
+          Ge[r * (NY + 1) + NS + 2 * NU + a] = h6 * Pe.B[r * NU + a] - h8 * cb_e;   // du_e
+        }
+        double s = -dk[r];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s -= Cm[r * NS + t] * ik[t];
+        Ge[r * (NY + 1) + NY] = s;
+      }
+      lu_solve<NS, NY + 1>(E, Ge);
+      // dx_m = Gm y + gm :  Gm = [Nsm, h/8 B_s, 0, -h/8 B_e] + Ne Ge ; gm = -i + Ne ge
+      double Gm[NS * (NY + 1)];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+#pragma unroll
+        for (int c = 0; c <= NY; ++c) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Ne[r * NS + t] * Ge[t * (NY + 1) + c];
+          Gm[r * (NY + 1) + c] = s;
+        }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) Gm[r * (NY + 1) + c] += Nsm[r * NS + c];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          Gm[r * (NY + 1) + NS + a] += h8 * Ps.B[r * NU + a];
+          Gm[r * (NY + 1) + NS + 2 * NU + a] -= h8 * Pe.B[r * NU + a];
+        }
+        Gm[r * (NY + 1) + NY] -= ik[r];
+      }
+
+      // ---- stage quadratic in y: Q = Gm^^T H_m Gm^ + Ge^^T P' Ge^ ; qc likewise (NY x NC) ----
+      // augmented maps: rows 0..NS-1 = G (dx), rows NS.. = selector of du_m (for m) / du_e (for e)
+      double T1[NW * (NY + 1)];   // H_m * [Gm^ | gm^]
+      double T2[NW * (NY + 1)];   // P'  * [Ge^ | ge^]
+#pragma unroll
+      for (int r = 0; r < NW; ++r)
+#pragma unroll
+        for (int c = 0; c <= NY; ++c) {
+          double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) { s1 += Wm[r * NW + t] * Gm[t * (NY + 1) + c]; s2 += P[r * NW + t] * Ge[t * (NY + 1) + c]; }
+#pragma unroll
+          for (int a = 0; a < NU; ++a) {
+            if (c == NS + NU + a) s1 += Wm[r * NW + NS + a];
+            if (c == NS + 2 * NU + a) s2 += P[r * NW + NS + a];
+          }
+          T1[r * (NY + 1) + c] = s1; T2[r * (NY + 1) + c] = s2;
+        }
+      double Q[NY * NY], qc[NY * NC];
+#pragma unroll
+      for (int r = 0; r < NY; ++r) {
+#pragma unroll
+        for (int c = 0; c < NY; ++c) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Gm[t * (NY + 1) + r] * T1[t * (NY + 1) + c] + Ge[t * (NY + 1) + r] * T2[t * (NY + 1) + c];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) {
+            if (r == NS + NU + a) s += T1[(NS + a) * (NY + 1) + c];
+            if (r == NS + 2 * NU + a) s += T2[(NS + a) * (NY + 1) + c];
+          }
+          Q[r * NY + c] = s;
+        }
+        // right-hand-side columns: G^T (H g^ [col 0] + gbar cols)
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) {
+            double vm = (cc == 0) ? (T1[t * (NY + 1) + NY] + wm * Pm.gw[t]) : ((cc == 1) ? g1_m[t] : 0.0);
+            double ve = pc[t * NC + cc] + ((cc == 0) ? T2[t * (NY + 1) + NY] : 0.0);
+            s += Gm[t * (NY + 1) + r] * vm + Ge[t * (NY + 1) + r] * ve;
+          }
+#pragma unroll
+          for (int a = 0; a < NU; ++a) {
+            if (r == NS + NU + a)
+              s += (cc == 0) ? (T1[(NS + a) * (NY + 1) + NY] + wm * Pm.gw[NS + a]) : ((cc == 1) ? g1_m[NS + a] : 0.0);
+            if (r == NS + 2 * NU + a)
+              s += pc[(NS + a) * NC + cc] + ((cc == 0) ? T2[(NS + a) * (NY + 1) + NY] : 0.0);
+          }
+          qc[r * NC + cc] = s;
+        }
+      }
+      // dual bookkeeping: d/dnu_i of the constant  ge^^T (pc' theta)
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s += Ge[t * (NY + 1) + NY] * pc[t * NC + 2 + i];
+        so.Tnu[i * NC + 0] += s;
+      }
+
+      // ---- eliminate q = (du_m, du_e): Cholesky of Qqq (convexified if needed) ----
+      double Lq[NQ * NQ], Kk[NQ * NW], kc[NQ * NC];
+      double qscale = 0.0;
+#pragma unroll
+      for (int r = 0; r < NQ; ++r)
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) { Lq[r * NQ + c] = Q[(NW + r) * NY + NW + c]; if (r == c) qscale = dmax(qscale, fabs(Lq[r * NQ + c])); }
+      so.nreg += chol_reg<NQ>(Lq, o.reg_floor);
+      (void)qscale;
+      if (so.nreg > 0 && so.abort_on_reg) return;
+#pragma unroll
+      for (int r = 0; r < NQ; ++r) {
+#pragma unroll
+        for (int c = 0; c < NW; ++c) Kk[r * NW + c] = Q[(NW + r) * NY + c];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) kc[r * NC + c] = qc[(NW + r) * NC + c];
+      }
+      chol_solve<NQ, NW>(Lq, Kk);
+      chol_solve<NQ, NC>(Lq, kc);
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+          double s = 0.0;
+#pragma unroll
+          for (int r = 0; r < NQ; ++r) s += qc[(NW + r) * NC + 2 + i] * kc[r * NC + cc];
+          so.Tnu[i * NC + cc] -= s;
+        }
+      // new value function (of s = (dx_s, du_s)), point s's own terms are added by the next stage
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+          double s = Q[r * NY + c];
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) s -= Q[r * NY + NW + t] * Kk[t * NW + c];
+          P[r * NW + c] = s;
+        }
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+          double s = qc[r * NC + cc];
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) s -= Q[r * NY + NW + t] * kc[t * NC + cc];
+          pc[r * NC + cc] = s;
+        }
+      }
+      // symmetrise P against round-off drift
+#pragma unroll
+      for (int r = 0; r < NW; ++r)
+#pragma unroll
+        for (int c = r + 1; c < NW; ++c) { const double v = 0.5 * (P[r * NW + c] + P[c * NW + r]); P[r * NW + c] = v; P[c * NW + r] = v; }
+
+      // ---- store what the forward sweep needs ----
+      const long base = (long)D::HEAD + (long)k * D::STAGE;
+#pragma unroll
+      for (int i = 0; i < NQ * NW; ++i) w.st[base + D::O_K + i] = Kk[i];
+#pragma unroll
+      for (int i = 0; i < NQ * NC; ++i) w.st[base + D::O_KC + i] = kc[i];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+#pragma unroll
+        for (int c = 0; c < NY; ++c) { w.st[base + D::O_GE + r * NY + c] = Ge[r * (NY + 1) + c]; w.st[base + D::O_GM + r * NY + c] = Gm[r * (NY + 1) + c]; }
+        w.st[base + D::O_gE + r] = Ge[r * (NY + 1) + NY];
+        w.st[base + D::O_gM + r] = Gm[r * (NY + 1) + NY];
+      }
+
+      // ---- carries for stage k-1 (whose end point is this stage's start point) ----
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        double s = -lamd[c] - 0.5 * lami[c];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s += Ps.A[t * NS + c] * (-h6 * lamd[t] - h8 * lami[t]);
+        pi_c[c] = s;
+        mu_c[c] = -h6 * lamd[c] - h8 * lami[c];
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s += Ps.B[t * NU + a] * (-h6 * lamd[t] - h8 * lami[t]);
+        ru_c[a] = s;
+      }
+      Pe = Ps;
+    }
+
+    // ---- first point (j = 0): x_0 is pinned (dx_0 = 0); add its control terms and eliminate du_0 ----
+    {
+      const double w0 = wsimp(K, 0, h);
+      so.f += w0 * Pe.g;
+      double sig0[NW], g10[NW], zlu0[NW], W0[NW * NW];
+#pragma unroll
+      for (int c = 0; c < NW; ++c) {
+        BV b = bound_terms(w, zi(K, 0, c), so.compl_max, so.compl_min);
+        sig0[c] = b.sigma; g10[c] = b.g1; zlu0[c] = b.zlu;
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) so.stat = dmax(so.stat, fabs(w0 * Pe.gw[NS + a] + zlu0[NS + a] + ru_c[a]));
+      Sys::contract(Pe.D2, mu_c, w0, W0);
+      double Puu[NU * NU], ku[NU * NC];
+      double uscale = 0.0;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+#pragma unroll
+        for (int b2 = 0; b2 < NU; ++b2) {
+          Puu[a * NU + b2] = P[(NS + a) * NW + NS + b2] + W0[(NS + a) * NW + NS + b2] + ((a == b2) ? sig0[NS + a] + delta : 0.0);
+          if (a == b2) uscale = dmax(uscale, fabs(Puu[a * NU + b2]));
+        }
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc)
+          ku[a * NC + cc] = pc[(NS + a) * NC + cc] + ((cc == 0) ? w0 * Pe.gw[NS + a] : ((cc == 1) ? g10[NS + a] : 0.0));
+      }
+      double pu_nu[NU * NS];
+#pragma unroll
+      for (int a = 0; a < NU; ++a)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) pu_nu[a * NS + i] = ku[a * NC + 2 + i];
+      so.nreg += chol_reg<NU>(Puu, o.reg_floor);
+      (void)uscale;
+      chol_solve<NU, NC>(Puu, ku);
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+          double s = 0.0;
+#pragma unroll
+          for (int a = 0; a < NU; ++a) s += pu_nu[a * NS + i] * ku[a * NC + cc];
+          so.Tnu[i * NC + cc] -= s;
+        }
+#pragma unroll
+      for (int i = 0; i < NU * NC; ++i) w.st[i] = ku[i];
+    }
+  }
+
+  // Solve for the terminal multipliers: (-Tnu[:,2:]) nu = Tnu[:,0] + mu Tnu[:,1]  (pinned components only).
+  MYR_HD static inline void solve_nu(const SweepOut& so, double mu, double* nu) {
+    using namespace detail;
+    double M[NS * NS], rhs[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      rhs[i] = so.Tnu[i * NC + 0] + mu * so.Tnu[i * NC + 1];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) M[i * NS + j] = -0.5 * (so.Tnu[i * NC + 2 + j] + so.Tnu[j * NC + 2 + i]);
+    }
+    double sc = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (!so.term_pinned[i]) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { M[i * NS + j] = 0.0; M[j * NS + i] = 0.0; }
+        M[i * NS + i] = 1.0; rhs[i] = 0.0;
+      }
+      sc = dmax(sc, fabs(M[i * NS + i]));
+    }
+    chol_reg<NS>(M, 1e-14 * dmax(sc, 1e-300));
+    chol_solve<NS, 1>(M, rhs);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) nu[i] = rhs[i];
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // Forward sweep: step dz for theta = (1, mu, nu); also step-length limits and merit slope.
+  // ------------------------------------------------------------------------------------------------
+  struct FwdOut { double alpha_p, alpha_d, gphi; };
+
+  MYR_HD static inline void step_limits(const HsWork& w, long i, double d, double mu, double wg_grad, double tau, FwdOut& fo) {
+    // wg_grad: objective gradient entry of this variable; accumulates gphi = grad(phi_mu)^T dz and the
+    // fraction-to-the-boundary limits for z (primal) and zL, zU (dual)
+    const double zv = w.z[i], l = w.lb[i], u = w.ub[i];
+    double gb = wg_grad;
+    if (l < u) {
+      if (l > -INFINITY) {
+        const double sl = zv - l, zl = w.zL[i];
+        gb -= mu / sl;
+        if (d < 0.0) fo.alpha_p = detail::dmin(fo.alpha_p, -tau * sl / d);
+        const double dzl = -zl + (mu - zl * d) / sl;
+        if (dzl < 0.0) fo.alpha_d = detail::dmin(fo.alpha_d, -tau * zl / dzl);
+      }
+      if (u < INFINITY) {
+        const double su = u - zv, zu = w.zU[i];
+        gb += mu / su;
+        if (d > 0.0) fo.alpha_p = detail::dmin(fo.alpha_p, tau * su / d);
+        const double dzu = -zu + (mu + zu * d) / su;
+        if (dzu < 0.0) fo.alpha_d = detail::dmin(fo.alpha_d, -tau * zu / dzu);
+      }
+    }
+    fo.gphi += gb * d;
+  }
+
+  MYR_HD static void forward(const HsWork& w, const HsSolveOpts& o, const double* p, double mu, const double* nu,
+                             const bool* term_pinned, FwdOut& fo) {
+    const int N = o.N, K = 2 * N + 1;
+    const double h = o.h;
+    const double tau = detail::dmax(0.99, 1.0 - mu);
+    fo.alpha_p = 1.0; fo.alpha_d = 1.0; fo.gphi = 0.0;
+    double th[NC];
+    th[0] = 1.0; th[1] = mu;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
+    double s[NW];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { s[c] = 0.0; w.dz[zi(K, 0, c)] = 0.0; }
+    // objective gradient needs g_w at each point: recompute the (cheap) cost gradient
+    double xx[NS], uu[NU], gg, gw[NW];
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+      double v = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) v -= w.st[a * NC + cc] * th[cc];
+      s[NS + a] = v;
+    }
+    auto point_grad = [&](int j) {
+#pragma unroll
+      for (int c = 0; c < NS; ++c) xx[c] = w.z[zi(K, j, c)];
+#pragma unroll
+      for (int c = 0; c < NU; ++c) uu[c] = w.z[zi(K, j, NS + c)];
+      Sys::cost_grad(xx, uu, p, &gg, gw);
+    };
+    {
+      point_grad(0);
+      const double w0 = wsimp(K, 0, h);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { w.dz[zi(K, 0, NS + a)] = s[NS + a]; step_limits(w, zi(K, 0, NS + a), s[NS + a], mu, w0 * gw[NS + a], tau, fo); }
+    }
+    for (int k = 0; k < N; ++k) {
+      const long base = (long)D::HEAD + (long)k * D::STAGE;
+      double y[NY];
+#pragma unroll
+      for (int c = 0; c < NW; ++c) y[c] = s[c];
+#pragma unroll
+      for (int r = 0; r < NQ; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int c = 0; c < NW; ++c) v -= w.st[base + D::O_K + r * NW + c] * s[c];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) v -= w.st[base + D::O_KC + r * NC + cc] * th[cc];
+        y[NW + r] = v;
+      }
+      double dxe[NS], dxm[NS];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double ve = w.st[base + D::O_gE + r], vm = w.st[base + D::O_gM + r];
+#pragma unroll
+        for (int c = 0; c < NY; ++c) { ve += w.st[base + D::O_GE + r * NY + c] * y[c]; vm += w.st[base + D::O_GM + r * NY + c] * y[c]; }
+        dxe[r] = ve; dxm[r] = vm;
+      }
+      const int jm = 2 * k + 1, je = 2 * k + 2;
+      if (k == N - 1) {
+#pragma unroll
+        for (int r = 0; r < NS; ++r) if (term_pinned[r]) dxe[r] = 0.0;
+      }
+      point_grad(jm);
+      const double wm = wsimp(K, jm, h);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) { w.dz[zi(K, jm, c)] = dxm[c]; step_limits(w, zi(K, jm, c), dxm[c], mu, wm * gw[c], tau, fo); }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { w.dz[zi(K, jm, NS + a)] = y[NW + a]; step_limits(w, zi(K, jm, NS + a), y[NW + a], mu, wm * gw[NS + a], tau, fo); }
+      point_grad(je);
+      const double we = wsimp(K, je, h);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) { w.dz[zi(K, je, c)] = dxe[c]; step_limits(w, zi(K, je, c), dxe[c], mu, we * gw[c], tau, fo); s[c] = dxe[c]; }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        const double v = y[NW + NU + a];
+        w.dz[zi(K, je, NS + a)] = v; step_limits(w, zi(K, je, NS + a), v, mu, we * gw[NS + a], tau, fo); s[NS + a] = v;
+      }
+    }
+  }
+
+  // merit pieces at z + alpha dz: objective, barrier, ||c||_1.  Returns false on a non-finite value.
+  MYR_HD static bool trial(const HsWork& w, const HsSolveOpts& o, const double* p, double alpha, double mu,
+                           double& f, double& bar, double& c1) {
+    const int N = o.N, K = 2 * N + 1;
+    const double h = o.h, h6 = h / 6.0, h8 = h / 8.0;
+    f = 0; bar = 0; c1 = 0;
+    double xs[NS], us[NU], fs[NS], xm[NS], um[NU], fm[NS], xe[NS], ue[NU], fe[NS];
+    auto get = [&](int j, double* x, double* u, double* ff) -> bool {
+      bool ok = true;
+#pragma unroll
+      for (int c = 0; c < NW; ++c) {
+        const long i = zi(K, j, c);
+        const double v = w.z[i] + alpha * w.dz[i];
+        const double l = w.lb[i], ub = w.ub[i];
+        if (l < ub) {
+          if (l > -INFINITY) { const double sl = v - l; if (!(sl > 0.0)) ok = false; else bar -= log(sl); }
+          if (ub < INFINITY) { const double su = ub - v; if (!(su > 0.0)) ok = false; else bar -= log(su); }
+        }
+        if (c < NS) x[c] = v; else u[c - NS] = v;
+      }
+      Sys::f(x, u, p, ff);
+      f += wsimp(K, j, h) * Sys::g(x, u, p);
+      return ok;
+    };
+    bool ok = get(0, xs, us, fs);
+    for (int k = 0; k < N; ++k) {
+      ok &= get(2 * k + 1, xm, um, fm);
+      ok &= get(2 * k + 2, xe, ue, fe);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        c1 += fabs((xe[c] - xs[c]) - h6 * (fs[c] + 4.0 * fm[c] + fe[c]));
+        c1 += fabs(xm[c] - 0.5 * (xs[c] + xe[c]) - h8 * (fs[c] - fe[c]));
+        xs[c] = xe[c]; fs[c] = fe[c];
+      }
+    }
+    bar *= mu;
+    return ok && detail::finite_(f) && detail::finite_(c1) && detail::finite_(bar);
+  }
+
+  // accept the step: z += a_p dz, zL += a_d dzL, zU += a_d dzU (with the usual safeguard on the bound multipliers)
+  MYR_HD static void update(const HsWork& w, int n, double ap, double ad, double mu) {
+    for (int i = 0; i < n; ++i) {
+      const double l = w.lb[i], u = w.ub[i];
+      const double zv = w.z[i], d = w.dz[i];
+      const double zn = zv + ap * d;
+      if (l < u) {
+        if (l > -INFINITY) {
+          const double sl = zv - l, zl = w.zL[i];
+          double v = zl + ad * (-zl + (mu - zl * d) / sl);
+          const double sn = zn - l;
+          v = detail::dmax(detail::dmin(v, 1e10 * mu / sn), mu / (1e10 * sn));
+          w.zL[i] = v;
+        }
+        if (u < INFINITY) {
+          const double su = u - zv, zu = w.zU[i];
+          double v = zu + ad * (-zu + (mu + zu * d) / su);
+          const double sn = u - zn;
+          v = detail::dmax(detail::dmin(v, 1e10 * mu / sn), mu / (1e10 * sn));
+          w.zU[i] = v;
+        }
+        w.z[i] = zn;
+      }
+    }
+  }
+
+  // starting point: pinned variables on their value, the others pushed strictly inside their bounds
+  MYR_HD static void init(const HsWork& w, int n) {
+    const double k1 = 1e-2, k2 = 1e-2;
+    for (int i = 0; i < n; ++i) {
+      const double l = w.lb[i], u = w.ub[i];
+      double v = w.z[i];
+      w.zL[i] = 0.0; w.zU[i] = 0.0;
+      if (!(l < u)) { v = l; }
+      else {
+        const bool hl = l > -INFINITY, hu = u < INFINITY;
+        if (hl && hu) {
+          const double pl = detail::dmin(k1 * detail::dmax(1.0, fabs(l)), k2 * (u - l));
+          const double pu = detail::dmin(k1 * detail::dmax(1.0, fabs(u)), k2 * (u - l));
+          v = detail::dmin(detail::dmax(v, l + pl), u - pu);
+        } else if (hl) v = detail::dmax(v, l + k1 * detail::dmax(1.0, fabs(l)));
+        else if (hu) v = detail::dmin(v, u - k1 * detail::dmax(1.0, fabs(u)));
+        if (hl) w.zL[i] = 1.0;
+        if (hu) w.zU[i] = 1.0;
+      }
+      w.z[i] = v;
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // The solve.
+  // ------------------------------------------------------------------------------------------------
+  MYR_HD static void solve(const HsWork& w, const HsSolveOpts& o, const double* p, HsSolveResult& res) {
+    using namespace detail;
+    const int K = 2 * o.N + 1, n = K * NW;
+    init(w, n);
+    double mu = o.mu_init, pen = 1.0;
+    double nuT[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) nuT[i] = 0.0;
+    const double mu_min = dmin(o.tol_compl, o.tol_stat) * 0.1;
+    res.status = 1; res.iters = o.max_iter;
+    int stall = 0;
+    double delta_last = 0.0;
+    SweepOut so;
+    for (int it = 0; it <= o.max_iter; ++it) {
+      // inertia correction (global, as in interior-point NLP codes): retry the factorisation with W + delta I
+      // until every stage pivot is positive; the last resort keeps the stage-local convexification.
+      double delta = 0.0;
+      for (int tr_ = 0; tr_ < 12; ++tr_) {
+        so.abort_on_reg = (tr_ < 11);
+        backward(w, o, p, nuT, delta, so);
+        if (so.nreg == 0) break;
+        if (delta == 0.0) delta = (delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4;
+        else delta *= (delta_last > 0.0) ? 8.0 : 100.0;
+        if (delta > 1e8) { so.abort_on_reg = false; }
+      }
+      if (delta > 0.0) delta_last = delta;
+      // KKT error with the usual multiplier scaling
+      double sd = 1.0;
+      {
+        double sm = so.sum_mult; int nm = so.n_mult;
+        for (int i = 0; i < n; ++i) {
+          const double l = w.lb[i], u = w.ub[i];
+          if (l < u) { if (l > -INFINITY) { sm += w.zL[i]; ++nm; } if (u < INFINITY) { sm += w.zU[i]; ++nm; } }
+        }
+        if (nm > 0) sd = dmax(1.0, sm / nm / 100.0);
+      }
+      const double stat = so.stat / sd, comp = so.compl_max / sd;
+      res.cost = so.f; res.feas = so.cinf; res.stat = stat; res.compl_ = comp;
+      if (!(finite_(so.f) && finite_(so.cinf) && finite_(so.stat))) { res.status = 2; res.iters = it; return; }
+      if (so.cinf <= o.tol_feas && stat <= o.tol_stat && comp <= o.tol_compl) { res.status = 0; res.iters = it; return; }
+      if (it == o.max_iter) break;
+      // barrier update (monotone, superlinear): error of the barrier problem vs kappa_eps * mu
+      for (int guard = 0; guard < 8; ++guard) {
+        // error of the barrier problem: complementarity |s*z - mu| from the extreme products
+        const double cerr = (so.compl_min <= so.compl_max) ? dmax(fabs(so.compl_max - mu), fabs(so.compl_min - mu)) : 0.0;
+        const double emu = dmax(dmax(stat, so.cinf), cerr / sd);
+        if (emu <= 10.0 * mu && mu > mu_min) {
+          const double nm = dmax(mu_min, dmin(0.2 * mu, mu * sqrt(mu)));
+          if (nm != mu) pen = 1.0;
+          mu = nm;
+        } else break;
+      }
+      double nu[NS];
+      solve_nu(so, mu, nu);
+      FwdOut fo;
+      forward(w, o, p, mu, nu, so.term_pinned, fo);
+      if (!(finite_(fo.gphi) && finite_(fo.alpha_p))) { res.status = 2; res.iters = it; return; }
+      // l1 merit: penalty large enough to make dz a descent direction
+      if (so.c1 > 0.0) {
+        const double need = fo.gphi / (0.9 * so.c1);
+        if (pen < need) pen = need + 1.0;
+      }
+      const double Dphi = fo.gphi - pen * so.c1;
+      double f0, bar0, c10;
+      trial(w, o, p, 0.0, mu, f0, bar0, c10);
+      const double phi0 = f0 + bar0 + pen * c10;
+      double a = fo.alpha_p;
+      bool ok = false;
+      for (int ls = 0; ls < 40; ++ls) {
+        double ft, bt, ct;
+        if (trial(w, o, p, a, mu, ft, bt, ct)) {
+          const double phit = ft + bt + pen * ct;
+          if (phit <= phi0 + 1e-8 * a * Dphi + 1e-13 * fabs(phi0)) { ok = true; break; }
+        }
+        a *= 0.5;
+      }
+      if (!ok) {
+        // no acceptable step along dz: take the tiny step anyway a few times (helps past round-off), then give up
+        if (++stall > 5) { res.status = 3; res.iters = it; return; }
+      } else stall = 0;
+      const double ad = fo.alpha_d;
+#ifdef MYR_TRACE
+      printf("it %3d f=%.8f cinf=%.2e stat=%.2e comp=%.2e mu=%.1e a=%.3g amax=%.3g ad=%.3g nreg=%d pen=%.3g gphi=%.3g ok=%d\n", it, so.f, so.cinf, stat, comp, mu, a, fo.alpha_p, ad, so.nreg, pen, fo.gphi, (int)ok);
+#endif
+      update(w, n, a, ad, mu);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
+    }
+    res.status = 1; res.iters = o.max_iter;
+  }
+};
+
+}  // namespace myriad

@@ -9,6 +9,7 @@
 
 #include "../../include/myriad_hip.h"
 #include "hs_eval.h"
+#include "hs_solver.h"
 #include "systems_gen.h"
 
 using namespace myriad;
@@ -52,6 +53,9 @@ struct myr_handle_s {
   void* dbuf = nullptr;
   size_t dbuf_bytes = 0;
   int eval_wpt = 4;
+  // solver scratch (batch-minor / SoA)
+  void* sbuf = nullptr;
+  size_t sbuf_bytes = 0;
 };
 
 static int ensure_dbuf(myr_handle h, size_t bytes) {
@@ -125,6 +129,7 @@ extern "C" int myr_destroy(myr_handle h) {
   if (!h) return MYR_OK;
   (void)hipSetDevice(h->d.device);
   if (h->dbuf) (void)hipFree(h->dbuf);
+  if (h->sbuf) (void)hipFree(h->sbuf);
   for (int i = 0; i < MYR_K_COUNT; ++i) {
     if (h->kt[i].a) (void)hipEventDestroy(h->kt[i].a);
     if (h->kt[i].b) (void)hipEventDestroy(h->kt[i].b);
@@ -248,14 +253,181 @@ extern "C" int myr_eval(myr_handle h, int32_t B, const double* z, const double* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// solve / rollout: kernels land in the next milestones
+// solve
 // ------------------------------------------------------------------------------------------------
+// [rows][cols] row-major  ->  [cols][ld] (ld >= rows): instance-major <-> batch-minor, 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                                        int rows, int cols, long ld) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int r = r0 + ty + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + i][tx] = src[(long)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int c = c0 + ty + i, r = r0 + tx;
+    if (r < rows && c < cols) dst[(long)c * ld + r] = tile[tx][ty + i];
+  }
+}
+// [cols][ld] -> [rows][cols]
+__global__ __launch_bounds__(256) void transpose_back_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                                             int rows, int cols, long ld) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int c = c0 + ty + i, r = r0 + tx;
+    if (r < rows && c < cols) tile[ty + i][tx] = src[(long)c * ld + r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int r = r0 + ty + i, c = c0 + tx;
+    if (r < rows && c < cols) dst[(long)r * cols + c] = tile[tx][ty + i];
+  }
+}
+
+// One trajectory per lane; every per-trajectory array is batch-minor (element i of trajectory b at a[i*Bp + b]),
+// so the 64 lanes of a wavefront always touch 64 consecutive doubles (one 512-byte coalesced access).
+template <class Sys>
+__global__ __launch_bounds__(64, 1)
+void hs_solve_kernel(int B, long Bp, HsSolveOpts o, double* z, double* lb, double* ub, double* zL, double* zU,
+                     double* lam, double* dz, double* st, const double* __restrict__ params, int params_stride,
+                     double* cost, int32_t* status, int32_t* iters, double* kkt) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double p[Sys::NP > 0 ? Sys::NP : 1];
+  if (params) {
+#pragma unroll
+    for (int i = 0; i < Sys::NP; ++i) p[i] = params[b * (long)params_stride + i];
+  } else {
+    Sys::default_params(p);
+  }
+  HsWork w{{z + b, Bp}, {lb + b, Bp}, {ub + b, Bp}, {zL + b, Bp}, {zU + b, Bp}, {lam + b, Bp}, {dz + b, Bp}, {st + b, Bp}};
+  HsSolveResult r;
+  HsSolver<Sys>::solve(w, o, p, r);
+  if (cost) cost[b] = r.cost;
+  if (status) status[b] = r.status;
+  if (iters) iters[b] = r.iters;
+  if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
+}
+
+template <class Sys>
+static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
+                           int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
+                           int32_t* iters, double* kkt) {
+  const int N = h->d.intervals;
+  const myr_dims& dm = h->dims;
+  const long Bp = ((long)B + 63) / 64 * 64;
+  const long n = dm.n, m = dm.m, nst = HsSol<Sys>::stage_doubles(N);
+  const size_t need = (size_t)Bp * (size_t)(6 * n + m + nst) * 8;
+  if (need > h->sbuf_bytes) {
+    if (h->sbuf) HIPCHK(hipFree(h->sbuf));
+    h->sbuf = nullptr; h->sbuf_bytes = 0;
+    HIPCHK(hipMalloc(&h->sbuf, need));
+    h->sbuf_bytes = need;
+  }
+  double* sz = (double*)h->sbuf;
+  double* slb = sz + n * Bp;
+  double* sub = slb + n * Bp;
+  double* szL = sub + n * Bp;
+  double* szU = szL + n * Bp;
+  double* sdz = szU + n * Bp;
+  double* slam = sdz + n * Bp;
+  double* sst = slam + m * Bp;
+  // padded lanes read garbage-free memory
+  HIPCHK(hipMemsetAsync(h->sbuf, 0, (size_t)Bp * (size_t)(3 * n) * 8, h->stream));
+  dim3 tb(256), tg((unsigned)((n + 31) / 32), (unsigned)((B + 31) / 32));
+  hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, h->stream, (const double*)z, sz, B, (int)n, Bp);
+  hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, h->stream, lb, slb, B, (int)n, Bp);
+  hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, h->stream, ub, sub, B, (int)n, Bp);
+  HsSolveOpts o;
+  o.N = N; o.h = h->d.T / N; o.max_iter = so.max_iter; o.tol_feas = so.tol_feas; o.tol_stat = so.tol_stat;
+  o.tol_compl = so.tol_compl; o.mu_init = so.mu_init;
+  KTimer& kt = h->kt[MYR_K_SOLVE];
+  HIPCHK(hipEventRecord(kt.a, h->stream));
+  hipLaunchKernelGGL(hs_solve_kernel<Sys>, dim3((unsigned)(Bp / 64)), dim3(64), 0, h->stream, B, Bp, o, sz, slb, sub, szL,
+                     szU, slam, sdz, sst, params, pstride, cost, status, iters, kkt);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(kt.b, h->stream));
+  hipLaunchKernelGGL(transpose_back_kernel, tg, tb, 0, h->stream, (const double*)sz, z, B, (int)n, Bp);
+  if (lam) {
+    dim3 tgl((unsigned)((m + 31) / 32), (unsigned)((B + 31) / 32));
+    hipLaunchKernelGGL(transpose_back_kernel, tgl, tb, 0, h->stream, (const double*)slam, lam, B, (int)m, Bp);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+  kt.sum_ms += ms;
+  kt.launches += 1;
+  return MYR_OK;
+}
+
+static int dispatch_solve(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
+                          int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
+                          int32_t* iters, double* kkt) {
+  switch (h->d.system_id) {
+    case MYR_SYS_CARTPOLE: return launch_hs_solve<SysCARTPOLE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_SYS_VANDERPOL: return launch_hs_solve<SysVANDERPOL>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_SYS_CANCERTREATMENT: return launch_hs_solve<SysCANCERTREATMENT>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_SYS_SIMPLECASE: return launch_hs_solve<SysSIMPLECASE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  }
+  return fail(MYR_E_ARG, "solve: unknown system");
+}
+
 extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, const double* ub,
                          const double* params, int32_t params_stride, const myr_solve_opts* opts,
                          double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt, int32_t mem) {
-  (void)h; (void)B; (void)z; (void)lb; (void)ub; (void)params; (void)params_stride; (void)opts;
-  (void)lam; (void)cost; (void)status; (void)iters; (void)kkt; (void)mem;
-  return fail(MYR_E_UNSUPPORTED, "myr_solve: not built yet");
+  if (!h || !z || !lb || !ub) return fail(MYR_E_ARG, "myr_solve: null handle, z, lb or ub");
+  if (B < 0) return fail(MYR_E_ARG, "myr_solve: negative batch");
+  if (B == 0) return MYR_OK;
+  if (params && params_stride != 0 && params_stride != h->dims.np)
+    return fail(MYR_E_ARG, "myr_solve: params_stride must be 0 (shared) or np");
+  if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "myr_solve: transcription not built");
+  myr_solve_opts so;
+  if (opts) so = *opts; else myr_default_solve_opts(&so);
+  if (so.max_iter < 0 || !(so.tol_feas > 0) || !(so.tol_stat > 0) || !(so.tol_compl > 0) || !(so.mu_init > 0))
+    return fail(MYR_E_ARG, "myr_solve: bad options");
+  HIPCHK(hipSetDevice(h->d.device));
+  const myr_dims& dm = h->dims;
+  if (mem == MYR_MEM_DEVICE)
+    return dispatch_solve(h, B, z, lb, ub, params, params_stride, so, lam, cost, status, iters, kkt);
+  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_solve: bad mem kind");
+  const size_t nz = (size_t)B * dm.n, nl = lam ? (size_t)B * dm.m : 0;
+  const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  const size_t total = 3 * al(nz) + al(nl) + al(npar) + al(B) /*cost*/ + al(B) /*status+iters as int32 pairs*/ + al(3 * (size_t)B);
+  int rc = ensure_dbuf(h, total * 8);
+  if (rc) return rc;
+  double* dz = (double*)h->dbuf;
+  double* dlb = dz + al(nz);
+  double* dub = dlb + al(nz);
+  double* dlam = dub + al(nz);
+  double* dp = dlam + al(nl);
+  double* dcost = dp + al(npar);
+  int32_t* dstat = (int32_t*)(dcost + al(B));
+  int32_t* dit = dstat + B;
+  double* dkkt = (double*)(dstat) + al(B);
+  HIPCHK(hipMemcpyAsync(dz, z, nz * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dlb, lb, nz * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dub, ub, nz * 8, hipMemcpyHostToDevice, h->stream));
+  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
+  rc = dispatch_solve(h, B, dz, dlb, dub, npar ? dp : nullptr, params_stride, so, nl ? dlam : nullptr, dcost, dstat, dit, dkkt);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(z, dz, nz * 8, hipMemcpyDeviceToHost, h->stream));
+  if (nl) HIPCHK(hipMemcpyAsync(lam, dlam, nl * 8, hipMemcpyDeviceToHost, h->stream));
+  if (cost) HIPCHK(hipMemcpyAsync(cost, dcost, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
+  if (status) HIPCHK(hipMemcpyAsync(status, dstat, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+  if (iters) HIPCHK(hipMemcpyAsync(iters, dit, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+  if (kkt) HIPCHK(hipMemcpyAsync(kkt, dkkt, (size_t)B * 24, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MYR_OK;
 }
 
 extern "C" int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u_rows, const double* x0, const double* us,

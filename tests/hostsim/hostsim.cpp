@@ -1,0 +1,85 @@
+// hostsim.cpp -- TEST-ONLY host build of the solver core (myriad_amd/csrc/hs_solver.h) so the per-trajectory
+// SQP algebra can be exercised by the CPU test-suite (`-m "not gpu"`) in a container without a GPU.
+// It is never loaded by the myriad_amd package and is not a fallback: the product path is the HIP kernel
+// that calls the very same HsSolver<Sys>::solve, one trajectory per lane.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../myriad_amd/csrc/hs_solver.h"
+
+using namespace myriad;
+
+template <class Sys>
+static void solve_batch(int N, double T, int B, double* z, const double* lb, const double* ub, const double* params,
+                        int pstride, int max_iter, double tol_feas, double tol_stat, double tol_compl, double mu_init,
+                        double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt) {
+  using S = HsSolver<Sys>;
+  const int K = 2 * N + 1, n = K * Sys::NW, m = 2 * N * Sys::NS;
+  HsSolveOpts o{N, T / N, max_iter, tol_feas, tol_stat, tol_compl, mu_init};
+  if (getenv("RHO")) o.rho_term = atof(getenv("RHO"));
+  if (getenv("REGF")) o.reg_floor = atof(getenv("REGF"));
+#pragma omp parallel for schedule(dynamic)
+  for (int b = 0; b < B; ++b) {
+    std::vector<double> zL(n), zU(n), dz(n), lbv(lb + (size_t)b * n, lb + (size_t)(b + 1) * n),
+        ubv(ub + (size_t)b * n, ub + (size_t)(b + 1) * n), st(HsSol<Sys>::stage_doubles(N));
+    double p[Sys::NP > 0 ? Sys::NP : 1];
+    if (params) for (int i = 0; i < Sys::NP; ++i) p[i] = params[(size_t)b * pstride + i];
+    else Sys::default_params(p);
+    HsWork w{{z + (size_t)b * n, 1}, {lbv.data(), 1}, {ubv.data(), 1}, {zL.data(), 1}, {zU.data(), 1},
+             {lam + (size_t)b * m, 1}, {dz.data(), 1}, {st.data(), 1}};
+    HsSolveResult r;
+    S::solve(w, o, p, r);
+    cost[b] = r.cost; status[b] = r.status; iters[b] = r.iters;
+    if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
+  }
+}
+
+// One Newton/SQP step at a given (interior) iterate: for checking the Riccati recursion against a dense KKT solve.
+template <class Sys>
+static void one_step(int N, double T, double* z, const double* lb, const double* ub, double* zL, double* zU,
+                     const double* nuT, double mu, double* lam, double* dz, double* nu_out, double* info) {
+  using S = HsSolver<Sys>;
+  const int K = 2 * N + 1, n = K * Sys::NW;
+  HsSolveOpts o{N, T / N, 1, 1e-8, 1e-6, 1e-7, mu};
+  if (getenv("RHO")) o.rho_term = atof(getenv("RHO"));
+  if (getenv("REGF")) o.reg_floor = atof(getenv("REGF"));
+  std::vector<double> st(HsSol<Sys>::stage_doubles(N)), lbv(lb, lb + n), ubv(ub, ub + n);
+  double p[Sys::NP > 0 ? Sys::NP : 1];
+  Sys::default_params(p);
+  HsWork w{{z, 1}, {lbv.data(), 1}, {ubv.data(), 1}, {zL, 1}, {zU, 1}, {lam, 1}, {dz, 1}, {st.data(), 1}};
+  typename S::SweepOut so;
+  so.abort_on_reg = false;
+  S::backward(w, o, p, nuT, 0.0, so);
+  S::solve_nu(so, mu, nu_out);
+  typename S::FwdOut fo;
+  S::forward(w, o, p, mu, nu_out, so.term_pinned, fo);
+  info[0] = so.f; info[1] = so.c1; info[2] = so.cinf; info[3] = so.stat; info[4] = so.compl_max;
+  info[5] = fo.alpha_p; info[6] = fo.alpha_d; info[7] = fo.gphi; info[8] = so.nreg;
+}
+
+extern "C" int hostsim_solve(int system_id, int N, double T, int B, double* z, const double* lb, const double* ub,
+                             const double* params, int pstride, int max_iter, double tol_feas, double tol_stat,
+                             double tol_compl, double mu_init, double* lam, double* cost, int32_t* status,
+                             int32_t* iters, double* kkt) {
+#define GO(S) solve_batch<S>(N, T, B, z, lb, ub, params, pstride, max_iter, tol_feas, tol_stat, tol_compl, mu_init, lam, cost, status, iters, kkt)
+  switch (system_id) {
+    case 0: GO(SysCARTPOLE); return 0;
+    case 1: GO(SysVANDERPOL); return 0;
+    case 2: GO(SysCANCERTREATMENT); return 0;
+    case 3: GO(SysSIMPLECASE); return 0;
+  }
+  return -1;
+}
+
+extern "C" int hostsim_step(int system_id, int N, double T, double* z, const double* lb, const double* ub, double* zL,
+                            double* zU, const double* nuT, double mu, double* lam, double* dz, double* nu_out, double* info) {
+#define ST(S) one_step<S>(N, T, z, lb, ub, zL, zU, nuT, mu, lam, dz, nu_out, info)
+  switch (system_id) {
+    case 0: ST(SysCARTPOLE); return 0;
+    case 1: ST(SysVANDERPOL); return 0;
+    case 2: ST(SysCANCERTREATMENT); return 0;
+    case 3: ST(SysSIMPLECASE); return 0;
+  }
+  return -1;
+}

@@ -1,0 +1,107 @@
+"""GPU parity tests of the batched SQP (myr_solve through the C-ABI) against the oracle's golden solutions,
+the oracle's callbacks, and size-independent optimality properties at the BASELINE size."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(N, B=64):
+  from myriad_amd import _lib
+  return _lib.Engine("CARTPOLE", "HERMITE_SIMPSON", N, 2.0, max_batch=B)
+
+
+def test_solve_matches_golden_trajectories(golden_dir):
+  """z* from the oracle's tightened SLSQP path (tests/golden/make_solve_golden.py): cost to 1e-9 relative,
+  trajectory to 1e-6 absolute (SURVEY.md 8(c) tolerances), feasibility re-checked by the oracle callbacks."""
+  from oracle import myriad_oracle as O
+  files = sorted(glob.glob(os.path.join(golden_dir, "solve_hs_cartpole_N*.npz")))
+  assert files
+  for path in files:
+    d = np.load(path)
+    N = int(d["N"])
+    eng = _engine(N)
+    res = eng.solve(d["z0"], d["lb"], d["ub"])
+    assert (res["status"] == 0).all(), (path, res["status"], res["kkt"])
+    np.testing.assert_allclose(res["cost"], d["cost"], rtol=1e-9, err_msg=path)
+    assert np.abs(res["z"] - d["z"]).max() < 1e-6, (path, np.abs(res["z"] - d["z"]).max())
+    for b in range(d["z"].shape[0]):
+      s = O.CartPole(); s.x_0 = d["x0"][b]
+      cb = O.Callbacks(O.hermite_simpson(s, N))
+      assert np.abs(cb.cons(res["z"][b])).max() <= 1e-8
+      assert cb.fun(res["z"][b]) == pytest.approx(res["cost"][b], rel=1e-12)
+      # stationarity with the returned multipliers on every free variable (pinned rows carry their own multiplier)
+      free = d["lb"][b] < d["ub"][b]
+      r = cb.grad(res["z"][b]) + cb.jac(res["z"][b]).T @ res["lam"][b]
+      inactive = free & (res["z"][b] - d["lb"][b] > 1e-3) & (d["ub"][b] - res["z"][b] > 1e-3)
+      assert np.abs(r[inactive]).max() < 1e-5
+    eng.close()
+
+
+def test_solve_random_batch_properties():
+  """Ragged batch of random x0 at N=25: converged, pinned variables exact, bounds respected, feasibility and
+  objective confirmed through the independent eval kernel."""
+  from oracle import myriad_oracle as O
+  N, B = 25, 77
+  s = O.CartPole()
+  x0 = O.random_x0(s, B, seed=5)
+  tr = O.hermite_simpson(s, N)
+  K = 2 * N + 1
+  z0 = np.stack([np.concatenate([np.linspace(x0[b], s.x_T, K).ravel(), np.zeros(K)]) for b in range(B)])
+  lb = np.tile(tr.bounds[:, 0], (B, 1)); ub = np.tile(tr.bounds[:, 1], (B, 1))
+  lb[:, :4] = x0; ub[:, :4] = x0
+  eng = _engine(N, B)
+  res = eng.solve(z0, lb, ub)
+  assert (res["status"] == 0).all()
+  z = res["z"]
+  assert np.array_equal(z[:, :4], x0) and np.array_equal(z[:, (K - 1) * 4:K * 4], np.tile(s.x_T, (B, 1)))
+  assert (z >= lb).all() and (z <= ub).all()
+  ev = eng.eval(z)
+  assert np.abs(ev["c"]).max() <= 1e-8
+  np.testing.assert_allclose(ev["f"], res["cost"], rtol=1e-12)
+  assert res["iters"].max() < 200
+  # solving again from the solution converges immediately to the same point (idempotence)
+  res2 = eng.solve(z, lb, ub)
+  assert (res2["status"] == 0).all()
+  np.testing.assert_allclose(res2["cost"], res["cost"], rtol=1e-7)
+
+
+def test_solve_nonconvergence_is_reported_not_raised():
+  """max_iter too small: status = MAXITER per instance, no exception (reference: solution['success'] is only printed,
+  nlp_solvers/__init__.py:64)."""
+  from oracle import myriad_oracle as O
+  N = 10
+  s = O.CartPole(); tr = O.hermite_simpson(s, N)
+  eng = _engine(N)
+  o = eng.default_opts(); o.max_iter = 2
+  res = eng.solve(tr.guess[None], tr.bounds[None, :, 0], tr.bounds[None, :, 1], opts=o)
+  assert res["status"][0] == 1 and res["iters"][0] == 2
+  assert eng.solve(np.zeros((0, eng.n)), np.zeros((0, eng.n)), np.zeros((0, eng.n)))["z"].shape == (0, eng.n)
+
+
+def test_solve_full_size_baseline_config():
+  """BASELINE config 2: N=100, B=4096 random x0.  All instances converge; feasibility via the eval kernel;
+  golden N=100 default-x0 cost (SciPy SLSQP 87.96437982986194 / trust-constr 87.96437633178395) within their
+  own stopping tolerance of ours."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  from bench import build_workload
+  N, B = 100, 4096
+  x0, z0, lb, ub, T = build_workload(B, N, 2019)
+  x0[0] = 0.0; z0[0, :] = 0.0
+  K = 2 * N + 1
+  z0[0, :K * 4] = np.linspace(np.zeros(4), np.array([1., np.pi, 0., 0.]), K).ravel()
+  lb[0, :4] = 0.0; ub[0, :4] = 0.0
+  eng = _engine(N, B)
+  res = eng.solve(z0, lb, ub)
+  assert (res["status"] == 0).mean() >= 0.999, np.bincount(res["status"])
+  ev = eng.eval(res["z"], want=("c", "f"))
+  ok = res["status"] == 0
+  assert np.abs(ev["c"][ok]).max() <= 1e-8
+  assert (res["z"] >= lb).all() and (res["z"] <= ub).all()
+  assert res["cost"][0] == pytest.approx(87.964376, rel=1e-7)
+  assert abs(res["cost"][0] - 87.96437982986194) < 1e-5      # SLSQP at default ftol=1e-6
+  assert abs(res["cost"][0] - 87.96437633178395) < 1e-6      # trust-constr

@@ -130,6 +130,12 @@ def gen_system(S):
   o.append(emit_block([("r", g)], "    "))
   o.append("    return r;")
   o.append("  }")
+  # g, gw only
+  o.append("  // running cost and its gradient wrt (x,u)")
+  o.append("  MYR_HD static inline void cost_grad(const double* x, const double* u, const double* p, double* go, double* gw) {")
+  o.append(unpack("    "))
+  o.append(emit_block([("*go", g)] + [(f"gw[{i}]", gw[i]) for i in range(nw)], "    "))
+  o.append("  }")
   # f, A, B, g, gw
   o.append("  // f, A=df/dx (row-major ns x ns), B=df/du (ns x nu), g, dg/d(x,u)")
   o.append("  MYR_HD static inline void lin(const double* x, const double* u, const double* p,")
@@ -141,23 +147,43 @@ def gen_system(S):
   ass += [("*go", g)] + [(f"gw[{i}]", gw[i]) for i in range(nw)]
   o.append(emit_block(ass, "    "))
   o.append("  }")
-  # everything + Hessian contraction
-  o.append("  // as lin(), plus W (NW x NW row-major, symmetric) = wg*d2g + sum_i mu[i]*d2 f_i wrt (x,u)")
-  o.append("  MYR_HD static inline void lin2(const double* x, const double* u, const double* p,")
-  o.append("                                 const double* mu, double wg,")
-  o.append("                                 double* fo, double* A, double* B, double* go, double* gw, double* W) {")
-  o.append(unpack("    "))
+  # everything + structurally non-zero second derivatives, and the matching contraction
+  d2 = []   # (kind, i, r, c, expr): kind 'f' -> d2 f_i / dw_r dw_c ; kind 'g' -> d2 g
   for i in range(ns):
-    o.append(f"    const double mu{i} = mu[{i}];")
-  ass2 = list(ass)
-  for i in range(nw):
-    for j in range(nw):
-      if j >= i:
-        ass2.append((f"W[{i * nw + j}]", H[i][j]))
+    for r in range(nw):
+      for c in range(r, nw):
+        e = sp.simplify(sp.diff(f[i], w[r], w[c]))
+        if e != 0:
+          d2.append(("f", i, r, c, e))
+  for r in range(nw):
+    for c in range(r, nw):
+      e = sp.simplify(sp.diff(g, w[r], w[c]))
+      if e != 0:
+        d2.append(("g", 0, r, c, e))
+  nnz2 = max(1, len(d2))
+  o.append(f"  static constexpr int NNZ2 = {nnz2};   // structurally non-zero second derivatives of (f, g)")
+  o.append("  // as lin(), plus D2[NNZ2]: the non-zero second derivatives (pattern known to contract())")
+  o.append("  MYR_HD static inline void lin_d2(const double* x, const double* u, const double* p,")
+  o.append("                                   double* fo, double* A, double* B, double* go, double* gw, double* D2) {")
+  o.append(unpack("    "))
+  ass2 = list(ass) + [(f"D2[{q}]", t[4]) for q, t in enumerate(d2)]
   o.append(emit_block(ass2, "    "))
-  for i in range(nw):
-    for j in range(i):
-      o.append(f"    W[{i * nw + j}] = W[{j * nw + i}];")
+  if not d2:
+    o.append("    D2[0] = 0;")
+  o.append("  }")
+  o.append("  // W (NW x NW row-major, symmetric) = wg * d2g + sum_i mu[i] * d2 f_i   (Hessian of the Lagrangian at one point)")
+  o.append("  MYR_HD static inline void contract(const double* D2, const double* mu, double wg, double* W) {")
+  o.append("    (void)D2; (void)mu; (void)wg;")
+  terms = {}
+  for q, (kind, i, r, c, e) in enumerate(d2):
+    coef = "wg" if kind == "g" else f"mu[{i}]"
+    terms.setdefault((r, c), []).append(f"{coef}*D2[{q}]")
+  for r in range(nw):
+    for c in range(r, nw):
+      rhs = " + ".join(terms.get((r, c), [])) or "0.0"
+      o.append(f"    W[{r * nw + c}] = {rhs};")
+      if c != r:
+        o.append(f"    W[{c * nw + r}] = W[{r * nw + c}];")
   o.append("  }")
   o.append("  MYR_HD static inline void default_params(double* p) {")
   for i, v in enumerate(S["pdefault"]):
