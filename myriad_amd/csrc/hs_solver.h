@@ -25,6 +25,7 @@
 // arrays strided by the padded batch so that lanes coalesce) and the host test twin (tests/hostsim, stride 1).
 #pragma once
 #include <math.h>
+#include <string.h>
 #include "systems_gen.h"
 
 namespace myriad {
@@ -71,7 +72,12 @@ namespace detail {
 
 MYR_HD inline double dmax(double a, double b) { return a > b ? a : b; }
 MYR_HD inline double dmin(double a, double b) { return a < b ? a : b; }
-MYR_HD inline bool finite_(double v) { return (v - v) == 0.0; }
+// finite <=> exponent field not all ones (bit test: immune to value-based folding under fast-math style flags)
+MYR_HD inline bool finite_(double v) {
+  unsigned long long b;
+  memcpy(&b, &v, sizeof(b));
+  return ((b >> 52) & 0x7ffULL) != 0x7ffULL;
+}
 
 // In-place LU (no pivoting; the matrices here are I + O(h)) of an n x n row-major matrix.
 template <int n>
@@ -195,35 +201,42 @@ struct HsSolver {
     return (j & 1) ? 4.0 * h / 6.0 : ((j == 0 || j == K - 1) ? h / 6.0 : 2.0 * h / 6.0);
   }
 
-  MYR_HD static inline void load_point(const HsWork& w, int K, int j, const double* p, HsPoint<Sys>& P, bool second) {
+  // Raw per-variable data of one collocation point (w = (x,u)): loaded UNCONDITIONALLY and up front so that the
+  // 5*NW loads of a point are independent and in flight together (the kernel is latency-bound; a load hidden
+  // behind a data-dependent branch costs a full memory round trip each).
+  struct VarBlk { double z[NW], l[NW], u[NW], zl[NW], zu[NW]; };
+  MYR_HD static inline void load_vars(const HsWork& w, int K, int j, VarBlk& V) {
 #pragma unroll
-    for (int c = 0; c < NS; ++c) P.x[c] = w.z[zi(K, j, c)];
+    for (int c = 0; c < NW; ++c) {
+      const long i = zi(K, j, c);
+      V.z[c] = w.z[i]; V.l[c] = w.lb[i]; V.u[c] = w.ub[i]; V.zl[c] = w.zL[i]; V.zu[c] = w.zU[i];
+    }
+  }
+  MYR_HD static inline void lin_point(const VarBlk& V, const double* p, HsPoint<Sys>& P) {
 #pragma unroll
-    for (int c = 0; c < NU; ++c) P.u[c] = w.z[zi(K, j, NS + c)];
-    if (second) Sys::lin_d2(P.x, P.u, p, P.f, P.A, P.B, &P.g, P.gw, P.D2);
-    else Sys::lin(P.x, P.u, p, P.f, P.A, P.B, &P.g, P.gw);
+    for (int c = 0; c < NS; ++c) P.x[c] = V.z[c];
+#pragma unroll
+    for (int c = 0; c < NU; ++c) P.u[c] = V.z[NS + c];
+    Sys::lin_d2(P.x, P.u, p, P.f, P.A, P.B, &P.g, P.gw, P.D2);
   }
 
-  // bound data of one variable: barrier Hessian sigma, base gradient part (-zL + zU) for the adjoint,
-  // mu-coefficient g1 = -1/(z-l) + 1/(u-z); also complementarity and pinned flag
+  // bound data of one variable (branch-free): barrier Hessian sigma, (-zL + zU) for the adjoint,
+  // mu-coefficient g1 = -1/(z-l) + 1/(u-z); complementarity extremes; pinned flag
   struct BV { double sigma, g1, zlu; bool pinned; };
-  MYR_HD static inline BV bound_terms(const HsWork& w, long i, double& compl_max, double& compl_min) {
+  MYR_HD static inline BV bound_terms(double zv, double l, double u, double zl, double zu, double& compl_max, double& compl_min) {
     BV r;
-    const double zv = w.z[i], l = w.lb[i], u = w.ub[i];
-    r.pinned = !(l < u);
-    r.sigma = 0.0; r.g1 = 0.0; r.zlu = 0.0;
-    if (!r.pinned) {
-      if (l > -INFINITY) {
-        const double sl = zv - l, zl = w.zL[i];
-        r.sigma += zl / sl; r.g1 -= 1.0 / sl; r.zlu -= zl;
-        compl_max = detail::dmax(compl_max, sl * zl); compl_min = detail::dmin(compl_min, sl * zl);
-      }
-      if (u < INFINITY) {
-        const double su = u - zv, zu = w.zU[i];
-        r.sigma += zu / su; r.g1 += 1.0 / su; r.zlu += zu;
-        compl_max = detail::dmax(compl_max, su * zu); compl_min = detail::dmin(compl_min, su * zu);
-      }
-    }
+    const bool fr = l < u;
+    const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+    const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
+    const double zlv = hl ? zl : 0.0, zuv = hu ? zu : 0.0;
+    const double il = hl ? 1.0 / sl : 0.0, iu = hu ? 1.0 / su : 0.0;
+    r.pinned = !fr;
+    r.sigma = zlv * il + zuv * iu;
+    r.g1 = iu - il;
+    r.zlu = zuv - zlv;
+    const double cl = sl * zlv, cu = su * zuv;
+    compl_max = detail::dmax(compl_max, detail::dmax(hl ? cl : compl_max, hu ? cu : compl_max));
+    compl_min = detail::dmin(compl_min, detail::dmin(hl ? cl : compl_min, hu ? cu : compl_min));
     return r;
   }
 
@@ -256,13 +269,14 @@ struct HsSolver {
     for (int i = 0; i < NW * NC; ++i) pc[i] = 0.0;
 
     HsPoint<Sys> Pe, Pm, Ps;
-    load_point(w, K, K - 1, p, Pe, true);
+    VarBlk Ve, Vm, Vs;
+    load_vars(w, K, K - 1, Ve);
+    lin_point(Ve, p, Pe);
     // adjoint carries from the later stage: costate on x_e rows, control-row partial residual, Hessian multiplier part
     double pi_c[NS], ru_c[NU], mu_c[NS];
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
-      const long i = zi(K, K - 1, c);
-      so.term_pinned[c] = !(w.lb[i] < w.ub[i]);
+      so.term_pinned[c] = !(Ve.l[c] < Ve.u[c]);
       pi_c[c] = so.term_pinned[c] ? nuT[c] : 0.0;
       mu_c[c] = 0.0;
       if (so.term_pinned[c]) {
@@ -274,10 +288,12 @@ struct HsSolver {
     for (int c = 0; c < NU; ++c) ru_c[c] = 0.0;
 
     for (int k = N - 1; k >= 0; --k) {
-      const int je = 2 * k + 2, jm = 2 * k + 1, js = 2 * k;
-      load_point(w, K, jm, p, Pm, true);
-      load_point(w, K, js, p, Ps, true);
-      const double we = wsimp(K, je, h), wm = wsimp(K, jm, h);
+      const int jm = 2 * k + 1, js = 2 * k;
+      load_vars(w, K, jm, Vm);
+      load_vars(w, K, js, Vs);
+      lin_point(Vm, p, Pm);
+      lin_point(Vs, p, Ps);
+      const double we = wsimp(K, 2 * k + 2, h), wm = wsimp(K, jm, h);
       so.f += we * Pe.g + wm * Pm.g;
 
       // ---- constraints of interval k (hermite_simpson.py:124-128, :167-170) ----
@@ -295,9 +311,9 @@ struct HsSolver {
       bool pin_e[NW];
 #pragma unroll
       for (int c = 0; c < NW; ++c) {
-        BV b = bound_terms(w, zi(K, je, c), so.compl_max, so.compl_min);
+        BV b = bound_terms(Ve.z[c], Ve.l[c], Ve.u[c], Ve.zl[c], Ve.zu[c], so.compl_max, so.compl_min);
         sig_e[c] = b.sigma; g1_e[c] = b.g1; zlu_e[c] = b.zlu; pin_e[c] = b.pinned;
-        BV bm = bound_terms(w, zi(K, jm, c), so.compl_max, so.compl_min);
+        BV bm = bound_terms(Vm.z[c], Vm.l[c], Vm.u[c], Vm.zl[c], Vm.zu[c], so.compl_max, so.compl_min);
         sig_m[c] = bm.sigma; g1_m[c] = bm.g1; zlu_m[c] = bm.zlu;
       }
 
@@ -584,6 +600,7 @@ struct HsSolver {
         ru_c[a] = s;
       }
       Pe = Ps;
+      Ve = Vs;
     }
 
     // ---- first point (j = 0): x_0 is pinned (dx_0 = 0); add its control terms and eliminate du_0 ----
@@ -593,7 +610,7 @@ struct HsSolver {
       double sig0[NW], g10[NW], zlu0[NW], W0[NW * NW];
 #pragma unroll
       for (int c = 0; c < NW; ++c) {
-        BV b = bound_terms(w, zi(K, 0, c), so.compl_max, so.compl_min);
+        BV b = bound_terms(Ve.z[c], Ve.l[c], Ve.u[c], Ve.zl[c], Ve.zu[c], so.compl_max, so.compl_min);
         sig0[c] = b.sigma; g10[c] = b.g1; zlu0[c] = b.zlu;
       }
 #pragma unroll
@@ -665,28 +682,26 @@ struct HsSolver {
   // ------------------------------------------------------------------------------------------------
   struct FwdOut { double alpha_p, alpha_d, gphi; };
 
-  MYR_HD static inline void step_limits(const HsWork& w, long i, double d, double mu, double wg_grad, double tau, FwdOut& fo) {
-    // wg_grad: objective gradient entry of this variable; accumulates gphi = grad(phi_mu)^T dz and the
-    // fraction-to-the-boundary limits for z (primal) and zL, zU (dual)
-    const double zv = w.z[i], l = w.lb[i], u = w.ub[i];
+  // accumulates gphi = grad(phi_mu)^T dz and the fraction-to-the-boundary limits for z (primal) and zL, zU (dual);
+  // branch-free, operands already in registers
+  MYR_HD static inline void step_limits(double zv, double l, double u, double zl, double zu, double d, double mu,
+                                        double wg_grad, double tau, FwdOut& fo) {
+    const bool fr = l < u;
+    const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+    const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
+    const double zlv = hl ? zl : 1.0, zuv = hu ? zu : 1.0;
     double gb = wg_grad;
-    if (l < u) {
-      if (l > -INFINITY) {
-        const double sl = zv - l, zl = w.zL[i];
-        gb -= mu / sl;
-        if (d < 0.0) fo.alpha_p = detail::dmin(fo.alpha_p, -tau * sl / d);
-        const double dzl = -zl + (mu - zl * d) / sl;
-        if (dzl < 0.0) fo.alpha_d = detail::dmin(fo.alpha_d, -tau * zl / dzl);
-      }
-      if (u < INFINITY) {
-        const double su = u - zv, zu = w.zU[i];
-        gb += mu / su;
-        if (d > 0.0) fo.alpha_p = detail::dmin(fo.alpha_p, tau * su / d);
-        const double dzu = -zu + (mu + zu * d) / su;
-        if (dzu < 0.0) fo.alpha_d = detail::dmin(fo.alpha_d, -tau * zu / dzu);
-      }
-    }
-    fo.gphi += gb * d;
+    gb -= hl ? mu / sl : 0.0;
+    gb += hu ? mu / su : 0.0;
+    const double dzl = -zlv + (mu - zlv * d) / sl;
+    const double dzu = -zuv + (mu + zuv * d) / su;
+    const double ap_l = (hl && d < 0.0) ? -tau * sl / d : 1.0;
+    const double ap_u = (hu && d > 0.0) ? tau * su / d : 1.0;
+    const double ad_l = (hl && dzl < 0.0) ? -tau * zlv / dzl : 1.0;
+    const double ad_u = (hu && dzu < 0.0) ? -tau * zuv / dzu : 1.0;
+    fo.alpha_p = detail::dmin(fo.alpha_p, detail::dmin(ap_l, ap_u));
+    fo.alpha_d = detail::dmin(fo.alpha_d, detail::dmin(ad_l, ad_u));
+    fo.gphi += fr ? gb * d : 0.0;
   }
 
   MYR_HD static void forward(const HsWork& w, const HsSolveOpts& o, const double* p, double mu, const double* nu,
@@ -702,8 +717,7 @@ struct HsSolver {
     double s[NW];
 #pragma unroll
     for (int c = 0; c < NS; ++c) { s[c] = 0.0; w.dz[zi(K, 0, c)] = 0.0; }
-    // objective gradient needs g_w at each point: recompute the (cheap) cost gradient
-    double xx[NS], uu[NU], gg, gw[NW];
+    // first-point controls
 #pragma unroll
     for (int a = 0; a < NU; ++a) {
       double v = 0.0;
@@ -711,21 +725,33 @@ struct HsSolver {
       for (int cc = 0; cc < NC; ++cc) v -= w.st[a * NC + cc] * th[cc];
       s[NS + a] = v;
     }
-    auto point_grad = [&](int j) {
+    VarBlk V;
+    double gg, gw[NW];
+    auto apply = [&](int j, const double* dx, const double* du) {
+      // objective gradient of point j (cheap closed form), then step limits / merit slope for its NW variables
+      load_vars(w, K, j, V);
+      Sys::cost_grad(V.z, V.z + NS, p, &gg, gw);
+      const double wj = wsimp(K, j, h);
 #pragma unroll
-      for (int c = 0; c < NS; ++c) xx[c] = w.z[zi(K, j, c)];
-#pragma unroll
-      for (int c = 0; c < NU; ++c) uu[c] = w.z[zi(K, j, NS + c)];
-      Sys::cost_grad(xx, uu, p, &gg, gw);
+      for (int c = 0; c < NW; ++c) {
+        const double d = c < NS ? dx[c] : du[c - NS];
+        w.dz[zi(K, j, c)] = d;
+        step_limits(V.z[c], V.l[c], V.u[c], V.zl[c], V.zu[c], d, mu, wj * gw[c], tau, fo);
+      }
     };
-    {
-      point_grad(0);
-      const double w0 = wsimp(K, 0, h);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) { w.dz[zi(K, 0, NS + a)] = s[NS + a]; step_limits(w, zi(K, 0, NS + a), s[NS + a], mu, w0 * gw[NS + a], tau, fo); }
-    }
+    apply(0, s, s + NS);
     for (int k = 0; k < N; ++k) {
       const long base = (long)D::HEAD + (long)k * D::STAGE;
+      // stage data: independent loads first
+      double Kk[NQ * NW], kc[NQ * NC], Ge[NS * NY], ge[NS], Gm[NS * NY], gm[NS];
+#pragma unroll
+      for (int i = 0; i < NQ * NW; ++i) Kk[i] = w.st[base + D::O_K + i];
+#pragma unroll
+      for (int i = 0; i < NQ * NC; ++i) kc[i] = w.st[base + D::O_KC + i];
+#pragma unroll
+      for (int i = 0; i < NS * NY; ++i) { Ge[i] = w.st[base + D::O_GE + i]; Gm[i] = w.st[base + D::O_GM + i]; }
+#pragma unroll
+      for (int i = 0; i < NS; ++i) { ge[i] = w.st[base + D::O_gE + i]; gm[i] = w.st[base + D::O_gM + i]; }
       double y[NY];
 #pragma unroll
       for (int c = 0; c < NW; ++c) y[c] = s[c];
@@ -733,39 +759,29 @@ struct HsSolver {
       for (int r = 0; r < NQ; ++r) {
         double v = 0.0;
 #pragma unroll
-        for (int c = 0; c < NW; ++c) v -= w.st[base + D::O_K + r * NW + c] * s[c];
+        for (int c = 0; c < NW; ++c) v -= Kk[r * NW + c] * s[c];
 #pragma unroll
-        for (int cc = 0; cc < NC; ++cc) v -= w.st[base + D::O_KC + r * NC + cc] * th[cc];
+        for (int cc = 0; cc < NC; ++cc) v -= kc[r * NC + cc] * th[cc];
         y[NW + r] = v;
       }
       double dxe[NS], dxm[NS];
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        double ve = w.st[base + D::O_gE + r], vm = w.st[base + D::O_gM + r];
+        double ve = ge[r], vm = gm[r];
 #pragma unroll
-        for (int c = 0; c < NY; ++c) { ve += w.st[base + D::O_GE + r * NY + c] * y[c]; vm += w.st[base + D::O_GM + r * NY + c] * y[c]; }
+        for (int c = 0; c < NY; ++c) { ve += Ge[r * NY + c] * y[c]; vm += Gm[r * NY + c] * y[c]; }
         dxe[r] = ve; dxm[r] = vm;
       }
-      const int jm = 2 * k + 1, je = 2 * k + 2;
       if (k == N - 1) {
 #pragma unroll
-        for (int r = 0; r < NS; ++r) if (term_pinned[r]) dxe[r] = 0.0;
+        for (int r = 0; r < NS; ++r) dxe[r] = term_pinned[r] ? 0.0 : dxe[r];
       }
-      point_grad(jm);
-      const double wm = wsimp(K, jm, h);
+      apply(2 * k + 1, dxm, y + NW);
+      apply(2 * k + 2, dxe, y + NW + NU);
 #pragma unroll
-      for (int c = 0; c < NS; ++c) { w.dz[zi(K, jm, c)] = dxm[c]; step_limits(w, zi(K, jm, c), dxm[c], mu, wm * gw[c], tau, fo); }
+      for (int c = 0; c < NS; ++c) s[c] = dxe[c];
 #pragma unroll
-      for (int a = 0; a < NU; ++a) { w.dz[zi(K, jm, NS + a)] = y[NW + a]; step_limits(w, zi(K, jm, NS + a), y[NW + a], mu, wm * gw[NS + a], tau, fo); }
-      point_grad(je);
-      const double we = wsimp(K, je, h);
-#pragma unroll
-      for (int c = 0; c < NS; ++c) { w.dz[zi(K, je, c)] = dxe[c]; step_limits(w, zi(K, je, c), dxe[c], mu, we * gw[c], tau, fo); s[c] = dxe[c]; }
-#pragma unroll
-      for (int a = 0; a < NU; ++a) {
-        const double v = y[NW + NU + a];
-        w.dz[zi(K, je, NS + a)] = v; step_limits(w, zi(K, je, NS + a), v, mu, we * gw[NS + a], tau, fo); s[NS + a] = v;
-      }
+      for (int a = 0; a < NU; ++a) s[NS + a] = y[NW + NU + a];
     }
   }
 
@@ -776,27 +792,31 @@ struct HsSolver {
     const double h = o.h, h6 = h / 6.0, h8 = h / 8.0;
     f = 0; bar = 0; c1 = 0;
     double xs[NS], us[NU], fs[NS], xm[NS], um[NU], fm[NS], xe[NS], ue[NU], fe[NS];
-    auto get = [&](int j, double* x, double* u, double* ff) -> bool {
-      bool ok = true;
+    int bad = 0;   // number of bound violations (kept as an integer count, not a bool chain)
+    auto get = [&](int j, double* x, double* u, double* ff) {
+      double zv[NW], dv[NW], lv[NW], uv[NW];
 #pragma unroll
       for (int c = 0; c < NW; ++c) {
         const long i = zi(K, j, c);
-        const double v = w.z[i] + alpha * w.dz[i];
-        const double l = w.lb[i], ub = w.ub[i];
-        if (l < ub) {
-          if (l > -INFINITY) { const double sl = v - l; if (!(sl > 0.0)) ok = false; else bar -= log(sl); }
-          if (ub < INFINITY) { const double su = ub - v; if (!(su > 0.0)) ok = false; else bar -= log(su); }
-        }
+        zv[c] = w.z[i]; dv[c] = w.dz[i]; lv[c] = w.lb[i]; uv[c] = w.ub[i];
+      }
+#pragma unroll
+      for (int c = 0; c < NW; ++c) {
+        const double v = zv[c] + alpha * dv[c];
+        const bool fr = lv[c] < uv[c];
+        const bool hl = fr && (lv[c] > -INFINITY), hu = fr && (uv[c] < INFINITY);
+        const double sl = hl ? v - lv[c] : 1.0, su = hu ? uv[c] - v : 1.0;
+        bad += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
+        bar -= log(sl > 0.0 ? sl : 1.0) + log(su > 0.0 ? su : 1.0);
         if (c < NS) x[c] = v; else u[c - NS] = v;
       }
       Sys::f(x, u, p, ff);
       f += wsimp(K, j, h) * Sys::g(x, u, p);
-      return ok;
     };
-    bool ok = get(0, xs, us, fs);
+    get(0, xs, us, fs);
     for (int k = 0; k < N; ++k) {
-      ok &= get(2 * k + 1, xm, um, fm);
-      ok &= get(2 * k + 2, xe, ue, fe);
+      get(2 * k + 1, xm, um, fm);
+      get(2 * k + 2, xe, ue, fe);
 #pragma unroll
       for (int c = 0; c < NS; ++c) {
         c1 += fabs((xe[c] - xs[c]) - h6 * (fs[c] + 4.0 * fm[c] + fe[c]));
@@ -805,32 +825,28 @@ struct HsSolver {
       }
     }
     bar *= mu;
-    return ok && detail::finite_(f) && detail::finite_(c1) && detail::finite_(bar);
+    if (bad != 0) return false;
+    if (!detail::finite_(f)) return false;
+    if (!detail::finite_(c1)) return false;
+    return detail::finite_(bar);
   }
 
   // accept the step: z += a_p dz, zL += a_d dzL, zU += a_d dzU (with the usual safeguard on the bound multipliers)
   MYR_HD static void update(const HsWork& w, int n, double ap, double ad, double mu) {
     for (int i = 0; i < n; ++i) {
-      const double l = w.lb[i], u = w.ub[i];
-      const double zv = w.z[i], d = w.dz[i];
-      const double zn = zv + ap * d;
-      if (l < u) {
-        if (l > -INFINITY) {
-          const double sl = zv - l, zl = w.zL[i];
-          double v = zl + ad * (-zl + (mu - zl * d) / sl);
-          const double sn = zn - l;
-          v = detail::dmax(detail::dmin(v, 1e10 * mu / sn), mu / (1e10 * sn));
-          w.zL[i] = v;
-        }
-        if (u < INFINITY) {
-          const double su = u - zv, zu = w.zU[i];
-          double v = zu + ad * (-zu + (mu + zu * d) / su);
-          const double sn = u - zn;
-          v = detail::dmax(detail::dmin(v, 1e10 * mu / sn), mu / (1e10 * sn));
-          w.zU[i] = v;
-        }
-        w.z[i] = zn;
-      }
+      const double l = w.lb[i], u = w.ub[i], zv = w.z[i], d = w.dz[i], zl = w.zL[i], zu = w.zU[i];
+      const bool fr = l < u;
+      const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+      const double zn = fr ? zv + ap * d : zv;
+      const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
+      const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
+      double vl = zl + ad * (-zl + (mu - zl * d) / sl);
+      double vu = zu + ad * (-zu + (mu + zu * d) / su);
+      vl = detail::dmax(detail::dmin(vl, 1e10 * mu / snl), mu / (1e10 * snl));
+      vu = detail::dmax(detail::dmin(vu, 1e10 * mu / snu), mu / (1e10 * snu));
+      w.z[i] = zn;
+      w.zL[i] = hl ? vl : 0.0;
+      w.zU[i] = hu ? vu : 0.0;
     }
   }
 
@@ -838,22 +854,19 @@ struct HsSolver {
   MYR_HD static void init(const HsWork& w, int n) {
     const double k1 = 1e-2, k2 = 1e-2;
     for (int i = 0; i < n; ++i) {
-      const double l = w.lb[i], u = w.ub[i];
-      double v = w.z[i];
-      w.zL[i] = 0.0; w.zU[i] = 0.0;
-      if (!(l < u)) { v = l; }
-      else {
-        const bool hl = l > -INFINITY, hu = u < INFINITY;
-        if (hl && hu) {
-          const double pl = detail::dmin(k1 * detail::dmax(1.0, fabs(l)), k2 * (u - l));
-          const double pu = detail::dmin(k1 * detail::dmax(1.0, fabs(u)), k2 * (u - l));
-          v = detail::dmin(detail::dmax(v, l + pl), u - pu);
-        } else if (hl) v = detail::dmax(v, l + k1 * detail::dmax(1.0, fabs(l)));
-        else if (hu) v = detail::dmin(v, u - k1 * detail::dmax(1.0, fabs(u)));
-        if (hl) w.zL[i] = 1.0;
-        if (hu) w.zU[i] = 1.0;
-      }
+      const double l = w.lb[i], u = w.ub[i], v0 = w.z[i];
+      const bool fr = l < u;
+      const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+      const double width = (hl && hu) ? (u - l) : INFINITY;
+      const double pl = detail::dmin(k1 * detail::dmax(1.0, fabs(l)), k2 * width);
+      const double pu = detail::dmin(k1 * detail::dmax(1.0, fabs(u)), k2 * width);
+      double v = v0;
+      v = hl ? detail::dmax(v, l + pl) : v;
+      v = hu ? detail::dmin(v, u - pu) : v;
+      v = fr ? v : l;
       w.z[i] = v;
+      w.zL[i] = hl ? 1.0 : 0.0;
+      w.zU[i] = hu ? 1.0 : 0.0;
     }
   }
 
@@ -891,8 +904,11 @@ struct HsSolver {
       {
         double sm = so.sum_mult; int nm = so.n_mult;
         for (int i = 0; i < n; ++i) {
-          const double l = w.lb[i], u = w.ub[i];
-          if (l < u) { if (l > -INFINITY) { sm += w.zL[i]; ++nm; } if (u < INFINITY) { sm += w.zU[i]; ++nm; } }
+          const double l = w.lb[i], u = w.ub[i], zl = w.zL[i], zu = w.zU[i];
+          const bool fr = l < u;
+          const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+          sm += (hl ? zl : 0.0) + (hu ? zu : 0.0);
+          nm += (hl ? 1 : 0) + (hu ? 1 : 0);
         }
         if (nm > 0) sd = dmax(1.0, sm / nm / 100.0);
       }

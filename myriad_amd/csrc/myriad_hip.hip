@@ -53,6 +53,7 @@ struct myr_handle_s {
   void* dbuf = nullptr;
   size_t dbuf_bytes = 0;
   int eval_wpt = 4;
+  int solve_lpw = 16;   // trajectories (active lanes) per wavefront in the solve kernel
   // solver scratch (batch-minor / SoA)
   void* sbuf = nullptr;
   size_t sbuf_bytes = 0;
@@ -121,6 +122,8 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
   }
   const char* w = getenv("MYRIAD_EVAL_WPT");
   if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4) h->eval_wpt = v; }
+  const char* l = getenv("MYRIAD_SOLVE_LPW");
+  if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
   *out = h;
   return MYR_OK;
 }
@@ -296,10 +299,14 @@ __global__ __launch_bounds__(256) void transpose_back_kernel(const double* __res
 // so the 64 lanes of a wavefront always touch 64 consecutive doubles (one 512-byte coalesced access).
 template <class Sys>
 __global__ __launch_bounds__(64, 1)
-void hs_solve_kernel(int B, long Bp, HsSolveOpts o, double* z, double* lb, double* ub, double* zL, double* zU,
+void hs_solve_kernel(int B, long Bp, int lanes_per_wave, HsSolveOpts o, double* z, double* lb, double* ub, double* zL, double* zU,
                      double* lam, double* dz, double* st, const double* __restrict__ params, int params_stride,
                      double* cost, int32_t* status, int32_t* iters, double* kkt) {
-  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // The kernel is latency-bound (long dependent fp64 chains, one wave per SIMD at best), so a wavefront may be
+  // launched partially populated: fewer trajectories per wave -> more waves in flight and a shorter wait for
+  // the slowest trajectory of each wave.
+  if ((int)threadIdx.x >= lanes_per_wave) return;
+  const long b = (long)blockIdx.x * lanes_per_wave + threadIdx.x;
   if (b >= B) return;
   double p[Sys::NP > 0 ? Sys::NP : 1];
   if (params) {
@@ -323,7 +330,10 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
                            int32_t* iters, double* kkt) {
   const int N = h->d.intervals;
   const myr_dims& dm = h->dims;
-  const long Bp = ((long)B + 63) / 64 * 64;
+  // batch-minor leading dimension: a multiple of 64 lanes, but an ODD multiple so that consecutive elements of a
+  // trajectory (stride Bp*8 bytes) rotate over HBM channels / L2 sets instead of camping on one (power-of-two stride)
+  long Bp = ((long)B + 63) / 64 * 64;
+  if (((Bp / 64) & 1) == 0) Bp += 64;
   const long n = dm.n, m = dm.m, nst = HsSol<Sys>::stage_doubles(N);
   const size_t need = (size_t)Bp * (size_t)(6 * n + m + nst) * 8;
   if (need > h->sbuf_bytes) {
@@ -351,7 +361,8 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   o.tol_compl = so.tol_compl; o.mu_init = so.mu_init;
   KTimer& kt = h->kt[MYR_K_SOLVE];
   HIPCHK(hipEventRecord(kt.a, h->stream));
-  hipLaunchKernelGGL(hs_solve_kernel<Sys>, dim3((unsigned)(Bp / 64)), dim3(64), 0, h->stream, B, Bp, o, sz, slb, sub, szL,
+  const int lpw = h->solve_lpw;
+  hipLaunchKernelGGL(hs_solve_kernel<Sys>, dim3((unsigned)((B + lpw - 1) / lpw)), dim3(64), 0, h->stream, B, Bp, lpw, o, sz, slb, sub, szL,
                      szU, slam, sdz, sst, params, pstride, cost, status, iters, kkt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
