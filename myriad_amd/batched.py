@@ -1,0 +1,36 @@
+"""Sharding of independent problem instances over the GPUs of one node (one process per GPU) and the path's single
+collective: the final gather of solutions over RCCL/xGMI (torch.distributed backend "nccl"; "gloo" in CPU tests).
+The reference has no multi-device code at all; instances are independent NLPs, so there is no
+data-path collective -- only this gather of z*, cost, status (<= 33 MB total at the BASELINE sizes)."""
+from __future__ import annotations
+
+from typing import Dict, Sequence, Tuple
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+  """Contiguous chunk [lo, hi) of `total` instances owned by `rank` (sizes differ by at most one)."""
+  if not (0 <= rank < world):
+    raise ValueError("rank out of range")
+  base, rem = divmod(total, world)
+  lo = rank * base + min(rank, rem)
+  return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_solutions(local: Dict[str, "torch.Tensor"], counts: Sequence[int], group=None) -> Dict[str, "torch.Tensor"]:
+  """all_gather the per-rank result tensors (first dim = local batch, possibly ragged across ranks: `counts[r]` rows
+  from rank r) and return them concatenated in rank order on every rank."""
+  import torch
+  import torch.distributed as dist
+  world = dist.get_world_size(group)
+  rank = dist.get_rank(group)
+  assert len(counts) == world and local[next(iter(local))].shape[0] == counts[rank]
+  mx = max(counts)
+  out = {}
+  for k, t in local.items():
+    pad = t
+    if t.shape[0] < mx:   # all_gather needs equal shapes: pad the short ranks
+      pad = torch.cat([t, t.new_zeros((mx - t.shape[0],) + tuple(t.shape[1:]))], dim=0)
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad.contiguous(), group=group)
+    out[k] = torch.cat([b[:counts[r]] for r, b in enumerate(bufs)], dim=0)
+  return out

@@ -10,6 +10,7 @@
 #include "../../include/myriad_hip.h"
 #include "hs_eval.h"
 #include "hs_solver.h"
+#include "rollout.h"
 #include "systems_gen.h"
 
 using namespace myriad;
@@ -101,9 +102,19 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
       dm.ngrad = si.cost_dep_x ? dm.n : K * si.nu;
       break;
     }
-    case MYR_TR_TRAPEZOIDAL:
-    case MYR_TR_SHOOTING:
-      return fail(MYR_E_UNSUPPORTED, "myr_create: transcription not built yet (HERMITE_SIMPSON only)");
+    case MYR_TR_TRAPEZOIDAL: {   // sizes only (rollout works; eval/solve kernels for this transcription: next round)
+      dm.x_rows = N + 1; dm.u_rows = N + 1;
+      dm.n = (N + 1) * (si.ns + si.nu);
+      dm.m = N * si.ns;
+      break;
+    }
+    case MYR_TR_SHOOTING: {
+      const int mc = desc->integration_method == MYR_INT_RK4 ? 2 : 1;
+      dm.x_rows = N + 1; dm.u_rows = mc * N * desc->controls_per_interval + 1;
+      dm.n = dm.x_rows * si.ns + dm.u_rows * si.nu;
+      dm.m = N * si.ns;
+      break;
+    }
     default:
       return fail(MYR_E_ARG, "myr_create: unknown transcription");
   }
@@ -441,9 +452,82 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
   return MYR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// rollout
+// ------------------------------------------------------------------------------------------------
+template <class Sys>
+__global__ __launch_bounds__(64)
+void rollout_kernel(int B, int method, int num_steps, double h, int u_rows, const double* __restrict__ x0,
+                    const double* __restrict__ us, const double* __restrict__ params, int params_stride,
+                    double* __restrict__ xs, double* __restrict__ cost) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double p[Sys::NP > 0 ? Sys::NP : 1];
+  if (params) {
+#pragma unroll
+    for (int i = 0; i < Sys::NP; ++i) p[i] = params[b * (long)params_stride + i];
+  } else {
+    Sys::default_params(p);
+  }
+  const double c = Rollout<Sys>::run(method, num_steps, h, u_rows, x0 + b * Sys::NS, us + b * (long)u_rows * Sys::NU, p,
+                                     xs ? xs + b * (long)(num_steps + 1) * Sys::NS : nullptr);
+  if (cost) cost[b] = c;
+}
+
+static int dispatch_rollout(myr_handle h, int B, int num_steps, int u_rows, const double* x0, const double* us,
+                            const double* params, int pstride, double* xs, double* cost) {
+  const int method = h->d.integration_method;
+  const double hs = h->d.T / num_steps;
+  KTimer& kt = h->kt[MYR_K_ROLLOUT];
+  HIPCHK(hipEventRecord(kt.a, h->stream));
+  dim3 g((unsigned)((B + 63) / 64)), t(64);
+#define RO(S) hipLaunchKernelGGL(rollout_kernel<S>, g, t, 0, h->stream, B, method, num_steps, hs, u_rows, x0, us, params, pstride, xs, cost)
+  switch (h->d.system_id) {
+    case MYR_SYS_CARTPOLE: RO(SysCARTPOLE); break;
+    case MYR_SYS_VANDERPOL: RO(SysVANDERPOL); break;
+    case MYR_SYS_CANCERTREATMENT: RO(SysCANCERTREATMENT); break;
+    case MYR_SYS_SIMPLECASE: RO(SysSIMPLECASE); break;
+    default: return fail(MYR_E_ARG, "rollout: unknown system");
+  }
+#undef RO
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(kt.b, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+  kt.sum_ms += ms; kt.launches += 1;
+  return MYR_OK;
+}
+
 extern "C" int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u_rows, const double* x0, const double* us,
                            const double* params, int32_t params_stride, double* xs, double* cost, int32_t mem) {
-  (void)h; (void)B; (void)num_steps; (void)u_rows; (void)x0; (void)us; (void)params; (void)params_stride;
-  (void)xs; (void)cost; (void)mem;
-  return fail(MYR_E_UNSUPPORTED, "myr_rollout: not built yet");
+  if (!h || !x0 || !us) return fail(MYR_E_ARG, "myr_rollout: null handle, x0 or us");
+  if (B < 0 || num_steps < 1 || u_rows < 1) return fail(MYR_E_ARG, "myr_rollout: bad sizes");
+  if (B == 0) return MYR_OK;
+  if (params && params_stride != 0 && params_stride != h->dims.np)
+    return fail(MYR_E_ARG, "myr_rollout: params_stride must be 0 (shared) or np");
+  HIPCHK(hipSetDevice(h->d.device));
+  const myr_dims& dm = h->dims;
+  if (mem == MYR_MEM_DEVICE) return dispatch_rollout(h, B, num_steps, u_rows, x0, us, params, params_stride, xs, cost);
+  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_rollout: bad mem kind");
+  const size_t nx0 = (size_t)B * dm.ns, nus = (size_t)B * u_rows * dm.nu;
+  const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
+  const size_t nxs = xs ? (size_t)B * (num_steps + 1) * dm.ns : 0, nc = cost ? (size_t)B : 0;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  int rc = ensure_dbuf(h, (al(nx0) + al(nus) + al(npar) + al(nxs) + al(nc)) * 8);
+  if (rc) return rc;
+  double* dx0 = (double*)h->dbuf;
+  double* dus = dx0 + al(nx0);
+  double* dp = dus + al(nus);
+  double* dxs = dp + al(npar);
+  double* dc = dxs + al(nxs);
+  HIPCHK(hipMemcpyAsync(dx0, x0, nx0 * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dus, us, nus * 8, hipMemcpyHostToDevice, h->stream));
+  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
+  rc = dispatch_rollout(h, B, num_steps, u_rows, dx0, dus, npar ? dp : nullptr, params_stride, nxs ? dxs : nullptr, nc ? dc : nullptr);
+  if (rc) return rc;
+  if (nxs) HIPCHK(hipMemcpyAsync(xs, dxs, nxs * 8, hipMemcpyDeviceToHost, h->stream));
+  if (nc) HIPCHK(hipMemcpyAsync(cost, dc, nc * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MYR_OK;
 }

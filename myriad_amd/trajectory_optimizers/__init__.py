@@ -1,0 +1,252 @@
+"""Host mirror of /root/reference/myriad/trajectory_optimizers/ (base.py:28-93, __init__.py:12-28,
+collocation/hermite_simpson.py:16-81, collocation/trapezoidal.py:16-77, shooting.py:16-77,247-275).
+
+The optimizer objects keep the reference's attribute names (hp, cfg, objective, constraints, bounds, guess, unravel,
+x_guess, u_guess, x_bounds, u_bounds, require_adj) and its solve() / solve_with_params(params, guess) methods; the
+callables evaluate on the GPU through the C-ABI.  New: solve_batch(x0s, params) for many instances at once."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import numpy as np
+
+from myriad_amd import _lib
+from myriad_amd.config import Config, HParams, IntegrationMethod, OptimizerType, QuadratureRule
+from myriad_amd.systems import SystemType
+from myriad_amd.utils import integrate_time_independent
+
+
+def _state_control_bounds(system, x_rows, u_rows, trap_quirk=False):
+  """hermite_simpson.py:55-81 / shooting.py:247-275 / trapezoidal.py:55-77."""
+  ns = system.x_0.shape[0]
+  nu = system.bounds.shape[0] - ns
+  xb = np.zeros((x_rows, ns, 2))
+  xb[:, :, :] = system.bounds[:-nu]
+  xb[0, :, :] = system.x_0[:, None]
+  if system.x_T is not None:
+    if trap_quirk:                                     # trapezoidal.py:71 (quirk Q2)
+      xb[-nu, :, :] = system.x_T[:, None]
+    else:
+      for i in range(len(system.x_T)):
+        if system.x_T[i] is not None:
+          xb[-1, i, :] = system.x_T[i]
+  xb = xb.reshape((-1, 2))
+  ub = np.empty((u_rows * nu, 2))
+  for i in range(nu, 0, -1):                           # control-major blocks (quirk Q1)
+    ub[(nu - i) * u_rows:(nu - i + 1) * u_rows] = system.bounds[-i]
+  return xb, ub
+
+
+def _rollout_guess(system, controls, interval_size, intervals, method, rows):
+  """shooting.py:56-74 / trapezoidal.py:36-50."""
+  rolled = None
+  def roll():
+    return integrate_time_independent(system.dynamics, system.x_0, controls, interval_size, intervals, method)[1]
+  if system.x_T is not None:
+    cols = []
+    for i in range(len(system.x_T)):
+      if system.x_T[i] is not None:
+        cols.append(np.linspace(system.x_0[i], system.x_T[i], num=rows).reshape(-1, 1))
+      else:
+        rolled = roll() if rolled is None else rolled
+        cols.append(rolled[:, i].reshape(-1, 1))
+    return np.hstack(cols)
+  return roll()
+
+
+class TrajectoryOptimizer(object):
+  """trajectory_optimizers/base.py:28-93."""
+  require_adj = False
+
+  def __init__(self, hp: HParams, cfg: Config, system, transcription: str, x_guess, u_guess, x_bounds, u_bounds):
+    self.hp, self.cfg, self.system = hp, cfg, system
+    self.transcription = transcription
+    self.x_guess, self.u_guess = x_guess, u_guess
+    self.x_bounds, self.u_bounds = x_bounds, u_bounds
+    self.guess = np.concatenate([x_guess.ravel(), u_guess.ravel()])      # ravel_pytree((x_guess, u_guess))
+    self.bounds = np.vstack((x_bounds, u_bounds))
+    self._x_shape, self._u_shape = x_guess.shape, u_guess.shape
+    self._engine: Optional[_lib.Engine] = None
+    if cfg.verbose:                                                        # base.py:53-63
+      print("hp opt type", hp.optimizer)
+      print("hp quadrature rule", hp.quadrature_rule)
+      print(f"guess.shape = {self.guess.shape}")
+      print(f"bounds.shape = {self.bounds.shape}")
+    if hp.system.name == "INVASIVEPLANT":                                  # base.py:65-67
+      raise NotImplementedError("Discrete systems are not compatible with Trajectory trajectory_optimizers")
+
+  # ---- device engine ------------------------------------------------------------------------------
+  @property
+  def engine(self) -> _lib.Engine:
+    if self._engine is None:
+      self._engine = _lib.Engine(self.system.name, self.transcription, self.hp.intervals, self.system.T,
+                                 controls_per_interval=self.hp.controls_per_interval,
+                                 integration_method=self.hp.integration_method.name)
+    return self._engine
+
+  def unravel(self, z):
+    z = np.asarray(z)
+    nx = int(np.prod(self._x_shape))
+    return z[..., :nx].reshape(z.shape[:-1] + self._x_shape), z[..., nx:].reshape(z.shape[:-1] + self._u_shape)
+
+  # ---- the reference's callables (evaluated by the hs_eval kernel) ---------------------------------
+  def _full_grad(self, g):
+    eng = self.engine
+    if eng.ngrad == eng.n:
+      return g
+    out = np.zeros(g.shape[:-1] + (eng.n,))
+    out[..., eng.x_rows * eng.ns:] = g
+    return out
+
+  def objective(self, variables):
+    return float(self.engine.eval(variables, params=self.system.device_params(), want=("f",))["f"][0])
+
+  def parametrized_objective(self, params, variables):
+    return float(self.engine.eval(variables, params=self.system.params_from_mapping(params), want=("f",))["f"][0])
+
+  def constraints(self, variables):
+    return self.engine.eval(variables, params=self.system.device_params(), want=("c",))["c"][0]
+
+  def parametrized_constraints(self, params, variables):
+    return self.engine.eval(variables, params=self.system.params_from_mapping(params), want=("c",))["c"][0]
+
+  def objective_grad(self, variables, params=None):
+    p = self.system.device_params() if params is None else self.system.params_from_mapping(params)
+    return self._full_grad(self.engine.eval(variables, params=p, want=("gradf",))["gradf"])[0]
+
+  def constraints_jac(self, variables, params=None):
+    """Dense Jacobian (what jax.jacrev(constraints) returns) assembled on the host from the kernel's stage blocks."""
+    p = self.system.device_params() if params is None else self.system.params_from_mapping(params)
+    blk = self.engine.eval(variables, params=p, want=("jblk",))["jblk"][0]
+    return hs_dense_from_blocks(blk.reshape(self.hp.intervals, -1), self.hp.intervals, self.engine.ns, self.engine.nu)
+
+  # ---- solve ---------------------------------------------------------------------------------------
+  def _opt_inputs(self, params=None, guess=None) -> Dict:
+    return {'objective': self.objective, 'guess': self.guess if guess is None else np.asarray(guess),
+            'constraints': self.constraints, 'bounds': self.bounds, 'unravel': self.unravel,
+            # descriptor for the device solver, which owns the transcription (SURVEY.md 8(b) inner boundary)
+            'optimizer': self, 'params': self.system.device_params() if params is None else self.system.params_from_mapping(params)}
+
+  def solve(self) -> Dict[str, np.ndarray]:
+    from myriad_amd.nlp_solvers import solve
+    return solve(self.hp, self.cfg, self._opt_inputs())
+
+  def solve_with_params(self, params, guess=None) -> Dict[str, np.ndarray]:
+    from myriad_amd.nlp_solvers import solve
+    return solve(self.hp, self.cfg, self._opt_inputs(params, guess))
+
+  def solve_batch(self, x0s=None, params=None, guess=None, max_iter=None) -> Dict[str, np.ndarray]:
+    """EXTENSION: B independent instances (random x0 and/or parameter sweeps) in one device call.
+    x0s [B,ns] replaces x_0 per instance (bounds row 0 and the reference's guess rule); params [B,np]."""
+    raise NotImplementedError
+
+
+class HermiteSimpsonCollocationOptimizer(TrajectoryOptimizer):
+  """collocation/hermite_simpson.py:16-81 (guess :37-48, bounds :55-81)."""
+
+  def __init__(self, hp: HParams, cfg: Config, system):
+    K = 2 * hp.intervals + 1
+    ns = system.x_0.shape[0]
+    nu = system.bounds.shape[0] - ns
+    u_guess = np.zeros((K, nu))
+    x_guess = np.linspace(system.x_0, system.x_T, num=K) if system.x_T is not None else np.ones((K, ns)) * 0.1
+    xb, ub = _state_control_bounds(system, K, K)
+    super().__init__(hp, cfg, system, "HERMITE_SIMPSON", x_guess, u_guess, xb, ub)
+
+  def batch_inputs(self, x0s):
+    """Per-instance guess and bounds for start states x0s [B,ns] (hermite_simpson.py:41,59 applied per instance)."""
+    x0s = np.asarray(x0s, dtype=np.float64)
+    B, K = x0s.shape[0], 2 * self.hp.intervals + 1
+    ns = x0s.shape[1]
+    if self.system.x_T is not None:
+      lin = np.linspace(0.0, 1.0, K)[None, :, None]
+      xs = x0s[:, None, :] * (1 - lin) + self.system.x_T[None, None, :] * lin
+    else:
+      xs = np.ones((B, K, ns)) * 0.1
+    z0 = np.concatenate([xs.reshape(B, -1), np.zeros((B, self.u_guess.size))], axis=1)
+    lb = np.tile(self.bounds[:, 0], (B, 1)); ub = np.tile(self.bounds[:, 1], (B, 1))
+    lb[:, :ns] = x0s; ub[:, :ns] = x0s
+    return z0, lb, ub
+
+  def solve_batch(self, x0s=None, params=None, guess=None, max_iter=None):
+    eng = self.engine
+    if x0s is None:
+      B = 1 if params is None or np.ndim(params) == 1 else np.shape(params)[0]
+      x0s = np.tile(self.system.x_0, (B, 1))
+    z0, lb, ub = self.batch_inputs(x0s)
+    if guess is not None:
+      z0 = np.broadcast_to(np.asarray(guess, dtype=np.float64), z0.shape).copy()
+    o = eng.default_opts()
+    o.max_iter = self.hp.max_iter if max_iter is None else max_iter
+    p = self.system.device_params() if params is None else np.asarray(params, dtype=np.float64)
+    res = eng.solve(z0, lb, ub, params=p, opts=o)
+    x, u = self.unravel(res["z"])
+    return {'x': x, 'u': u, 'xs_and_us': res["z"], 'cost': res["cost"], 'lambda': res["lam"],
+            'status': res["status"], 'iters': res["iters"], 'kkt': res["kkt"]}
+
+
+class TrapezoidalCollocationOptimizer(TrajectoryOptimizer):
+  """collocation/trapezoidal.py:16-77 (host part; device kernels for this transcription: next round)."""
+
+  def __init__(self, hp: HParams, cfg: Config, system):
+    N = hp.intervals
+    ns = system.x_0.shape[0]
+    nu = system.bounds.shape[0] - ns
+    h = system.T / N
+    u_guess = np.zeros((N + 1, nu))
+    x_guess = _rollout_guess(system, u_guess, h, N, hp.integration_method, N + 1)
+    xb, ub = _state_control_bounds(system, N + 1, N + 1, trap_quirk=True)
+    super().__init__(hp, cfg, system, "TRAPEZOIDAL", x_guess, u_guess, xb, ub)
+
+
+class MultipleShootingOptimizer(TrajectoryOptimizer):
+  """shooting.py:16-77,247-275 (host part; device kernels for this transcription: next round)."""
+
+  def __init__(self, hp: HParams, cfg: Config, system, key=None):
+    I, cpi = hp.intervals, hp.controls_per_interval
+    ns = system.x_0.shape[0]
+    nu = system.bounds.shape[0] - ns
+    mc = 2 if hp.integration_method == IntegrationMethod.RK4 else 1
+    u_guess = np.zeros((mc * I * cpi + 1, nu))
+    x_guess = _rollout_guess(system, u_guess[::mc * cpi], system.T / I, I, hp.integration_method, I + 1)
+    assert len(x_guess) == I + 1
+    xb, ub = _state_control_bounds(system, I + 1, mc * I * cpi + 1)
+    super().__init__(hp, cfg, system, "SHOOTING", x_guess, u_guess, xb, ub)
+
+
+def get_optimizer(hp: HParams, cfg: Config, system):
+  """trajectory_optimizers/__init__.py:12-28."""
+  if hp.optimizer == OptimizerType.COLLOCATION:
+    if hp.quadrature_rule == QuadratureRule.TRAPEZOIDAL:
+      optimizer = TrapezoidalCollocationOptimizer(hp, cfg, system)
+    elif hp.quadrature_rule == QuadratureRule.HERMITE_SIMPSON:
+      optimizer = HermiteSimpsonCollocationOptimizer(hp, cfg, system)
+    else:
+      raise KeyError
+  elif hp.optimizer == OptimizerType.SHOOTING:
+    optimizer = MultipleShootingOptimizer(hp, cfg, system)
+  elif hp.optimizer == OptimizerType.FBSM:
+    raise NotImplementedError("FBSM (forward_backward_sweep.py) is outside the hot path (SURVEY.md section 2, row 14)")
+  else:
+    raise KeyError
+  return optimizer
+
+
+def hs_dense_from_blocks(blk: np.ndarray, N: int, ns: int, nu: int) -> np.ndarray:
+  """Dense (2 N ns) x (K (ns+nu)) Jacobian from the eval kernel's stage blocks (include/myriad_hip.h, myr_eval)."""
+  K = 2 * N + 1
+  J = np.zeros((2 * N * ns, K * (ns + nu)))
+  szs = [ns * ns] * 3 + [ns * nu] * 3 + [ns * ns] * 2 + [ns * nu] * 2
+  cuts = np.cumsum(szs)[:-1]
+  for k in range(N):
+    pr = np.split(blk[k], cuts)
+    rd = slice(k * ns, (k + 1) * ns)
+    ri = slice(N * ns + k * ns, N * ns + (k + 1) * ns)
+    cx = lambda q: slice(q * ns, (q + 1) * ns)
+    cu = lambda q: slice(K * ns + q * nu, K * ns + (q + 1) * nu)
+    s, m, e = 2 * k, 2 * k + 1, 2 * k + 2
+    J[rd, cx(s)] = pr[0].reshape(ns, ns); J[rd, cx(m)] = pr[1].reshape(ns, ns); J[rd, cx(e)] = pr[2].reshape(ns, ns)
+    J[rd, cu(s)] = pr[3].reshape(ns, nu); J[rd, cu(m)] = pr[4].reshape(ns, nu); J[rd, cu(e)] = pr[5].reshape(ns, nu)
+    J[ri, cx(s)] = pr[6].reshape(ns, ns); J[ri, cx(e)] = pr[7].reshape(ns, ns); J[ri, cx(m)] = np.eye(ns)
+    J[ri, cu(s)] = pr[8].reshape(ns, nu); J[ri, cu(e)] = pr[9].reshape(ns, nu)
+  return J

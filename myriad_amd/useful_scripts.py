@@ -1,0 +1,76 @@
+"""Host mirror of run_setup / run_trajectory_opt (/root/reference/myriad/useful_scripts.py:26-76,104-137)."""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import enum
+import typing
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy as np
+
+from myriad_amd.config import Config, HParams
+from myriad_amd.trajectory_optimizers import get_optimizer
+from myriad_amd.utils import get_defect, get_state_trajectory_and_cost
+
+
+def _add_dataclass_arguments(parser: argparse.ArgumentParser, cls):
+  """What simple_parsing.ArgumentParser.add_arguments does for the reference (useful_scripts.py:108-110): one
+  --flag per dataclass field; enums are parsed by MEMBER NAME (README.md:82-85); Tuple[...] fields take N values."""
+  hints = typing.get_type_hints(cls)
+  for f in dataclasses.fields(cls):
+    t = hints[f.name]
+    if isinstance(t, type) and issubclass(t, enum.Enum):
+      parser.add_argument(f"--{f.name}", type=lambda s, t=t: t[s], default=f.default, choices=list(t), metavar="{" + ",".join(t.__members__) + "}")
+    elif t is bool:
+      parser.add_argument(f"--{f.name}", type=lambda s: s.lower() in ("1", "true", "yes", "y"), default=f.default, nargs="?", const=True)
+    elif typing.get_origin(t) is tuple:
+      et = typing.get_args(t)[0]
+      parser.add_argument(f"--{f.name}", type=et, nargs=len(typing.get_args(t)), default=f.default)
+    else:
+      parser.add_argument(f"--{f.name}", type=t, default=f.default)
+
+
+def run_setup(argv=None):
+  parser = argparse.ArgumentParser()
+  _add_dataclass_arguments(parser, HParams)
+  _add_dataclass_arguments(parser, Config)
+  args = vars(parser.parse_args(argv))
+  hp = HParams(**{f.name: (tuple(args[f.name]) if isinstance(args[f.name], list) else args[f.name]) for f in dataclasses.fields(HParams)})
+  cfg = Config(**{f.name: (tuple(args[f.name]) if isinstance(args[f.name], list) else args[f.name]) for f in dataclasses.fields(Config)})
+  print(hp)
+  print(cfg)
+  np.random.seed(hp.seed)          # useful_scripts.py:135
+  return hp, cfg
+
+
+def run_trajectory_opt(hp: HParams, cfg: Config, save_as: str = None, params_path: str = None) -> Tuple[float, Optional[np.ndarray]]:
+  """useful_scripts.py:26-76: solve, then roll the TRUE dynamics forward under the solved controls and return
+  (integrated cost, terminal defect)."""
+  plot_path = f'plots/{hp.system.name}/trajectory_opt/'
+  if cfg.plot:
+    Path(plot_path).mkdir(parents=True, exist_ok=True)
+  if save_as is not None:
+    save_as = plot_path + save_as
+  if params_path is not None:
+    import pickle as pkl
+    params = pkl.load(open(params_path, 'rb'))
+    system = hp.system(**params)
+    print("loaded params:", params)
+  else:
+    system = hp.system()
+    print("made default system")
+  optimizer = get_optimizer(hp, cfg, system)
+  solution = optimizer.solve()
+  u = solution['u']
+  true_system = hp.system()
+  opt_x, c = get_state_trajectory_and_cost(hp, true_system, true_system.x_0, u)
+  defect = get_defect(true_system, opt_x)
+  if cfg.plot:
+    try:
+      from myriad_amd.plotting import plot
+      plot(hp, true_system, data={'x': opt_x, 'u': u, 'cost': c, 'defect': defect}, save_as=save_as)
+    except Exception as e:  # plotting is presentation only
+      print("plot skipped:", e)
+  return c, defect

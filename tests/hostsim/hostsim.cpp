@@ -7,6 +7,7 @@
 #include <string.h>
 #include <vector>
 #include "../../myriad_amd/csrc/hs_solver.h"
+#include "../../myriad_amd/csrc/rollout.h"
 
 using namespace myriad;
 
@@ -82,4 +83,17 @@ extern "C" int hostsim_step(int system_id, int N, double T, double* z, const dou
     case 3: ST(SysSIMPLECASE); return 0;
   }
   return -1;
+}
+
+extern "C" double hostsim_rollout(int system_id, int method, int num_steps, double h, int u_rows, const double* x0,
+                                  const double* us, const double* params, double* xs) {
+#define RL(S) { double p[S::NP > 0 ? S::NP : 1]; if (params) for (int i = 0; i < S::NP; ++i) p[i] = params[i]; else S::default_params(p); \
+                return Rollout<S>::run(method, num_steps, h, u_rows, x0, us, p, xs); }
+  switch (system_id) {
+    case 0: RL(SysCARTPOLE)
+    case 1: RL(SysVANDERPOL)
+    case 2: RL(SysCANCERTREATMENT)
+    case 3: RL(SysSIMPLECASE)
+  }
+  return NAN;
 }

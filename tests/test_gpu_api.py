@@ -1,0 +1,101 @@
+"""GPU tests of the reference-shaped Python API (get_optimizer(...).solve(), solve_with_params, run_trajectory_opt,
+rollout) running on the HIP kernels through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from myriad_amd.config import Config, HParams, IntegrationMethod, NLPSolverType, OptimizerType, QuadratureRule
+from myriad_amd.systems import SystemType
+
+CFG = Config(verbose=False, plot=False)
+
+
+def _hp(N=25, **kw):
+  return HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
+                 integration_method=IntegrationMethod.RK4, intervals=N, **kw)
+
+
+def test_run_trajectory_opt_returns_cost_and_defect(golden_dir):
+  """useful_scripts.py:26-76 contract: (integrated cost of the true-dynamics RK4 rollout under the solved controls,
+  terminal defect); pinned by the oracle's restatement of utils.py:258-324 on the golden solution."""
+  from myriad_amd.useful_scripts import run_trajectory_opt
+  from oracle import myriad_oracle as O
+  c, defect = run_trajectory_opt(_hp(25), CFG)
+  d = np.load(os.path.join(golden_dir, "solve_hs_cartpole_N25.npz"))
+  s = O.CartPole()
+  u_gold = d["z"][0][51 * 4:].reshape(51, 1)
+  xs, c_or = O.get_state_trajectory_and_cost(s, 25, "RK4", s.x_0, u_gold)
+  assert c == pytest.approx(c_or, rel=1e-6)
+  np.testing.assert_allclose(defect, O.get_defect(s, xs), atol=1e-5)
+  assert defect.shape == (4,) and np.abs(defect).max() < 5e-2      # HS N=25 solution re-integrated by RK4
+
+
+def test_optimizer_solve_result_keys_and_shapes():
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = _hp(10)
+  opt = get_optimizer(hp, CFG, hp.system())
+  sol = opt.solve()
+  assert set(sol) == {'x', 'u', 'xs_and_us', 'cost', 'lambda'}           # nlp_solvers/__init__.py:90-96
+  assert sol['x'].shape == (21, 4) and sol['u'].shape == (21, 1) and sol['xs_and_us'].shape == (105,) and sol['lambda'].shape == (80,)
+  assert sol['cost'] == pytest.approx(85.80432338009395, rel=1e-9)        # golden N=10
+  assert np.abs(opt.constraints(sol['xs_and_us'])).max() <= 1e-8
+  assert opt.objective(sol['xs_and_us']) == pytest.approx(sol['cost'], rel=1e-12)
+  # warm start from the solution (base.py:81-93 solve_with_params(params, guess))
+  sol2 = opt.solve_with_params({'g': 9.81, 'm1': 1.0, 'm2': 0.3, 'length': 0.5}, guess=sol['xs_and_us'])
+  assert sol2['cost'] == pytest.approx(sol['cost'], rel=1e-7)
+  # a different model: heavier pole needs more effort
+  sol3 = opt.solve_with_params({'g': 9.81, 'm1': 1.0, 'm2': 0.6, 'length': 0.5})
+  assert sol3['cost'] > sol['cost'] * 1.05
+
+
+def test_scipy_branch_on_gpu_callbacks_agrees_with_sqp():
+  """The reference's NLPSolverType.SLSQP branch (nlp_solvers/__init__.py:50-52) fed by the HIP eval kernel."""
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = _hp(5, nlpsolver=NLPSolverType.SLSQP)
+  opt = get_optimizer(hp, CFG, hp.system())
+  sol = opt.solve()
+  hp2 = _hp(5, nlpsolver=NLPSolverType.SQP)
+  sol2 = get_optimizer(hp2, CFG, hp2.system()).solve()
+  assert sol['cost'] == pytest.approx(sol2['cost'], rel=1e-4)
+  assert 'lambda' not in sol                                              # absent for SLSQP, as in the reference
+
+
+def test_solve_batch_extension_parameter_sweep():
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = _hp(10)
+  opt = get_optimizer(hp, CFG, hp.system())
+  rng = np.random.default_rng(1)
+  B = 33
+  params = np.array([9.81, 1.0, 0.3, 0.5]) * (1 + 0.1 * rng.uniform(-1, 1, (B, 4)))
+  x0s = np.clip(0.1 * rng.standard_normal((B, 4)), -1, 1)
+  res = opt.solve_batch(x0s=x0s, params=params)
+  assert (res['status'] == 0).all() and res['x'].shape == (B, 21, 4) and res['u'].shape == (B, 21, 1)
+  assert np.array_equal(res['x'][:, 0, :], x0s)
+  ev = opt.engine.eval(res['xs_and_us'], params=params, want=("c",))
+  assert np.abs(ev["c"]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("method", ["EULER", "HEUN", "MIDPOINT", "RK4"])
+def test_rollout_kernel_matches_oracle(method):
+  from myriad_amd import _lib
+  from oracle import myriad_oracle as O
+  rng = np.random.default_rng(2)
+  for name in ("CARTPOLE", "VANDERPOL", "CANCERTREATMENT", "SIMPLECASE"):
+    s = O.SYSTEMS[name]()
+    S, B = 40, 5
+    rows = (2 if method == "RK4" else 1) * S + 1
+    us = 0.2 * rng.standard_normal((B, rows, 1))
+    if name == "CANCERTREATMENT":
+      us = np.abs(us)
+    x0 = np.tile(s.x_0, (B, 1)) * (1 + 0.01 * rng.standard_normal((B, s.ns)))
+    eng = _lib.Engine(name, "SHOOTING", 1, s.T / 8, controls_per_interval=S, integration_method=method)
+    xs, cost = eng.rollout(x0, us, S)
+    s.T = s.T / 8
+    for b in range(B):
+      oxs, oc = O.get_state_trajectory_and_cost(s, S, method, x0[b], us[b])
+      np.testing.assert_allclose(xs[b], oxs, rtol=1e-12, atol=1e-13)
+      assert cost[b] == pytest.approx(oc, rel=1e-12, abs=1e-14)
+    eng.close()

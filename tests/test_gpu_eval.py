@@ -70,8 +70,10 @@ def test_eval_edge_cases():
   assert set(out) == {"c"}
   with pytest.raises(ValueError):
     eng.eval(np.zeros((2, eng.n + 1)))
+  trap = _lib.Engine("CARTPOLE", "TRAPEZOIDAL", 4, 2.0)     # sizes known, kernels not built for it yet
+  assert (trap.n, trap.m) == (25, 16)
   with pytest.raises(NotImplementedError):
-    _lib.Engine("CARTPOLE", "TRAPEZOIDAL", 4, 2.0)
+    trap.eval(np.zeros((1, trap.n)))
 
 
 def test_eval_full_size_properties():

@@ -1,0 +1,130 @@
+"""CPU tests of the host-side mirror of the reference API: HParams derived fields, CLI parsing by enum member name,
+guesses/bounds vs the oracle's restatement, error behaviour, sharding + gather with gloo (world_size 2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from myriad_amd.config import (Config, HParams, IntegrationMethod, NLPSolverType, OptimizerType, QuadratureRule)
+from myriad_amd.systems import SystemType
+from myriad_amd.trajectory_optimizers import get_optimizer, hs_dense_from_blocks
+from myriad_amd.useful_scripts import run_setup
+from myriad_amd.batched import shard_range
+
+CFG = Config(verbose=False, plot=False)
+
+
+def test_hparams_post_init_pins():
+  """SURVEY.md 8(b) pins of config.py:97-112."""
+  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, intervals=100)
+  assert (hp.controls_per_interval, hp.num_steps, hp.stepsize, hp.state_size, hp.control_size) == (1, 100, 0.02, 4, 1)
+  hp = HParams(system=SystemType.VANDERPOL, optimizer=OptimizerType.SHOOTING, intervals=1, controls_per_interval=50)
+  assert (hp.num_steps, hp.stepsize, hp.state_size) == (50, 0.2, 2)
+  hp = HParams(system=SystemType.CANCERTREATMENT, max_iter=500)
+  assert (hp.num_steps, hp.stepsize, hp.max_iter) == (100, 0.2, 500)
+  hp = HParams(system=SystemType.SIMPLECASE, intervals=10)
+  assert (hp.num_steps, hp.stepsize) == (1000, 0.001)
+  assert hp.minibatch_size == 3
+  assert HParams(nlpsolver=NLPSolverType.EXTRAGRADIENT).max_iter == 10000
+  assert HParams().nlpsolver == NLPSolverType.IPOPT and HParams().quadrature_rule == QuadratureRule.TRAPEZOIDAL
+
+
+def test_cli_parses_enums_by_member_name():
+  """README.md:82-85 command lines."""
+  hp, cfg = run_setup(["--system=CARTPOLE", "--optimizer=COLLOCATION", "--intervals=100"])
+  assert hp.system == SystemType.CARTPOLE and hp.quadrature_rule == QuadratureRule.TRAPEZOIDAL   # README:83 is trapezoidal!
+  hp, cfg = run_setup(["--system=VANDERPOL", "--optimizer=SHOOTING", "--intervals=1", "--controls_per_interval=50",
+                       "--integration_method=RK4", "--nlpsolver=SQP", "--verbose=false", "--hidden_layers", "64", "64"])
+  assert hp.integration_method == IntegrationMethod.RK4 and hp.nlpsolver == NLPSolverType.SQP
+  assert cfg.verbose is False and hp.hidden_layers == (64, 64)
+  with pytest.raises((SystemExit, KeyError)):
+    run_setup(["--system=NOPE"])
+
+
+@pytest.mark.parametrize("sysname,opt,quad,method,kw", [
+  ("CARTPOLE", "COLLOCATION", "HERMITE_SIMPSON", "RK4", dict(intervals=100)),
+  ("CARTPOLE", "COLLOCATION", "TRAPEZOIDAL", "HEUN", dict(intervals=100)),
+  ("VANDERPOL", "SHOOTING", "TRAPEZOIDAL", "HEUN", dict(intervals=1, controls_per_interval=50)),
+  ("CANCERTREATMENT", "SHOOTING", "TRAPEZOIDAL", "HEUN", dict(intervals=1, controls_per_interval=100)),
+  ("SIMPLECASE", "SHOOTING", "TRAPEZOIDAL", "HEUN", dict(intervals=10, controls_per_interval=100)),
+  ("SIMPLECASE", "SHOOTING", "TRAPEZOIDAL", "RK4", dict(intervals=3, controls_per_interval=4)),
+])
+def test_guess_and_bounds_match_oracle(sysname, opt, quad, method, kw):
+  from oracle import myriad_oracle as O
+  hp = HParams(system=SystemType[sysname], optimizer=OptimizerType[opt], quadrature_rule=QuadratureRule[quad],
+               integration_method=IntegrationMethod[method], **kw)
+  o = get_optimizer(hp, CFG, hp.system())
+  tr = O.make_transcription(O.SYSTEMS[sysname](), opt, hp.intervals, hp.controls_per_interval, quad, method)
+  np.testing.assert_allclose(o.guess, tr.guess, rtol=0, atol=1e-15)
+  assert np.array_equal(o.bounds, tr.bounds)
+  x, u = o.unravel(o.guess)
+  assert x.shape == (tr.x_rows, tr.ns) and u.shape == (tr.u_rows, tr.nu)
+  for attr in ("hp", "cfg", "objective", "parametrized_objective", "constraints", "parametrized_constraints", "bounds",
+               "guess", "unravel", "require_adj", "x_guess", "u_guess", "x_bounds", "u_bounds", "solve", "solve_with_params"):
+    assert hasattr(o, attr), attr
+
+
+def test_error_behaviour_matches_reference():
+  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.FBSM)
+  with pytest.raises(NotImplementedError):
+    get_optimizer(hp, CFG, hp.system())
+  from myriad_amd.nlp_solvers import solve
+  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON, intervals=4)
+  hp.nlpsolver = "bogus"
+  with pytest.raises(ValueError):        # nlp_solvers/__init__.py:59-61
+    solve(hp, CFG, {'optimizer': None, 'guess': None, 'bounds': None, 'unravel': None})
+
+
+def test_cartpole_params_from_mapping_takes_abs():
+  s = SystemType.CARTPOLE()
+  np.testing.assert_allclose(s.params_from_mapping({'g': -9.0, 'm1': 2.0}), [9.0, 2.0, 0.3, 0.5])   # cartpole.py:90-93
+
+
+def test_block_to_dense_roundtrip_matches_oracle_helper():
+  from oracle import myriad_oracle as O
+  rng = np.random.default_rng(0)
+  N, ns, nu = 3, 4, 1
+  blk = rng.standard_normal((N, 5 * ns * ns + 5 * ns * nu))
+  assert np.array_equal(hs_dense_from_blocks(blk, N, ns, nu), O.hs_dense_from_blocks(blk, N, ns, nu))
+
+
+def test_shard_range_covers_everything():
+  for total, world in [(4096, 8), (4096, 3), (5, 8), (0, 2)]:
+    spans = [shard_range(total, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == total
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _gloo_worker(rank, world, port, q):
+  import torch
+  import torch.distributed as dist
+  from myriad_amd.batched import shard_range, gather_solutions
+  os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  total = 11                                     # ragged: 6 + 5
+  counts = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+  lo, hi = shard_range(total, rank, world)
+  idx = torch.arange(lo, hi, dtype=torch.float64)
+  local = {"z": idx[:, None] * torch.ones(1, 7, dtype=torch.float64), "cost": idx * 2, "status": (idx % 3).to(torch.int32)}
+  out = gather_solutions(local, counts)
+  ok = (out["z"].shape == (total, 7) and torch.equal(out["z"][:, 0], torch.arange(total, dtype=torch.float64))
+        and torch.equal(out["cost"], 2 * torch.arange(total, dtype=torch.float64))
+        and torch.equal(out["status"], (torch.arange(total) % 3).to(torch.int32)))
+  t = torch.tensor([1.0 + rank]); dist.all_reduce(t, op=dist.ReduceOp.MAX)      # max-over-ranks timing reduction of bench.py
+  q.put((rank, bool(ok), float(t)))
+  dist.destroy_process_group()
+
+
+def test_gather_solutions_gloo_world2():
+  """The N>1 path of bench.py / solve_batch on CPU: world_size 2, gloo, ragged shards."""
+  import torch.multiprocessing as mp
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = 29500 + (os.getpid() % 2000)
+  ps = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+  [p.start() for p in ps]
+  res = sorted(q.get(timeout=120) for _ in range(2))
+  [p.join(60) for p in ps]
+  assert res == [(0, True, 2.0), (1, True, 2.0)]
