@@ -189,7 +189,9 @@ def main():
                    "achieved": alg / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                    "frac": alg / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                    "alg_bytes_per_launch": alg, "avg_ms": ev_ms, "launches": ev_n},
-      "solver_kernel": {"kernel": "hs_solve_kernel<CARTPOLE> (one trajectory per lane, whole SQP in one launch)",
+      "solver_kernel": {"kernel": ("hs_solve_wave_kernel<CARTPOLE> (one trajectory per wavefront, whole SQP in one launch)"
+                                   if os.environ.get("MYRIAD_SOLVE_MODE", "wave") != "lane" else
+                                   "hs_solve_kernel<CARTPOLE> (one trajectory per lane, whole SQP in one launch)"),
                         "avg_ms": sv_ms, "launches": sv_n, "bound": "latency/occupancy (see DESIGN.md)"},
     }
     if world == 1 and a.cpu_budget > 0:

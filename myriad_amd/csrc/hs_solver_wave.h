@@ -1,0 +1,943 @@
+// hs_solver_wave.h -- the SAME interior-point SQP as hs_solver.h, mapped ONE TRAJECTORY PER WAVEFRONT.
+//
+// hs_solver.h runs a whole trajectory in one lane: simple, host-testable, and right when the batch is large enough
+// to fill the machine with lanes (B >~ 64k); but its time is max_iterations x (sequential work of one lane), and at
+// the BASELINE batch (4096) most of the chip idles.  Here the 64 lanes of a wavefront share one trajectory:
+//   * everything that is independent across collocation points or intervals is done lanes-over-points /
+//     lanes-over-intervals (dynamics + derivatives with their sin/cos, bound terms, interval eliminations
+//     (LU of E, G_e, G_m), adjoint maps, Lagrangian Hessians, midpoint Schur terms, step limits, merit trials,
+//     updates);
+//   * only two recursions stay sequential over the N stages and are executed cooperatively through LDS:
+//     the Riccati sweep (lanes over the elements of the 5x5 / 7x7 / 7x6 blocks) and the forward state recursion;
+//     the adjoint recursion is reduced to an affine recurrence Pi_{k-1} = M_k Pi_k + v_k with M, v staged in LDS.
+// Trajectory data stays instance-major in HBM (the caller's z/lb/ub rows are used in place, no transposes);
+// per-trajectory scratch is one contiguous block, so every parallel phase reads/writes it with unit stride.
+// The algorithm, its constants and its control flow are those of HsSolver<Sys>::solve (hs_solver.h) -- the two
+// kernels are tested against each other and against the same golden trajectories.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hs_solver.h"
+
+namespace myriad {
+
+__device__ inline double wv_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline double wv_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o, 64); v = v > t ? v : t; }
+  return v;
+}
+__device__ inline double wv_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o, 64); v = v < t ? v : t; }
+  return v;
+}
+__device__ inline int wv_isum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <class Sys>
+struct HsWave {
+  using S = HsSolver<Sys>;
+  using D = HsSol<Sys>;
+  static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = NY + 1;
+  // per-point record, SoA over points: field f of point j at pt[f*K + j]
+  static constexpr int PF_F = 0, PF_A = PF_F + NS, PF_B = PF_A + NS * NS, PF_GW = PF_B + NS * NU, PF_D2 = PF_GW + NW,
+                       PF_SIG = PF_D2 + Sys::NNZ2, PF_G1 = PF_SIG + NW, PF_ZLU = PF_G1 + NW, PF_N = PF_ZLU + NW;
+  // per-point Hessian record, AoS: H (NW x NW), g0 (NW), g1 (NW)
+  static constexpr int HR_H = 0, HR_G0 = NW * NW, HR_G1 = HR_G0 + NW, HR_N = HR_G1 + NW;
+  // per-stage record, AoS
+  static constexpr int SG_GE = 0, SG_GM = SG_GE + NS * NY1, SG_LD = SG_GM + NS * NY1, SG_LD0 = SG_LD + NS * NS,
+                       SG_LI = SG_LD0 + NS, SG_LI0 = SG_LI + NS * NS, SG_QM = SG_LI0 + NS, SG_QCM = SG_QM + NY * NY,
+                       SG_N = SG_QCM + NY * 2;
+  static constexpr int KST = NQ * NW + NQ * NC;   // K | kc per stage (LDS)
+
+  __host__ __device__ static long scratch_doubles(int N) {
+    const long K = 2 * N + 1, n = K * NW;
+    return 3 * n + (long)PF_N * K + (long)HR_N * K + (long)SG_N * N + 2L * N * NS /* lambda when the caller passes none */;
+  }
+  // LDS doubles: region R0 (adjoint M|v, later K|kc, later trial x|f), Pi, Y, exchange
+  __host__ __device__ static int r0_doubles(int N) {
+    const int a = N * (NS * NS + NS), b = N * KST, c = 2 * (2 * N + 1) * NS;
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+  }
+  static constexpr int EXCH = NW * NW + NW * NC + NS * NY1 + HR_N + NY * NY + NY * 2 + NW * NY1 + NY * NY + NY * NC +
+                              KST + NS * NC + NU * NC + NW + 8;
+  __host__ __device__ static size_t lds_bytes(int N) { return (size_t)(r0_doubles(N) + N * NS + N * NY + EXCH) * 8 + 64; }
+
+  struct Ctx {
+    int N, K, n, lane;
+    double h, h6, h8;
+    double *z, *zL, *zU, *dz, *lam, *pt, *hr, *st;
+    const double *lb, *ub;
+    double p[Sys::NP > 0 ? Sys::NP : 1];
+    bool term_pinned[NS];
+    // LDS
+    double *r0, *sPi, *sY, *sP, *sPc, *sGe, *sHe, *sQm, *sQcm, *sT2, *sQ, *sQc, *sK, *sTnu, *sKu, *sS;
+  };
+
+  __device__ static inline long zi(const Ctx& c, int j, int comp) { return S::zi(c.K, j, comp); }
+
+  // ---- phase 1: lanes over points -- linearisation, bound terms ----------------------------------------------
+  struct P1 { double f, cmax, cmin, sm; int nm; };
+  __device__ static void points_lin(Ctx& c, P1& o) {
+    double f = 0, cmax = 0, cmin = INFINITY, sm = 0; int nm = 0;
+    for (int j = c.lane; j < c.K; j += 64) {
+      typename S::VarBlk V;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const long i = zi(c, j, q);
+        V.z[q] = c.z[i]; V.l[q] = c.lb[i]; V.u[q] = c.ub[i]; V.zl[q] = c.zL[i]; V.zu[q] = c.zU[i];
+      }
+      HsPoint<Sys> P;
+      S::lin_point(V, c.p, P);
+      double* pt = c.pt + j;
+      const int K = c.K;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) pt[(PF_F + q) * K] = P.f[q];
+#pragma unroll
+      for (int q = 0; q < NS * NS; ++q) pt[(PF_A + q) * K] = P.A[q];
+#pragma unroll
+      for (int q = 0; q < NS * NU; ++q) pt[(PF_B + q) * K] = P.B[q];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) pt[(PF_GW + q) * K] = P.gw[q];
+#pragma unroll
+      for (int q = 0; q < Sys::NNZ2; ++q) pt[(PF_D2 + q) * K] = P.D2[q];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        typename S::BV b = S::bound_terms(V.z[q], V.l[q], V.u[q], V.zl[q], V.zu[q], cmax, cmin);
+        pt[(PF_SIG + q) * K] = b.sigma; pt[(PF_G1 + q) * K] = b.g1; pt[(PF_ZLU + q) * K] = b.zlu;
+        const bool fr = V.l[q] < V.u[q];
+        const bool hl = fr && (V.l[q] > -INFINITY), hu = fr && (V.u[q] < INFINITY);
+        sm += (hl ? V.zl[q] : 0.0) + (hu ? V.zu[q] : 0.0);
+        nm += (hl ? 1 : 0) + (hu ? 1 : 0);
+      }
+      f += S::wsimp(K, j, c.h) * P.g;
+    }
+    o.f = wv_sum(f); o.cmax = wv_max(cmax); o.cmin = wv_min(cmin); o.sm = wv_sum(sm); o.nm = wv_isum(nm);
+  }
+
+  __device__ static inline void read_pt(const Ctx& c, int j, double* x, double* f, double* A, double* B) {
+    const double* pt = c.pt + j;
+    const int K = c.K;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { x[q] = c.z[(long)j * NS + q]; f[q] = pt[(PF_F + q) * K]; }
+#pragma unroll
+    for (int q = 0; q < NS * NS; ++q) A[q] = pt[(PF_A + q) * K];
+#pragma unroll
+    for (int q = 0; q < NS * NU; ++q) B[q] = pt[(PF_B + q) * K];
+  }
+
+  // ---- phase 2: lanes over intervals -- constraints, eliminations, adjoint maps -------------------------------
+  __device__ static void intervals_elim(Ctx& c, double& c1o, double& cinfo) {
+    using namespace detail;
+    const int N = c.N, K = c.K;
+    const double h6 = c.h6, h8 = c.h8;
+    double c1 = 0, cinf = 0;
+    for (int k = c.lane; k < N; k += 64) {
+      const int js = 2 * k, jm = 2 * k + 1, je = 2 * k + 2;
+      double xs[NS], fs[NS], As[NS * NS], Bs[NS * NU], xm[NS], fm[NS], Am[NS * NS], Bm[NS * NU], xe[NS], fe[NS], Ae[NS * NS], Be[NS * NU];
+      read_pt(c, js, xs, fs, As, Bs); read_pt(c, jm, xm, fm, Am, Bm); read_pt(c, je, xe, fe, Ae, Be);
+      double dk[NS], ik[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        dk[q] = (xe[q] - xs[q]) - h6 * (fs[q] + 4.0 * fm[q] + fe[q]);
+        ik[q] = xm[q] - 0.5 * (xs[q] + xe[q]) - h8 * (fs[q] - fe[q]);
+        c1 += fabs(dk[q]) + fabs(ik[q]);
+        cinf = dmax(cinf, dmax(fabs(dk[q]), fabs(ik[q])));
+      }
+      double Cm[NS * NS], Ne[NS * NS], Nsm[NS * NS], E[NS * NS];
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const double id = (r == q) ? 1.0 : 0.0;
+          Cm[r * NS + q] = 4.0 * h6 * Am[r * NS + q];
+          Ne[r * NS + q] = 0.5 * id - h8 * Ae[r * NS + q];
+          Nsm[r * NS + q] = 0.5 * id + h8 * As[r * NS + q];
+        }
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = ((r == q) ? 1.0 : 0.0) - h6 * Ae[r * NS + q];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s -= Cm[r * NS + t] * Ne[t * NS + q];
+          E[r * NS + q] = s;
+        }
+      lu_factor<NS>(E);
+      double* st = c.st + (long)k * SG_N;
+      // Ge | ge
+      double Ge[NS * NY1];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = ((r == q) ? 1.0 : 0.0) + h6 * As[r * NS + q];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Cm[r * NS + t] * Nsm[t * NS + q];
+          Ge[r * NY1 + q] = s;
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          double cbs = 0.0, cbe = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) { cbs += Cm[r * NS + t] * Bs[t * NU + a]; cbe += Cm[r * NS + t] * Be[t * NU + a]; }
+          Ge[r * NY1 + NS + a] = h6 * Bs[r * NU + a] + h8 * cbs;
+          Ge[r * NY1 + NS + NU + a] = 4.0 * h6 * Bm[r * NU + a];
+          Ge[r * NY1 + NS + 2 * NU + a] = h6 * Be[r * NU + a] - h8 * cbe;
+        }
+        double s = -dk[r];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s -= Cm[r * NS + t] * ik[t];
+        Ge[r * NY1 + NY] = s;
+      }
+      lu_solve<NS, NY1>(E, Ge);
+#pragma unroll
+      for (int q = 0; q < NS * NY1; ++q) st[SG_GE + q] = Ge[q];
+      // Gm | gm
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double row[NY1];
+#pragma unroll
+        for (int q = 0; q <= NY; ++q) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Ne[r * NS + t] * Ge[t * NY1 + q];
+          row[q] = s;
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) row[q] += Nsm[r * NS + q];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { row[NS + a] += h8 * Bs[r * NU + a]; row[NS + 2 * NU + a] -= h8 * Be[r * NU + a]; }
+        row[NY] -= ik[r];
+#pragma unroll
+        for (int q = 0; q <= NY; ++q) st[SG_GM + r * NY1 + q] = row[q];
+      }
+      // adjoint maps: lam_d = Ld Pi + ld0, lam_i = Li Pi + li0, Pi_prev = M Pi + v
+      const double* pm = c.pt + jm; const double* pe = c.pt + je;
+      const double wm = S::wsimp(K, jm, c.h), we = S::wsimp(K, je, c.h);
+      double rm[NS], owne[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        rm[q] = wm * pm[(PF_GW + q) * K] + pm[(PF_ZLU + q) * K];
+        owne[q] = (k == N - 1 && c.term_pinned[q]) ? 0.0 : (we * pe[(PF_GW + q) * K] + pe[(PF_ZLU + q) * K]);
+      }
+      double Ld[NS * NS], ld0[NS], Li[NS * NS], li0[NS];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        double y[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) y[q] = (q == i) ? 1.0 : 0.0;
+        lu_solve_t<NS>(E, y);            // y = E^-T e_i  -> column i of E^-T
+#pragma unroll
+        for (int q = 0; q < NS; ++q) Ld[q * NS + i] = -y[q];
+      }
+      {
+        double t0[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = owne[q];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Ne[t * NS + q] * rm[t];
+          t0[q] = s;
+        }
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+          double s = 0.0;
+#pragma unroll
+          for (int q = 0; q < NS; ++q) s += Ld[r * NS + q] * t0[q];
+          ld0[r] = s;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Cm[t * NS + r] * Ld[t * NS + q];
+          Li[r * NS + q] = s;
+        }
+        double s = -rm[r];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s += Cm[t * NS + r] * ld0[t];
+        li0[r] = s;
+      }
+#pragma unroll
+      for (int q = 0; q < NS * NS; ++q) { st[SG_LD + q] = Ld[q]; st[SG_LI + q] = Li[q]; }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) { st[SG_LD0 + q] = ld0[q]; st[SG_LI0 + q] = li0[q]; }
+      // Pi_prev = (-I - h6 As^T) lam_d + (-I/2 - h8 As^T) lam_i
+      double* M = c.r0 + (long)k * (NS * NS + NS);
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+#pragma unroll
+        for (int q = 0; q <= NS; ++q) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) {
+            const double sd = ((r == t) ? -1.0 : 0.0) - h6 * As[t * NS + r];
+            const double si = ((r == t) ? -0.5 : 0.0) - h8 * As[t * NS + r];
+            s += sd * (q < NS ? Ld[t * NS + q] : ld0[t]) + si * (q < NS ? Li[t * NS + q] : li0[t]);
+          }
+          if (q < NS) M[r * NS + q] = s; else M[NS * NS + r] = s;
+        }
+      }
+    }
+    c1o = wv_sum(c1); cinfo = wv_max(cinf);
+  }
+
+  // adjoint recurrence (every lane redundantly; operands are LDS broadcasts): Pi_k for k = N-1 .. 0
+  __device__ static void adjoint_recur(Ctx& c, const double* nuT) {
+    double pi[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) pi[q] = c.term_pinned[q] ? nuT[q] : 0.0;
+    for (int k = c.N - 1; k >= 0; --k) {
+      if (c.lane < NS) c.sPi[k * NS + c.lane] = pi[c.lane < NS ? c.lane : 0];
+      const double* M = c.r0 + (long)k * (NS * NS + NS);
+      double nx[NS];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double s = M[NS * NS + r];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) s += M[r * NS + q] * pi[q];
+        nx[r] = s;
+      }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) pi[q] = nx[q];
+    }
+  }
+
+  // ---- phase 3: lanes over intervals -- multipliers ------------------------------------------------------------
+  __device__ static void intervals_lambda(Ctx& c, double& lam_inf, double& sum_mult) {
+    double li = 0, sm = 0;
+    for (int k = c.lane; k < c.N; k += 64) {
+      const double* st = c.st + (long)k * SG_N;
+      double pi[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) pi[q] = c.sPi[k * NS + q];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double d = st[SG_LD0 + r], i2 = st[SG_LI0 + r];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { d += st[SG_LD + r * NS + q] * pi[q]; i2 += st[SG_LI + r * NS + q] * pi[q]; }
+        c.lam[(long)k * NS + r] = d;
+        c.lam[(long)c.N * NS + (long)k * NS + r] = i2;
+        li = detail::dmax(li, detail::dmax(fabs(d), fabs(i2)));
+        sm += fabs(d) + fabs(i2);
+      }
+    }
+    lam_inf = wv_max(li); sum_mult = wv_sum(sm);
+  }
+
+  // ---- phase 4: lanes over points -- Lagrangian Hessian, gradient columns, control-row stationarity ------------
+  __device__ static void points_hess(Ctx& c, double& stat) {
+    const int N = c.N, K = c.K;
+    const double h6 = c.h6, h8 = c.h8;
+    double st_ = 0;
+    for (int j = c.lane; j < K; j += 64) {
+      const double* pt = c.pt + j;
+      double a[NS];
+      if (j & 1) {
+        const int k = (j - 1) >> 1;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) a[q] = -4.0 * h6 * c.lam[(long)k * NS + q];
+      } else {
+        const int kL = (j >> 1) - 1, kR = j >> 1;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = 0.0;
+          if (kL >= 0) s += -h6 * c.lam[(long)kL * NS + q] + h8 * c.lam[(long)N * NS + (long)kL * NS + q];
+          if (kR < N) s += -h6 * c.lam[(long)kR * NS + q] - h8 * c.lam[(long)N * NS + (long)kR * NS + q];
+          a[q] = s;
+        }
+      }
+      const double wj = S::wsimp(K, j, c.h);
+      double gw[NW], D2[Sys::NNZ2], W[NW * NW];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) gw[q] = pt[(PF_GW + q) * K];
+#pragma unroll
+      for (int q = 0; q < Sys::NNZ2; ++q) D2[q] = pt[(PF_D2 + q) * K];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        double r = wj * gw[NS + u] + pt[(PF_ZLU + NS + u) * K];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) r += pt[(PF_B + t * NU + u) * K] * a[t];
+        st_ = detail::dmax(st_, fabs(r));
+      }
+      Sys::contract(D2, a, wj, W);
+      double* hr = c.hr + (long)j * HR_N;
+      const bool last = (j == K - 1);
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+        const bool zr = last && r < NS && c.term_pinned[r];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+          const bool zq = last && q < NS && c.term_pinned[q];
+          hr[HR_H + r * NW + q] = (zr || zq) ? 0.0 : (W[r * NW + q] + ((r == q) ? pt[(PF_SIG + r) * K] : 0.0));
+        }
+        hr[HR_G0 + r] = zr ? 0.0 : wj * gw[r];
+        hr[HR_G1 + r] = zr ? 0.0 : pt[(PF_G1 + r) * K];
+      }
+    }
+    stat = wv_max(st_);
+  }
+
+  // ---- phase 5: lanes over intervals -- midpoint Schur terms Qm = Gm^^T (H_m + delta I) Gm^, qcm ----------------
+  __device__ static void intervals_qm(Ctx& c, double delta) {
+    for (int k = c.lane; k < c.N; k += 64) {
+      double* st = c.st + (long)k * SG_N;
+      const double* hr = c.hr + (long)(2 * k + 1) * HR_N;
+      double Gm[NS * NY1], H[NW * NW], T1[NW * NY1];
+#pragma unroll
+      for (int q = 0; q < NS * NY1; ++q) Gm[q] = st[SG_GM + q];
+#pragma unroll
+      for (int q = 0; q < NW * NW; ++q) H[q] = hr[HR_H + q];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) H[q * NW + q] += delta;
+#pragma unroll
+      for (int r = 0; r < NW; ++r)
+#pragma unroll
+        for (int q = 0; q <= NY; ++q) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += H[r * NW + t] * Gm[t * NY1 + q];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) if (q == NS + NU + a) s += H[r * NW + NS + a];
+          T1[r * NY1 + q] = s;
+        }
+#pragma unroll
+      for (int r = 0; r < NY; ++r) {
+#pragma unroll
+        for (int q = 0; q < NY; ++q) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Gm[t * NY1 + r] * T1[t * NY1 + q];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) if (r == NS + NU + a) s += T1[(NS + a) * NY1 + q];
+          st[SG_QM + r * NY + q] = s;
+        }
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+          s0 += Gm[t * NY1 + r] * (T1[t * NY1 + NY] + hr[HR_G0 + t]);
+          s1 += Gm[t * NY1 + r] * hr[HR_G1 + t];
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) if (r == NS + NU + a) { s0 += T1[(NS + a) * NY1 + NY] + hr[HR_G0 + NS + a]; s1 += hr[HR_G1 + NS + a]; }
+        st[SG_QCM + r * 2 + 0] = s0; st[SG_QCM + r * 2 + 1] = s1;
+      }
+    }
+  }
+
+  // ---- phase 6: Riccati sweep, sequential over stages, lanes over block elements --------------------------------
+  // returns the number of regularised pivots (wave-uniform); aborts at the first one when `abort_on_reg`.
+  static constexpr int IN_N = NS * NY1 + NY * NY + NY * 2 + HR_N;   // per-stage inputs: Ge|ge, Qm, qcm, point-e record
+  __device__ static inline double load_in(const Ctx& c, int k, int e) {
+    const double* st = c.st + (long)k * SG_N;
+    if (e < NS * NY1) return st[SG_GE + e];
+    e -= NS * NY1;
+    if (e < NY * NY + NY * 2) return st[SG_QM + e];           // Qm and qcm are contiguous in the stage record
+    e -= NY * NY + NY * 2;
+    return c.hr[(long)(2 * k + 2) * HR_N + e];
+  }
+  __device__ static inline void store_in(const Ctx& c, int e, double v) {
+    if (e < NS * NY1) { c.sGe[e] = v; return; }
+    e -= NS * NY1;
+    if (e < NY * NY) { c.sQm[e] = v; return; }
+    e -= NY * NY;
+    if (e < NY * 2) { c.sQcm[e] = v; return; }
+    e -= NY * 2;
+    c.sHe[e] = v;
+  }
+
+  __device__ static int riccati(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
+    using namespace detail;
+    const int lane = c.lane, N = c.N;
+    constexpr int NLD = (IN_N + 63) / 64;
+    // init value function: P = rho on pinned terminal diagonals, nu columns
+    for (int e = lane; e < NW * NW; e += 64) {
+      const int r = e / NW, q = e % NW;
+      c.sP[e] = (r == q && r < NS && c.term_pinned[r]) ? o.rho_term : 0.0;
+    }
+    for (int e = lane; e < NW * NC; e += 64) {
+      const int r = e / NC, cc = e % NC;
+      c.sPc[e] = (r < NS && cc == 2 + r && c.term_pinned[r]) ? 1.0 : 0.0;
+    }
+    for (int e = lane; e < NS * NC; e += 64) c.sTnu[e] = 0.0;
+    int nreg = 0;
+    double pre[NLD];
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) { const int e = lane + 64 * t; pre[t] = e < IN_N ? load_in(c, N - 1, e) : 0.0; }
+    for (int k = N - 1; k >= 0; --k) {
+      // (a) stage inputs -> LDS; prefetch the next stage
+#pragma unroll
+      for (int t = 0; t < NLD; ++t) { const int e = lane + 64 * t; if (e < IN_N) store_in(c, e, pre[t]); }
+      if (k > 0) {
+#pragma unroll
+        for (int t = 0; t < NLD; ++t) { const int e = lane + 64 * t; pre[t] = e < IN_N ? load_in(c, k - 1, e) : 0.0; }
+      }
+      __syncthreads();
+      // (b) P' = P + H_e (+ delta), pc' = pc + gbar_e
+      for (int e = lane; e < NW * NW + NW; e += 64) {
+        if (e < NW * NW) {
+          const int r = e / NW, q = e % NW;
+          const bool pinned_diag = (k == N - 1) && r < NS && c.term_pinned[r];
+          c.sP[e] += c.sHe[HR_H + e] + ((r == q && !pinned_diag) ? delta : 0.0);
+        } else {
+          const int r = e - NW * NW;
+          c.sPc[r * NC + 0] += c.sHe[HR_G0 + r];
+          c.sPc[r * NC + 1] += c.sHe[HR_G1 + r];
+        }
+      }
+      __syncthreads();
+      // (c) T2 = P' [Ge^ | ge^]
+      for (int e = lane; e < NW * NY1; e += 64) {
+        const int r = e / NY1, q = e % NY1;
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s += c.sP[r * NW + t] * c.sGe[t * NY1 + q];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) if (q == NS + 2 * NU + a) s += c.sP[r * NW + NS + a];
+        c.sT2[e] = s;
+      }
+      __syncthreads();
+      // (d) Q = Qm + Ge^^T T2 ; qc = qcm + Ge^^T (T2[:,NY] [col 0] + pc') ; Tnu[:,0] += ge^T pc'[:, nu cols]
+      for (int e = lane; e < NY * NY + NY * NC + NS; e += 64) {
+        if (e < NY * NY) {
+          const int r = e / NY, q = e % NY;
+          double s = c.sQm[e];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += c.sGe[t * NY1 + r] * c.sT2[t * NY1 + q];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) if (r == NS + 2 * NU + a) s += c.sT2[(NS + a) * NY1 + q];
+          c.sQ[e] = s;
+        } else if (e < NY * NY + NY * NC) {
+          const int f = e - NY * NY, r = f / NC, cc = f % NC;
+          double s = cc < 2 ? c.sQcm[r * 2 + cc] : 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += c.sGe[t * NY1 + r] * (c.sPc[t * NC + cc] + (cc == 0 ? c.sT2[t * NY1 + NY] : 0.0));
+#pragma unroll
+          for (int a = 0; a < NU; ++a)
+            if (r == NS + 2 * NU + a) s += c.sPc[(NS + a) * NC + cc] + (cc == 0 ? c.sT2[(NS + a) * NY1 + NY] : 0.0);
+          c.sQc[f] = s;
+        } else {
+          const int i = e - NY * NY - NY * NC;
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += c.sGe[t * NY1 + NY] * c.sPc[t * NC + 2 + i];
+          c.sTnu[i * NC + 0] += s;
+        }
+      }
+      __syncthreads();
+      // (e) Cholesky of Qqq (every lane, identical), gains K (NQ x NW) and kc (NQ x NC): one column per lane
+      double Lq[NQ * NQ];
+#pragma unroll
+      for (int r = 0; r < NQ; ++r)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) Lq[r * NQ + q] = c.sQ[(NW + r) * NY + NW + q];
+      nreg += chol_reg<NQ>(Lq, o.reg_floor);
+      if (nreg > 0 && abort_on_reg) return nreg;
+      if (lane < NW + NC) {
+        double col[NQ];
+#pragma unroll
+        for (int r = 0; r < NQ; ++r) col[r] = lane < NW ? c.sQ[(NW + r) * NY + lane] : c.sQc[(NW + r) * NC + (lane - NW)];
+        chol_solve<NQ, 1>(Lq, col);
+        double* Kst = c.sK + (long)k * KST;
+#pragma unroll
+        for (int r = 0; r < NQ; ++r) {
+          if (lane < NW) Kst[r * NW + lane] = col[r]; else Kst[NQ * NW + r * NC + (lane - NW)] = col[r];
+        }
+      }
+      __syncthreads();
+      // (f) P = Qss - Qsq K (symmetrised), pc = qc_s - Qsq kc, Tnu -= qc_q[:, nu]^T kc
+      {
+        const double* Kst = c.sK + (long)k * KST;
+        for (int e = lane; e < NW * NW + NW * NC + NS * NC; e += 64) {
+          if (e < NW * NW) {
+            const int r = e / NW, q = e % NW;
+            double s1 = c.sQ[r * NY + q], s2 = c.sQ[q * NY + r];
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) { s1 -= c.sQ[r * NY + NW + t] * Kst[t * NW + q]; s2 -= c.sQ[q * NY + NW + t] * Kst[t * NW + r]; }
+            c.sP[e] = 0.5 * (s1 + s2);
+          } else if (e < NW * NW + NW * NC) {
+            const int f = e - NW * NW, r = f / NC, cc = f % NC;
+            double s = c.sQc[r * NC + cc];
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) s -= c.sQ[r * NY + NW + t] * Kst[NQ * NW + t * NC + cc];
+            c.sPc[f] = s;
+          } else {
+            const int f = e - NW * NW - NW * NC, i = f / NC, cc = f % NC;
+            double s = 0.0;
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) s += c.sQc[(NW + t) * NC + 2 + i] * Kst[NQ * NW + t * NC + cc];
+            c.sTnu[f] -= s;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // first point: dx_0 = 0; add its control terms, eliminate du_0 (every lane redundantly; tiny)
+    {
+      const double* hr = c.hr;   // point 0
+      double Puu[NU * NU], ku[NU * NC], pun[NU * NS];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+#pragma unroll
+        for (int b = 0; b < NU; ++b) Puu[a * NU + b] = c.sP[(NS + a) * NW + NS + b] + hr[HR_H + (NS + a) * NW + NS + b] + ((a == b) ? delta : 0.0);
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc)
+          ku[a * NC + cc] = c.sPc[(NS + a) * NC + cc] + (cc == 0 ? hr[HR_G0 + NS + a] : (cc == 1 ? hr[HR_G1 + NS + a] : 0.0));
+#pragma unroll
+        for (int i = 0; i < NS; ++i) pun[a * NS + i] = ku[a * NC + 2 + i];
+      }
+      nreg += chol_reg<NU>(Puu, o.reg_floor);
+      chol_solve<NU, NC>(Puu, ku);
+      __syncthreads();
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < NU; ++a) s += pun[a * NS + i] * ku[a * NC + cc];
+            c.sTnu[i * NC + cc] -= s;
+          }
+#pragma unroll
+        for (int i = 0; i < NU * NC; ++i) c.sKu[i] = ku[i];
+      }
+      __syncthreads();
+    }
+    return nreg;
+  }
+
+  // ---- phase 8: forward state recursion (sequential, cooperative); y_k -> LDS -----------------------------------
+  __device__ static void forward_recur(Ctx& c, const double* th) {
+    const int lane = c.lane, N = c.N;
+    if (lane < NW) {
+      double v = 0.0;
+      if (lane >= NS) {
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) v -= c.sKu[(lane - NS) * NC + cc] * th[cc];
+      }
+      c.sS[lane] = v;
+    }
+    double pre = (lane < NS * NY1) ? c.st[SG_GE + lane] : 0.0;   // stage 0
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+      if (lane < NS * NY1) c.sGe[lane] = pre;
+      if (k + 1 < N && lane < NS * NY1) pre = c.st[(long)(k + 1) * SG_N + SG_GE + lane];
+      const double* Kst = c.sK + (long)k * KST;
+      double* y = c.sY + (long)k * NY;
+      if (lane < NW) y[lane] = c.sS[lane];
+      else if (lane < NW + NQ) {
+        const int r = lane - NW;
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) v -= Kst[r * NW + q] * c.sS[q];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) v -= Kst[NQ * NW + r * NC + cc] * th[cc];
+        y[NW + r] = v;
+      }
+      __syncthreads();
+      if (lane < NS) {
+        double v = c.sGe[lane * NY1 + NY];
+#pragma unroll
+        for (int q = 0; q < NY; ++q) v += c.sGe[lane * NY1 + q] * y[q];
+        if (k == N - 1 && c.term_pinned[lane]) v = 0.0;
+        c.sS[lane] = v;
+      } else if (lane < NW) {
+        c.sS[lane] = y[NW + NU + (lane - NS)];
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- phase 9: lanes over intervals -- step for midpoint / end point variables ---------------------------------
+  __device__ static void intervals_dz(Ctx& c) {
+    const int N = c.N;
+    if (c.lane < NW) c.dz[zi(c, 0, c.lane)] = c.lane < NS ? 0.0 : c.sY[c.lane];
+    for (int k = c.lane; k < N; k += 64) {
+      const double* st = c.st + (long)k * SG_N;
+      double y[NY];
+#pragma unroll
+      for (int q = 0; q < NY; ++q) y[q] = c.sY[(long)k * NY + q];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double vm = st[SG_GM + r * NY1 + NY], ve = st[SG_GE + r * NY1 + NY];
+#pragma unroll
+        for (int q = 0; q < NY; ++q) { vm += st[SG_GM + r * NY1 + q] * y[q]; ve += st[SG_GE + r * NY1 + q] * y[q]; }
+        if (k == N - 1 && c.term_pinned[r]) ve = 0.0;
+        c.dz[zi(c, 2 * k + 1, r)] = vm;
+        c.dz[zi(c, 2 * k + 2, r)] = ve;
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        c.dz[zi(c, 2 * k + 1, NS + a)] = y[NW + a];
+        c.dz[zi(c, 2 * k + 2, NS + a)] = y[NW + NU + a];
+      }
+    }
+  }
+
+  // ---- phase 10: lanes over points -- step limits and merit slope ------------------------------------------------
+  __device__ static void points_limits(Ctx& c, double mu, typename S::FwdOut& fo) {
+    const double tau = detail::dmax(0.99, 1.0 - mu);
+    typename S::FwdOut l; l.alpha_p = 1.0; l.alpha_d = 1.0; l.gphi = 0.0;
+    for (int j = c.lane; j < c.K; j += 64) {
+      const double wj = S::wsimp(c.K, j, c.h);
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const long i = zi(c, j, q);
+        S::step_limits(c.z[i], c.lb[i], c.ub[i], c.zL[i], c.zU[i], c.dz[i], mu, wj * c.pt[(PF_GW + q) * c.K + j], tau, l);
+      }
+    }
+    fo.alpha_p = wv_min(l.alpha_p); fo.alpha_d = wv_min(l.alpha_d); fo.gphi = wv_sum(l.gphi);
+  }
+
+  // ---- merit trial at z + alpha dz --------------------------------------------------------------------------------
+  __device__ static bool trial(Ctx& c, double alpha, double mu, double& f, double& bar, double& c1) {
+    const int N = c.N, K = c.K;
+    double* sX = c.r0; double* sF = c.r0 + (long)K * NS;
+    double fa = 0, ba = 0; int bad = 0;
+    for (int j = c.lane; j < K; j += 64) {
+      double x[NS], u[NU], ff[NS];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const long i = zi(c, j, q);
+        const double v = c.z[i] + alpha * c.dz[i];
+        const double l = c.lb[i], ub = c.ub[i];
+        const bool fr = l < ub;
+        const bool hl = fr && (l > -INFINITY), hu = fr && (ub < INFINITY);
+        const double sl = hl ? v - l : 1.0, su = hu ? ub - v : 1.0;
+        bad += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
+        ba -= log(sl > 0.0 ? sl : 1.0) + log(su > 0.0 ? su : 1.0);
+        if (q < NS) x[q] = v; else u[q - NS] = v;
+      }
+      Sys::f(x, u, c.p, ff);
+      fa += S::wsimp(K, j, c.h) * Sys::g(x, u, c.p);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) { sX[j * NS + q] = x[q]; sF[j * NS + q] = ff[q]; }
+    }
+    __syncthreads();
+    double ca = 0;
+    for (int k = c.lane; k < N; k += 64) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const double xs = sX[(2 * k) * NS + q], xm = sX[(2 * k + 1) * NS + q], xe = sX[(2 * k + 2) * NS + q];
+        const double fs = sF[(2 * k) * NS + q], fm = sF[(2 * k + 1) * NS + q], fe = sF[(2 * k + 2) * NS + q];
+        ca += fabs((xe - xs) - c.h6 * (fs + 4.0 * fm + fe));
+        ca += fabs(xm - 0.5 * (xs + xe) - c.h8 * (fs - fe));
+      }
+    }
+    __syncthreads();
+    f = wv_sum(fa); bar = mu * wv_sum(ba); c1 = wv_sum(ca);
+    bad = wv_isum(bad);
+    if (bad != 0) return false;
+    if (!detail::finite_(f)) return false;
+    if (!detail::finite_(c1)) return false;
+    return detail::finite_(bar);
+  }
+
+  __device__ static void update(Ctx& c, double ap, double ad, double mu) {
+    for (int i = c.lane; i < c.n; i += 64) {
+      const double l = c.lb[i], u = c.ub[i], zv = c.z[i], d = c.dz[i], zl = c.zL[i], zu = c.zU[i];
+      const bool fr = l < u;
+      const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+      const double zn = fr ? zv + ap * d : zv;
+      const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
+      const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
+      double vl = zl + ad * (-zl + (mu - zl * d) / sl);
+      double vu = zu + ad * (-zu + (mu + zu * d) / su);
+      vl = detail::dmax(detail::dmin(vl, 1e10 * mu / snl), mu / (1e10 * snl));
+      vu = detail::dmax(detail::dmin(vu, 1e10 * mu / snu), mu / (1e10 * snu));
+      c.z[i] = zn; c.zL[i] = hl ? vl : 0.0; c.zU[i] = hu ? vu : 0.0;
+    }
+  }
+
+  __device__ static void init(Ctx& c) {
+    const double k1 = 1e-2, k2 = 1e-2;
+    for (int i = c.lane; i < c.n; i += 64) {
+      const double l = c.lb[i], u = c.ub[i], v0 = c.z[i];
+      const bool fr = l < u;
+      const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+      const double width = (hl && hu) ? (u - l) : INFINITY;
+      const double pl = detail::dmin(k1 * detail::dmax(1.0, fabs(l)), k2 * width);
+      const double pu = detail::dmin(k1 * detail::dmax(1.0, fabs(u)), k2 * width);
+      double v = v0;
+      v = hl ? detail::dmax(v, l + pl) : v;
+      v = hu ? detail::dmin(v, u - pu) : v;
+      v = fr ? v : l;
+      c.z[i] = v; c.zL[i] = hl ? 1.0 : 0.0; c.zU[i] = hu ? 1.0 : 0.0;
+    }
+  }
+
+  // ---- the solve (control flow identical to HsSolver<Sys>::solve) ------------------------------------------------
+  __device__ static void solve(Ctx& c, const HsSolveOpts& o, HsSolveResult& res) {
+    using namespace detail;
+    init(c);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { const long i = zi(c, c.K - 1, q); c.term_pinned[q] = !(c.lb[i] < c.ub[i]); }
+    double mu = o.mu_init, pen = 1.0;
+    double nuT[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) nuT[i] = 0.0;
+    const double mu_min = dmin(o.tol_compl, o.tol_stat) * 0.1;
+    res.status = 1; res.iters = o.max_iter;
+    int stall = 0;
+    double delta_last = 0.0;
+    for (int it = 0; it <= o.max_iter; ++it) {
+      P1 p1;
+      points_lin(c, p1);
+      __syncthreads();
+      double c1, cinf, lam_inf, sum_mult, stat_raw;
+      intervals_elim(c, c1, cinf);
+      __syncthreads();
+      adjoint_recur(c, nuT);
+      __syncthreads();
+      intervals_lambda(c, lam_inf, sum_mult);
+      __syncthreads();
+      points_hess(c, stat_raw);
+      __syncthreads();
+      // inertia correction with retries (only the delta-dependent phases are redone)
+      double delta = 0.0;
+      int nreg = 0;
+      for (int tr_ = 0; tr_ < 12; ++tr_) {
+        bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
+        intervals_qm(c, delta);
+        __syncthreads();
+        nreg = riccati(c, o, delta, abort_on_reg);
+        __syncthreads();
+        if (nreg == 0) break;
+        if (!abort_on_reg) break;
+        if (delta == 0.0) delta = (delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4;
+        else delta *= (delta_last > 0.0) ? 8.0 : 100.0;
+      }
+      if (delta > 0.0) delta_last = delta;
+      const int nm = 2 * c.N * NS + p1.nm;
+      const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
+      const double stat = stat_raw / sd, comp = p1.cmax / sd;
+      res.cost = p1.f; res.feas = cinf; res.stat = stat; res.compl_ = comp;
+      if (!(finite_(p1.f) && finite_(cinf) && finite_(stat_raw))) { res.status = 2; res.iters = it; return; }
+      if (cinf <= o.tol_feas && stat <= o.tol_stat && comp <= o.tol_compl) { res.status = 0; res.iters = it; return; }
+      if (it == o.max_iter) break;
+      for (int guard = 0; guard < 8; ++guard) {
+        const double cerr = (p1.cmin <= p1.cmax) ? dmax(fabs(p1.cmax - mu), fabs(p1.cmin - mu)) : 0.0;
+        const double emu = dmax(dmax(stat, cinf), cerr / sd);
+        if (emu <= 10.0 * mu && mu > mu_min) {
+          const double nmu = dmax(mu_min, dmin(0.2 * mu, mu * sqrt(mu)));
+          if (nmu != mu) pen = 1.0;
+          mu = nmu;
+        } else break;
+      }
+      // terminal multipliers (every lane, identical)
+      typename S::SweepOut so;
+#pragma unroll
+      for (int i = 0; i < NS * NC; ++i) so.Tnu[i] = c.sTnu[i];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) so.term_pinned[i] = c.term_pinned[i];
+      double nu[NS];
+      S::solve_nu(so, mu, nu);
+      double th[NC];
+      th[0] = 1.0; th[1] = mu;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
+      forward_recur(c, th);
+      __syncthreads();
+      intervals_dz(c);
+      __syncthreads();
+      typename S::FwdOut fo;
+      points_limits(c, mu, fo);
+      if (!(finite_(fo.gphi) && finite_(fo.alpha_p))) { res.status = 2; res.iters = it; return; }
+      if (c1 > 0.0) {
+        const double need = fo.gphi / (0.9 * c1);
+        if (pen < need) pen = need + 1.0;
+      }
+      const double Dphi = fo.gphi - pen * c1;
+      double f0, bar0, c10;
+      trial(c, 0.0, mu, f0, bar0, c10);
+      const double phi0 = f0 + bar0 + pen * c10;
+      double a = fo.alpha_p;
+      bool ok = false;
+      for (int ls = 0; ls < 40; ++ls) {
+        double ft, bt, ct;
+        if (trial(c, a, mu, ft, bt, ct)) {
+          const double phit = ft + bt + pen * ct;
+          if (phit <= phi0 + 1e-8 * a * Dphi + 1e-13 * fabs(phi0)) { ok = true; break; }
+        }
+        a *= 0.5;
+      }
+      if (!ok) {
+        if (++stall > 5) { res.status = 3; res.iters = it; return; }
+      } else stall = 0;
+      update(c, a, fo.alpha_d, mu);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
+      __syncthreads();
+    }
+    res.status = 1; res.iters = o.max_iter;
+  }
+};
+
+// grid = B wavefronts (one 64-thread workgroup per trajectory); dynamic LDS = HsWave<Sys>::lds_bytes(N)
+template <class Sys>
+__global__ __launch_bounds__(64)
+void hs_solve_wave_kernel(int B, HsSolveOpts o, double* __restrict__ z, const double* __restrict__ lb,
+                          const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
+                          const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
+                          int32_t* iters, double* kkt) {
+  using W = HsWave<Sys>;
+  extern __shared__ __attribute__((aligned(16))) char smem_wave[];
+  const long b = blockIdx.x;
+  if (b >= B) return;
+  typename W::Ctx c;
+  c.N = o.N; c.K = 2 * o.N + 1; c.n = c.K * W::NW; c.lane = threadIdx.x;
+  c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
+  c.z = z + b * (long)c.n; c.lb = lb + b * (long)c.n; c.ub = ub + b * (long)c.n;
+  double* s = scratch + b * scratch_stride;
+  c.zL = s; s += c.n; c.zU = s; s += c.n; c.dz = s; s += c.n;
+  c.pt = s; s += (long)W::PF_N * c.K;
+  c.hr = s; s += (long)W::HR_N * c.K;
+  c.st = s; s += (long)W::SG_N * c.N;
+  c.lam = lam ? lam + b * (long)(2 * c.N * W::NS) : s;
+  if (params) {
+#pragma unroll
+    for (int i = 0; i < Sys::NP; ++i) c.p[i] = params[b * (long)params_stride + i];
+  } else {
+    Sys::default_params(c.p);
+  }
+  double* l = reinterpret_cast<double*>(smem_wave);
+  c.r0 = l; l += W::r0_doubles(c.N);
+  c.sK = c.r0;
+  c.sPi = l; l += c.N * W::NS;
+  c.sY = l; l += c.N * W::NY;
+  c.sP = l; l += W::NW * W::NW;
+  c.sPc = l; l += W::NW * W::NC;
+  c.sGe = l; l += W::NS * W::NY1;
+  c.sHe = l; l += W::HR_N;
+  c.sQm = l; l += W::NY * W::NY;
+  c.sQcm = l; l += W::NY * 2;
+  c.sT2 = l; l += W::NW * W::NY1;
+  c.sQ = l; l += W::NY * W::NY;
+  c.sQc = l; l += W::NY * W::NC;
+  c.sTnu = l; l += W::NS * W::NC;
+  c.sKu = l; l += W::NU * W::NC;
+  c.sS = l; l += W::NW;
+  HsSolveResult r;
+  W::solve(c, o, r);
+  if (threadIdx.x == 0) {
+    if (cost) cost[b] = r.cost;
+    if (status) status[b] = r.status;
+    if (iters) iters[b] = r.iters;
+    if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
+  }
+}
+
+}  // namespace myriad

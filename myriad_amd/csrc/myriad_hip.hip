@@ -10,6 +10,7 @@
 #include "../../include/myriad_hip.h"
 #include "hs_eval.h"
 #include "hs_solver.h"
+#include "hs_solver_wave.h"
 #include "rollout.h"
 #include "systems_gen.h"
 
@@ -54,6 +55,7 @@ struct myr_handle_s {
   void* dbuf = nullptr;
   size_t dbuf_bytes = 0;
   int eval_wpt = 4;
+  int solve_mode = 1;   // 1: one trajectory per wavefront (hs_solver_wave.h); 0: one trajectory per lane (hs_solver.h)
   int solve_lpw = 16;   // trajectories (active lanes) per wavefront in the solve kernel
   // solver scratch (batch-minor / SoA)
   void* sbuf = nullptr;
@@ -133,6 +135,8 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
   }
   const char* w = getenv("MYRIAD_EVAL_WPT");
   if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4) h->eval_wpt = v; }
+  const char* md = getenv("MYRIAD_SOLVE_MODE");
+  if (md) h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1;
   const char* l = getenv("MYRIAD_SOLVE_LPW");
   if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
   *out = h;
@@ -341,6 +345,37 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
                            int32_t* iters, double* kkt) {
   const int N = h->d.intervals;
   const myr_dims& dm = h->dims;
+  if (h->solve_mode == 1) {
+    using W = HsWave<Sys>;
+    const size_t lds = W::lds_bytes(N);
+    if (lds > 160 * 1024) return fail(MYR_E_CAPACITY, "hs_solve(wave): intervals too large for the LDS working set");
+    long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
+    if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate trajectories over HBM channels
+    const size_t need = (size_t)B * (size_t)stride * 8;
+    if (need > h->sbuf_bytes) {
+      if (h->sbuf) HIPCHK(hipFree(h->sbuf));
+      h->sbuf = nullptr; h->sbuf_bytes = 0;
+      HIPCHK(hipMalloc(&h->sbuf, need));
+      h->sbuf_bytes = need;
+    }
+    HsSolveOpts o;
+    o.N = N; o.h = h->d.T / N; o.max_iter = so.max_iter; o.tol_feas = so.tol_feas; o.tol_stat = so.tol_stat;
+    o.tol_compl = so.tol_compl; o.mu_init = so.mu_init;
+    auto kern = hs_solve_wave_kernel<Sys>;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KTimer& kt = h->kt[MYR_K_SOLVE];
+    HIPCHK(hipEventRecord(kt.a, h->stream));
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, h->stream, B, o, z, lb, ub, lam, (double*)h->sbuf, stride,
+                       params, pstride, cost, status, iters, kkt);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(kt.b, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+    kt.sum_ms += ms;
+    kt.launches += 1;
+    return MYR_OK;
+  }
   // batch-minor leading dimension: a multiple of 64 lanes, but an ODD multiple so that consecutive elements of a
   // trajectory (stride Bp*8 bytes) rotate over HBM channels / L2 sets instead of camping on one (power-of-two stride)
   long Bp = ((long)B + 63) / 64 * 64;

@@ -112,3 +112,28 @@ def test_solve_full_size_baseline_config():
   assert res["cost"][0] == pytest.approx(87.964376, rel=1e-7)
   assert abs(res["cost"][0] - 87.96437982986194) < 1e-5      # SLSQP at default ftol=1e-6
   assert abs(res["cost"][0] - 87.96437633178395) < 1e-6      # trust-constr
+
+
+def test_wave_and_lane_kernels_agree(monkeypatch):
+  """The two mappings of the same algorithm (one trajectory per wavefront / per lane) must produce the same iterates
+  up to round-off: same iteration counts on almost every instance, same costs."""
+  from oracle import myriad_oracle as O
+  N, B = 25, 40
+  s = O.CartPole()
+  x0 = O.random_x0(s, B, seed=11)
+  tr = O.hermite_simpson(s, N)
+  K = 2 * N + 1
+  z0 = np.stack([np.concatenate([np.linspace(x0[b], s.x_T, K).ravel(), np.zeros(K)]) for b in range(B)])
+  lb = np.tile(tr.bounds[:, 0], (B, 1)); ub = np.tile(tr.bounds[:, 1], (B, 1))
+  lb[:, :4] = x0; ub[:, :4] = x0
+  out = {}
+  for mode in ("wave", "lane"):
+    monkeypatch.setenv("MYRIAD_SOLVE_MODE", mode)
+    eng = _engine(N, B)
+    out[mode] = eng.solve(z0, lb, ub)
+    eng.close()
+  assert (out["wave"]["status"] == 0).all() and (out["lane"]["status"] == 0).all()
+  np.testing.assert_allclose(out["wave"]["cost"], out["lane"]["cost"], rtol=1e-9)
+  assert (out["wave"]["iters"] == out["lane"]["iters"]).mean() >= 0.8
+  assert np.abs(out["wave"]["z"] - out["lane"]["z"]).max() < 1e-6
+  assert np.abs(out["wave"]["lam"] - out["lane"]["lam"]).max() < 1e-4 * max(1.0, np.abs(out["lane"]["lam"]).max())
