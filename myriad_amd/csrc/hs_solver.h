@@ -35,6 +35,12 @@ struct HsSolveOpts {
   double h;
   int max_iter;
   double tol_feas, tol_stat, tol_compl, mu_init;
+  double kappa_mu = 0.2, theta_mu = 1.5, kappa_eps = 10.0;   // barrier update: mu <- max(mu_min, min(kappa_mu mu, mu^theta_mu)) when E_mu <= kappa_eps mu
+  int dual_follow = 0;     // 1: bound multipliers follow the primal backtracking factor (ablation knob)
+  double lm_init = 3e-5;   // Levenberg-Marquardt damping seeded when the line search cuts a step to <= 1/4 (0 = off)
+  int nonmono = 3;         // non-monotone Armijo memory (0 = monotone)
+  int recenter = 3;        // after this many consecutive accepted steps below recenter_alpha: mu <- 10 mu (0 = off)
+  double recenter_alpha = 0.2;
   double reg_floor = 1e-3; // smallest pivot accepted in the per-stage Cholesky (inertia correction threshold)
   double rho_term = 1e4;   // quadratic weight on pinned terminal states inside the QP (does not change its solution)
 };
@@ -883,13 +889,15 @@ struct HsSolver {
     for (int i = 0; i < NS; ++i) nuT[i] = 0.0;
     const double mu_min = dmin(o.tol_compl, o.tol_stat) * 0.1;
     res.status = 1; res.iters = o.max_iter;
-    int stall = 0;
-    double delta_last = 0.0;
+    int stall = 0, small_steps = 0;
+    double delta_last = 0.0, lm = 0.0;
+    constexpr int NMMAX = 8;
+    double hist[NMMAX]; int nhist = 0, hpos = 0; double hist_mu = -1.0, hist_pen = -1.0;
     SweepOut so;
     for (int it = 0; it <= o.max_iter; ++it) {
       // inertia correction (global, as in interior-point NLP codes): retry the factorisation with W + delta I
       // until every stage pivot is positive; the last resort keeps the stage-local convexification.
-      double delta = 0.0;
+      double delta = lm;     // Levenberg-Marquardt floor adapted from the line-search history (see below)
       for (int tr_ = 0; tr_ < 12; ++tr_) {
         so.abort_on_reg = (tr_ < 11);
         backward(w, o, p, nuT, delta, so);
@@ -898,7 +906,7 @@ struct HsSolver {
         else delta *= (delta_last > 0.0) ? 8.0 : 100.0;
         if (delta > 1e8) { so.abort_on_reg = false; }
       }
-      if (delta > 0.0) delta_last = delta;
+      if (delta > lm) delta_last = delta;
       // KKT error with the usual multiplier scaling
       double sd = 1.0;
       {
@@ -922,9 +930,8 @@ struct HsSolver {
         // error of the barrier problem: complementarity |s*z - mu| from the extreme products
         const double cerr = (so.compl_min <= so.compl_max) ? dmax(fabs(so.compl_max - mu), fabs(so.compl_min - mu)) : 0.0;
         const double emu = dmax(dmax(stat, so.cinf), cerr / sd);
-        if (emu <= 10.0 * mu && mu > mu_min) {
-          const double nm = dmax(mu_min, dmin(0.2 * mu, mu * sqrt(mu)));
-          if (nm != mu) pen = 1.0;
+        if (emu <= o.kappa_eps * mu && mu > mu_min) {
+          const double nm = dmax(mu_min, dmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
           mu = nm;
         } else break;
       }
@@ -942,13 +949,22 @@ struct HsSolver {
       double f0, bar0, c10;
       trial(w, o, p, 0.0, mu, f0, bar0, c10);
       const double phi0 = f0 + bar0 + pen * c10;
+      // non-monotone Armijo reference (Grippo-Lampariello-Lucidi): the largest of the last NM merit values of the
+      // SAME merit function (history is dropped whenever mu or the penalty changes); cures Maratos-type stalls
+      if (mu != hist_mu || pen != hist_pen) { nhist = 0; hpos = 0; hist_mu = mu; hist_pen = pen; }
+      double phiref = phi0;
+      for (int j = 0; j < nhist; ++j) phiref = dmax(phiref, hist[j]);
+      if (o.nonmono > 0) { hist[hpos % o.nonmono] = phi0; ++hpos; if (nhist < o.nonmono) ++nhist; }
       double a = fo.alpha_p;
       bool ok = false;
       for (int ls = 0; ls < 40; ++ls) {
         double ft, bt, ct;
+#ifdef MYR_TRACE
+        { bool tk = trial(w, o, p, a, mu, ft, bt, ct); if (it >= 30 && it <= 32) printf("   it %d ls %d a=%.3g ok=%d | f %.8f->%.8f bar %.6f->%.6f c1 %.3e->%.3e  phi0=%.8f phiref=%.8f Dphi=%.3e\n", it, ls, a, (int)tk, f0, ft, bar0, bt, c10, ct, phi0, phiref, Dphi); }
+#endif
         if (trial(w, o, p, a, mu, ft, bt, ct)) {
           const double phit = ft + bt + pen * ct;
-          if (phit <= phi0 + 1e-8 * a * Dphi + 1e-13 * fabs(phi0)) { ok = true; break; }
+          if (phit <= phiref + 1e-8 * a * Dphi + 1e-13 * fabs(phi0)) { ok = true; break; }
         }
         a *= 0.5;
       }
@@ -956,13 +972,27 @@ struct HsSolver {
         // no acceptable step along dz: take the tiny step anyway a few times (helps past round-off), then give up
         if (++stall > 5) { res.status = 3; res.iters = it; return; }
       } else stall = 0;
-      const double ad = fo.alpha_d;
+      // bound multipliers follow the primal backtracking factor (keeps s*z near mu when the line search cuts the step)
+      const double ad = o.dual_follow ? fo.alpha_d * (a / fo.alpha_p) : fo.alpha_d;
 #ifdef MYR_TRACE
       printf("it %3d f=%.8f cinf=%.2e stat=%.2e comp=%.2e mu=%.1e a=%.3g amax=%.3g ad=%.3g nreg=%d pen=%.3g gphi=%.3g ok=%d\n", it, so.f, so.cinf, stat, comp, mu, a, fo.alpha_p, ad, so.nreg, pen, fo.gphi, (int)ok);
 #endif
       update(w, n, a, ad, mu);
 #pragma unroll
       for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
+      // re-centering: a run of tiny accepted steps means the iterate left the neighbourhood of the central path for
+      // this mu (barrier parameter reduced too early); go back up one decade instead of crawling
+      // step-quality feedback: a step cut hard by the line search means the quadratic model over-reaches ->
+      // damp the next Newton system (W + lm I); full steps relax the damping again
+      if (o.lm_init > 0.0) {
+        const double ratio = a / fo.alpha_p;
+        if (ratio <= 0.25) lm = dmin(1e2, dmax(o.lm_init, 4.0 * lm));
+        else if (ratio >= 0.99) { lm *= 0.25; if (lm < 0.1 * o.lm_init) lm = 0.0; }
+      }
+      if (o.recenter > 0) {
+        small_steps = (a < o.recenter_alpha) ? small_steps + 1 : 0;
+        if (small_steps >= o.recenter && mu < o.mu_init) { mu = dmin(o.mu_init, 10.0 * mu); small_steps = 0; }
+      }
     }
     res.status = 1; res.iters = o.max_iter;
   }

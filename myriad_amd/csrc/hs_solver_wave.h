@@ -791,8 +791,10 @@ struct HsWave {
     for (int i = 0; i < NS; ++i) nuT[i] = 0.0;
     const double mu_min = dmin(o.tol_compl, o.tol_stat) * 0.1;
     res.status = 1; res.iters = o.max_iter;
-    int stall = 0;
-    double delta_last = 0.0;
+    int stall = 0, small_steps = 0;
+    double delta_last = 0.0, lm = 0.0;
+    constexpr int NMMAX = 8;
+    double hist[NMMAX]; int nhist = 0, hpos = 0; double hist_mu = -1.0, hist_pen = -1.0;
     for (int it = 0; it <= o.max_iter; ++it) {
       P1 p1;
       points_lin(c, p1);
@@ -807,7 +809,7 @@ struct HsWave {
       points_hess(c, stat_raw);
       __syncthreads();
       // inertia correction with retries (only the delta-dependent phases are redone)
-      double delta = 0.0;
+      double delta = lm;
       int nreg = 0;
       for (int tr_ = 0; tr_ < 12; ++tr_) {
         bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
@@ -820,7 +822,7 @@ struct HsWave {
         if (delta == 0.0) delta = (delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4;
         else delta *= (delta_last > 0.0) ? 8.0 : 100.0;
       }
-      if (delta > 0.0) delta_last = delta;
+      if (delta > lm) delta_last = delta;
       const int nm = 2 * c.N * NS + p1.nm;
       const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
       const double stat = stat_raw / sd, comp = p1.cmax / sd;
@@ -831,9 +833,8 @@ struct HsWave {
       for (int guard = 0; guard < 8; ++guard) {
         const double cerr = (p1.cmin <= p1.cmax) ? dmax(fabs(p1.cmax - mu), fabs(p1.cmin - mu)) : 0.0;
         const double emu = dmax(dmax(stat, cinf), cerr / sd);
-        if (emu <= 10.0 * mu && mu > mu_min) {
-          const double nmu = dmax(mu_min, dmin(0.2 * mu, mu * sqrt(mu)));
-          if (nmu != mu) pen = 1.0;
+        if (emu <= o.kappa_eps * mu && mu > mu_min) {
+          const double nmu = dmax(mu_min, dmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
           mu = nmu;
         } else break;
       }
@@ -864,22 +865,36 @@ struct HsWave {
       double f0, bar0, c10;
       trial(c, 0.0, mu, f0, bar0, c10);
       const double phi0 = f0 + bar0 + pen * c10;
+      // non-monotone Armijo reference (see hs_solver.h)
+      if (mu != hist_mu || pen != hist_pen) { nhist = 0; hpos = 0; hist_mu = mu; hist_pen = pen; }
+      double phiref = phi0;
+      for (int j = 0; j < nhist; ++j) phiref = dmax(phiref, hist[j]);
+      if (o.nonmono > 0) { hist[hpos % o.nonmono] = phi0; ++hpos; if (nhist < o.nonmono) ++nhist; }
       double a = fo.alpha_p;
       bool ok = false;
       for (int ls = 0; ls < 40; ++ls) {
         double ft, bt, ct;
         if (trial(c, a, mu, ft, bt, ct)) {
           const double phit = ft + bt + pen * ct;
-          if (phit <= phi0 + 1e-8 * a * Dphi + 1e-13 * fabs(phi0)) { ok = true; break; }
+          if (phit <= phiref + 1e-8 * a * Dphi + 1e-13 * fabs(phi0)) { ok = true; break; }
         }
         a *= 0.5;
       }
       if (!ok) {
         if (++stall > 5) { res.status = 3; res.iters = it; return; }
       } else stall = 0;
-      update(c, a, fo.alpha_d, mu);
+      update(c, a, o.dual_follow ? fo.alpha_d * (a / fo.alpha_p) : fo.alpha_d, mu);
 #pragma unroll
       for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
+      if (o.lm_init > 0.0) {     // step-quality feedback -> Levenberg-Marquardt damping (see hs_solver.h)
+        const double ratio = a / fo.alpha_p;
+        if (ratio <= 0.25) lm = dmin(1e2, dmax(o.lm_init, 4.0 * lm));
+        else if (ratio >= 0.99) { lm *= 0.25; if (lm < 0.1 * o.lm_init) lm = 0.0; }
+      }
+      if (o.recenter > 0) {
+        small_steps = (a < o.recenter_alpha) ? small_steps + 1 : 0;
+        if (small_steps >= o.recenter && mu < o.mu_init) { mu = dmin(o.mu_init, 10.0 * mu); small_steps = 0; }
+      }
       __syncthreads();
     }
     res.status = 1; res.iters = o.max_iter;

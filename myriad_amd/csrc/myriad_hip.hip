@@ -339,6 +339,17 @@ void hs_solve_kernel(int B, long Bp, int lanes_per_wave, HsSolveOpts o, double* 
   if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
 }
 
+static HsSolveOpts make_opts(myr_handle h, const myr_solve_opts& so) {
+  HsSolveOpts o;
+  o.N = h->d.intervals; o.h = h->d.T / h->d.intervals; o.max_iter = so.max_iter; o.tol_feas = so.tol_feas;
+  o.tol_stat = so.tol_stat; o.tol_compl = so.tol_compl; o.mu_init = so.mu_init;
+  if (const char* e = getenv("MYRIAD_NONMONO")) o.nonmono = atoi(e);      // developer knobs (globalisation ablations)
+  if (const char* e = getenv("MYRIAD_RECENTER")) o.recenter = atoi(e);
+  if (o.nonmono < 0) o.nonmono = 0;
+  if (o.nonmono > 8) o.nonmono = 8;
+  return o;
+}
+
 template <class Sys>
 static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                            int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
@@ -358,9 +369,7 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
       HIPCHK(hipMalloc(&h->sbuf, need));
       h->sbuf_bytes = need;
     }
-    HsSolveOpts o;
-    o.N = N; o.h = h->d.T / N; o.max_iter = so.max_iter; o.tol_feas = so.tol_feas; o.tol_stat = so.tol_stat;
-    o.tol_compl = so.tol_compl; o.mu_init = so.mu_init;
+    HsSolveOpts o = make_opts(h, so);
     auto kern = hs_solve_wave_kernel<Sys>;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KTimer& kt = h->kt[MYR_K_SOLVE];
@@ -402,9 +411,7 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, h->stream, (const double*)z, sz, B, (int)n, Bp);
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, h->stream, lb, slb, B, (int)n, Bp);
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, h->stream, ub, sub, B, (int)n, Bp);
-  HsSolveOpts o;
-  o.N = N; o.h = h->d.T / N; o.max_iter = so.max_iter; o.tol_feas = so.tol_feas; o.tol_stat = so.tol_stat;
-  o.tol_compl = so.tol_compl; o.mu_init = so.mu_init;
+  HsSolveOpts o = make_opts(h, so);
   KTimer& kt = h->kt[MYR_K_SOLVE];
   HIPCHK(hipEventRecord(kt.a, h->stream));
   const int lpw = h->solve_lpw;

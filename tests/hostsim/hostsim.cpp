@@ -20,6 +20,15 @@ static void solve_batch(int N, double T, int B, double* z, const double* lb, con
   HsSolveOpts o{N, T / N, max_iter, tol_feas, tol_stat, tol_compl, mu_init};
   if (getenv("RHO")) o.rho_term = atof(getenv("RHO"));
   if (getenv("REGF")) o.reg_floor = atof(getenv("REGF"));
+  if (getenv("NONM")) o.nonmono = atoi(getenv("NONM"));
+  if (getenv("DUALF")) o.dual_follow = atoi(getenv("DUALF"));
+  if (getenv("LM")) o.lm_init = atof(getenv("LM"));
+  if (getenv("KMU")) o.kappa_mu = atof(getenv("KMU"));
+  if (getenv("TMU")) o.theta_mu = atof(getenv("TMU"));
+  if (getenv("KEPS")) o.kappa_eps = atof(getenv("KEPS"));
+  if (getenv("RECN")) o.recenter = atoi(getenv("RECN"));
+  if (getenv("RECA")) o.recenter_alpha = atof(getenv("RECA"));
+
 #pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < B; ++b) {
     std::vector<double> zL(n), zU(n), dz(n), lbv(lb + (size_t)b * n, lb + (size_t)(b + 1) * n),
