@@ -77,7 +77,7 @@ __device__ inline void hs_build_stencil(HsStencil* tab, double h, int tid, int n
 
 // grid.x = B (one trajectory per workgroup), block = 64*WPT threads.
 // dynamic LDS: K*REC doubles + JPI stencil entries + reduction scratch.
-template <class Sys, int WPT>
+template <class Sys, int WPT, bool NTS = false>
 __global__ __launch_bounds__(64 * WPT)
 void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double* __restrict__ params,
                     int params_stride, double* __restrict__ fout, double* __restrict__ gout,
@@ -164,7 +164,7 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
       const double fs = rs[L::OFF_F + i], fm = rs[REC + L::OFF_F + i], fe = rs[2 * REC + L::OFF_F + i];
       const double d = (xe - xs) - h6 * (fs + 4.0 * fm + fe);               // hermite_simpson.py:124-128
       const double it = xm - 0.5 * (xs + xe) - h8 * (fs - fe);              // hermite_simpson.py:167-170
-      cb[e] = isint ? it : d;
+      if (NTS) __builtin_nontemporal_store(isint ? it : d, &cb[e]); else cb[e] = isint ? it : d;
     }
   }
 
@@ -181,7 +181,11 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
         double2 v;
         v.x = fma(s0.coef, rk[s0.off], s0.ident);
         v.y = fma(s1.coef, rk[s1.off], s1.ident);
-        jb[e2] = v;
+        if (NTS) {
+          typedef double d2v __attribute__((ext_vector_type(2)));
+          d2v vv; vv.x = v.x; vv.y = v.y;
+          __builtin_nontemporal_store(vv, reinterpret_cast<d2v*>(&jb[e2]));
+        } else jb[e2] = v;
       }
     } else {
       double* jb = jout + b * (long)N * JPI;

@@ -55,6 +55,7 @@ struct myr_handle_s {
   void* dbuf = nullptr;
   size_t dbuf_bytes = 0;
   int eval_wpt = 4;
+  int eval_nt = 1;      // non-temporal stores for the c / J-block streams
   int solve_mode = 1;   // 1: one trajectory per wavefront (hs_solver_wave.h); 0: one trajectory per lane (hs_solver.h)
   int solve_lpw = 16;   // trajectories (active lanes) per wavefront in the solve kernel
   // solver scratch (batch-minor / SoA)
@@ -134,7 +135,8 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
     HIPCHK(hipEventCreate(&h->kt[i].b));
   }
   const char* w = getenv("MYRIAD_EVAL_WPT");
-  if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4) h->eval_wpt = v; }
+  if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8) h->eval_wpt = v; }
+  if (const char* e = getenv("MYRIAD_EVAL_NT")) h->eval_nt = atoi(e);
   const char* md = getenv("MYRIAD_SOLVE_MODE");
   if (md) h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1;
   const char* l = getenv("MYRIAD_SOLVE_LPW");
@@ -190,26 +192,20 @@ static int launch_hs_eval(myr_handle h, int B, const double* z, const double* pa
   if (lds > 160 * 1024) return fail(MYR_E_CAPACITY, "hs_eval: intervals too large for the 160 KiB LDS record");
   KTimer& kt = h->kt[MYR_K_EVAL];
   HIPCHK(hipEventRecord(kt.a, h->stream));
-  switch (wpt) {
-    case 1: {
-      auto kern = hs_eval_kernel<Sys, 1>;
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);
-      break;
-    }
-    case 2: {
-      auto kern = hs_eval_kernel<Sys, 2>;
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3(B), dim3(128), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);
-      break;
-    }
-    default: {
-      auto kern = hs_eval_kernel<Sys, 4>;
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);
-      break;
-    }
+#define MYR_EVAL_LAUNCH(W, NTV)                                                                                   \
+  {                                                                                                               \
+    auto kern = hs_eval_kernel<Sys, W, NTV>;                                                                      \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(kern, dim3(B), dim3(64 * W), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);    \
   }
+  const bool nt = h->eval_nt != 0;
+  switch (wpt) {
+    case 1: if (nt) MYR_EVAL_LAUNCH(1, true) else MYR_EVAL_LAUNCH(1, false) break;
+    case 2: if (nt) MYR_EVAL_LAUNCH(2, true) else MYR_EVAL_LAUNCH(2, false) break;
+    case 8: if (nt) MYR_EVAL_LAUNCH(8, true) else MYR_EVAL_LAUNCH(8, false) break;
+    default: if (nt) MYR_EVAL_LAUNCH(4, true) else MYR_EVAL_LAUNCH(4, false) break;
+  }
+#undef MYR_EVAL_LAUNCH
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

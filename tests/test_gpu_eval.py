@@ -80,6 +80,7 @@ def test_eval_full_size_properties():
   """BASELINE config 2 size (N=100, B=4096): size-independent properties -- a feasible trajectory built by
   construction has zero interpolation residual; J blocks are linear in h-scaled A/B; device == host path."""
   import torch
+  torch.cuda.init()                      # make torch own a context before the library allocates
   from myriad_amd import _lib
   from oracle import myriad_oracle as O
   N, B = 100, 4096

@@ -12,8 +12,8 @@ ap.add_argument("--intervals", type=int, default=100)
 ap.add_argument("--iters", type=int, default=50)
 a = ap.parse_args()
 B, N = a.batch, a.intervals
-for wpt in ("1", "2", "4"):
-  os.environ["MYRIAD_EVAL_WPT"] = wpt
+for wpt, nt in (("1","0"), ("2","0"), ("4","0"), ("8","0"), ("4","1"), ("8","1")):
+  os.environ["MYRIAD_EVAL_WPT"] = wpt; os.environ["MYRIAD_EVAL_NT"] = nt
   eng = _lib.Engine("CARTPOLE", "HERMITE_SIMPSON", N, 2.0, max_batch=B)
   g = torch.Generator(device="cpu").manual_seed(0)
   z = torch.randn(B, eng.n, dtype=torch.float64, generator=g).cuda()
@@ -28,6 +28,6 @@ for wpt in ("1", "2", "4"):
   ms, n = eng.kernel_time(_lib.K_EVAL)
   K = 2 * N + 1
   alg = 8 * (K * 5 + 16 + 2 * N * 4 + N * 100 + K * 1 + 1) * B
-  print(json.dumps({"wpt": int(wpt), "B": B, "N": N, "ms": ms, "launches": n, "alg_bytes": alg,
+  print(json.dumps({"wpt": int(wpt), "nt": int(nt), "B": B, "N": N, "ms": ms, "launches": n, "alg_bytes": alg,
                     "GBps": alg / ms / 1e6, "frac_of_8TBps": alg / ms / 1e6 / 8000}))
   eng.close()
