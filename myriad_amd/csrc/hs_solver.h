@@ -35,6 +35,8 @@ struct HsSolveOpts {
   double h;
   int max_iter;
   double tol_feas, tol_stat, tol_compl, mu_init;
+  int cpi = 1;             // controls per interval (shooting)
+  int method = 1;          // integration method id (shooting): 0 Euler, 1 Heun, 2 midpoint, 3 RK4
   double kappa_mu = 0.2, theta_mu = 1.5, kappa_eps = 10.0;   // barrier update: mu <- max(mu_min, min(kappa_mu mu, mu^theta_mu)) when E_mu <= kappa_eps mu
   int dual_follow = 0;     // 1: bound multipliers follow the primal backtracking factor (ablation knob)
   double lm_init = 3e-5;   // Levenberg-Marquardt damping seeded when the line search cuts a step to <= 1/4 (0 = off)
@@ -876,13 +878,24 @@ struct HsSolver {
     }
   }
 
-  // ------------------------------------------------------------------------------------------------
-  // The solve.
-  // ------------------------------------------------------------------------------------------------
-  MYR_HD static void solve(const HsWork& w, const HsSolveOpts& o, const double* p, HsSolveResult& res) {
+  MYR_HD static inline int nvars(const HsSolveOpts& o) { return (2 * o.N + 1) * NW; }
+  MYR_HD static void solve(const HsWork& w, const HsSolveOpts& o, const double* p, HsSolveResult& res);
+};
+
+// ----------------------------------------------------------------------------------------------------
+// The interior-point outer loop, shared by every transcription core (Hermite-Simpson here, trapezoidal and
+// shooting in os_solver.h).  `Core` supplies: NS, nvars(o), init, SweepOut, backward, solve_nu, FwdOut, forward,
+// trial, update.
+// ----------------------------------------------------------------------------------------------------
+template <class Core>
+struct IpLoop {
+  MYR_HD static void run(const HsWork& w, const HsSolveOpts& o, const double* p, HsSolveResult& res) {
     using namespace detail;
-    const int K = 2 * o.N + 1, n = K * NW;
-    init(w, n);
+    constexpr int NS = Core::NS;
+    using SweepOut = typename Core::SweepOut;
+    using FwdOut = typename Core::FwdOut;
+    const int n = Core::nvars(o);
+    Core::init(w, n);
     double mu = o.mu_init, pen = 1.0;
     double nuT[NS];
 #pragma unroll
@@ -900,7 +913,7 @@ struct HsSolver {
       double delta = lm;     // Levenberg-Marquardt floor adapted from the line-search history (see below)
       for (int tr_ = 0; tr_ < 12; ++tr_) {
         so.abort_on_reg = (tr_ < 11);
-        backward(w, o, p, nuT, delta, so);
+        Core::backward(w, o, p, nuT, delta, so);
         if (so.nreg == 0) break;
         if (delta == 0.0) delta = (delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4;
         else delta *= (delta_last > 0.0) ? 8.0 : 100.0;
@@ -936,9 +949,9 @@ struct HsSolver {
         } else break;
       }
       double nu[NS];
-      solve_nu(so, mu, nu);
+      Core::solve_nu(so, mu, nu);
       FwdOut fo;
-      forward(w, o, p, mu, nu, so.term_pinned, fo);
+      Core::forward(w, o, p, mu, nu, so.term_pinned, fo);
       if (!(finite_(fo.gphi) && finite_(fo.alpha_p))) { res.status = 2; res.iters = it; return; }
       // l1 merit: penalty large enough to make dz a descent direction
       if (so.c1 > 0.0) {
@@ -947,7 +960,7 @@ struct HsSolver {
       }
       const double Dphi = fo.gphi - pen * so.c1;
       double f0, bar0, c10;
-      trial(w, o, p, 0.0, mu, f0, bar0, c10);
+      Core::trial(w, o, p, 0.0, mu, f0, bar0, c10);
       const double phi0 = f0 + bar0 + pen * c10;
       // non-monotone Armijo reference (Grippo-Lampariello-Lucidi): the largest of the last NM merit values of the
       // SAME merit function (history is dropped whenever mu or the penalty changes); cures Maratos-type stalls
@@ -959,10 +972,7 @@ struct HsSolver {
       bool ok = false;
       for (int ls = 0; ls < 40; ++ls) {
         double ft, bt, ct;
-#ifdef MYR_TRACE
-        { bool tk = trial(w, o, p, a, mu, ft, bt, ct); if (it >= 30 && it <= 32) printf("   it %d ls %d a=%.3g ok=%d | f %.8f->%.8f bar %.6f->%.6f c1 %.3e->%.3e  phi0=%.8f phiref=%.8f Dphi=%.3e\n", it, ls, a, (int)tk, f0, ft, bar0, bt, c10, ct, phi0, phiref, Dphi); }
-#endif
-        if (trial(w, o, p, a, mu, ft, bt, ct)) {
+        if (Core::trial(w, o, p, a, mu, ft, bt, ct)) {
           const double phit = ft + bt + pen * ct;
           if (phit <= phiref + 1e-8 * a * Dphi + 1e-13 * fabs(phi0)) { ok = true; break; }
         }
@@ -977,7 +987,7 @@ struct HsSolver {
 #ifdef MYR_TRACE
       printf("it %3d f=%.8f cinf=%.2e stat=%.2e comp=%.2e mu=%.1e a=%.3g amax=%.3g ad=%.3g nreg=%d pen=%.3g gphi=%.3g ok=%d\n", it, so.f, so.cinf, stat, comp, mu, a, fo.alpha_p, ad, so.nreg, pen, fo.gphi, (int)ok);
 #endif
-      update(w, n, a, ad, mu);
+      Core::update(w, n, a, ad, mu);
 #pragma unroll
       for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
       // re-centering: a run of tiny accepted steps means the iterate left the neighbourhood of the central path for
@@ -997,5 +1007,10 @@ struct HsSolver {
     res.status = 1; res.iters = o.max_iter;
   }
 };
+
+template <class Sys>
+MYR_HD void HsSolver<Sys>::solve(const HsWork& w, const HsSolveOpts& o, const double* p, HsSolveResult& res) {
+  IpLoop<HsSolver<Sys>>::run(w, o, p, res);
+}
 
 }  // namespace myriad

@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../myriad_amd/csrc/hs_solver.h"
 #include "../../myriad_amd/csrc/rollout.h"
+#include "../../myriad_amd/csrc/os_solver.h"
 
 using namespace myriad;
 
@@ -105,4 +106,54 @@ extern "C" double hostsim_rollout(int system_id, int method, int num_steps, doub
     case 3: RL(SysSIMPLECASE)
   }
   return NAN;
+}
+
+// generic batch driver for the one-step cores (trapezoid / shooting)
+template <class Core, class Sys>
+static void os_batch(const HsSolveOpts& o0, int n, int m, long nst, int B, double* z, const double* lb, const double* ub,
+                     const double* params, int pstride, double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt) {
+#pragma omp parallel for schedule(dynamic)
+  for (int b = 0; b < B; ++b) {
+    std::vector<double> zL(n), zU(n), dz(n), lbv(lb + (size_t)b * n, lb + (size_t)(b + 1) * n),
+        ubv(ub + (size_t)b * n, ub + (size_t)(b + 1) * n), st(nst);
+    double p[Sys::NP > 0 ? Sys::NP : 1];
+    if (params) for (int i = 0; i < Sys::NP; ++i) p[i] = params[(size_t)b * pstride + i];
+    else Sys::default_params(p);
+    HsWork w{{z + (size_t)b * n, 1}, {lbv.data(), 1}, {ubv.data(), 1}, {zL.data(), 1}, {zU.data(), 1},
+             {lam + (size_t)b * m, 1}, {dz.data(), 1}, {st.data(), 1}};
+    HsSolveResult r;
+    HsSolveOpts o = o0;
+    Core::solve(w, o, p, r);
+    cost[b] = r.cost; status[b] = r.status; iters[b] = r.iters;
+    if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
+  }
+}
+
+extern "C" int hostsim_solve_trap(int system_id, int N, double T, int B, double* z, const double* lb, const double* ub,
+                                  const double* params, int pstride, int max_iter, double* lam, double* cost,
+                                  int32_t* status, int32_t* iters, double* kkt) {
+  HsSolveOpts o{N, T / N, max_iter, 1e-8, 1e-6, 1e-7, 0.1};
+#define TR(S) os_batch<TrapCore<S>, S>(o, (N + 1) * S::NW, N * S::NS, TrapCore<S>::stage_doubles(N), B, z, lb, ub, params, pstride, lam, cost, status, iters, kkt)
+  switch (system_id) {
+    case 0: TR(SysCARTPOLE); return 0;
+    case 1: TR(SysVANDERPOL); return 0;
+    case 2: TR(SysCANCERTREATMENT); return 0;
+    case 3: TR(SysSIMPLECASE); return 0;
+  }
+  return -1;
+}
+
+extern "C" int hostsim_solve_shoot(int system_id, int I, int cpi, int method, double T, int B, double* z, const double* lb,
+                                   const double* ub, const double* params, int pstride, int max_iter, double* lam,
+                                   double* cost, int32_t* status, int32_t* iters, double* kkt) {
+  HsSolveOpts o{I, T / I, max_iter, 1e-8, 1e-6, 1e-7, 0.1};
+  o.cpi = cpi; o.method = method;
+#define SH(S) os_batch<ShootCore<S>, S>(o, (I + 1) * S::NS + (I * cpi + 1) * S::NU, I * S::NS, ShootCore<S>::stage_doubles(I, cpi), B, z, lb, ub, params, pstride, lam, cost, status, iters, kkt)
+  switch (system_id) {
+    case 0: SH(SysCARTPOLE); return 0;
+    case 1: SH(SysVANDERPOL); return 0;
+    case 2: SH(SysCANCERTREATMENT); return 0;
+    case 3: SH(SysSIMPLECASE); return 0;
+  }
+  return -1;
 }
