@@ -38,6 +38,9 @@ struct HsSolveOpts {
   int cpi = 1;             // controls per interval (shooting)
   int method = 1;          // integration method id (shooting): 0 Euler, 1 Heun, 2 midpoint, 3 RK4
   double kappa_mu = 0.2, theta_mu = 1.5, kappa_eps = 10.0;   // barrier update: mu <- max(mu_min, min(kappa_mu mu, mu^theta_mu)) when E_mu <= kappa_eps mu
+  int lm_abs = 1;
+  double kappa_sigma = 1e10;   // bound multipliers are kept within [mu/(kappa s), kappa mu/s] after each step
+  double tau_min = 0.99;   // fraction-to-the-boundary parameter: tau = max(tau_min, 1 - mu)
   int dual_follow = 0;     // 1: bound multipliers follow the primal backtracking factor (ablation knob)
   double lm_init = 3e-5;   // Levenberg-Marquardt damping seeded when the line search cuts a step to <= 1/4 (0 = off)
   int nonmono = 3;         // non-monotone Armijo memory (0 = monotone)
@@ -716,7 +719,7 @@ struct HsSolver {
                              const bool* term_pinned, FwdOut& fo) {
     const int N = o.N, K = 2 * N + 1;
     const double h = o.h;
-    const double tau = detail::dmax(0.99, 1.0 - mu);
+    const double tau = detail::dmax(o.tau_min, 1.0 - mu);
     fo.alpha_p = 1.0; fo.alpha_d = 1.0; fo.gphi = 0.0;
     double th[NC];
     th[0] = 1.0; th[1] = mu;
@@ -840,7 +843,7 @@ struct HsSolver {
   }
 
   // accept the step: z += a_p dz, zL += a_d dzL, zU += a_d dzU (with the usual safeguard on the bound multipliers)
-  MYR_HD static void update(const HsWork& w, int n, double ap, double ad, double mu) {
+  MYR_HD static void update(const HsWork& w, int n, double ap, double ad, double mu, double ksig = 1e10) {
     for (int i = 0; i < n; ++i) {
       const double l = w.lb[i], u = w.ub[i], zv = w.z[i], d = w.dz[i], zl = w.zL[i], zu = w.zU[i];
       const bool fr = l < u;
@@ -850,8 +853,8 @@ struct HsSolver {
       const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
       double vl = zl + ad * (-zl + (mu - zl * d) / sl);
       double vu = zu + ad * (-zu + (mu + zu * d) / su);
-      vl = detail::dmax(detail::dmin(vl, 1e10 * mu / snl), mu / (1e10 * snl));
-      vu = detail::dmax(detail::dmin(vu, 1e10 * mu / snu), mu / (1e10 * snu));
+      vl = detail::dmax(detail::dmin(vl, ksig * mu / snl), mu / (ksig * snl));
+      vu = detail::dmax(detail::dmin(vu, ksig * mu / snu), mu / (ksig * snu));
       w.z[i] = zn;
       w.zL[i] = hl ? vl : 0.0;
       w.zU[i] = hu ? vu : 0.0;
@@ -987,7 +990,7 @@ struct IpLoop {
 #ifdef MYR_TRACE
       printf("it %3d f=%.8f cinf=%.2e stat=%.2e comp=%.2e mu=%.1e a=%.3g amax=%.3g ad=%.3g nreg=%d pen=%.3g gphi=%.3g ok=%d\n", it, so.f, so.cinf, stat, comp, mu, a, fo.alpha_p, ad, so.nreg, pen, fo.gphi, (int)ok);
 #endif
-      Core::update(w, n, a, ad, mu);
+      Core::update(w, n, a, ad, mu, o.kappa_sigma);
 #pragma unroll
       for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
       // re-centering: a run of tiny accepted steps means the iterate left the neighbourhood of the central path for
@@ -995,7 +998,7 @@ struct IpLoop {
       // step-quality feedback: a step cut hard by the line search means the quadratic model over-reaches ->
       // damp the next Newton system (W + lm I); full steps relax the damping again
       if (o.lm_init > 0.0) {
-        const double ratio = a / fo.alpha_p;
+        const double ratio = o.lm_abs ? a : a / fo.alpha_p;   // step actually taken, relative to the full Newton step
         if (ratio <= 0.25) lm = dmin(1e2, dmax(o.lm_init, 4.0 * lm));
         else if (ratio >= 0.99) { lm *= 0.25; if (lm < 0.1 * o.lm_init) lm = 0.0; }
       }

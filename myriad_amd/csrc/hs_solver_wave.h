@@ -687,8 +687,8 @@ struct HsWave {
   }
 
   // ---- phase 10: lanes over points -- step limits and merit slope ------------------------------------------------
-  __device__ static void points_limits(Ctx& c, double mu, typename S::FwdOut& fo) {
-    const double tau = detail::dmax(0.99, 1.0 - mu);
+  __device__ static void points_limits(Ctx& c, const HsSolveOpts& o, double mu, typename S::FwdOut& fo) {
+    const double tau = detail::dmax(o.tau_min, 1.0 - mu);
     typename S::FwdOut l; l.alpha_p = 1.0; l.alpha_d = 1.0; l.gphi = 0.0;
     for (int j = c.lane; j < c.K; j += 64) {
       const double wj = S::wsimp(c.K, j, c.h);
@@ -745,7 +745,7 @@ struct HsWave {
     return detail::finite_(bar);
   }
 
-  __device__ static void update(Ctx& c, double ap, double ad, double mu) {
+  __device__ static void update(Ctx& c, double ap, double ad, double mu, double ksig) {
     for (int i = c.lane; i < c.n; i += 64) {
       const double l = c.lb[i], u = c.ub[i], zv = c.z[i], d = c.dz[i], zl = c.zL[i], zu = c.zU[i];
       const bool fr = l < u;
@@ -755,8 +755,8 @@ struct HsWave {
       const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
       double vl = zl + ad * (-zl + (mu - zl * d) / sl);
       double vu = zu + ad * (-zu + (mu + zu * d) / su);
-      vl = detail::dmax(detail::dmin(vl, 1e10 * mu / snl), mu / (1e10 * snl));
-      vu = detail::dmax(detail::dmin(vu, 1e10 * mu / snu), mu / (1e10 * snu));
+      vl = detail::dmax(detail::dmin(vl, ksig * mu / snl), mu / (ksig * snl));
+      vu = detail::dmax(detail::dmin(vu, ksig * mu / snu), mu / (ksig * snu));
       c.z[i] = zn; c.zL[i] = hl ? vl : 0.0; c.zU[i] = hu ? vu : 0.0;
     }
   }
@@ -855,7 +855,7 @@ struct HsWave {
       intervals_dz(c);
       __syncthreads();
       typename S::FwdOut fo;
-      points_limits(c, mu, fo);
+      points_limits(c, o, mu, fo);
       if (!(finite_(fo.gphi) && finite_(fo.alpha_p))) { res.status = 2; res.iters = it; return; }
       if (c1 > 0.0) {
         const double need = fo.gphi / (0.9 * c1);
@@ -883,11 +883,11 @@ struct HsWave {
       if (!ok) {
         if (++stall > 5) { res.status = 3; res.iters = it; return; }
       } else stall = 0;
-      update(c, a, o.dual_follow ? fo.alpha_d * (a / fo.alpha_p) : fo.alpha_d, mu);
+      update(c, a, o.dual_follow ? fo.alpha_d * (a / fo.alpha_p) : fo.alpha_d, mu, o.kappa_sigma);
 #pragma unroll
       for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
       if (o.lm_init > 0.0) {     // step-quality feedback -> Levenberg-Marquardt damping (see hs_solver.h)
-        const double ratio = a / fo.alpha_p;
+        const double ratio = o.lm_abs ? a : a / fo.alpha_p;   // step actually taken, relative to the full Newton step
         if (ratio <= 0.25) lm = dmin(1e2, dmax(o.lm_init, 4.0 * lm));
         else if (ratio >= 0.99) { lm *= 0.25; if (lm < 0.1 * o.lm_init) lm = 0.0; }
       }

@@ -11,6 +11,7 @@
 #include "hs_eval.h"
 #include "hs_solver.h"
 #include "hs_solver_wave.h"
+#include "os_solver.h"
 #include "rollout.h"
 #include "systems_gen.h"
 
@@ -308,9 +309,9 @@ __global__ __launch_bounds__(256) void transpose_back_kernel(const double* __res
 
 // One trajectory per lane; every per-trajectory array is batch-minor (element i of trajectory b at a[i*Bp + b]),
 // so the 64 lanes of a wavefront always touch 64 consecutive doubles (one 512-byte coalesced access).
-template <class Sys>
+template <class Core, class Sys>
 __global__ __launch_bounds__(64, 1)
-void hs_solve_kernel(int B, long Bp, int lanes_per_wave, HsSolveOpts o, double* z, double* lb, double* ub, double* zL, double* zU,
+void lane_solve_kernel(int B, long Bp, int lanes_per_wave, HsSolveOpts o, double* z, double* lb, double* ub, double* zL, double* zU,
                      double* lam, double* dz, double* st, const double* __restrict__ params, int params_stride,
                      double* cost, int32_t* status, int32_t* iters, double* kkt) {
   // The kernel is latency-bound (long dependent fp64 chains, one wave per SIMD at best), so a wavefront may be
@@ -328,7 +329,7 @@ void hs_solve_kernel(int B, long Bp, int lanes_per_wave, HsSolveOpts o, double* 
   }
   HsWork w{{z + b, Bp}, {lb + b, Bp}, {ub + b, Bp}, {zL + b, Bp}, {zU + b, Bp}, {lam + b, Bp}, {dz + b, Bp}, {st + b, Bp}};
   HsSolveResult r;
-  HsSolver<Sys>::solve(w, o, p, r);
+  Core::solve(w, o, p, r);
   if (cost) cost[b] = r.cost;
   if (status) status[b] = r.status;
   if (iters) iters[b] = r.iters;
@@ -339,12 +340,18 @@ static HsSolveOpts make_opts(myr_handle h, const myr_solve_opts& so) {
   HsSolveOpts o;
   o.N = h->d.intervals; o.h = h->d.T / h->d.intervals; o.max_iter = so.max_iter; o.tol_feas = so.tol_feas;
   o.tol_stat = so.tol_stat; o.tol_compl = so.tol_compl; o.mu_init = so.mu_init;
+  o.cpi = h->d.controls_per_interval; o.method = h->d.integration_method;
   if (const char* e = getenv("MYRIAD_NONMONO")) o.nonmono = atoi(e);      // developer knobs (globalisation ablations)
   if (const char* e = getenv("MYRIAD_RECENTER")) o.recenter = atoi(e);
   if (o.nonmono < 0) o.nonmono = 0;
   if (o.nonmono > 8) o.nonmono = 8;
   return o;
 }
+
+template <class Core, class Sys>
+static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const double* lb, const double* ub, const double* params,
+                             int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
+                             int32_t* iters, double* kkt);
 
 template <class Sys>
 static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
@@ -381,11 +388,20 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     kt.launches += 1;
     return MYR_OK;
   }
+  return launch_lane_solve<HsSolver<Sys>, Sys>(h, B, HsSol<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+}
+
+// lane-per-trajectory path, any sweep core (Hermite-Simpson, trapezoidal, shooting)
+template <class Core, class Sys>
+static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const double* lb, const double* ub, const double* params,
+                             int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
+                             int32_t* iters, double* kkt) {
+  const myr_dims& dm = h->dims;
   // batch-minor leading dimension: a multiple of 64 lanes, but an ODD multiple so that consecutive elements of a
   // trajectory (stride Bp*8 bytes) rotate over HBM channels / L2 sets instead of camping on one (power-of-two stride)
   long Bp = ((long)B + 63) / 64 * 64;
   if (((Bp / 64) & 1) == 0) Bp += 64;
-  const long n = dm.n, m = dm.m, nst = HsSol<Sys>::stage_doubles(N);
+  const long n = dm.n, m = dm.m;
   const size_t need = (size_t)Bp * (size_t)(6 * n + m + nst) * 8;
   if (need > h->sbuf_bytes) {
     if (h->sbuf) HIPCHK(hipFree(h->sbuf));
@@ -411,7 +427,7 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   KTimer& kt = h->kt[MYR_K_SOLVE];
   HIPCHK(hipEventRecord(kt.a, h->stream));
   const int lpw = h->solve_lpw;
-  hipLaunchKernelGGL(hs_solve_kernel<Sys>, dim3((unsigned)((B + lpw - 1) / lpw)), dim3(64), 0, h->stream, B, Bp, lpw, o, sz, slb, sub, szL,
+  hipLaunchKernelGGL((lane_solve_kernel<Core, Sys>), dim3((unsigned)((B + lpw - 1) / lpw)), dim3(64), 0, h->stream, B, Bp, lpw, o, sz, slb, sub, szL,
                      szU, slam, sdz, sst, params, pstride, cost, status, iters, kkt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
@@ -429,14 +445,32 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   return MYR_OK;
 }
 
+template <class Sys>
+static int solve_for_system(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
+                            int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
+                            int32_t* iters, double* kkt) {
+  const int N = h->d.intervals, cpi = h->d.controls_per_interval;
+  switch (h->d.transcription) {
+    case MYR_TR_HERMITE_SIMPSON:
+      return launch_hs_solve<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_TR_TRAPEZOIDAL:
+      return launch_lane_solve<TrapCore<Sys>, Sys>(h, B, TrapCore<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_TR_SHOOTING:
+      if (h->d.integration_method != MYR_INT_EULER && h->d.integration_method != MYR_INT_HEUN)
+        return fail(MYR_E_UNSUPPORTED, "myr_solve: shooting solve is built for EULER and HEUN steps (RK4 / MIDPOINT: rollout only)");
+      return launch_lane_solve<ShootCore<Sys>, Sys>(h, B, ShootCore<Sys>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  }
+  return fail(MYR_E_ARG, "solve: unknown transcription");
+}
+
 static int dispatch_solve(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                           int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                           int32_t* iters, double* kkt) {
   switch (h->d.system_id) {
-    case MYR_SYS_CARTPOLE: return launch_hs_solve<SysCARTPOLE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-    case MYR_SYS_VANDERPOL: return launch_hs_solve<SysVANDERPOL>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-    case MYR_SYS_CANCERTREATMENT: return launch_hs_solve<SysCANCERTREATMENT>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-    case MYR_SYS_SIMPLECASE: return launch_hs_solve<SysSIMPLECASE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_SYS_CARTPOLE: return solve_for_system<SysCARTPOLE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_SYS_VANDERPOL: return solve_for_system<SysVANDERPOL>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_SYS_CANCERTREATMENT: return solve_for_system<SysCANCERTREATMENT>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_SYS_SIMPLECASE: return solve_for_system<SysSIMPLECASE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   return fail(MYR_E_ARG, "solve: unknown system");
 }
@@ -449,7 +483,6 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
   if (B == 0) return MYR_OK;
   if (params && params_stride != 0 && params_stride != h->dims.np)
     return fail(MYR_E_ARG, "myr_solve: params_stride must be 0 (shared) or np");
-  if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "myr_solve: transcription not built");
   myr_solve_opts so;
   if (opts) so = *opts; else myr_default_solve_opts(&so);
   if (so.max_iter < 0 || !(so.tol_feas > 0) || !(so.tol_stat > 0) || !(so.tol_compl > 0) || !(so.mu_init > 0))

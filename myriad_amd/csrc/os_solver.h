@@ -188,7 +188,7 @@ struct TrapCore {
     }
   }
   MYR_HD static void init(const HsWork& w, int n) { H::init(w, n); }
-  MYR_HD static void update(const HsWork& w, int n, double ap, double ad, double mu) { H::update(w, n, ap, ad, mu); }
+  MYR_HD static void update(const HsWork& w, int n, double ap, double ad, double mu, double ksig) { H::update(w, n, ap, ad, mu, ksig); }
   MYR_HD static void solve_nu(const SweepOut& so, double mu, double* nu) { H::solve_nu(so, mu, nu); }
 
   MYR_HD static void backward(const HsWork& w, const HsSolveOpts& o, const double* p, const double* nuT, double delta, SweepOut& so) {
@@ -346,7 +346,7 @@ struct TrapCore {
                              const bool* term_pinned, FwdOut& fo) {
     const int N = o.N, Kp = N + 1;
     const double h = o.h;
-    const double tau = detail::dmax(0.99, 1.0 - mu);
+    const double tau = detail::dmax(o.tau_min, 1.0 - mu);
     fo.alpha_p = 1.0; fo.alpha_d = 1.0; fo.gphi = 0.0;
     double th[NC];
     th[0] = 1.0; th[1] = mu;
@@ -466,7 +466,7 @@ struct ShootCore {
   MYR_HD static inline double hstep(const HsSolveOpts& o) { return o.h / o.cpi; }                          // o.h = T / intervals
 
   MYR_HD static void init(const HsWork& w, int n) { H::init(w, n); }
-  MYR_HD static void update(const HsWork& w, int n, double ap, double ad, double mu) { H::update(w, n, ap, ad, mu); }
+  MYR_HD static void update(const HsWork& w, int n, double ap, double ad, double mu, double ksig) { H::update(w, n, ap, ad, mu, ksig); }
   MYR_HD static void solve_nu(const SweepOut& so, double mu, double* nu) { H::solve_nu(so, mu, nu); }
 
   // one integration step of [x; integral of g]  (utils.py:41-44 Heun, :52-54 Euler), plain values
@@ -761,7 +761,7 @@ struct ShootCore {
                              const bool* term_pinned, FwdOut& fo) {
     (void)p;
     const int I = o.N, cpi = o.cpi, S = I * cpi;
-    const double tau = detail::dmax(0.99, 1.0 - mu);
+    const double tau = detail::dmax(o.tau_min, 1.0 - mu);
     fo.alpha_p = 1.0; fo.alpha_d = 1.0; fo.gphi = 0.0;
     double th[NC];
     th[0] = 1.0; th[1] = mu;

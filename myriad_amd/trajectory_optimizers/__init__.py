@@ -135,11 +135,51 @@ class TrajectoryOptimizer(object):
     from myriad_amd.nlp_solvers import solve
     return solve(self.hp, self.cfg, self._opt_inputs(params, guess))
 
-  def solve_batch(self, x0s=None, params=None, guess=None, max_iter=None) -> Dict[str, np.ndarray]:
-    """EXTENSION: B independent instances (random x0 and/or parameter sweeps) in one device call.
-    x0s [B,ns] replaces x_0 per instance (bounds row 0 and the reference's guess rule); params [B,np]."""
+  def batch_inputs(self, x0s, params=None):
+    """Per-instance (z0, lb, ub) for start states x0s [B,ns], by the reference's own guess / bounds rules."""
     raise NotImplementedError
 
+  def solve_batch(self, x0s=None, params=None, guess=None, max_iter=None) -> Dict[str, np.ndarray]:
+    """EXTENSION (the reference solves one instance per call): B independent instances -- random x0 and/or parameter
+    sweeps -- in one device call.  x0s [B,ns] replaces x_0 per instance (bounds row 0 and the guess rule);
+    params [B,np] are per-instance model parameters in device order (system.param_names)."""
+    eng = self.engine
+    if x0s is None:
+      B = 1 if params is None or np.ndim(params) == 1 else np.shape(params)[0]
+      x0s = np.tile(self.system.x_0, (B, 1))
+    x0s = np.asarray(x0s, dtype=np.float64)
+    p = self.system.device_params() if params is None else np.asarray(params, dtype=np.float64)
+    z0, lb, ub = self.batch_inputs(x0s, p)
+    if guess is not None:
+      z0 = np.broadcast_to(np.asarray(guess, dtype=np.float64), z0.shape).copy()
+    o = eng.default_opts()
+    o.max_iter = self.hp.max_iter if max_iter is None else max_iter
+    res = eng.solve(z0, lb, ub, params=p, opts=o)
+    x, u = self.unravel(res["z"])
+    return {'x': x, 'u': u, 'xs_and_us': res["z"], 'cost': res["cost"], 'lambda': res["lam"],
+            'status': res["status"], 'iters': res["iters"], 'kkt': res["kkt"]}
+
+  def _batch_bounds(self, x0s):
+    B, ns = x0s.shape
+    lb = np.tile(self.bounds[:, 0], (B, 1)); ub = np.tile(self.bounds[:, 1], (B, 1))
+    lb[:, :ns] = x0s; ub[:, :ns] = x0s
+    return lb, ub
+
+  def _batch_state_guess(self, x0s, p, rows, controls_rows):
+    """shooting.py:56-74 / trapezoidal.py:36-50 per instance: linspace(x0, x_T) where x_T is given, otherwise a coarse
+    rollout with zero controls -- done for the whole batch by the rollout kernel."""
+    B, ns = x0s.shape
+    xT = self.system.x_T
+    if xT is not None and all(v is not None for v in xT):
+      lin = np.linspace(0.0, 1.0, rows)[None, :, None]
+      return x0s[:, None, :] * (1 - lin) + np.asarray(xT, dtype=np.float64)[None, None, :] * lin
+    nu = self.u_guess.shape[1]
+    xs, _ = self.engine.rollout(x0s, np.zeros((B, controls_rows, nu)), rows - 1, params=p)
+    if xT is not None:
+      for i, v in enumerate(xT):
+        if v is not None:
+          xs[:, :, i] = x0s[:, i, None] + (v - x0s[:, i, None]) * np.linspace(0.0, 1.0, rows)[None, :]
+    return xs
 
 class HermiteSimpsonCollocationOptimizer(TrajectoryOptimizer):
   """collocation/hermite_simpson.py:16-81 (guess :37-48, bounds :55-81)."""
@@ -153,8 +193,8 @@ class HermiteSimpsonCollocationOptimizer(TrajectoryOptimizer):
     xb, ub = _state_control_bounds(system, K, K)
     super().__init__(hp, cfg, system, "HERMITE_SIMPSON", x_guess, u_guess, xb, ub)
 
-  def batch_inputs(self, x0s):
-    """Per-instance guess and bounds for start states x0s [B,ns] (hermite_simpson.py:41,59 applied per instance)."""
+  def batch_inputs(self, x0s, params=None):
+    """hermite_simpson.py:41,59 applied per instance."""
     x0s = np.asarray(x0s, dtype=np.float64)
     B, K = x0s.shape[0], 2 * self.hp.intervals + 1
     ns = x0s.shape[1]
@@ -164,25 +204,8 @@ class HermiteSimpsonCollocationOptimizer(TrajectoryOptimizer):
     else:
       xs = np.ones((B, K, ns)) * 0.1
     z0 = np.concatenate([xs.reshape(B, -1), np.zeros((B, self.u_guess.size))], axis=1)
-    lb = np.tile(self.bounds[:, 0], (B, 1)); ub = np.tile(self.bounds[:, 1], (B, 1))
-    lb[:, :ns] = x0s; ub[:, :ns] = x0s
+    lb, ub = self._batch_bounds(x0s)
     return z0, lb, ub
-
-  def solve_batch(self, x0s=None, params=None, guess=None, max_iter=None):
-    eng = self.engine
-    if x0s is None:
-      B = 1 if params is None or np.ndim(params) == 1 else np.shape(params)[0]
-      x0s = np.tile(self.system.x_0, (B, 1))
-    z0, lb, ub = self.batch_inputs(x0s)
-    if guess is not None:
-      z0 = np.broadcast_to(np.asarray(guess, dtype=np.float64), z0.shape).copy()
-    o = eng.default_opts()
-    o.max_iter = self.hp.max_iter if max_iter is None else max_iter
-    p = self.system.device_params() if params is None else np.asarray(params, dtype=np.float64)
-    res = eng.solve(z0, lb, ub, params=p, opts=o)
-    x, u = self.unravel(res["z"])
-    return {'x': x, 'u': u, 'xs_and_us': res["z"], 'cost': res["cost"], 'lambda': res["lam"],
-            'status': res["status"], 'iters': res["iters"], 'kkt': res["kkt"]}
 
 
 class TrapezoidalCollocationOptimizer(TrajectoryOptimizer):
@@ -198,6 +221,13 @@ class TrapezoidalCollocationOptimizer(TrajectoryOptimizer):
     xb, ub = _state_control_bounds(system, N + 1, N + 1, trap_quirk=True)
     super().__init__(hp, cfg, system, "TRAPEZOIDAL", x_guess, u_guess, xb, ub)
 
+  def batch_inputs(self, x0s, params=None):
+    N = self.hp.intervals
+    xs = self._batch_state_guess(x0s, params, N + 1, N + 1)
+    z0 = np.concatenate([xs.reshape(x0s.shape[0], -1), np.zeros((x0s.shape[0], self.u_guess.size))], axis=1)
+    lb, ub = self._batch_bounds(x0s)
+    return z0, lb, ub
+
 
 class MultipleShootingOptimizer(TrajectoryOptimizer):
   """shooting.py:16-77,247-275 (host part; device kernels for this transcription: next round)."""
@@ -212,6 +242,28 @@ class MultipleShootingOptimizer(TrajectoryOptimizer):
     assert len(x_guess) == I + 1
     xb, ub = _state_control_bounds(system, I + 1, mc * I * cpi + 1)
     super().__init__(hp, cfg, system, "SHOOTING", x_guess, u_guess, xb, ub)
+    self._mc = mc
+
+  def batch_inputs(self, x0s, params=None):
+    I = self.hp.intervals
+    if self.system.x_T is not None and all(v is not None for v in self.system.x_T):
+      xs = self._batch_state_guess(x0s, params, I + 1, I + 1)
+    else:
+      # coarse rollout: `intervals` steps of size T/intervals under zero controls (shooting.py:66-74); needs an engine whose
+      # step count is `intervals`, i.e. controls_per_interval = 1
+      from myriad_amd import _lib
+      eng = _lib.Engine(self.system.name, "SHOOTING", I, self.system.T, controls_per_interval=1,
+                        integration_method=self.hp.integration_method.name)
+      B = x0s.shape[0]
+      xs, _ = eng.rollout(x0s, np.zeros((B, self._mc * I + 1, self.u_guess.shape[1])), I, params=params)
+      eng.close()
+      if self.system.x_T is not None:
+        for i, v in enumerate(self.system.x_T):
+          if v is not None:
+            xs[:, :, i] = x0s[:, i, None] + (v - x0s[:, i, None]) * np.linspace(0.0, 1.0, I + 1)[None, :]
+    z0 = np.concatenate([xs.reshape(x0s.shape[0], -1), np.zeros((x0s.shape[0], self.u_guess.size))], axis=1)
+    lb, ub = self._batch_bounds(x0s)
+    return z0, lb, ub
 
 
 def get_optimizer(hp: HParams, cfg: Config, system):

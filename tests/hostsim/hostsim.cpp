@@ -24,6 +24,9 @@ static void solve_batch(int N, double T, int B, double* z, const double* lb, con
   if (getenv("NONM")) o.nonmono = atoi(getenv("NONM"));
   if (getenv("DUALF")) o.dual_follow = atoi(getenv("DUALF"));
   if (getenv("LM")) o.lm_init = atof(getenv("LM"));
+  if (getenv("TAU")) o.tau_min = atof(getenv("TAU"));
+  if (getenv("LMABS")) o.lm_abs = atoi(getenv("LMABS"));
+  if (getenv("KSIG")) o.kappa_sigma = atof(getenv("KSIG"));
   if (getenv("KMU")) o.kappa_mu = atof(getenv("KMU"));
   if (getenv("TMU")) o.theta_mu = atof(getenv("TMU"));
   if (getenv("KEPS")) o.kappa_eps = atof(getenv("KEPS"));
@@ -123,6 +126,11 @@ static void os_batch(const HsSolveOpts& o0, int n, int m, long nst, int B, doubl
              {lam + (size_t)b * m, 1}, {dz.data(), 1}, {st.data(), 1}};
     HsSolveResult r;
     HsSolveOpts o = o0;
+    if (getenv("TAU")) o.tau_min = atof(getenv("TAU"));
+    if (getenv("LMABS")) o.lm_abs = atoi(getenv("LMABS"));
+    if (getenv("KSIG")) o.kappa_sigma = atof(getenv("KSIG"));
+    if (getenv("MU0")) o.mu_init = atof(getenv("MU0"));
+    if (getenv("LM")) o.lm_init = atof(getenv("LM"));
     Core::solve(w, o, p, r);
     cost[b] = r.cost; status[b] = r.status; iters[b] = r.iters;
     if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
