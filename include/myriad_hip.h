@@ -100,6 +100,11 @@ void myr_default_solve_opts(myr_solve_opts* o);
  *                           then              Ixs,Ixe (ns x ns), Ius,Iue (ns x nu)           [interp rows];
  *                           the identity d interp / d x_m is implied and not stored
  *                           (jblk = N*(5 ns^2 + 5 ns nu)).
+ *                           TRAPEZOIDAL: per interval  Cxs = h/2 A_s + I, Cxe = h/2 A_e - I (ns x ns),
+ *                           Cus = h/2 B_s, Cue = h/2 B_e (ns x nu)   (jblk = N*(2 ns^2 + 2 ns nu)).
+ *                           SHOOTING (EULER/HEUN): per interval  Jx = d c_k/d x_k (ns x ns), then
+ *                           Ju = d c_k / d u_{k cpi .. (k+1) cpi} (ns x (cpi+1) nu); d c_k/d x_{k+1} = -I implied;
+ *                           gradf is the full gradient (ngrad = n).
  * Any output pointer may be NULL to skip it.
  */
 int myr_eval(myr_handle h, int32_t B, const double* z, const double* params, int32_t params_stride,

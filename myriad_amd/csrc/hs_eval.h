@@ -19,7 +19,9 @@
 
 namespace myriad {
 
-template <class Sys>
+enum { EVAL_HS = 0, EVAL_TRAP = 1 };
+
+template <class Sys, int SCHEME = EVAL_HS>
 struct HsLayout {
   static constexpr int NS = Sys::NS, NU = Sys::NU, NW = Sys::NW;
   // per-point LDS record: x | f | A | B ; padded to an odd number of doubles (bank-conflict-free b64 access)
@@ -27,7 +29,10 @@ struct HsLayout {
   static constexpr int REC_RAW = 2 * NS + NS * NS + NS * NU;
   static constexpr int REC = (REC_RAW % 2 == 0) ? REC_RAW + 1 : REC_RAW;
   // per-interval Jacobian stencil: Dxs,Dxm,Dxe,Dus,Dum,Due,Ixs,Ixe,Ius,Iue
-  static constexpr int JPI = 5 * NS * NS + 5 * NS * NU;
+  // trapezoidal: Cxs = h/2 A_s + I, Cxe = h/2 A_e - I (ns x ns), Cus = h/2 B_s, Cue = h/2 B_e (ns x nu)
+  static constexpr int JPI = SCHEME == EVAL_HS ? 5 * NS * NS + 5 * NS * NU : 2 * NS * NS + 2 * NS * NU;
+  static constexpr int PPI = SCHEME == EVAL_HS ? 2 : 1;      // points advanced per interval
+  static constexpr int CPI = SCHEME == EVAL_HS ? 2 : 1;      // constraint blocks (of ns rows) per interval
   static constexpr int NGRAD_PER_PT = Sys::COST_DEP_X ? NW : NU;
 };
 
@@ -39,11 +44,27 @@ struct HsStencil {   // out = coef * rec[2k*REC + off] + ident
 };
 
 // Fill the per-interval stencil table (JPI entries) -- same for every interval and instance.
-template <class Sys>
+template <class Sys, int SCHEME>
 __device__ inline void hs_build_stencil(HsStencil* tab, double h, int tid, int nthreads) {
-  using L = HsLayout<Sys>;
+  using L = HsLayout<Sys, SCHEME>;
   constexpr int NS = L::NS, NU = L::NU, REC = L::REC;
   const double h6 = h / 6.0, h8 = h / 8.0;
+  if (SCHEME == EVAL_TRAP) {
+    const double hh = 0.5 * h;
+    for (int r = tid; r < L::JPI; r += nthreads) {
+      int q = r, blk, row, col; bool isx;
+      if (q < 2 * NS * NS) { blk = q / (NS * NS); q %= NS * NS; row = q / NS; col = q % NS; isx = true; }
+      else { q -= 2 * NS * NS; blk = 2 + q / (NS * NU); q %= NS * NU; row = q / NU; col = q % NU; isx = false; }
+      HsStencil s;
+      s.coef = hh;
+      s.ident = (blk == 0 && row == col) ? 1.0 : ((blk == 1 && row == col) ? -1.0 : 0.0);   // trapezoidal.py:161-163
+      const int pt = (blk == 0 || blk == 2) ? 0 : 1;
+      s.off = pt * REC + (isx ? (L::OFF_A + row * NS + col) : (L::OFF_B + row * NU + col));
+      s.pad = 0;
+      tab[r] = s;
+    }
+    return;
+  }
   for (int r = tid; r < L::JPI; r += nthreads) {
     // decode block
     int q = r;
@@ -77,16 +98,16 @@ __device__ inline void hs_build_stencil(HsStencil* tab, double h, int tid, int n
 
 // grid.x = B (one trajectory per workgroup), block = 64*WPT threads.
 // dynamic LDS: K*REC doubles + JPI stencil entries + reduction scratch.
-template <class Sys, int WPT, bool NTS = false>
+template <class Sys, int WPT, bool NTS = false, int SCHEME = EVAL_HS>
 __global__ __launch_bounds__(64 * WPT)
 void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double* __restrict__ params,
                     int params_stride, double* __restrict__ fout, double* __restrict__ gout,
                     double* __restrict__ cout, double* __restrict__ jout) {
-  using L = HsLayout<Sys>;
-  constexpr int NS = L::NS, NU = L::NU, NW = L::NW, REC = L::REC, JPI = L::JPI;
+  using L = HsLayout<Sys, SCHEME>;
+  constexpr int NS = L::NS, NU = L::NU, NW = L::NW, REC = L::REC, JPI = L::JPI, PPI = L::PPI;
   constexpr int NT = 64 * WPT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int K = 2 * N + 1;
+  const int K = PPI * N + 1;
   const int n = K * NW;
   double* rec = reinterpret_cast<double*>(smem_raw);                       // K*REC
   HsStencil* tab = reinterpret_cast<HsStencil*>(rec + ((K * REC + 1) & ~1));  // JPI entries, 16-B aligned
@@ -103,7 +124,7 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
     Sys::default_params(p);
   }
 
-  hs_build_stencil<Sys>(tab, h, tid, NT);
+  hs_build_stencil<Sys, SCHEME>(tab, h, tid, NT);
 
   // ---- phase 1: per-point dynamics, Jacobians, cost ----
   const double h6 = h / 6.0;
@@ -123,7 +144,8 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
 #pragma unroll
     for (int i = 0; i < NS * NU; ++i) r[L::OFF_B + i] = Bm[i];
     // Simpson weight of point j in  sum_k h/6 (g_s + 4 g_m + g_e)   (hermite_simpson.py:212-214)
-    const double w = (j & 1) ? 4.0 * h6 : ((j == 0 || j == K - 1) ? h6 : 2.0 * h6);
+    const double w = SCHEME == EVAL_HS ? ((j & 1) ? 4.0 * h6 : ((j == 0 || j == K - 1) ? h6 : 2.0 * h6))
+                                       : ((j == 0 || j == K - 1) ? 0.5 * h : h);      // trapezoidal.py:80-94
     facc += w * g;
     if (gout) {
       double* gb = gout + b * (long)(K * L::NGRAD_PER_PT);
@@ -152,19 +174,27 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
 
   // ---- phase 2a: constraints  c = [defects (interval-major, state-minor) ; interpolation residuals] ----
   if (cout) {
-    double* cb = cout + b * (long)(2 * N * NS);
+    double* cb = cout + b * (long)(L::CPI * N * NS);
     const double h8 = h / 8.0;
     const int half = N * NS;
-    for (int e = tid; e < 2 * half; e += NT) {
+    for (int e = tid; e < L::CPI * half; e += NT) {
       const int isint = e >= half;
       const int q = isint ? e - half : e;
       const int k = q / NS, i = q - k * NS;
-      const double* rs = rec + (2 * k) * REC;
-      const double xs = rs[L::OFF_X + i], xm = rs[REC + L::OFF_X + i], xe = rs[2 * REC + L::OFF_X + i];
-      const double fs = rs[L::OFF_F + i], fm = rs[REC + L::OFF_F + i], fe = rs[2 * REC + L::OFF_F + i];
-      const double d = (xe - xs) - h6 * (fs + 4.0 * fm + fe);               // hermite_simpson.py:124-128
-      const double it = xm - 0.5 * (xs + xe) - h8 * (fs - fe);              // hermite_simpson.py:167-170
-      if (NTS) __builtin_nontemporal_store(isint ? it : d, &cb[e]); else cb[e] = isint ? it : d;
+      const double* rs = rec + (PPI * k) * REC;
+      double val;
+      if (SCHEME == EVAL_HS) {
+        const double xs = rs[L::OFF_X + i], xm = rs[REC + L::OFF_X + i], xe = rs[2 * REC + L::OFF_X + i];
+        const double fs = rs[L::OFF_F + i], fm = rs[REC + L::OFF_F + i], fe = rs[2 * REC + L::OFF_F + i];
+        const double d = (xe - xs) - h6 * (fs + 4.0 * fm + fe);               // hermite_simpson.py:124-128
+        const double it = xm - 0.5 * (xs + xe) - h8 * (fs - fe);              // hermite_simpson.py:167-170
+        val = isint ? it : d;
+      } else {
+        const double xs = rs[L::OFF_X + i], xe = rs[REC + L::OFF_X + i];
+        const double fs = rs[L::OFF_F + i], fe = rs[REC + L::OFF_F + i];
+        val = 0.5 * h * (fs + fe) - (xe - xs);                                // trapezoidal.py:161-163
+      }
+      if (NTS) __builtin_nontemporal_store(val, &cb[e]); else cb[e] = val;
     }
   }
 
@@ -176,7 +206,7 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
       for (int e2 = tid; e2 < npairs; e2 += NT) {
         const int e = e2 << 1;
         const int k = e / JPI, r = e - k * JPI;                               // r even, r+1 < JPI
-        const double* rk = rec + (2 * k) * REC;
+        const double* rk = rec + (PPI * k) * REC;
         const HsStencil s0 = tab[r], s1 = tab[r + 1];
         double2 v;
         v.x = fma(s0.coef, rk[s0.off], s0.ident);
@@ -192,16 +222,16 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
       for (int e = tid; e < N * JPI; e += NT) {
         const int k = e / JPI, r = e - k * JPI;
         const HsStencil s0 = tab[r];
-        jb[e] = fma(s0.coef, rec[(2 * k) * REC + s0.off], s0.ident);
+        jb[e] = fma(s0.coef, rec[(PPI * k) * REC + s0.off], s0.ident);
       }
     }
   }
 }
 
-template <class Sys>
+template <class Sys, int SCHEME = EVAL_HS>
 inline size_t hs_eval_lds_bytes(int N, int wpt) {
-  using L = HsLayout<Sys>;
-  const int K = 2 * N + 1;
+  using L = HsLayout<Sys, SCHEME>;
+  const int K = L::PPI * N + 1;
   return (size_t)((K * L::REC + 1) & ~1) * 8 + (size_t)L::JPI * sizeof(HsStencil) + (size_t)wpt * 8 + 16;
 }
 

@@ -12,6 +12,7 @@
 #include "hs_solver.h"
 #include "hs_solver_wave.h"
 #include "os_solver.h"
+#include "shoot_eval.h"
 #include "rollout.h"
 #include "systems_gen.h"
 
@@ -106,10 +107,12 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
       dm.ngrad = si.cost_dep_x ? dm.n : K * si.nu;
       break;
     }
-    case MYR_TR_TRAPEZOIDAL: {   // sizes only (rollout works; eval/solve kernels for this transcription: next round)
+    case MYR_TR_TRAPEZOIDAL: {
       dm.x_rows = N + 1; dm.u_rows = N + 1;
       dm.n = (N + 1) * (si.ns + si.nu);
       dm.m = N * si.ns;
+      dm.jblk = N * (2 * si.ns * si.ns + 2 * si.ns * si.nu);
+      dm.ngrad = si.cost_dep_x ? dm.n : (N + 1) * si.nu;
       break;
     }
     case MYR_TR_SHOOTING: {
@@ -117,6 +120,8 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
       dm.x_rows = N + 1; dm.u_rows = mc * N * desc->controls_per_interval + 1;
       dm.n = dm.x_rows * si.ns + dm.u_rows * si.nu;
       dm.m = N * si.ns;
+      dm.jblk = N * (si.ns * si.ns + si.ns * (desc->controls_per_interval + 1) * si.nu);   // EULER / HEUN layout
+      dm.ngrad = dm.n;
       break;
     }
     default:
@@ -183,19 +188,19 @@ extern "C" int myr_kernel_time_reset(myr_handle h) {
 // ------------------------------------------------------------------------------------------------
 // eval
 // ------------------------------------------------------------------------------------------------
-template <class Sys>
+template <class Sys, int SCHEME>
 static int launch_hs_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
                           double* f, double* g, double* c, double* j) {
   const int N = h->d.intervals;
   const double hstep = h->d.T / N;
   const int wpt = h->eval_wpt;
-  const size_t lds = hs_eval_lds_bytes<Sys>(N, wpt);
+  const size_t lds = hs_eval_lds_bytes<Sys, SCHEME>(N, wpt);
   if (lds > 160 * 1024) return fail(MYR_E_CAPACITY, "hs_eval: intervals too large for the 160 KiB LDS record");
   KTimer& kt = h->kt[MYR_K_EVAL];
   HIPCHK(hipEventRecord(kt.a, h->stream));
 #define MYR_EVAL_LAUNCH(W, NTV)                                                                                   \
   {                                                                                                               \
-    auto kern = hs_eval_kernel<Sys, W, NTV>;                                                                      \
+    auto kern = hs_eval_kernel<Sys, W, NTV, SCHEME>;                                                                   \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(kern, dim3(B), dim3(64 * W), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);    \
   }
@@ -217,13 +222,51 @@ static int launch_hs_eval(myr_handle h, int B, const double* z, const double* pa
   return MYR_OK;
 }
 
+template <class Sys>
+static int launch_shoot_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
+                             double* f, double* g, double* c, double* j) {
+  const int I = h->d.intervals, cpi = h->d.controls_per_interval, method = h->d.integration_method;
+  if (method != MYR_INT_EULER && method != MYR_INT_HEUN)
+    return fail(MYR_E_UNSUPPORTED, "myr_eval: shooting eval is built for EULER and HEUN steps");
+  const size_t need = (size_t)B * (size_t)(cpi + 1) * Sys::NS * 8;
+  if (need > h->sbuf_bytes) {
+    if (h->sbuf) HIPCHK(hipFree(h->sbuf));
+    h->sbuf = nullptr; h->sbuf_bytes = 0;
+    HIPCHK(hipMalloc(&h->sbuf, need));
+    h->sbuf_bytes = need;
+  }
+  KTimer& kt = h->kt[MYR_K_EVAL];
+  HIPCHK(hipEventRecord(kt.a, h->stream));
+  hipLaunchKernelGGL(shoot_eval_kernel<Sys>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, I, cpi, method, h->d.T,
+                     z, params, pstride, f, g, c, j, (double*)h->sbuf);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(kt.b, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+  kt.sum_ms += ms;
+  kt.launches += 1;
+  return MYR_OK;
+}
+
+template <class Sys>
+static int eval_for_system(myr_handle h, int B, const double* z, const double* params, int pstride,
+                           double* f, double* g, double* c, double* j) {
+  switch (h->d.transcription) {
+    case MYR_TR_HERMITE_SIMPSON: return launch_hs_eval<Sys, EVAL_HS>(h, B, z, params, pstride, f, g, c, j);
+    case MYR_TR_TRAPEZOIDAL: return launch_hs_eval<Sys, EVAL_TRAP>(h, B, z, params, pstride, f, g, c, j);
+    case MYR_TR_SHOOTING: return launch_shoot_eval<Sys>(h, B, z, params, pstride, f, g, c, j);
+  }
+  return fail(MYR_E_ARG, "eval: unknown transcription");
+}
+
 static int dispatch_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
                          double* f, double* g, double* c, double* j) {
   switch (h->d.system_id) {
-    case MYR_SYS_CARTPOLE: return launch_hs_eval<SysCARTPOLE>(h, B, z, params, pstride, f, g, c, j);
-    case MYR_SYS_VANDERPOL: return launch_hs_eval<SysVANDERPOL>(h, B, z, params, pstride, f, g, c, j);
-    case MYR_SYS_CANCERTREATMENT: return launch_hs_eval<SysCANCERTREATMENT>(h, B, z, params, pstride, f, g, c, j);
-    case MYR_SYS_SIMPLECASE: return launch_hs_eval<SysSIMPLECASE>(h, B, z, params, pstride, f, g, c, j);
+    case MYR_SYS_CARTPOLE: return eval_for_system<SysCARTPOLE>(h, B, z, params, pstride, f, g, c, j);
+    case MYR_SYS_VANDERPOL: return eval_for_system<SysVANDERPOL>(h, B, z, params, pstride, f, g, c, j);
+    case MYR_SYS_CANCERTREATMENT: return eval_for_system<SysCANCERTREATMENT>(h, B, z, params, pstride, f, g, c, j);
+    case MYR_SYS_SIMPLECASE: return eval_for_system<SysSIMPLECASE>(h, B, z, params, pstride, f, g, c, j);
   }
   return fail(MYR_E_ARG, "eval: unknown system");
 }
@@ -235,7 +278,6 @@ extern "C" int myr_eval(myr_handle h, int32_t B, const double* z, const double* 
   if (B == 0) return MYR_OK;
   if (params && params_stride != 0 && params_stride != h->dims.np)
     return fail(MYR_E_ARG, "myr_eval: params_stride must be 0 (shared) or np");
-  if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "myr_eval: transcription not built");
   HIPCHK(hipSetDevice(h->d.device));
   const myr_dims& dm = h->dims;
   if (mem == MYR_MEM_DEVICE) return dispatch_eval(h, B, z, params, params_stride, f, gradf, c, jblk);

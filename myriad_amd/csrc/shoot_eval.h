@@ -1,0 +1,153 @@
+// shoot_eval.h -- shooting transcription evaluation (K3/K4 in DESIGN.md): constraints, their Jacobian as interval
+// blocks, objective and its full gradient.
+//
+// Replaces jit(constraints), jit(jacrev(constraints)), jit(objective), jit(grad(objective))
+// (/root/reference/myriad/nlp_solvers/__init__.py:32-40) for /root/reference/myriad/trajectory_optimizers/shooting.py:
+//   constraints :230-241 (integrate_time_independent_in_parallel over the intervals, utils.py:80-134)
+//   objective   :169-210 (augmented state [x; integral of g]; the reference integrates twice, here once).
+// One trajectory per lane (Euler / Heun steps).  Per interval: forward rollout (states parked in scratch), then ONE
+// reverse sweep carrying the ns x ns adjoint of the end state and the adjoint of the running cost -- reverse mode
+// like the reference's jacrev, but all ns+1 rows at once.
+// Flop/latency bound (2*cpi dependent dynamics evaluations per interval); algorithmic bytes are a few KB/instance.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "os_solver.h"
+
+namespace myriad {
+
+// jblk layout per interval k: Jx = d c_k / d x_k (ns x ns, row-major), then Ju = d c_k / d u_{k*cpi .. (k+1)*cpi}
+// (ns x (cpi+1)*nu, row-major); d c_k / d x_{k+1} = -I is implied.
+template <class Sys>
+__global__ __launch_bounds__(64)
+void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double* __restrict__ z,
+                       const double* __restrict__ params, int params_stride, double* __restrict__ fout,
+                       double* __restrict__ gout, double* __restrict__ cout, double* __restrict__ jout,
+                       double* __restrict__ scratch) {
+  using SC = ShootCore<Sys>;
+  constexpr int NS = Sys::NS, NU = Sys::NU, NW = Sys::NW, NY = NW + NU;
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int S = I * cpi;
+  const long n = (long)(I + 1) * NS + (long)(S + 1) * NU;
+  const double h = T / S;
+  const double* zb = z + b * n;
+  const double* ub = zb + (long)(I + 1) * NS;
+  double p[Sys::NP > 0 ? Sys::NP : 1];
+  if (params) {
+#pragma unroll
+    for (int i = 0; i < Sys::NP; ++i) p[i] = params[b * (long)params_stride + i];
+  } else {
+    Sys::default_params(p);
+  }
+  double* xs = scratch + b * (long)(cpi + 1) * NS;      // states of the current interval
+  const long jpi = (long)NS * NS + (long)NS * (cpi + 1) * NU;
+  double* gb = gout ? gout + b * n : nullptr;
+  if (gb) for (long i = 0; i < n; ++i) gb[i] = 0.0;
+  double ftot = 0.0;
+  for (int k = 0; k < I; ++k) {
+    double x[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) x[c] = zb[(long)k * NS + c];
+    for (int j = 0; j < cpi; ++j) {
+      const int i = k * cpi + j;
+      double xn[NS], dc;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) xs[(long)j * NS + c] = x[c];
+      SC::step_val(method, h, x, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, xn, dc);
+      ftot += dc;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) x[c] = xn[c];
+    }
+    if (cout) {
+#pragma unroll
+      for (int c = 0; c < NS; ++c) cout[b * (long)I * NS + (long)k * NS + c] = x[c] - zb[(long)(k + 1) * NS + c];   // shooting.py:239-241
+    }
+    if (!jout && !gb) continue;
+    // reverse sweep: Lam = d x_end / d x_{j+1} (ns x ns), a = d (cost of the rest of the interval) / d x_{j+1}
+    double Lam[NS * NS], a[NS], pendJ[NS * NU], pendg[NU];
+#pragma unroll
+    for (int r = 0; r < NS; ++r)
+#pragma unroll
+      for (int c = 0; c < NS; ++c) Lam[r * NS + c] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) a[c] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NS * NU; ++q) pendJ[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NU; ++q) pendg[q] = 0.0;
+    double* jb = jout ? jout + b * (long)I * jpi + (long)k * jpi : nullptr;
+    const double zero[NS] = {0};
+    for (int j = cpi - 1; j >= 0; --j) {
+      const int i = k * cpi + j;
+      double xi[NS], Fy[NS * NY], gy[NY], Hs[NY * NY];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) xi[c] = xs[(long)j * NS + c];
+      SC::step_lin(method, h, xi, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, zero, Fy, gy, Hs);
+      // column block of u_{i+1}: this step's d/du_next + what step i+1 contributed as its own d/du
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        double gsum = pendg[u] + gy[NW + u];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) gsum += a[t] * Fy[t * NY + NW + u];
+        if (gb) gb[(long)(I + 1) * NS + (long)(i + 1) * NU + u] += gsum;
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+          double s = pendJ[r * NU + u];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Lam[r * NS + t] * Fy[t * NY + NW + u];
+          if (jb) jb[NS * NS + (long)r * (cpi + 1) * NU + (long)(j + 1) * NU + u] = s;
+        }
+      }
+      // pending contribution of this step to its own control u_i, then propagate the adjoints through the step
+      double nL[NS * NS], na[NS];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        double g2 = gy[NS + u];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) g2 += a[t] * Fy[t * NY + NS + u];
+        pendg[u] = g2;
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Lam[r * NS + t] * Fy[t * NY + NS + u];
+          pendJ[r * NU + u] = s;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        double s = gy[c];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s += a[t] * Fy[t * NY + c];
+        na[c] = s;
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+          double v = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) v += Lam[r * NS + t] * Fy[t * NY + c];
+          nL[r * NS + c] = v;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NS * NS; ++q) Lam[q] = nL[q];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) a[c] = na[c];
+    }
+    // first control of the interval and the node state
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (gb) gb[(long)(I + 1) * NS + (long)(k * cpi) * NU + u] += pendg[u];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) if (jb) jb[NS * NS + (long)r * (cpi + 1) * NU + u] = pendJ[r * NU + u];
+    }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+      if (gb) gb[(long)k * NS + c] += a[c];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) if (jb) jb[r * NS + c] = Lam[r * NS + c];
+    }
+  }
+  if (fout) fout[b] = ftot;
+}
+
+}  // namespace myriad

@@ -117,8 +117,13 @@ class TrajectoryOptimizer(object):
   def constraints_jac(self, variables, params=None):
     """Dense Jacobian (what jax.jacrev(constraints) returns) assembled on the host from the kernel's stage blocks."""
     p = self.system.device_params() if params is None else self.system.params_from_mapping(params)
-    blk = self.engine.eval(variables, params=p, want=("jblk",))["jblk"][0]
-    return hs_dense_from_blocks(blk.reshape(self.hp.intervals, -1), self.hp.intervals, self.engine.ns, self.engine.nu)
+    blk = self.engine.eval(variables, params=p, want=("jblk",))["jblk"][0].reshape(self.hp.intervals, -1)
+    N, ns, nu = self.hp.intervals, self.engine.ns, self.engine.nu
+    if self.transcription == "HERMITE_SIMPSON":
+      return hs_dense_from_blocks(blk, N, ns, nu)
+    if self.transcription == "TRAPEZOIDAL":
+      return trap_dense_from_blocks(blk, N, ns, nu)
+    return shoot_dense_from_blocks(blk, N, self.hp.controls_per_interval, ns, nu)
 
   # ---- solve ---------------------------------------------------------------------------------------
   def _opt_inputs(self, params=None, guess=None) -> Dict:
@@ -301,4 +306,32 @@ def hs_dense_from_blocks(blk: np.ndarray, N: int, ns: int, nu: int) -> np.ndarra
     J[rd, cu(s)] = pr[3].reshape(ns, nu); J[rd, cu(m)] = pr[4].reshape(ns, nu); J[rd, cu(e)] = pr[5].reshape(ns, nu)
     J[ri, cx(s)] = pr[6].reshape(ns, ns); J[ri, cx(e)] = pr[7].reshape(ns, ns); J[ri, cx(m)] = np.eye(ns)
     J[ri, cu(s)] = pr[8].reshape(ns, nu); J[ri, cu(e)] = pr[9].reshape(ns, nu)
+  return J
+
+
+def trap_dense_from_blocks(blk: np.ndarray, N: int, ns: int, nu: int) -> np.ndarray:
+  """Dense (N ns) x ((N+1)(ns+nu)) trapezoidal Jacobian from the per-interval blocks Cxs, Cxe, Cus, Cue."""
+  J = np.zeros((N * ns, (N + 1) * (ns + nu)))
+  cuts = np.cumsum([ns * ns, ns * ns, ns * nu])
+  for k in range(N):
+    a, b, c, d = np.split(blk[k], cuts)
+    r = slice(k * ns, (k + 1) * ns)
+    J[r, k * ns:(k + 1) * ns] = a.reshape(ns, ns)
+    J[r, (k + 1) * ns:(k + 2) * ns] = b.reshape(ns, ns)
+    J[r, (N + 1) * ns + k * nu:(N + 1) * ns + (k + 1) * nu] = c.reshape(ns, nu)
+    J[r, (N + 1) * ns + (k + 1) * nu:(N + 1) * ns + (k + 2) * nu] = d.reshape(ns, nu)
+  return J
+
+
+def shoot_dense_from_blocks(blk: np.ndarray, I: int, cpi: int, ns: int, nu: int) -> np.ndarray:
+  """Dense (I ns) x ((I+1) ns + (I cpi + 1) nu) shooting Jacobian (Euler/Heun control layout) from the per-interval
+  blocks Jx (ns x ns), Ju (ns x (cpi+1) nu); d c_k / d x_{k+1} = -I is implied."""
+  n = (I + 1) * ns + (I * cpi + 1) * nu
+  J = np.zeros((I * ns, n))
+  for k in range(I):
+    r = slice(k * ns, (k + 1) * ns)
+    J[r, k * ns:(k + 1) * ns] = blk[k][:ns * ns].reshape(ns, ns)
+    J[r, (k + 1) * ns:(k + 2) * ns] = -np.eye(ns)
+    u0 = (I + 1) * ns + k * cpi * nu
+    J[r, u0:u0 + (cpi + 1) * nu] = blk[k][ns * ns:].reshape(ns, (cpi + 1) * nu)
   return J

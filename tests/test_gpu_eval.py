@@ -70,10 +70,11 @@ def test_eval_edge_cases():
   assert set(out) == {"c"}
   with pytest.raises(ValueError):
     eng.eval(np.zeros((2, eng.n + 1)))
-  trap = _lib.Engine("CARTPOLE", "TRAPEZOIDAL", 4, 2.0)     # sizes known, kernels not built for it yet
-  assert (trap.n, trap.m) == (25, 16)
-  with pytest.raises(NotImplementedError):
-    trap.eval(np.zeros((1, trap.n)))
+  trap = _lib.Engine("CARTPOLE", "TRAPEZOIDAL", 4, 2.0)
+  assert (trap.n, trap.m, trap.jblk) == (25, 16, 4 * (2 * 16 + 2 * 4))
+  rk = _lib.Engine("CARTPOLE", "SHOOTING", 2, 2.0, controls_per_interval=3, integration_method="RK4")
+  with pytest.raises(NotImplementedError):                     # RK4 shooting: rollout only
+    rk.eval(np.zeros((1, rk.n)))
 
 
 def test_eval_full_size_properties():

@@ -107,3 +107,39 @@ def test_cancertreatment_parameter_sweep_config4_shape():
   # default-parameter instance reproduces the survey's number (App. C: 20.5735535185)
   d = opt.solve()
   assert d['cost'] == pytest.approx(20.57355337, rel=1e-8)
+
+
+@pytest.mark.parametrize("sysname,opt,quad,method,kw", [
+  ("CARTPOLE", "COLLOCATION", "TRAPEZOIDAL", "HEUN", dict(intervals=12)),
+  ("VANDERPOL", "COLLOCATION", "TRAPEZOIDAL", "HEUN", dict(intervals=7)),
+  ("CANCERTREATMENT", "COLLOCATION", "TRAPEZOIDAL", "HEUN", dict(intervals=5)),
+  ("CARTPOLE", "SHOOTING", "TRAPEZOIDAL", "HEUN", dict(intervals=4, controls_per_interval=6)),
+  ("VANDERPOL", "SHOOTING", "TRAPEZOIDAL", "HEUN", dict(intervals=1, controls_per_interval=50)),
+  ("CANCERTREATMENT", "SHOOTING", "TRAPEZOIDAL", "HEUN", dict(intervals=1, controls_per_interval=100)),
+  ("SIMPLECASE", "SHOOTING", "TRAPEZOIDAL", "HEUN", dict(intervals=10, controls_per_interval=100)),
+  ("VANDERPOL", "SHOOTING", "TRAPEZOIDAL", "EULER", dict(intervals=3, controls_per_interval=4)),
+])
+def test_eval_callbacks_match_oracle(sysname, opt, quad, method, kw):
+  """objective / grad / constraints / jacobian of the trapezoidal and shooting transcriptions (the four callbacks the
+  reference jits, nlp_solvers/__init__.py:32-40) from the eval kernels vs the oracle's autodiff."""
+  hp = HParams(system=SystemType[sysname], optimizer=OptimizerType[opt], quadrature_rule=QuadratureRule[quad],
+               integration_method=IntegrationMethod[method], **kw)
+  O, s, tr, cb = _oracle(sysname, opt, hp)
+  o = get_optimizer(hp, CFG, hp.system())
+  rng = np.random.default_rng(5)
+  z = tr.guess + 0.1 * rng.standard_normal(tr.guess.size)
+  if sysname == "CANCERTREATMENT":
+    z[:tr.x_rows] = np.abs(z[:tr.x_rows]) + 0.05
+    z[tr.x_rows:] = np.abs(z[tr.x_rows:])
+  np.testing.assert_allclose(o.constraints(z), cb.cons(z), rtol=1e-11, atol=1e-12)
+  assert o.objective(z) == pytest.approx(cb.fun(z), rel=1e-12)
+  np.testing.assert_allclose(o.objective_grad(z), cb.grad(z), rtol=1e-10, atol=1e-11)
+  np.testing.assert_allclose(o.constraints_jac(z), cb.jac(z), rtol=1e-10, atol=1e-11)
+
+
+def test_scipy_branch_runs_on_shooting_gpu_callbacks():
+  """The reference's default test path (tests/tests.py:46-60: SIMPLECASE, SHOOTING, SLSQP, HEUN, 1 x 50) on GPU callbacks."""
+  hp = HParams(system=SystemType.SIMPLECASE, optimizer=OptimizerType.SHOOTING, nlpsolver=NLPSolverType.SLSQP,
+               integration_method=IntegrationMethod.HEUN, intervals=1, controls_per_interval=50)
+  sol = get_optimizer(hp, CFG, hp.system()).solve()
+  assert sol['cost'] == pytest.approx(-1.3544209454574183, rel=1e-5)      # SLSQP at its default ftol=1e-6

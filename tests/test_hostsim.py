@@ -132,3 +132,48 @@ def test_rollout_core_matches_oracle(sim, method, mid):
     oxs, oc = O.get_state_trajectory_and_cost(s2, S, method, s.x_0, us)
     np.testing.assert_allclose(xs, oxs, rtol=1e-12, atol=1e-13)
     assert c == pytest.approx(oc, rel=1e-12, abs=1e-14)
+
+
+def _os_lib(sim):
+  dp = C.c_void_p
+  sim.hostsim_solve_trap.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, dp, dp, dp, dp, dp]
+  sim.hostsim_solve_shoot.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, dp, dp, dp, dp, dp]
+  return sim
+
+
+@pytest.mark.parametrize("name,N", [("CARTPOLE", 25), ("VANDERPOL", 30), ("CANCERTREATMENT", 30), ("SIMPLECASE", 20)])
+def test_trapezoid_core_matches_oracle_slsqp(sim, name, N):
+  """csrc/os_solver.h TrapCore (README.md:83's transcription) vs the oracle's SLSQP path."""
+  sim = _os_lib(sim)
+  s = O.SYSTEMS[name](); tr = O.trapezoidal(s, N); cb = O.Callbacks(tr)
+  z = tr.guess[None].copy(); lb = np.ascontiguousarray(tr.bounds[None, :, 0]); ub = np.ascontiguousarray(tr.bounds[None, :, 1])
+  lam = np.zeros((1, N * s.ns)); cost = np.zeros(1); st = np.zeros(1, np.int32); it = np.zeros(1, np.int32); kkt = np.zeros((1, 3))
+  sim.hostsim_solve_trap(SID[name], N, s.T, 1, A(z), A(lb), A(ub), None, 0, 500, A(lam), A(cost), A(st), A(it), A(kkt))
+  assert st[0] == 0
+  assert np.abs(cb.cons(z[0])).max() <= 1e-8 and cb.fun(z[0]) == pytest.approx(cost[0], rel=1e-12)
+  r = O.solve(tr, "SLSQP", extra_options={"ftol": 1e-13}, cb=cb)
+  assert cost[0] == pytest.approx(r["cost"], rel=1e-7) and np.abs(z[0] - r["xs_and_us"]).max() < 1e-4
+  rr = cb.grad(z[0]) + cb.jac(z[0]).T @ lam[0]
+  inact = (lb[0] < ub[0]) & (z[0] - lb[0] > 1e-3) & (ub[0] - z[0] > 1e-3)
+  assert np.abs(rr[inact]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name,I,cpi,method", [("SIMPLECASE", 10, 100, "HEUN"), ("VANDERPOL", 1, 50, "HEUN"),
+                                               ("CANCERTREATMENT", 1, 100, "HEUN"), ("CARTPOLE", 10, 5, "HEUN"),
+                                               ("SIMPLECASE", 4, 10, "EULER")])
+def test_shooting_core_matches_oracle_slsqp(sim, name, I, cpi, method):
+  """csrc/os_solver.h ShootCore (lifted step-level Riccati) on the BASELINE shooting shapes (configs 1, 3, 4) vs the
+  oracle's SLSQP path; the survey's App. C costs are reproduced."""
+  sim = _os_lib(sim)
+  s = O.SYSTEMS[name](); tr = O.shooting(s, I, cpi, method); cb = O.Callbacks(tr)
+  z = tr.guess[None].copy(); lb = np.ascontiguousarray(tr.bounds[None, :, 0]); ub = np.ascontiguousarray(tr.bounds[None, :, 1])
+  lam = np.zeros((1, I * s.ns)); cost = np.zeros(1); st = np.zeros(1, np.int32); it = np.zeros(1, np.int32); kkt = np.zeros((1, 3))
+  sim.hostsim_solve_shoot(SID[name], I, cpi, {"EULER": 0, "HEUN": 1}[method], s.T, 1, A(z), A(lb), A(ub), None, 0, 500,
+                          A(lam), A(cost), A(st), A(it), A(kkt))
+  assert st[0] == 0
+  assert np.abs(cb.cons(z[0])).max() <= 1e-8 and cb.fun(z[0]) == pytest.approx(cost[0], rel=1e-11)
+  r = O.solve(tr, "SLSQP", max_iter=500, extra_options={"ftol": 1e-13}, cb=cb)
+  assert cost[0] == pytest.approx(r["cost"], rel=1e-6)
+  survey = {("SIMPLECASE", 10): -1.3543305221, ("VANDERPOL", 1): 2.8731963348, ("CANCERTREATMENT", 1): 20.5735535185}
+  if (name, I) in survey and method == "HEUN":
+    assert cost[0] == pytest.approx(survey[(name, I)], rel=2e-5)     # SLSQP at default ftol (SURVEY.md App. C)
