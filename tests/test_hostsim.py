@@ -176,4 +176,4 @@ def test_shooting_core_matches_oracle_slsqp(sim, name, I, cpi, method):
   assert cost[0] == pytest.approx(r["cost"], rel=1e-6)
   survey = {("SIMPLECASE", 10): -1.3543305221, ("VANDERPOL", 1): 2.8731963348, ("CANCERTREATMENT", 1): 20.5735535185}
   if (name, I) in survey and method == "HEUN":
-    assert cost[0] == pytest.approx(survey[(name, I)], rel=2e-5)     # SLSQP at default ftol
+    assert cost[0] == pytest.approx(survey[(name, I)], rel=1e-4) and cost[0] <= survey[(name, I)] + 1e-9   # SLSQP at default ftol=1e-6 stops slightly short
