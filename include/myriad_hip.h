@@ -34,7 +34,10 @@ extern "C" {
 #endif
 
 /* system ids: members of myriad.systems.SystemType on the hot path (systems/__init__.py:29-50) */
-enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2, MYR_SYS_SIMPLECASE = 3 };
+enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2, MYR_SYS_SIMPLECASE = 3,
+       /* NodeSystem over CARTPOLE with a (64,64) sigmoid MLP (systems/neural_ode/node_system.py:14-42,
+          neural_ode/create_node.py:110-117): params = the 4804 weights, see csrc/node_system.h for the order */
+       MYR_SYS_NODE_CARTPOLE = 4 };
 /* transcription: OptimizerType x QuadratureRule (config.py:12-57) */
 enum { MYR_TR_HERMITE_SIMPSON = 0, MYR_TR_TRAPEZOIDAL = 1, MYR_TR_SHOOTING = 2 };
 /* IntegrationMethod (config.py:46-50) */

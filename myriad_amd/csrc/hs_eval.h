@@ -116,13 +116,9 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
   const int tid = threadIdx.x;
   const long b = blockIdx.x;
   const double* zb = z + b * (long)n;
-  double p[Sys::NP > 0 ? Sys::NP : 1];
-  if (params) {
-#pragma unroll
-    for (int i = 0; i < Sys::NP; ++i) p[i] = params[b * (long)params_stride + i];
-  } else {
-    Sys::default_params(p);
-  }
+  SysParams<Sys> pp;
+  pp.load(params, b, params_stride);
+  const double* p = pp.get();
 
   hs_build_stencil<Sys, SCHEME>(tab, h, tid, NT);
 

@@ -402,8 +402,8 @@ struct HsSolver {
         mue[c] = mu_c[c] - h6 * lamd[c] + h8 * lami[c];
         mum[c] = -4.0 * h6 * lamd[c];
       }
-      Sys::contract(Pe.D2, mue, we, We);
-      Sys::contract(Pm.D2, mum, wm, Wm);
+      Sys::hessian(Pe.x, Pe.u, p, Pe.D2, mue, we, We);
+      Sys::hessian(Pm.x, Pm.u, p, Pm.D2, mum, wm, Wm);
       // value function after adding point e's own terms: P' = P + H_e, pc' = pc + gbar_e
 #pragma unroll
       for (int r = 0; r < NW; ++r) {
@@ -626,7 +626,7 @@ struct HsSolver {
       }
 #pragma unroll
       for (int a = 0; a < NU; ++a) so.stat = dmax(so.stat, fabs(w0 * Pe.gw[NS + a] + zlu0[NS + a] + ru_c[a]));
-      Sys::contract(Pe.D2, mu_c, w0, W0);
+      Sys::hessian(Pe.x, Pe.u, p, Pe.D2, mu_c, w0, W0);
       double Puu[NU * NU], ku[NU * NC];
       double uscale = 0.0;
 #pragma unroll

@@ -75,7 +75,7 @@ struct HsWave {
     double h, h6, h8;
     double *z, *zL, *zU, *dz, *lam, *pt, *hr, *st;
     const double *lb, *ub;
-    double p[Sys::NP > 0 ? Sys::NP : 1];
+    SysParams<Sys> pp;
     bool term_pinned[NS];
     // LDS
     double *r0, *sPi, *sY, *sP, *sPc, *sGe, *sHe, *sQm, *sQcm, *sT2, *sQ, *sQc, *sK, *sTnu, *sKu, *sS;
@@ -95,7 +95,7 @@ struct HsWave {
         V.z[q] = c.z[i]; V.l[q] = c.lb[i]; V.u[q] = c.ub[i]; V.zl[q] = c.zL[i]; V.zu[q] = c.zU[i];
       }
       HsPoint<Sys> P;
-      S::lin_point(V, c.p, P);
+      S::lin_point(V, c.pp.get(), P);
       double* pt = c.pt + j;
       const int K = c.K;
 #pragma unroll
@@ -371,7 +371,14 @@ struct HsWave {
         for (int t = 0; t < NS; ++t) r += pt[(PF_B + t * NU + u) * K] * a[t];
         st_ = detail::dmax(st_, fabs(r));
       }
-      Sys::contract(D2, a, wj, W);
+      {
+        double xj[NS], uj[NU];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) xj[q] = c.z[zi(c, j, q)];
+#pragma unroll
+        for (int q = 0; q < NU; ++q) uj[q] = c.z[zi(c, j, NS + q)];
+        Sys::hessian(xj, uj, c.pp.get(), D2, a, wj, W);
+      }
       double* hr = c.hr + (long)j * HR_N;
       const bool last = (j == K - 1);
 #pragma unroll
@@ -720,8 +727,8 @@ struct HsWave {
         ba -= log(sl > 0.0 ? sl : 1.0) + log(su > 0.0 ? su : 1.0);
         if (q < NS) x[q] = v; else u[q - NS] = v;
       }
-      Sys::f(x, u, c.p, ff);
-      fa += S::wsimp(K, j, c.h) * Sys::g(x, u, c.p);
+      Sys::f(x, u, c.pp.get(), ff);
+      fa += S::wsimp(K, j, c.h) * Sys::g(x, u, c.pp.get());
 #pragma unroll
       for (int q = 0; q < NS; ++q) { sX[j * NS + q] = x[q]; sF[j * NS + q] = ff[q]; }
     }
@@ -922,12 +929,7 @@ void hs_solve_wave_kernel(int B, HsSolveOpts o, double* __restrict__ z, const do
   c.hr = s; s += (long)W::HR_N * c.K;
   c.st = s; s += (long)W::SG_N * c.N;
   c.lam = lam ? lam + b * (long)(2 * c.N * W::NS) : s;
-  if (params) {
-#pragma unroll
-    for (int i = 0; i < Sys::NP; ++i) c.p[i] = params[b * (long)params_stride + i];
-  } else {
-    Sys::default_params(c.p);
-  }
+  c.pp.load(params, b, params_stride);
   double* l = reinterpret_cast<double*>(smem_wave);
   c.r0 = l; l += W::r0_doubles(c.N);
   c.sK = c.r0;

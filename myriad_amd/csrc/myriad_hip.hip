@@ -15,6 +15,7 @@
 #include "shoot_eval.h"
 #include "rollout.h"
 #include "systems_gen.h"
+#include "node_system.h"
 
 using namespace myriad;
 
@@ -37,6 +38,7 @@ static bool sys_info(int id, SysInfo* s) {
     case MYR_SYS_VANDERPOL: *s = {SysVANDERPOL::NS, SysVANDERPOL::NU, SysVANDERPOL::NP, SysVANDERPOL::COST_DEP_X}; return true;
     case MYR_SYS_CANCERTREATMENT: *s = {SysCANCERTREATMENT::NS, SysCANCERTREATMENT::NU, SysCANCERTREATMENT::NP, SysCANCERTREATMENT::COST_DEP_X}; return true;
     case MYR_SYS_SIMPLECASE: *s = {SysSIMPLECASE::NS, SysSIMPLECASE::NU, SysSIMPLECASE::NP, SysSIMPLECASE::COST_DEP_X}; return true;
+    case MYR_SYS_NODE_CARTPOLE: *s = {SysNODE_CARTPOLE::NS, SysNODE_CARTPOLE::NU, SysNODE_CARTPOLE::NP, SysNODE_CARTPOLE::COST_DEP_X}; return true;
   }
   return false;
 }
@@ -267,6 +269,7 @@ static int dispatch_eval(myr_handle h, int B, const double* z, const double* par
     case MYR_SYS_VANDERPOL: return eval_for_system<SysVANDERPOL>(h, B, z, params, pstride, f, g, c, j);
     case MYR_SYS_CANCERTREATMENT: return eval_for_system<SysCANCERTREATMENT>(h, B, z, params, pstride, f, g, c, j);
     case MYR_SYS_SIMPLECASE: return eval_for_system<SysSIMPLECASE>(h, B, z, params, pstride, f, g, c, j);
+    case MYR_SYS_NODE_CARTPOLE: return eval_for_system<SysNODE_CARTPOLE>(h, B, z, params, pstride, f, g, c, j);
   }
   return fail(MYR_E_ARG, "eval: unknown system");
 }
@@ -278,6 +281,7 @@ extern "C" int myr_eval(myr_handle h, int32_t B, const double* z, const double* 
   if (B == 0) return MYR_OK;
   if (params && params_stride != 0 && params_stride != h->dims.np)
     return fail(MYR_E_ARG, "myr_eval: params_stride must be 0 (shared) or np");
+  if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, "myr_eval: a NODE system needs its weights in `params`");
   HIPCHK(hipSetDevice(h->d.device));
   const myr_dims& dm = h->dims;
   if (mem == MYR_MEM_DEVICE) return dispatch_eval(h, B, z, params, params_stride, f, gradf, c, jblk);
@@ -362,13 +366,9 @@ void lane_solve_kernel(int B, long Bp, int lanes_per_wave, HsSolveOpts o, double
   if ((int)threadIdx.x >= lanes_per_wave) return;
   const long b = (long)blockIdx.x * lanes_per_wave + threadIdx.x;
   if (b >= B) return;
-  double p[Sys::NP > 0 ? Sys::NP : 1];
-  if (params) {
-#pragma unroll
-    for (int i = 0; i < Sys::NP; ++i) p[i] = params[b * (long)params_stride + i];
-  } else {
-    Sys::default_params(p);
-  }
+  SysParams<Sys> pp;
+  pp.load(params, b, params_stride);
+  const double* p = pp.get();
   HsWork w{{z + b, Bp}, {lb + b, Bp}, {ub + b, Bp}, {zL + b, Bp}, {zU + b, Bp}, {lam + b, Bp}, {dz + b, Bp}, {st + b, Bp}};
   HsSolveResult r;
   Core::solve(w, o, p, r);
@@ -513,6 +513,7 @@ static int dispatch_solve(myr_handle h, int B, double* z, const double* lb, cons
     case MYR_SYS_VANDERPOL: return solve_for_system<SysVANDERPOL>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     case MYR_SYS_CANCERTREATMENT: return solve_for_system<SysCANCERTREATMENT>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     case MYR_SYS_SIMPLECASE: return solve_for_system<SysSIMPLECASE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_SYS_NODE_CARTPOLE: return solve_for_system<SysNODE_CARTPOLE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   return fail(MYR_E_ARG, "solve: unknown system");
 }
@@ -525,6 +526,7 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
   if (B == 0) return MYR_OK;
   if (params && params_stride != 0 && params_stride != h->dims.np)
     return fail(MYR_E_ARG, "myr_solve: params_stride must be 0 (shared) or np");
+  if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, "myr_solve: a NODE system needs its weights in `params`");
   myr_solve_opts so;
   if (opts) so = *opts; else myr_default_solve_opts(&so);
   if (so.max_iter < 0 || !(so.tol_feas > 0) || !(so.tol_stat > 0) || !(so.tol_compl > 0) || !(so.mu_init > 0))
@@ -575,13 +577,9 @@ void rollout_kernel(int B, int method, int num_steps, double h, int u_rows, cons
                     double* __restrict__ xs, double* __restrict__ cost) {
   const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  double p[Sys::NP > 0 ? Sys::NP : 1];
-  if (params) {
-#pragma unroll
-    for (int i = 0; i < Sys::NP; ++i) p[i] = params[b * (long)params_stride + i];
-  } else {
-    Sys::default_params(p);
-  }
+  SysParams<Sys> pp;
+  pp.load(params, b, params_stride);
+  const double* p = pp.get();
   const double c = Rollout<Sys>::run(method, num_steps, h, u_rows, x0 + b * Sys::NS, us + b * (long)u_rows * Sys::NU, p,
                                      xs ? xs + b * (long)(num_steps + 1) * Sys::NS : nullptr);
   if (cost) cost[b] = c;
@@ -600,6 +598,7 @@ static int dispatch_rollout(myr_handle h, int B, int num_steps, int u_rows, cons
     case MYR_SYS_VANDERPOL: RO(SysVANDERPOL); break;
     case MYR_SYS_CANCERTREATMENT: RO(SysCANCERTREATMENT); break;
     case MYR_SYS_SIMPLECASE: RO(SysSIMPLECASE); break;
+    case MYR_SYS_NODE_CARTPOLE: RO(SysNODE_CARTPOLE); break;
     default: return fail(MYR_E_ARG, "rollout: unknown system");
   }
 #undef RO
@@ -619,6 +618,7 @@ extern "C" int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u
   if (B == 0) return MYR_OK;
   if (params && params_stride != 0 && params_stride != h->dims.np)
     return fail(MYR_E_ARG, "myr_rollout: params_stride must be 0 (shared) or np");
+  if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, "myr_rollout: a NODE system needs its weights in `params`");
   HIPCHK(hipSetDevice(h->d.device));
   const myr_dims& dm = h->dims;
   if (mem == MYR_MEM_DEVICE) return dispatch_rollout(h, B, num_steps, u_rows, x0, us, params, params_stride, xs, cost);

@@ -266,7 +266,7 @@ struct TrapCore {
       double mue[NS], We[NW * NW];
 #pragma unroll
       for (int c = 0; c < NS; ++c) mue[c] = mu_c[c] + hh * lam[c];
-      Sys::contract(Pe.D2, mue, we, We);
+      Sys::hessian(Pe.x, Pe.u, p, Pe.D2, mue, we, We);
 #pragma unroll
       for (int r = 0; r < NW; ++r) {
         const bool zr = (j == N - 1) && r < NS && so.term_pinned[r];
@@ -328,7 +328,7 @@ struct TrapCore {
       }
 #pragma unroll
       for (int a = 0; a < NU; ++a) so.stat = dmax(so.stat, fabs(w0 * Pe.gw[NS + a] + zlu0[NS + a] + ru_c[a]));
-      Sys::contract(Pe.D2, mu_c, w0, W0);
+      Sys::hessian(Pe.x, Pe.u, p, Pe.D2, mu_c, w0, W0);
       double Huu[NU * NU], g0u[NU], g1u[NU], ku[NU * NC];
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
@@ -507,7 +507,7 @@ struct ShootCore {
       double W1[NW * NW], mu1[NS];
 #pragma unroll
       for (int c = 0; c < NS; ++c) mu1[c] = h * pin[c];
-      Sys::contract(P1.D2, mu1, h, W1);
+      Sys::hessian(P1.x, P1.u, p, P1.D2, mu1, h, W1);
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
 #pragma unroll
@@ -574,8 +574,8 @@ struct ShootCore {
       for (int t = 0; t < NS; ++t) s += P2.A[t * NS + c] * pin[t];
       mu1[c] = hh * pin[c] + h * hh * s;
     }
-    Sys::contract(P1.D2, mu1, hh, W1);
-    Sys::contract(P2.D2, pin, 1.0, W2);
+    Sys::hessian(P1.x, P1.u, p, P1.D2, mu1, hh, W1);
+    Sys::hessian(P2.x, P2.u, p, P2.D2, pin, 1.0, W2);
     double T[NW * NY];
 #pragma unroll
     for (int r = 0; r < NW; ++r)

@@ -32,13 +32,9 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
   const double h = T / S;
   const double* zb = z + b * n;
   const double* ub = zb + (long)(I + 1) * NS;
-  double p[Sys::NP > 0 ? Sys::NP : 1];
-  if (params) {
-#pragma unroll
-    for (int i = 0; i < Sys::NP; ++i) p[i] = params[b * (long)params_stride + i];
-  } else {
-    Sys::default_params(p);
-  }
+  SysParams<Sys> pp;
+  pp.load(params, b, params_stride);
+  const double* p = pp.get();
   double* xs = scratch + b * (long)(cpi + 1) * NS;      // states of the current interval
   const long jpi = (long)NS * NS + (long)NS * (cpi + 1) * NU;
   double* gb = gout ? gout + b * n : nullptr;

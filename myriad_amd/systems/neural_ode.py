@@ -1,0 +1,69 @@
+"""Host mirror of myriad.systems.neural_ode.node_system.NodeSystem (/root/reference/myriad/systems/neural_ode/node_system.py:14-42)
+and of the network definition in /root/reference/myriad/neural_ode/create_node.py:110-131.
+
+`NodeSystem(node, true_system)` keeps the true system's x_0, x_T, T, bounds and cost; its parametrized dynamics are
+the MLP.  `params` is the Haiku-style mapping {'linear': {'w','b'}, 'linear_1': {...}, 'linear_2': {...}} that
+`solve_with_params(node.params)` receives (useful_scripts.py:86-88)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from myriad_amd.systems import FiniteHorizonControlSystem
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+class NeuralODE:
+  """The part of create_node.NeuralODE the planning path uses: .params (Haiku layout) and .net.apply."""
+
+  def __init__(self, params=None, hidden_layers=(64, 64)):
+    self.hidden_layers = tuple(hidden_layers)
+    self.params = params
+
+  @classmethod
+  def load_fitted_cartpole(cls):
+    """The committed (64,64) weight set fitted to the CARTPOLE field (tools/fit_node_cartpole.py)."""
+    d = np.load(os.path.join(_DATA, "node_cartpole_64x64.npz"))
+    params = {k: {"w": d[k + "/w"], "b": d[k + "/b"]} for k in ("linear", "linear_1", "linear_2")}
+    return cls(params, (64, 64))
+
+  def apply(self, params, x_and_u):
+    h = np.asarray(x_and_u, dtype=np.float64)
+    keys = ["linear"] + [f"linear_{i}" for i in range(1, len(self.hidden_layers) + 1)]
+    for k in keys[:-1]:
+      h = 1.0 / (1.0 + np.exp(-(h @ params[k]["w"] + params[k]["b"])))
+    return h @ params[keys[-1]]["w"] + params[keys[-1]]["b"]
+
+
+class NodeSystem(FiniteHorizonControlSystem):
+  """node_system.py:14-42."""
+  param_names = ()
+
+  def __init__(self, node: NeuralODE, true_system: FiniteHorizonControlSystem):
+    self.node = node
+    self.true_system = true_system
+    if true_system.name != "CARTPOLE" or tuple(node.hidden_layers) != (64, 64):
+      raise NotImplementedError("device code is built for NodeSystem(CARTPOLE) with hidden_layers=(64, 64) (BASELINE config 5)")
+    self.name = "NODE_CARTPOLE"
+    super().__init__(x_0=true_system.x_0, x_T=true_system.x_T, T=true_system.T, bounds=true_system.bounds,
+                     terminal_cost=true_system.terminal_cost)
+
+  def dynamics(self, x_t, u_t, t=None):                      # true dynamics (:31-32)
+    return self.true_system.dynamics(x_t, u_t)
+
+  def parametrized_dynamics(self, params, x_t, u_t, t=None):  # NODE dynamics (:35-38)
+    return self.node.apply(params, np.append(x_t, u_t))
+
+  def cost(self, x_t, u_t, t=None):                          # true cost (:41-42)
+    return self.true_system.cost(x_t, u_t, t)
+
+  def device_params(self) -> np.ndarray:
+    return self.params_from_mapping(self.node.params)
+
+  def params_from_mapping(self, params) -> np.ndarray:
+    """Flatten the Haiku mapping into the device order w1|b1|w2|b2|w3|b3 (csrc/node_system.h)."""
+    ks = ("linear", "linear_1", "linear_2")
+    return np.concatenate([np.concatenate([np.asarray(params[k]["w"], dtype=np.float64).ravel(),
+                                           np.asarray(params[k]["b"], dtype=np.float64).ravel()]) for k in ks])

@@ -171,6 +171,24 @@ class SimpleCase(System):
     return (-self.A * x + self.B * u ** 2)[..., 0]
 
 
+class NodeCartPole(CartPole):
+  """myriad/systems/neural_ode/node_system.py:14-42 over CARTPOLE: dynamics = net.apply(params, [x;u]) with the MLP of
+  myriad/neural_ode/create_node.py:110-117 (Linear+sigmoid per hidden layer, Linear out; Haiku y = x @ w + b);
+  cost of the true system.  `params`: {'linear': {'w','b'}, 'linear_1': ..., 'linear_2': ...}."""
+  name = "NODE_CARTPOLE"
+
+  def __init__(self, params):
+    super().__init__()
+    self.mlp = [( _t(params[k]["w"]), _t(params[k]["b"])) for k in ("linear", "linear_1", "linear_2")]
+
+  def dynamics(self, x, u):
+    h = torch.cat([x, u], dim=-1)
+    for w, b in self.mlp[:-1]:
+      h = torch.sigmoid(h @ w + b)
+    w, b = self.mlp[-1]
+    return h @ w + b
+
+
 SYSTEMS = {c.name: c for c in (CartPole, VanDerPol, CancerTreatment, SimpleCase)}
 
 

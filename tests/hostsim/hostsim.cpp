@@ -37,9 +37,9 @@ static void solve_batch(int N, double T, int B, double* z, const double* lb, con
   for (int b = 0; b < B; ++b) {
     std::vector<double> zL(n), zU(n), dz(n), lbv(lb + (size_t)b * n, lb + (size_t)(b + 1) * n),
         ubv(ub + (size_t)b * n, ub + (size_t)(b + 1) * n), st(HsSol<Sys>::stage_doubles(N));
-    double p[Sys::NP > 0 ? Sys::NP : 1];
-    if (params) for (int i = 0; i < Sys::NP; ++i) p[i] = params[(size_t)b * pstride + i];
-    else Sys::default_params(p);
+    SysParams<Sys> pp;
+    pp.load(params, b, pstride);
+    const double* p = pp.get();
     HsWork w{{z + (size_t)b * n, 1}, {lbv.data(), 1}, {ubv.data(), 1}, {zL.data(), 1}, {zU.data(), 1},
              {lam + (size_t)b * m, 1}, {dz.data(), 1}, {st.data(), 1}};
     HsSolveResult r;
@@ -119,9 +119,9 @@ static void os_batch(const HsSolveOpts& o0, int n, int m, long nst, int B, doubl
   for (int b = 0; b < B; ++b) {
     std::vector<double> zL(n), zU(n), dz(n), lbv(lb + (size_t)b * n, lb + (size_t)(b + 1) * n),
         ubv(ub + (size_t)b * n, ub + (size_t)(b + 1) * n), st(nst);
-    double p[Sys::NP > 0 ? Sys::NP : 1];
-    if (params) for (int i = 0; i < Sys::NP; ++i) p[i] = params[(size_t)b * pstride + i];
-    else Sys::default_params(p);
+    SysParams<Sys> pp;
+    pp.load(params, b, pstride);
+    const double* p = pp.get();
     HsWork w{{z + (size_t)b * n, 1}, {lbv.data(), 1}, {ubv.data(), 1}, {zL.data(), 1}, {zU.data(), 1},
              {lam + (size_t)b * m, 1}, {dz.data(), 1}, {st.data(), 1}};
     HsSolveResult r;

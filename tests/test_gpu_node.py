@@ -1,0 +1,69 @@
+"""GPU parity tests of the neural-ODE path (BASELINE config 5): CARTPOLE + NodeSystem (2 x 64 sigmoid MLP) through the
+Hermite-Simpson transcription -- eval kernel vs the oracle's autodiff, solve through solve_with_params."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from myriad_amd.config import Config, HParams, IntegrationMethod, NLPSolverType, OptimizerType, QuadratureRule
+from myriad_amd.systems import SystemType
+from myriad_amd.systems.neural_ode import NeuralODE, NodeSystem
+from myriad_amd.trajectory_optimizers import get_optimizer
+
+CFG = Config(verbose=False, plot=False)
+
+
+def _setup(N):
+  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
+               integration_method=IntegrationMethod.RK4, intervals=N, hidden_layers=(64, 64), nlpsolver=NLPSolverType.SQP)
+  node = NeuralODE.load_fitted_cartpole()
+  node_system = NodeSystem(node, hp.system())             # useful_scripts.py:82-84
+  return hp, node, get_optimizer(hp, CFG, node_system)
+
+
+def test_node_eval_matches_oracle_autodiff():
+  from oracle import myriad_oracle as O
+  N = 6
+  hp, node, opt = _setup(N)
+  s = O.NodeCartPole(node.params)
+  tr = O.hermite_simpson(s, N)
+  cb = O.Callbacks(tr)
+  rng = np.random.default_rng(0)
+  z = tr.guess + 0.3 * rng.standard_normal(tr.guess.size)
+  np.testing.assert_allclose(opt.parametrized_constraints(node.params, z), cb.cons(z), rtol=1e-11, atol=1e-12)
+  assert opt.parametrized_objective(node.params, z) == pytest.approx(cb.fun(z), rel=1e-12)
+  np.testing.assert_allclose(opt.constraints_jac(z, params=node.params), cb.jac(z), rtol=1e-10, atol=1e-11)
+  np.testing.assert_allclose(opt.objective_grad(z, params=node.params), cb.grad(z), rtol=1e-12, atol=1e-13)
+  # the network reproduces the true field where it was fitted (R^2 = 0.997): sanity of the committed weights
+  true = get_optimizer(hp, CFG, hp.system())
+  assert np.abs(opt.parametrized_constraints(node.params, tr.guess) - true.constraints(tr.guess)).max() < 1.0   # h=1/3, rms field error 0.7
+
+
+def test_node_solve_with_params_converges_and_is_kkt_point():
+  """run_node_trajectory_opt's core (useful_scripts.py:79-89): plan through the network."""
+  from oracle import myriad_oracle as O
+  N = 20
+  hp, node, opt = _setup(N)
+  sol = opt.solve_with_params(node.params)
+  z = sol['xs_and_us']
+  s = O.NodeCartPole(node.params)
+  cb = O.Callbacks(O.hermite_simpson(s, N))
+  assert np.abs(cb.cons(z)).max() <= 1e-8
+  assert cb.fun(z) == pytest.approx(sol['cost'], rel=1e-12)
+  lb, ub = opt.bounds[:, 0], opt.bounds[:, 1]
+  r = cb.grad(z) + cb.jac(z).T @ sol['lambda']
+  inact = (lb < ub) & (z - lb > 1e-3) & (ub - z > 1e-3)
+  assert np.abs(r[inact]).max() < 1e-5
+  # planning through the fitted network lands near the true-dynamics optimum (golden N=25: 87.95; N=20 similar)
+  assert 60.0 < sol['cost'] < 130.0
+
+
+def test_node_batch_config5_shape():
+  """BASELINE config 5 shape on one GPU's shard: N=100, 128 random x0, one shared weight set."""
+  from oracle import myriad_oracle as O
+  hp, node, opt = _setup(100)
+  x0 = O.random_x0(O.CartPole(), 128, seed=2019)
+  res = opt.solve_batch(x0s=x0, params=opt.system.device_params())
+  assert (res['status'] == 0).mean() >= 0.98, np.bincount(res['status'])
+  ev = opt.engine.eval(res['xs_and_us'], params=opt.system.device_params(), want=("c",))
+  assert np.abs(ev["c"][res['status'] == 0]).max() <= 1e-8

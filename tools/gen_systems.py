@@ -116,6 +116,7 @@ def gen_system(S):
   o.append(f"  static constexpr int ID = {S['id']}, NS = {ns}, NU = {nu}, NP = {npar}, NW = {nw};")
   o.append(f"  static constexpr bool COST_DEP_X = {'true' if cost_dep_x else 'false'};")
   o.append(f"  static constexpr const char* NAME = \"{name}\";")
+  o.append("  static constexpr bool PARAMS_BY_POINTER = false;   // parameters are a handful of scalars: copied to registers")
   # f
   o.append("  // dynamics f(x,u)")
   o.append("  MYR_HD static inline void f(const double* x, const double* u, const double* p, double* fo) {")
@@ -185,6 +186,12 @@ def gen_system(S):
       if c != r:
         o.append(f"    W[{c * nw + r}] = W[{r * nw + c}];")
   o.append("  }")
+  o.append("  // Hessian of the Lagrangian at one point from the data lin_d2() produced (uniform interface with SysNODE)")
+  o.append("  MYR_HD static inline void hessian(const double* x, const double* u, const double* p, const double* D2,")
+  o.append("                                    const double* mu, double wg, double* W) {")
+  o.append("    (void)x; (void)u; (void)p;")
+  o.append("    contract(D2, mu, wg, W);")
+  o.append("  }")
   o.append("  MYR_HD static inline void default_params(double* p) {")
   for i, v in enumerate(S["pdefault"]):
     o.append(f"    p[{i}] = {v!r};  // {S['pnames'][i]}")
@@ -211,6 +218,24 @@ def main():
   for S in systems():
     parts.append(gen_system(S))
     parts.append("")
+  parts.append("""// Per-thread view of a system's parameters: small parameter sets are copied into registers, large ones (the
+// weights of a neural-ODE system) are used in place through a pointer.
+template <class Sys>
+struct SysParams {
+  double buf[Sys::PARAMS_BY_POINTER ? 1 : (Sys::NP > 0 ? Sys::NP : 1)];
+  const double* ptr;
+  MYR_HD inline void load(const double* params, long b, int stride) {
+    if constexpr (Sys::PARAMS_BY_POINTER) {
+      ptr = params + b * (long)stride;
+    } else {
+      ptr = nullptr;
+      if (params) { for (int i = 0; i < Sys::NP; ++i) buf[i] = params[b * (long)stride + i]; }
+      else Sys::default_params(buf);
+    }
+  }
+  MYR_HD inline const double* get() const { if constexpr (Sys::PARAMS_BY_POINTER) return ptr; else return buf; }
+};
+""")
   parts.append("}  // namespace myriad")
   with open(OUT, "w") as fh:
     fh.write("\n".join(parts) + "\n")
