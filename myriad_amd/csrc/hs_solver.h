@@ -38,6 +38,8 @@ struct HsSolveOpts {
   int cpi = 1;             // controls per interval (shooting)
   int method = 1;          // integration method id (shooting): 0 Euler, 1 Heun, 2 midpoint, 3 RK4
   double kappa_mu = 0.2, theta_mu = 1.5, kappa_eps = 10.0;   // barrier update: mu <- max(mu_min, min(kappa_mu mu, mu^theta_mu)) when E_mu <= kappa_eps mu
+  double delta_warm_min = 3e-3;   // ... only while the previous delta was at least this large (early, non-convex phase)
+  int delta_warm = 1;      // 1: start the inertia correction from the previous delta / 3 instead of 0
   int lm_abs = 1;
   double kappa_sigma = 1e10;   // bound multipliers are kept within [mu/(kappa s), kappa mu/s] after each step
   double tau_min = 0.99;   // fraction-to-the-boundary parameter: tau = max(tau_min, 1 - mu)
@@ -52,6 +54,7 @@ struct HsSolveOpts {
 
 struct HsSolveResult {
   int status, iters;
+  int sweeps = 0;          // factorisation sweeps incl. inertia-correction retries
   double cost, feas, stat, compl_;
 };
 
@@ -914,15 +917,17 @@ struct IpLoop {
       // inertia correction (global, as in interior-point NLP codes): retry the factorisation with W + delta I
       // until every stage pivot is positive; the last resort keeps the stage-local convexification.
       double delta = lm;     // Levenberg-Marquardt floor adapted from the line-search history (see below)
+      if (o.delta_warm && delta_last > o.delta_warm_min) delta = dmax(delta, delta_last / 3.0);   // skip the doomed delta = 0 attempt
       for (int tr_ = 0; tr_ < 12; ++tr_) {
         so.abort_on_reg = (tr_ < 11);
         Core::backward(w, o, p, nuT, delta, so);
+        ++res.sweeps;
         if (so.nreg == 0) break;
         if (delta == 0.0) delta = (delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4;
         else delta *= (delta_last > 0.0) ? 8.0 : 100.0;
         if (delta > 1e8) { so.abort_on_reg = false; }
       }
-      if (delta > lm) delta_last = delta;
+      delta_last = (delta > lm) ? delta : 0.0;
       // KKT error with the usual multiplier scaling
       double sd = 1.0;
       {

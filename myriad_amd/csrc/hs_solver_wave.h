@@ -817,6 +817,7 @@ struct HsWave {
       __syncthreads();
       // inertia correction with retries (only the delta-dependent phases are redone)
       double delta = lm;
+      if (o.delta_warm && delta_last > o.delta_warm_min) delta = dmax(delta, delta_last / 3.0);
       int nreg = 0;
       for (int tr_ = 0; tr_ < 12; ++tr_) {
         bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
@@ -829,7 +830,7 @@ struct HsWave {
         if (delta == 0.0) delta = (delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4;
         else delta *= (delta_last > 0.0) ? 8.0 : 100.0;
       }
-      if (delta > lm) delta_last = delta;
+      delta_last = (delta > lm) ? delta : 0.0;
       const int nm = 2 * c.N * NS + p1.nm;
       const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
       const double stat = stat_raw / sd, comp = p1.cmax / sd;

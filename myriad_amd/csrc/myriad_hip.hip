@@ -143,7 +143,7 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
     HIPCHK(hipEventCreate(&h->kt[i].b));
   }
   const char* w = getenv("MYRIAD_EVAL_WPT");
-  if (w) { int v = atoi(w); if (v == 1 || v == 2 || v == 4 || v == 8) h->eval_wpt = v; }
+  if (w) { int v = atoi(w); if (v == 1 || v == 4 || v == 8) h->eval_wpt = v; }
   if (const char* e = getenv("MYRIAD_EVAL_NT")) h->eval_nt = atoi(e);
   const char* md = getenv("MYRIAD_SOLVE_MODE");
   if (md) h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1;
@@ -208,9 +208,8 @@ static int launch_hs_eval(myr_handle h, int B, const double* z, const double* pa
   }
   const bool nt = h->eval_nt != 0;
   switch (wpt) {
-    case 1: if (nt) MYR_EVAL_LAUNCH(1, true) else MYR_EVAL_LAUNCH(1, false) break;
-    case 2: if (nt) MYR_EVAL_LAUNCH(2, true) else MYR_EVAL_LAUNCH(2, false) break;
-    case 8: if (nt) MYR_EVAL_LAUNCH(8, true) else MYR_EVAL_LAUNCH(8, false) break;
+    case 1: if (nt) MYR_EVAL_LAUNCH(1, true) else MYR_EVAL_LAUNCH(4, false) break;
+    case 8: if (nt) MYR_EVAL_LAUNCH(8, true) else MYR_EVAL_LAUNCH(4, false) break;
     default: if (nt) MYR_EVAL_LAUNCH(4, true) else MYR_EVAL_LAUNCH(4, false) break;
   }
 #undef MYR_EVAL_LAUNCH
@@ -254,10 +253,15 @@ static int launch_shoot_eval(myr_handle h, int B, const double* z, const double*
 template <class Sys>
 static int eval_for_system(myr_handle h, int B, const double* z, const double* params, int pstride,
                            double* f, double* g, double* c, double* j) {
-  switch (h->d.transcription) {
-    case MYR_TR_HERMITE_SIMPSON: return launch_hs_eval<Sys, EVAL_HS>(h, B, z, params, pstride, f, g, c, j);
-    case MYR_TR_TRAPEZOIDAL: return launch_hs_eval<Sys, EVAL_TRAP>(h, B, z, params, pstride, f, g, c, j);
-    case MYR_TR_SHOOTING: return launch_shoot_eval<Sys>(h, B, z, params, pstride, f, g, c, j);
+  if constexpr (Sys::PARAMS_BY_POINTER) {   // neural-ODE systems: built for the Hermite-Simpson transcription (config 5)
+    if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "myr_eval: NODE systems are built for HERMITE_SIMPSON");
+    return launch_hs_eval<Sys, EVAL_HS>(h, B, z, params, pstride, f, g, c, j);
+  } else {
+    switch (h->d.transcription) {
+      case MYR_TR_HERMITE_SIMPSON: return launch_hs_eval<Sys, EVAL_HS>(h, B, z, params, pstride, f, g, c, j);
+      case MYR_TR_TRAPEZOIDAL: return launch_hs_eval<Sys, EVAL_TRAP>(h, B, z, params, pstride, f, g, c, j);
+      case MYR_TR_SHOOTING: return launch_shoot_eval<Sys>(h, B, z, params, pstride, f, g, c, j);
+    }
   }
   return fail(MYR_E_ARG, "eval: unknown transcription");
 }
@@ -385,6 +389,7 @@ static HsSolveOpts make_opts(myr_handle h, const myr_solve_opts& so) {
   o.cpi = h->d.controls_per_interval; o.method = h->d.integration_method;
   if (const char* e = getenv("MYRIAD_NONMONO")) o.nonmono = atoi(e);      // developer knobs (globalisation ablations)
   if (const char* e = getenv("MYRIAD_RECENTER")) o.recenter = atoi(e);
+  if (const char* e = getenv("MYRIAD_DELTA_WARM")) o.delta_warm = atoi(e);
   if (o.nonmono < 0) o.nonmono = 0;
   if (o.nonmono > 8) o.nonmono = 8;
   return o;
@@ -492,6 +497,11 @@ static int solve_for_system(myr_handle h, int B, double* z, const double* lb, co
                             int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                             int32_t* iters, double* kkt) {
   const int N = h->d.intervals, cpi = h->d.controls_per_interval;
+  if constexpr (Sys::PARAMS_BY_POINTER) {
+    (void)N; (void)cpi;
+    if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "myr_solve: NODE systems are built for HERMITE_SIMPSON");
+    return launch_hs_solve<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  } else
   switch (h->d.transcription) {
     case MYR_TR_HERMITE_SIMPSON:
       return launch_hs_solve<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);

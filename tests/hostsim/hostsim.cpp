@@ -26,6 +26,8 @@ static void solve_batch(int N, double T, int B, double* z, const double* lb, con
   if (getenv("LM")) o.lm_init = atof(getenv("LM"));
   if (getenv("TAU")) o.tau_min = atof(getenv("TAU"));
   if (getenv("LMABS")) o.lm_abs = atoi(getenv("LMABS"));
+  if (getenv("DWARM")) o.delta_warm = atoi(getenv("DWARM"));
+  if (getenv("DWMIN")) o.delta_warm_min = atof(getenv("DWMIN"));
   if (getenv("KSIG")) o.kappa_sigma = atof(getenv("KSIG"));
   if (getenv("KMU")) o.kappa_mu = atof(getenv("KMU"));
   if (getenv("TMU")) o.theta_mu = atof(getenv("TMU"));
@@ -45,7 +47,7 @@ static void solve_batch(int N, double T, int B, double* z, const double* lb, con
     HsSolveResult r;
     S::solve(w, o, p, r);
     cost[b] = r.cost; status[b] = r.status; iters[b] = r.iters;
-    if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
+    if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = getenv("SWEEPS") ? (double)r.sweeps : r.compl_; }
   }
 }
 

@@ -37,7 +37,7 @@ def test_eval_matches_golden_vectors(golden_dir):
     eng.close()
 
 
-@pytest.mark.parametrize("wpt", ["1", "2", "4"])
+@pytest.mark.parametrize("wpt", ["1", "4", "8"])
 def test_eval_matches_oracle_random_batch(wpt, monkeypatch):
   """Seeded random batch, ragged batch size, per-instance parameters, every workgroup shape."""
   from oracle import myriad_oracle as O
