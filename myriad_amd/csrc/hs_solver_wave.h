@@ -8,7 +8,7 @@
 //     (LU of E, G_e, G_m), adjoint maps, Lagrangian Hessians, midpoint Schur terms, step limits, merit trials,
 //     updates);
 //   * only two recursions stay sequential over the N stages and are executed cooperatively through LDS:
-//     the Riccati sweep (lanes over the elements of the 5x5 / 7x7 / 7x6 blocks) and the forward state recursion;
+//     the Riccati sweep (one column of the stage blocks per lane, see riccati()) and the forward state recursion;
 //     the adjoint recursion is reduced to an affine recurrence Pi_{k-1} = M_k Pi_k + v_k with M, v staged in LDS.
 // Trajectory data stays instance-major in HBM (the caller's z/lb/ub rows are used in place, no transposes);
 // per-trajectory scratch is one contiguous block, so every parallel phase reads/writes it with unit stride.
@@ -66,8 +66,7 @@ struct HsWave {
     const int a = N * (NS * NS + NS), b = N * KST, c = 2 * (2 * N + 1) * NS;
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
   }
-  static constexpr int EXCH = NW * NW + NW * NC + NS * NY1 + HR_N + NY * NY + NY * 2 + NW * NY1 + NY * NY + NY * NC +
-                              KST + NS * NC + NU * NC + NW + 8;
+  static constexpr int EXCH = NW * NW + NW * NC + NS * NY1 + NS * NC + NU * NC + NW + 8;
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)(r0_doubles(N) + N * NS + N * NY + EXCH) * 8 + 64; }
 
   struct Ctx {
@@ -78,8 +77,16 @@ struct HsWave {
     SysParams<Sys> pp;
     bool term_pinned[NS];
     // LDS
-    double *r0, *sPi, *sY, *sP, *sPc, *sGe, *sHe, *sQm, *sQcm, *sT2, *sQ, *sQc, *sK, *sTnu, *sKu, *sS;
+    double *r0, *sPi, *sY, *sP, *sPc, *sGe, *sK, *sTnu, *sKu, *sS;
+#ifdef MYR_PHASE_TIMING
+    long long tph[16], t0;
+#endif
   };
+#ifdef MYR_PHASE_TIMING
+#define MYR_PH(i) { const long long t1_ = clock64(); c.tph[i] += t1_ - c.t0; c.t0 = t1_; }
+#else
+#define MYR_PH(i)
+#endif
 
   __device__ static inline long zi(const Ctx& c, int j, int comp) { return S::zi(c.K, j, comp); }
 
@@ -443,153 +450,171 @@ struct HsWave {
     }
   }
 
-  // ---- phase 6: Riccati sweep, sequential over stages, lanes over block elements --------------------------------
-  // returns the number of regularised pivots (wave-uniform); aborts at the first one when `abort_on_reg`.
-  static constexpr int IN_N = NS * NY1 + NY * NY + NY * 2 + HR_N;   // per-stage inputs: Ge|ge, Qm, qcm, point-e record
-  __device__ static inline double load_in(const Ctx& c, int k, int e) {
-    const double* st = c.st + (long)k * SG_N;
-    if (e < NS * NY1) return st[SG_GE + e];
-    e -= NS * NY1;
-    if (e < NY * NY + NY * 2) return st[SG_QM + e];           // Qm and qcm are contiguous in the stage record
-    e -= NY * NY + NY * 2;
-    return c.hr[(long)(2 * k + 2) * HR_N + e];
-  }
-  __device__ static inline void store_in(const Ctx& c, int e, double v) {
-    if (e < NS * NY1) { c.sGe[e] = v; return; }
-    e -= NS * NY1;
-    if (e < NY * NY) { c.sQm[e] = v; return; }
-    e -= NY * NY;
-    if (e < NY * 2) { c.sQcm[e] = v; return; }
-    e -= NY * 2;
-    c.sHe[e] = v;
+  // ---- phase 6: Riccati sweep, sequential over stages, ONE COLUMN PER LANE ---------------------------------------
+  // The stage update  [Q | qc] = [Qm | qcm] + Ge^^T (P' [Ge^ | ge^] + [0 | pc'])  followed by the elimination of
+  // q = (du_m, du_e) acts column by column, so lane j < NY carries column j of Q, lane NY + cc carries column cc of
+  // the right-hand sides (gradient, mu, nu_1..nu_NS), and between stages lane j < NW keeps column j of P and lane
+  // NY + cc column cc of pc in registers.  Every lane runs the SAME instruction stream (no element-dependent
+  // branches); the only shared data per stage are P' (NW x NW, through LDS), Ge|ge (LDS) and a handful of entries of
+  // the q columns, which are read with v_readlane.  One barrier per stage.
+  // Returns the number of regularised pivots (wave-uniform); aborts at the first one when `abort_on_reg`.
+  __device__ static inline double rdlane(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
   }
 
   __device__ static int riccati(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
     using namespace detail;
+    static_assert(NY + NC <= 64, "one column per lane");
     const int lane = c.lane, N = c.N;
-    constexpr int NLD = (IN_N + 63) / 64;
-    // init value function: P = rho on pinned terminal diagonals, nu columns
-    for (int e = lane; e < NW * NW; e += 64) {
-      const int r = e / NW, q = e % NW;
-      c.sP[e] = (r == q && r < NS && c.term_pinned[r]) ? o.rho_term : 0.0;
+    const bool isP = lane < NW;                 // column `lane` of P / of H_e
+    const bool isY = lane < NY;                 // column `lane` of Q
+    const int cc = lane - NY;                   // column cc of the right-hand sides when 0 <= cc < NC
+    const bool isC = cc >= 0 && cc < NC;
+    const bool isVal = isP || isC;
+    // per-lane addressing of the stage inputs
+    const bool m_on = isY || (isC && cc < 2);   // Qm column (unit stride; Qm is symmetric) | qcm column (stride 2)
+    const int m_off = isY ? SG_QM + lane * NY : SG_QCM + (cc == 1 ? 1 : 0);
+    const int m_str = isY ? 1 : 2;
+    const bool h_on = isP || (isC && cc < 2);   // H_e column | g0 | g1 of the end point
+    const int h_off = isP ? HR_H + lane * NW : (cc == 1 ? HR_G1 : HR_G0);
+    const int v_col = isY ? lane : NY;          // own column of Ge^ (Q lanes), ge^ (gradient column), none otherwise
+    const double v_on = (isY || cc == 0) ? 1.0 : 0.0;
+    constexpr int NGE = NS * NY1, NGL = (NGE + 63) / 64;
+
+    double val[NW], tnuB[NS], tnuA = 0.0;
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+      const bool pin = r < NS && c.term_pinned[r < NS ? r : 0];
+      val[r] = (isP && r == lane && pin) ? o.rho_term : ((isC && cc == 2 + r && pin) ? 1.0 : 0.0);
     }
-    for (int e = lane; e < NW * NC; e += 64) {
-      const int r = e / NC, cc = e % NC;
-      c.sPc[e] = (r < NS && cc == 2 + r && c.term_pinned[r]) ? 1.0 : 0.0;
-    }
-    for (int e = lane; e < NS * NC; e += 64) c.sTnu[e] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) tnuB[i] = 0.0;
     int nreg = 0;
-    double pre[NLD];
+    double m_pre[NY], h_pre[NW], g_pre[NGL];
+    {
+      const double* st = c.st + (long)(N - 1) * SG_N;
+      const double* hr = c.hr + (long)(2 * N) * HR_N;
 #pragma unroll
-    for (int t = 0; t < NLD; ++t) { const int e = lane + 64 * t; pre[t] = e < IN_N ? load_in(c, N - 1, e) : 0.0; }
+      for (int r = 0; r < NY; ++r) m_pre[r] = m_on ? st[m_off + r * m_str] : 0.0;
+#pragma unroll
+      for (int r = 0; r < NW; ++r) h_pre[r] = h_on ? hr[h_off + r] : 0.0;
+#pragma unroll
+      for (int t = 0; t < NGL; ++t) { const int e = lane + 64 * t; g_pre[t] = e < NGE ? st[SG_GE + e] : 0.0; }
+    }
     for (int k = N - 1; k >= 0; --k) {
-      // (a) stage inputs -> LDS; prefetch the next stage
+      double m[NY];
 #pragma unroll
-      for (int t = 0; t < NLD; ++t) { const int e = lane + 64 * t; if (e < IN_N) store_in(c, e, pre[t]); }
-      if (k > 0) {
+      for (int r = 0; r < NY; ++r) m[r] = m_pre[r];
+      // (a) P' = P + H_e + delta I (not on the pinned terminal diagonal), pc' = pc + gbar_e; share P' and Ge|ge
 #pragma unroll
-        for (int t = 0; t < NLD; ++t) { const int e = lane + 64 * t; pre[t] = e < IN_N ? load_in(c, k - 1, e) : 0.0; }
+      for (int r = 0; r < NW; ++r) {
+        const bool pinned_diag = (k == N - 1) && r < NS && c.term_pinned[r < NS ? r : 0];
+        val[r] += h_pre[r] + ((isP && r == lane && !pinned_diag) ? delta : 0.0);
+      }
+      if (isP) {
+#pragma unroll
+        for (int r = 0; r < NW; ++r) c.sP[lane * NW + r] = val[r];
+      }
+#pragma unroll
+      for (int t = 0; t < NGL; ++t) { const int e = lane + 64 * t; if (e < NGE) c.sGe[e] = g_pre[t]; }
+      if (k > 0) {       // prefetch the next stage while this one is processed
+        const double* st = c.st + (long)(k - 1) * SG_N;
+        const double* hr = c.hr + (long)(2 * k) * HR_N;
+#pragma unroll
+        for (int r = 0; r < NY; ++r) m_pre[r] = m_on ? st[m_off + r * m_str] : 0.0;
+#pragma unroll
+        for (int r = 0; r < NW; ++r) h_pre[r] = h_on ? hr[h_off + r] : 0.0;
+#pragma unroll
+        for (int t = 0; t < NGL; ++t) { const int e = lane + 64 * t; g_pre[t] = e < NGE ? st[SG_GE + e] : 0.0; }
       }
       __syncthreads();
-      // (b) P' = P + H_e (+ delta), pc' = pc + gbar_e
-      for (int e = lane; e < NW * NW + NW; e += 64) {
-        if (e < NW * NW) {
-          const int r = e / NW, q = e % NW;
-          const bool pinned_diag = (k == N - 1) && r < NS && c.term_pinned[r];
-          c.sP[e] += c.sHe[HR_H + e] + ((r == q && !pinned_diag) ? delta : 0.0);
-        } else {
-          const int r = e - NW * NW;
-          c.sPc[r * NC + 0] += c.sHe[HR_G0 + r];
-          c.sPc[r * NC + 1] += c.sHe[HR_G1 + r];
-        }
+      // (b) tv = P' v + (pc' on the right-hand-side lanes),  v = own column of [Ge^ | ge^]
+      double v[NW], tv[NW];
+#pragma unroll
+      for (int t = 0; t < NS; ++t) v[t] = v_on * c.sGe[t * NY1 + v_col];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) v[NS + a] = (lane == NS + 2 * NU + a) ? 1.0 : 0.0;
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+        double s = isC ? val[r] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) s += c.sP[r * NW + q] * v[q];
+        tv[r] = s;
       }
-      __syncthreads();
-      // (c) T2 = P' [Ge^ | ge^]
-      for (int e = lane; e < NW * NY1; e += 64) {
-        const int r = e / NY1, q = e % NY1;
+      // (c) own column of [Q | qc] = [Qm | qcm] + Ge^^T tv
+      double col[NY];
+#pragma unroll
+      for (int r = 0; r < NY; ++r) {
+        double s = m[r];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s += c.sGe[t * NY1 + r] * tv[t];
+        if (r >= NS + 2 * NU) s += tv[NS + (r - NS - 2 * NU)];
+        col[r] = s;
+      }
+      // terminal-multiplier bookkeeping, part 1 (lanes NY+2+i): Tnu[i][0] += ge^T pc'[:, nu_i]
+      {
         double s = 0.0;
 #pragma unroll
-        for (int t = 0; t < NS; ++t) s += c.sP[r * NW + t] * c.sGe[t * NY1 + q];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) if (q == NS + 2 * NU + a) s += c.sP[r * NW + NS + a];
-        c.sT2[e] = s;
+        for (int t = 0; t < NS; ++t) s += c.sGe[t * NY1 + NY] * val[t];
+        tnuA += s;
       }
-      __syncthreads();
-      // (d) Q = Qm + Ge^^T T2 ; qc = qcm + Ge^^T (T2[:,NY] [col 0] + pc') ; Tnu[:,0] += ge^T pc'[:, nu cols]
-      for (int e = lane; e < NY * NY + NY * NC + NS; e += 64) {
-        if (e < NY * NY) {
-          const int r = e / NY, q = e % NY;
-          double s = c.sQm[e];
-#pragma unroll
-          for (int t = 0; t < NS; ++t) s += c.sGe[t * NY1 + r] * c.sT2[t * NY1 + q];
-#pragma unroll
-          for (int a = 0; a < NU; ++a) if (r == NS + 2 * NU + a) s += c.sT2[(NS + a) * NY1 + q];
-          c.sQ[e] = s;
-        } else if (e < NY * NY + NY * NC) {
-          const int f = e - NY * NY, r = f / NC, cc = f % NC;
-          double s = cc < 2 ? c.sQcm[r * 2 + cc] : 0.0;
-#pragma unroll
-          for (int t = 0; t < NS; ++t) s += c.sGe[t * NY1 + r] * (c.sPc[t * NC + cc] + (cc == 0 ? c.sT2[t * NY1 + NY] : 0.0));
-#pragma unroll
-          for (int a = 0; a < NU; ++a)
-            if (r == NS + 2 * NU + a) s += c.sPc[(NS + a) * NC + cc] + (cc == 0 ? c.sT2[(NS + a) * NY1 + NY] : 0.0);
-          c.sQc[f] = s;
-        } else {
-          const int i = e - NY * NY - NY * NC;
-          double s = 0.0;
-#pragma unroll
-          for (int t = 0; t < NS; ++t) s += c.sGe[t * NY1 + NY] * c.sPc[t * NC + 2 + i];
-          c.sTnu[i * NC + 0] += s;
-        }
-      }
-      __syncthreads();
-      // (e) Cholesky of Qqq (every lane, identical), gains K (NQ x NW) and kc (NQ x NC): one column per lane
+      // (d) Cholesky of Qqq (identical on every lane), own column of the gains K | kc
       double Lq[NQ * NQ];
 #pragma unroll
       for (int r = 0; r < NQ; ++r)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) Lq[r * NQ + q] = c.sQ[(NW + r) * NY + NW + q];
+        for (int q = 0; q < NQ; ++q) Lq[r * NQ + q] = rdlane(col[NW + r], NW + q);
       nreg += chol_reg<NQ>(Lq, o.reg_floor);
       if (nreg > 0 && abort_on_reg) return nreg;
-      if (lane < NW + NC) {
-        double col[NQ];
+      double kk[NQ];
 #pragma unroll
-        for (int r = 0; r < NQ; ++r) col[r] = lane < NW ? c.sQ[(NW + r) * NY + lane] : c.sQc[(NW + r) * NC + (lane - NW)];
-        chol_solve<NQ, 1>(Lq, col);
+      for (int r = 0; r < NQ; ++r) kk[r] = col[NW + r];
+      chol_solve<NQ, 1>(Lq, kk);
+      {
         double* Kst = c.sK + (long)k * KST;
+        if (isP) {
 #pragma unroll
-        for (int r = 0; r < NQ; ++r) {
-          if (lane < NW) Kst[r * NW + lane] = col[r]; else Kst[NQ * NW + r * NC + (lane - NW)] = col[r];
+          for (int r = 0; r < NQ; ++r) Kst[r * NW + lane] = kk[r];
+        } else if (isC) {
+#pragma unroll
+          for (int r = 0; r < NQ; ++r) Kst[NQ * NW + r * NC + cc] = kk[r];
         }
       }
-      __syncthreads();
-      // (f) P = Qss - Qsq K (symmetrised), pc = qc_s - Qsq kc, Tnu -= qc_q[:, nu]^T kc
-      {
-        const double* Kst = c.sK + (long)k * KST;
-        for (int e = lane; e < NW * NW + NW * NC + NS * NC; e += 64) {
-          if (e < NW * NW) {
-            const int r = e / NW, q = e % NW;
-            double s1 = c.sQ[r * NY + q], s2 = c.sQ[q * NY + r];
+      // (e) value function: own column of P = Qss - Qsq K,  pc = qc_s - Qsq kc
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) { s1 -= c.sQ[r * NY + NW + t] * Kst[t * NW + q]; s2 -= c.sQ[q * NY + NW + t] * Kst[t * NW + r]; }
-            c.sP[e] = 0.5 * (s1 + s2);
-          } else if (e < NW * NW + NW * NC) {
-            const int f = e - NW * NW, r = f / NC, cc = f % NC;
-            double s = c.sQc[r * NC + cc];
+      for (int r = 0; r < NW; ++r) {
+        double s = col[r];
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) s -= c.sQ[r * NY + NW + t] * Kst[NQ * NW + t * NC + cc];
-            c.sPc[f] = s;
-          } else {
-            const int f = e - NW * NW - NW * NC, i = f / NC, cc = f % NC;
-            double s = 0.0;
+        for (int t = 0; t < NQ; ++t) s -= rdlane(col[r], NW + t) * kk[t];
+        val[r] = isVal ? s : 0.0;
+      }
+      // terminal-multiplier bookkeeping, part 2 (lane NY+cc holds Tnu[:, cc]): Tnu[i][cc] -= qc_q[:, nu_i]^T kc[:, cc]
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) s += c.sQc[(NW + t) * NC + 2 + i] * Kst[NQ * NW + t * NC + cc];
-            c.sTnu[f] -= s;
-          }
-        }
+      for (int i = 0; i < NS; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) s += rdlane(col[NW + t], NY + 2 + i) * kk[t];
+        tnuB[i] -= s;
       }
       __syncthreads();
     }
+    // hand P, pc, Tnu to the first-point step through LDS
+    if (isP) {
+#pragma unroll
+      for (int r = 0; r < NW; ++r) c.sP[r * NW + lane] = val[r];
+    }
+    if (isC) {
+#pragma unroll
+      for (int r = 0; r < NW; ++r) c.sPc[r * NC + cc] = val[r];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) c.sTnu[i * NC + cc] = tnuB[i];
+    }
+    __syncthreads();
+    if (isC && cc >= 2) c.sTnu[(cc - 2) * NC + 0] += tnuA;
+    __syncthreads();
     // first point: dx_0 = 0; add its control terms, eliminate du_0 (every lane redundantly; tiny)
     {
       const double* hr = c.hr;   // point 0
@@ -806,15 +831,20 @@ struct HsWave {
       P1 p1;
       points_lin(c, p1);
       __syncthreads();
+      MYR_PH(0)
       double c1, cinf, lam_inf, sum_mult, stat_raw;
       intervals_elim(c, c1, cinf);
       __syncthreads();
+      MYR_PH(1)
       adjoint_recur(c, nuT);
       __syncthreads();
+      MYR_PH(2)
       intervals_lambda(c, lam_inf, sum_mult);
       __syncthreads();
+      MYR_PH(3)
       points_hess(c, stat_raw);
       __syncthreads();
+      MYR_PH(4)
       // inertia correction with retries (only the delta-dependent phases are redone)
       double delta = lm;
       if (o.delta_warm && delta_last > o.delta_warm_min) delta = dmax(delta, delta_last / 3.0);
@@ -823,8 +853,10 @@ struct HsWave {
         bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
         intervals_qm(c, delta);
         __syncthreads();
+        MYR_PH(5)
         nreg = riccati(c, o, delta, abort_on_reg);
         __syncthreads();
+        MYR_PH(6)
         if (nreg == 0) break;
         if (!abort_on_reg) break;
         if (delta == 0.0) delta = (delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4;
@@ -858,12 +890,16 @@ struct HsWave {
       th[0] = 1.0; th[1] = mu;
 #pragma unroll
       for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
+      MYR_PH(7)
       forward_recur(c, th);
       __syncthreads();
+      MYR_PH(8)
       intervals_dz(c);
       __syncthreads();
+      MYR_PH(9)
       typename S::FwdOut fo;
       points_limits(c, o, mu, fo);
+      MYR_PH(10)
       if (!(finite_(fo.gphi) && finite_(fo.alpha_p))) { res.status = 2; res.iters = it; return; }
       if (c1 > 0.0) {
         const double need = fo.gphi / (0.9 * c1);
@@ -891,7 +927,9 @@ struct HsWave {
       if (!ok) {
         if (++stall > 5) { res.status = 3; res.iters = it; return; }
       } else stall = 0;
+      MYR_PH(11)
       update(c, a, o.dual_follow ? fo.alpha_d * (a / fo.alpha_p) : fo.alpha_d, mu, o.kappa_sigma);
+      MYR_PH(12)
 #pragma unroll
       for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
       if (o.lm_init > 0.0) {     // step-quality feedback -> Levenberg-Marquardt damping (see hs_solver.h)
@@ -939,17 +977,22 @@ void hs_solve_wave_kernel(int B, HsSolveOpts o, double* __restrict__ z, const do
   c.sP = l; l += W::NW * W::NW;
   c.sPc = l; l += W::NW * W::NC;
   c.sGe = l; l += W::NS * W::NY1;
-  c.sHe = l; l += W::HR_N;
-  c.sQm = l; l += W::NY * W::NY;
-  c.sQcm = l; l += W::NY * 2;
-  c.sT2 = l; l += W::NW * W::NY1;
-  c.sQ = l; l += W::NY * W::NY;
-  c.sQc = l; l += W::NY * W::NC;
   c.sTnu = l; l += W::NS * W::NC;
   c.sKu = l; l += W::NU * W::NC;
   c.sS = l; l += W::NW;
   HsSolveResult r;
+#ifdef MYR_PHASE_TIMING
+  for (int i = 0; i < 16; ++i) c.tph[i] = 0;
+  c.t0 = clock64();
+#endif
   W::solve(c, o, r);
+#ifdef MYR_PHASE_TIMING
+  if (threadIdx.x == 0 && b < 4) {
+    printf("traj %ld it %d: lin %lld elim %lld adj %lld lam %lld hess %lld qm %lld ricc %lld nu %lld fwd %lld dz %lld lim %lld ls %lld upd %lld\n",
+           b, r.iters, c.tph[0], c.tph[1], c.tph[2], c.tph[3], c.tph[4], c.tph[5], c.tph[6], c.tph[7], c.tph[8], c.tph[9],
+           c.tph[10], c.tph[11], c.tph[12]);
+  }
+#endif
   if (threadIdx.x == 0) {
     if (cost) cost[b] = r.cost;
     if (status) status[b] = r.status;
