@@ -39,7 +39,8 @@ struct HsSolveOpts {
   int method = 1;          // integration method id (shooting): 0 Euler, 1 Heun, 2 midpoint, 3 RK4
   double kappa_mu = 0.2, theta_mu = 1.5, kappa_eps = 10.0;   // barrier update: mu <- max(mu_min, min(kappa_mu mu, mu^theta_mu)) when E_mu <= kappa_eps mu
   double delta_warm_min = 3e-3;   // ... only while the previous delta was at least this large (early, non-convex phase)
-  int delta_warm = 1;      // 1: start the inertia correction from the previous delta / 3 instead of 0
+  int delta_warm = 0;      // 1: start the inertia correction from the previous delta / 3 instead of 0 (set per problem
+                           // class by the caller: pays when a sweep costs more than a linearisation)
   int lm_abs = 1;
   double kappa_sigma = 1e10;   // bound multipliers are kept within [mu/(kappa s), kappa mu/s] after each step
   double tau_min = 0.99;   // fraction-to-the-boundary parameter: tau = max(tau_min, 1 - mu)

@@ -55,29 +55,31 @@ struct HsWave {
   static constexpr int SG_GE = 0, SG_GM = SG_GE + NS * NY1, SG_LD = SG_GM + NS * NY1, SG_LD0 = SG_LD + NS * NS,
                        SG_LI = SG_LD0 + NS, SG_LI0 = SG_LI + NS * NS, SG_QM = SG_LI0 + NS, SG_QCM = SG_QM + NY * NY,
                        SG_N = SG_QCM + NY * 2;
-  static constexpr int KST = NQ * NW + NQ * NC;   // K | kc per stage (LDS)
+  static constexpr int KST = NQ * NW + NQ * NC;   // K | kc per stage (global scratch)
+  static constexpr int PHI = NW * (NW + 1);       // closed-loop stage map Phi | phi per stage (LDS)
 
   __host__ __device__ static long scratch_doubles(int N) {
     const long K = 2 * N + 1, n = K * NW;
-    return 3 * n + (long)PF_N * K + (long)HR_N * K + (long)SG_N * N + 2L * N * NS /* lambda when the caller passes none */;
+    return 3 * n + (long)PF_N * K + (long)HR_N * K + (long)SG_N * N + (long)KST * N +
+           2L * N * NS /* lambda when the caller passes none */;
   }
-  // LDS doubles: region R0 (adjoint M|v, later K|kc, later trial x|f), Pi, Y, exchange
+  // LDS doubles: region R0 (adjoint M|v, later Phi|phi, later trial x|f), Pi, S, exchange
   __host__ __device__ static int r0_doubles(int N) {
-    const int a = N * (NS * NS + NS), b = N * KST, c = 2 * (2 * N + 1) * NS;
+    const int a = N * (NS * NS + NS), b = N * PHI, c = 2 * (2 * N + 1) * NS;
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
   }
-  static constexpr int EXCH = NW * NW + NW * NC + NS * NY1 + NS * NC + NU * NC + NW + 8;
-  __host__ __device__ static size_t lds_bytes(int N) { return (size_t)(r0_doubles(N) + N * NS + N * NY + EXCH) * 8 + 64; }
+  static constexpr int EXCH = NW * NW + NW * NC + NS * NY1 + NS * NC + NU * NC + 8;
+  __host__ __device__ static size_t lds_bytes(int N) { return (size_t)(r0_doubles(N) + N * NS + (N + 1) * NW + EXCH) * 8 + 64; }
 
   struct Ctx {
     int N, K, n, lane;
     double h, h6, h8;
-    double *z, *zL, *zU, *dz, *lam, *pt, *hr, *st;
+    double *z, *zL, *zU, *dz, *lam, *pt, *hr, *st, *kg;
     const double *lb, *ub;
     SysParams<Sys> pp;
     bool term_pinned[NS];
     // LDS
-    double *r0, *sPi, *sY, *sP, *sPc, *sGe, *sK, *sTnu, *sKu, *sS;
+    double *r0, *sPi, *sS, *sP, *sPc, *sGe, *sTnu, *sKu;
 #ifdef MYR_PHASE_TIMING
     long long tph[16], t0;
 #endif
@@ -300,24 +302,35 @@ struct HsWave {
     c1o = wv_sum(c1); cinfo = wv_max(cinf);
   }
 
-  // adjoint recurrence (every lane redundantly; operands are LDS broadcasts): Pi_k for k = N-1 .. 0
+  // adjoint recurrence Pi_{k-1} = M_k Pi_k + v_k, k = N-1 .. 0: lane r < NS owns row r of M|v (LDS, prefetched one
+  // stage ahead); Pi travels between lanes with v_readlane, so a stage is NS FMAs + NS readlanes and no barrier.
   __device__ static void adjoint_recur(Ctx& c, const double* nuT) {
-    double pi[NS];
+    const int lane = c.lane, r = lane < NS ? lane : 0;
+    constexpr int MV = NS * NS + NS;
+    double piq[NS], own = 0.0;
 #pragma unroll
-    for (int q = 0; q < NS; ++q) pi[q] = c.term_pinned[q] ? nuT[q] : 0.0;
+    for (int q = 0; q < NS; ++q) { piq[q] = c.term_pinned[q] ? nuT[q] : 0.0; own = (q == lane) ? piq[q] : own; }
+    double pre[NS + 1];
+    {
+      const double* M = c.r0 + (long)(c.N - 1) * MV;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) pre[q] = M[r * NS + q];
+      pre[NS] = M[NS * NS + r];
+    }
     for (int k = c.N - 1; k >= 0; --k) {
-      if (c.lane < NS) c.sPi[k * NS + c.lane] = pi[c.lane < NS ? c.lane : 0];
-      const double* M = c.r0 + (long)k * (NS * NS + NS);
-      double nx[NS];
+      if (lane < NS) c.sPi[k * NS + lane] = own;
+      double v = pre[NS];
 #pragma unroll
-      for (int r = 0; r < NS; ++r) {
-        double s = M[NS * NS + r];
+      for (int q = 0; q < NS; ++q) v += pre[q] * piq[q];
+      if (k > 0) {
+        const double* M = c.r0 + (long)(k - 1) * MV;
 #pragma unroll
-        for (int q = 0; q < NS; ++q) s += M[r * NS + q] * pi[q];
-        nx[r] = s;
+        for (int q = 0; q < NS; ++q) pre[q] = M[r * NS + q];
+        pre[NS] = M[NS * NS + r];
       }
 #pragma unroll
-      for (int q = 0; q < NS; ++q) pi[q] = nx[q];
+      for (int q = 0; q < NS; ++q) piq[q] = rdlane(v, q);
+      own = v;
     }
   }
 
@@ -574,7 +587,7 @@ struct HsWave {
       for (int r = 0; r < NQ; ++r) kk[r] = col[NW + r];
       chol_solve<NQ, 1>(Lq, kk);
       {
-        double* Kst = c.sK + (long)k * KST;
+        double* Kst = c.kg + (long)k * KST;
         if (isP) {
 #pragma unroll
           for (int r = 0; r < NQ; ++r) Kst[r * NW + lane] = kk[r];
@@ -650,65 +663,108 @@ struct HsWave {
     return nreg;
   }
 
-  // ---- phase 8: forward state recursion (sequential, cooperative); y_k -> LDS -----------------------------------
-  __device__ static void forward_recur(Ctx& c, const double* th) {
-    const int lane = c.lane, N = c.N;
-    if (lane < NW) {
-      double v = 0.0;
-      if (lane >= NS) {
+  // ---- phase 8a: lanes over intervals -- closed-loop stage maps  s_{k+1} = Phi_k s_k + phi_k, s = (dx, du) of a knot
+  // (the gains applied to the elimination rows, for the multipliers theta = (1, mu, nu)); rows -> LDS region R0
+  __device__ static void intervals_phi(Ctx& c, const double* th) {
+    const int N = c.N;
+    for (int k = c.lane; k < N; k += 64) {
+      const double* Kst = c.kg + (long)k * KST;
+      const double* st = c.st + (long)k * SG_N;
+      double Kk[NQ * NW], kq[NQ];
 #pragma unroll
-        for (int cc = 0; cc < NC; ++cc) v -= c.sKu[(lane - NS) * NC + cc] * th[cc];
-      }
-      c.sS[lane] = v;
-    }
-    double pre = (lane < NS * NY1) ? c.st[SG_GE + lane] : 0.0;   // stage 0
-    __syncthreads();
-    for (int k = 0; k < N; ++k) {
-      if (lane < NS * NY1) c.sGe[lane] = pre;
-      if (k + 1 < N && lane < NS * NY1) pre = c.st[(long)(k + 1) * SG_N + SG_GE + lane];
-      const double* Kst = c.sK + (long)k * KST;
-      double* y = c.sY + (long)k * NY;
-      if (lane < NW) y[lane] = c.sS[lane];
-      else if (lane < NW + NQ) {
-        const int r = lane - NW;
+      for (int q = 0; q < NQ * NW; ++q) Kk[q] = Kst[q];
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) {
         double v = 0.0;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) v -= Kst[r * NW + q] * c.sS[q];
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) v -= Kst[NQ * NW + r * NC + cc] * th[cc];
-        y[NW + r] = v;
+        for (int cc = 0; cc < NC; ++cc) v += Kst[NQ * NW + t * NC + cc] * th[cc];
+        kq[t] = v;
       }
-      __syncthreads();
-      if (lane < NS) {
-        double v = c.sGe[lane * NY1 + NY];
+      double* P = c.r0 + (long)k * PHI;
 #pragma unroll
-        for (int q = 0; q < NY; ++q) v += c.sGe[lane * NY1 + q] * y[q];
-        if (k == N - 1 && c.term_pinned[lane]) v = 0.0;
-        c.sS[lane] = v;
-      } else if (lane < NW) {
-        c.sS[lane] = y[NW + NU + (lane - NS)];
+      for (int i = 0; i < NS; ++i) {
+        double g[NY1];
+#pragma unroll
+        for (int q = 0; q <= NY; ++q) g[q] = st[SG_GE + i * NY1 + q];
+        const bool pin = (k == N - 1) && c.term_pinned[i];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+          double v = g[q];
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) v -= g[NW + t] * Kk[t * NW + q];
+          P[i * (NW + 1) + q] = pin ? 0.0 : v;
+        }
+        double v = g[NY];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) v -= g[NW + t] * kq[t];
+        P[i * (NW + 1) + NW] = pin ? 0.0 : v;
       }
-      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) P[(NS + a) * (NW + 1) + q] = -Kk[(NU + a) * NW + q];
+        P[(NS + a) * (NW + 1) + NW] = -kq[NU + a];
+      }
+    }
+  }
+
+  // ---- phase 8b: forward recursion (sequential): lane r < NW owns row r of Phi|phi (prefetched one stage ahead),
+  // s travels between lanes with v_readlane; s_k -> LDS for phase 9.  No barrier inside the loop.
+  __device__ static void forward_recur(Ctx& c, const double* th) {
+    const int lane = c.lane, N = c.N, r = lane < NW ? lane : 0;
+    double v = 0.0;
+    if (lane >= NS && lane < NW) {
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) v -= c.sKu[(lane - NS) * NC + cc] * th[cc];
+    }
+    double sq[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sq[q] = rdlane(v, q);
+    if (lane < NW) c.sS[lane] = v;
+    double pre[NW + 1];
+#pragma unroll
+    for (int q = 0; q <= NW; ++q) pre[q] = c.r0[r * (NW + 1) + q];
+    for (int k = 0; k < N; ++k) {
+      v = pre[NW];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) v += pre[q] * sq[q];
+      if (k + 1 < N) {
+        const double* P = c.r0 + (long)(k + 1) * PHI + r * (NW + 1);
+#pragma unroll
+        for (int q = 0; q <= NW; ++q) pre[q] = P[q];
+      }
+#pragma unroll
+      for (int q = 0; q < NW; ++q) sq[q] = rdlane(v, q);
+      if (lane < NW) c.sS[(k + 1) * NW + lane] = v;
     }
   }
 
   // ---- phase 9: lanes over intervals -- step for midpoint / end point variables ---------------------------------
-  __device__ static void intervals_dz(Ctx& c) {
+  __device__ static void intervals_dz(Ctx& c, const double* th) {
     const int N = c.N;
-    if (c.lane < NW) c.dz[zi(c, 0, c.lane)] = c.lane < NS ? 0.0 : c.sY[c.lane];
+    if (c.lane < NW) c.dz[zi(c, 0, c.lane)] = c.lane < NS ? 0.0 : c.sS[c.lane];
     for (int k = c.lane; k < N; k += 64) {
       const double* st = c.st + (long)k * SG_N;
+      const double* Kst = c.kg + (long)k * KST;
       double y[NY];
 #pragma unroll
-      for (int q = 0; q < NY; ++q) y[q] = c.sY[(long)k * NY + q];
+      for (int q = 0; q < NW; ++q) y[q] = c.sS[(long)k * NW + q];
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) v -= Kst[t * NW + q] * y[q];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) v -= Kst[NQ * NW + t * NC + cc] * th[cc];
+        y[NW + t] = v;
+      }
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        double vm = st[SG_GM + r * NY1 + NY], ve = st[SG_GE + r * NY1 + NY];
+        double vm = st[SG_GM + r * NY1 + NY];
 #pragma unroll
-        for (int q = 0; q < NY; ++q) { vm += st[SG_GM + r * NY1 + q] * y[q]; ve += st[SG_GE + r * NY1 + q] * y[q]; }
-        if (k == N - 1 && c.term_pinned[r]) ve = 0.0;
+        for (int q = 0; q < NY; ++q) vm += st[SG_GM + r * NY1 + q] * y[q];
         c.dz[zi(c, 2 * k + 1, r)] = vm;
-        c.dz[zi(c, 2 * k + 2, r)] = ve;
+        c.dz[zi(c, 2 * k + 2, r)] = c.sS[(long)(k + 1) * NW + r];     // = Ge y + ge (0 on a pinned terminal state)
       }
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
@@ -891,10 +947,13 @@ struct HsWave {
 #pragma unroll
       for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
       MYR_PH(7)
+      intervals_phi(c, th);
+      __syncthreads();
+      MYR_PH(13)
       forward_recur(c, th);
       __syncthreads();
       MYR_PH(8)
-      intervals_dz(c);
+      intervals_dz(c, th);
       __syncthreads();
       MYR_PH(9)
       typename S::FwdOut fo;
@@ -947,9 +1006,12 @@ struct HsWave {
   }
 };
 
+#ifndef MYR_WAVE_MIN_WAVES
+#define MYR_WAVE_MIN_WAVES 1   // waves per SIMD the register allocation must allow (occupancy)
+#endif
 // grid = B wavefronts (one 64-thread workgroup per trajectory); dynamic LDS = HsWave<Sys>::lds_bytes(N)
 template <class Sys>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, MYR_WAVE_MIN_WAVES)
 void hs_solve_wave_kernel(int B, HsSolveOpts o, double* __restrict__ z, const double* __restrict__ lb,
                           const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                           const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
@@ -967,19 +1029,18 @@ void hs_solve_wave_kernel(int B, HsSolveOpts o, double* __restrict__ z, const do
   c.pt = s; s += (long)W::PF_N * c.K;
   c.hr = s; s += (long)W::HR_N * c.K;
   c.st = s; s += (long)W::SG_N * c.N;
+  c.kg = s; s += (long)W::KST * c.N;
   c.lam = lam ? lam + b * (long)(2 * c.N * W::NS) : s;
   c.pp.load(params, b, params_stride);
   double* l = reinterpret_cast<double*>(smem_wave);
   c.r0 = l; l += W::r0_doubles(c.N);
-  c.sK = c.r0;
   c.sPi = l; l += c.N * W::NS;
-  c.sY = l; l += c.N * W::NY;
+  c.sS = l; l += (c.N + 1) * W::NW;
   c.sP = l; l += W::NW * W::NW;
   c.sPc = l; l += W::NW * W::NC;
   c.sGe = l; l += W::NS * W::NY1;
   c.sTnu = l; l += W::NS * W::NC;
   c.sKu = l; l += W::NU * W::NC;
-  c.sS = l; l += W::NW;
   HsSolveResult r;
 #ifdef MYR_PHASE_TIMING
   for (int i = 0; i < 16; ++i) c.tph[i] = 0;

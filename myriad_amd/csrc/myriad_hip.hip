@@ -387,6 +387,10 @@ static HsSolveOpts make_opts(myr_handle h, const myr_solve_opts& so) {
   o.N = h->d.intervals; o.h = h->d.T / h->d.intervals; o.max_iter = so.max_iter; o.tol_feas = so.tol_feas;
   o.tol_stat = so.tol_stat; o.tol_compl = so.tol_compl; o.mu_init = so.mu_init;
   o.cpi = h->d.controls_per_interval; o.method = h->d.integration_method;
+  // warm-started inertia correction: trades factorisation sweeps for (slightly more) iterations, which pays when a
+  // sweep costs more than a linearisation -- collocation with closed-form dynamics; not shooting (the rollout
+  // linearisation dominates, and the correction decays too slowly for its stragglers) nor network dynamics
+  o.delta_warm = (h->d.transcription != MYR_TR_SHOOTING && h->d.system_id != MYR_SYS_NODE_CARTPOLE) ? 1 : 0;
   if (const char* e = getenv("MYRIAD_NONMONO")) o.nonmono = atoi(e);      // developer knobs (globalisation ablations)
   if (const char* e = getenv("MYRIAD_RECENTER")) o.recenter = atoi(e);
   if (const char* e = getenv("MYRIAD_DELTA_WARM")) o.delta_warm = atoi(e);

@@ -28,6 +28,14 @@ struct SysNODE {
   static constexpr int NNZ2 = 1;                      // no stored second derivatives: hessian() recomputes
   static constexpr const char* NAME = "NODE";
 
+  // The network evaluations are real function calls on the device (MYR_NODE_FN): each is thousands of flops, so the
+  // call costs nothing, and the solver kernels stay at a size the register allocator handles (inlined, the wave kernel
+  // of this system grew to 40k instructions with ~4k spilled SGPRs).
+#ifdef __HIP_DEVICE_COMPILE__
+#define MYR_NODE_FN __device__ __attribute__((noinline)) static
+#else
+#define MYR_NODE_FN MYR_HD static inline
+#endif
   MYR_HD static inline double sig(double a) { return 1.0 / (1.0 + exp(-a)); }
 
   // forward pass keeping the hidden activations
@@ -56,7 +64,7 @@ struct SysNODE {
     }
   }
 
-  MYR_HD static inline void f(const double* x, const double* u, const double* p, double* fo) {
+  MYR_NODE_FN void f(const double* x, const double* u, const double* p, double* fo) {
     double h1[H1], h2[H2];
     fwd(x, u, p, h1, h2, fo);
   }
@@ -75,7 +83,7 @@ struct SysNODE {
   }
 
   // f, A = df/dx, B = df/du (reverse mode: one backward pass per output row), g, dg
-  MYR_HD static inline void lin(const double* x, const double* u, const double* p, double* fo, double* A, double* B, double* go, double* gw) {
+  MYR_NODE_FN void lin(const double* x, const double* u, const double* p, double* fo, double* A, double* B, double* go, double* gw) {
     double h1[H1], h2[H2];
     fwd(x, u, p, h1, h2, fo);
     for (int r = 0; r < NS; ++r) {
@@ -109,7 +117,7 @@ struct SysNODE {
   // W = wg * d2 g + d2 (mu^T MLP) / dw2   with  d2(mu^T MLP) = W1 (D1 + S1 W2 D2 W2^T S1) W1^T  (w-space, see below)
   //   g2 = W3 mu, D2 = diag(g2 * s''(a2)), g1 = W2 (g2 * s'(a2)), D1 = diag(g1 * s''(a1)), S1 = diag(s'(a1)),
   //   s' = h(1-h), s'' = h(1-h)(1-2h)
-  MYR_HD static inline void hessian(const double* x, const double* u, const double* p, const double* D2unused,
+  MYR_NODE_FN void hessian(const double* x, const double* u, const double* p, const double* D2unused,
                                     const double* mu, double wg, double* W) {
     (void)D2unused;
     double h1[H1], h2[H2], out[NS];

@@ -12,13 +12,8 @@
 
 using namespace myriad;
 
-template <class Sys>
-static void solve_batch(int N, double T, int B, double* z, const double* lb, const double* ub, const double* params,
-                        int pstride, int max_iter, double tol_feas, double tol_stat, double tol_compl, double mu_init,
-                        double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt) {
-  using S = HsSolver<Sys>;
-  const int K = 2 * N + 1, n = K * Sys::NW, m = 2 * N * Sys::NS;
-  HsSolveOpts o{N, T / N, max_iter, tol_feas, tol_stat, tol_compl, mu_init};
+// test/dev knobs: every solver option can be overridden from the environment
+static void apply_env(HsSolveOpts& o) {
   if (getenv("RHO")) o.rho_term = atof(getenv("RHO"));
   if (getenv("REGF")) o.reg_floor = atof(getenv("REGF"));
   if (getenv("NONM")) o.nonmono = atoi(getenv("NONM"));
@@ -34,6 +29,16 @@ static void solve_batch(int N, double T, int B, double* z, const double* lb, con
   if (getenv("KEPS")) o.kappa_eps = atof(getenv("KEPS"));
   if (getenv("RECN")) o.recenter = atoi(getenv("RECN"));
   if (getenv("RECA")) o.recenter_alpha = atof(getenv("RECA"));
+}
+
+template <class Sys>
+static void solve_batch(int N, double T, int B, double* z, const double* lb, const double* ub, const double* params,
+                        int pstride, int max_iter, double tol_feas, double tol_stat, double tol_compl, double mu_init,
+                        double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt) {
+  using S = HsSolver<Sys>;
+  const int K = 2 * N + 1, n = K * Sys::NW, m = 2 * N * Sys::NS;
+  HsSolveOpts o{N, T / N, max_iter, tol_feas, tol_stat, tol_compl, mu_init};
+  apply_env(o);
 
 #pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < B; ++b) {
@@ -143,6 +148,7 @@ extern "C" int hostsim_solve_trap(int system_id, int N, double T, int B, double*
                                   const double* params, int pstride, int max_iter, double* lam, double* cost,
                                   int32_t* status, int32_t* iters, double* kkt) {
   HsSolveOpts o{N, T / N, max_iter, 1e-8, 1e-6, 1e-7, 0.1};
+  apply_env(o);
 #define TR(S) os_batch<TrapCore<S>, S>(o, (N + 1) * S::NW, N * S::NS, TrapCore<S>::stage_doubles(N), B, z, lb, ub, params, pstride, lam, cost, status, iters, kkt)
   switch (system_id) {
     case 0: TR(SysCARTPOLE); return 0;
@@ -158,6 +164,7 @@ extern "C" int hostsim_solve_shoot(int system_id, int I, int cpi, int method, do
                                    double* cost, int32_t* status, int32_t* iters, double* kkt) {
   HsSolveOpts o{I, T / I, max_iter, 1e-8, 1e-6, 1e-7, 0.1};
   o.cpi = cpi; o.method = method;
+  apply_env(o);
 #define SH(S) os_batch<ShootCore<S>, S>(o, (I + 1) * S::NS + (I * cpi + 1) * S::NU, I * S::NS, ShootCore<S>::stage_doubles(I, cpi), B, z, lb, ub, params, pstride, lam, cost, status, iters, kkt)
   switch (system_id) {
     case 0: SH(SysCARTPOLE); return 0;

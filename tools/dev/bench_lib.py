@@ -5,8 +5,9 @@ from myriad_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from bench import build_workload
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-x0, z0, lb, ub, T = build_workload(B, 100, 2019)
-eng = _lib.Engine("CARTPOLE", "HERMITE_SIMPSON", 100, T, max_batch=B)
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+x0, z0, lb, ub, T = build_workload(B, N, 2019)
+eng = _lib.Engine("CARTPOLE", "HERMITE_SIMPSON", N, T, max_batch=B)
 for _ in range(3):
   res = eng.solve(z0, lb, ub)
 print(sys.argv[1], "converged", (res["status"] == 0).mean(), "kernel ms avg", eng.kernel_time(_lib.K_SOLVE))
