@@ -35,6 +35,54 @@ __device__ inline double wv_min(double v) {
   for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o, 64); v = v < t ? v : t; }
   return v;
 }
+// reciprocal from v_rcp_f64 + two Newton steps (the operands here are pivots already known to exceed reg_floor)
+__device__ inline double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+// L D L^T of a small SPD block with the SAME pivot rule as detail::chol_reg (the pivots d_j are the squares of the
+// Cholesky diagonal): a <- unit lower factor (strict lower part), dinv <- 1 / d.  No sqrt, one reciprocal per pivot.
+template <int n>
+__device__ inline int ldl_reg(double* a, double* dinv, double floor_) {
+  int nreg = 0;
+  double d[n];
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    double dj = a[j * n + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) dj -= a[j * n + k] * a[j * n + k] * d[k];
+    if (!(dj > floor_)) { dj = detail::dmax(fabs(dj), floor_); ++nreg; }
+    d[j] = dj;
+    dinv[j] = fast_rcp(dj);
+#pragma unroll
+    for (int i = j + 1; i < n; ++i) {
+      double t = a[i * n + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= a[i * n + k] * a[j * n + k] * d[k];
+      a[i * n + j] = t * dinv[j];
+    }
+  }
+  return nreg;
+}
+template <int n>
+__device__ inline void ldl_solve(const double* a, const double* dinv, double* b) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int k = 0; k < i; ++k) b[i] -= a[i * n + k] * b[k];
+  }
+#pragma unroll
+  for (int i = 0; i < n; ++i) b[i] *= dinv[i];
+#pragma unroll
+  for (int i = n - 1; i >= 0; --i) {
+#pragma unroll
+    for (int k = i + 1; k < n; ++k) b[i] -= a[k * n + i] * b[k];
+  }
+}
+
 __device__ inline int wv_isum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -56,11 +104,12 @@ struct HsWave {
                        SG_LI = SG_LD0 + NS, SG_LI0 = SG_LI + NS * NS, SG_QM = SG_LI0 + NS, SG_QCM = SG_QM + NY * NY,
                        SG_N = SG_QCM + NY * 2;
   static constexpr int KST = NQ * NW + NQ * NC;   // K | kc per stage (global scratch)
+  static constexpr int ZR = 2 * NY + 2;           // block of zeros (masked stage inputs of the Riccati lanes read it)
   static constexpr int PHI = NW * (NW + 1);       // closed-loop stage map Phi | phi per stage (LDS)
 
   __host__ __device__ static long scratch_doubles(int N) {
     const long K = 2 * N + 1, n = K * NW;
-    return 3 * n + (long)PF_N * K + (long)HR_N * K + (long)SG_N * N + (long)KST * N +
+    return 3 * n + (long)PF_N * K + (long)HR_N * K + (long)SG_N * N + (long)KST * N + ZR +
            2L * N * NS /* lambda when the caller passes none */;
   }
   // LDS doubles: region R0 (adjoint M|v, later Phi|phi, later trial x|f), Pi, S, exchange
@@ -74,7 +123,7 @@ struct HsWave {
   struct Ctx {
     int N, K, n, lane;
     double h, h6, h8;
-    double *z, *zL, *zU, *dz, *lam, *pt, *hr, *st, *kg;
+    double *z, *zL, *zU, *dz, *lam, *pt, *hr, *st, *kg, *zr;
     const double *lb, *ub;
     SysParams<Sys> pp;
     bool term_pinned[NS];
@@ -487,46 +536,50 @@ struct HsWave {
     const int cc = lane - NY;                   // column cc of the right-hand sides when 0 <= cc < NC
     const bool isC = cc >= 0 && cc < NC;
     const bool isVal = isP || isC;
-    // per-lane addressing of the stage inputs
+    // per-lane addressing of the stage inputs: base pointer + stride per stage; lanes without an input (the nu
+    // columns have no qcm, lanes past the columns have nothing) read a block of zeros, so every load is unconditional
     const bool m_on = isY || (isC && cc < 2);   // Qm column (unit stride; Qm is symmetric) | qcm column (stride 2)
-    const int m_off = isY ? SG_QM + lane * NY : SG_QCM + (cc == 1 ? 1 : 0);
+    const double* m_ptr = m_on ? c.st + (isY ? SG_QM + lane * NY : SG_QCM + (cc == 1 ? 1 : 0)) : c.zr;
     const int m_str = isY ? 1 : 2;
-    const bool h_on = isP || (isC && cc < 2);   // H_e column | g0 | g1 of the end point
-    const int h_off = isP ? HR_H + lane * NW : (cc == 1 ? HR_G1 : HR_G0);
+    const long m_step = m_on ? SG_N : 0;
+    const bool h_on = isP || (isC && cc < 2);   // H_e column | g0 | g1 of the end point (point 2k+2 for stage k)
+    const double* h_ptr = h_on ? c.hr + (isP ? HR_H + lane * NW : (cc == 1 ? HR_G1 : HR_G0)) : c.zr;
+    const long h_step = h_on ? 2 * HR_N : 0;
     const int v_col = isY ? lane : NY;          // own column of Ge^ (Q lanes), ge^ (gradient column), none otherwise
     const double v_on = (isY || cc == 0) ? 1.0 : 0.0;
+    const double c_on = isC ? 1.0 : 0.0;
     constexpr int NGE = NS * NY1, NGL = (NGE + 63) / 64;
 
-    double val[NW], tnuB[NS], tnuA = 0.0;
+    // delta on the own diagonal entry; the pinned terminal diagonal carries rho instead (rho - delta + delta below)
+    double val[NW], dvec[NW], tnuB[NS], tnuA = 0.0;
 #pragma unroll
     for (int r = 0; r < NW; ++r) {
       const bool pin = r < NS && c.term_pinned[r < NS ? r : 0];
-      val[r] = (isP && r == lane && pin) ? o.rho_term : ((isC && cc == 2 + r && pin) ? 1.0 : 0.0);
+      dvec[r] = (isP && r == lane) ? delta : 0.0;
+      val[r] = (isP && r == lane && pin) ? o.rho_term - delta : ((isC && cc == 2 + r && pin) ? 1.0 : 0.0);
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i) tnuB[i] = 0.0;
     int nreg = 0;
     double m_pre[NY], h_pre[NW], g_pre[NGL];
     {
+      const double* mp = m_ptr + (long)(N - 1) * m_step;
+      const double* hp = h_ptr + (long)(N - 1) * h_step + (h_on ? 2 * HR_N : 0);
       const double* st = c.st + (long)(N - 1) * SG_N;
-      const double* hr = c.hr + (long)(2 * N) * HR_N;
 #pragma unroll
-      for (int r = 0; r < NY; ++r) m_pre[r] = m_on ? st[m_off + r * m_str] : 0.0;
+      for (int r = 0; r < NY; ++r) m_pre[r] = mp[r * m_str];
 #pragma unroll
-      for (int r = 0; r < NW; ++r) h_pre[r] = h_on ? hr[h_off + r] : 0.0;
+      for (int r = 0; r < NW; ++r) h_pre[r] = hp[r];
 #pragma unroll
-      for (int t = 0; t < NGL; ++t) { const int e = lane + 64 * t; g_pre[t] = e < NGE ? st[SG_GE + e] : 0.0; }
+      for (int t = 0; t < NGL; ++t) { const int e = lane + 64 * t; g_pre[t] = st[SG_GE + (e < NGE ? e : NGE - 1)]; }
     }
     for (int k = N - 1; k >= 0; --k) {
       double m[NY];
 #pragma unroll
       for (int r = 0; r < NY; ++r) m[r] = m_pre[r];
-      // (a) P' = P + H_e + delta I (not on the pinned terminal diagonal), pc' = pc + gbar_e; share P' and Ge|ge
+      // (a) P' = P + H_e + delta I, pc' = pc + gbar_e; share P' and Ge|ge
 #pragma unroll
-      for (int r = 0; r < NW; ++r) {
-        const bool pinned_diag = (k == N - 1) && r < NS && c.term_pinned[r < NS ? r : 0];
-        val[r] += h_pre[r] + ((isP && r == lane && !pinned_diag) ? delta : 0.0);
-      }
+      for (int r = 0; r < NW; ++r) val[r] += h_pre[r] + dvec[r];
       if (isP) {
 #pragma unroll
         for (int r = 0; r < NW; ++r) c.sP[lane * NW + r] = val[r];
@@ -534,14 +587,15 @@ struct HsWave {
 #pragma unroll
       for (int t = 0; t < NGL; ++t) { const int e = lane + 64 * t; if (e < NGE) c.sGe[e] = g_pre[t]; }
       if (k > 0) {       // prefetch the next stage while this one is processed
+        const double* mp = m_ptr + (long)(k - 1) * m_step;
+        const double* hp = h_ptr + (long)(k - 1) * h_step + (h_on ? 2 * HR_N : 0);
         const double* st = c.st + (long)(k - 1) * SG_N;
-        const double* hr = c.hr + (long)(2 * k) * HR_N;
 #pragma unroll
-        for (int r = 0; r < NY; ++r) m_pre[r] = m_on ? st[m_off + r * m_str] : 0.0;
+        for (int r = 0; r < NY; ++r) m_pre[r] = mp[r * m_str];
 #pragma unroll
-        for (int r = 0; r < NW; ++r) h_pre[r] = h_on ? hr[h_off + r] : 0.0;
+        for (int r = 0; r < NW; ++r) h_pre[r] = hp[r];
 #pragma unroll
-        for (int t = 0; t < NGL; ++t) { const int e = lane + 64 * t; g_pre[t] = e < NGE ? st[SG_GE + e] : 0.0; }
+        for (int t = 0; t < NGL; ++t) { const int e = lane + 64 * t; g_pre[t] = st[SG_GE + (e < NGE ? e : NGE - 1)]; }
       }
       __syncthreads();
       // (b) tv = P' v + (pc' on the right-hand-side lanes),  v = own column of [Ge^ | ge^]
@@ -552,7 +606,7 @@ struct HsWave {
       for (int a = 0; a < NU; ++a) v[NS + a] = (lane == NS + 2 * NU + a) ? 1.0 : 0.0;
 #pragma unroll
       for (int r = 0; r < NW; ++r) {
-        double s = isC ? val[r] : 0.0;
+        double s = c_on * val[r];
 #pragma unroll
         for (int q = 0; q < NW; ++q) s += c.sP[r * NW + q] * v[q];
         tv[r] = s;
@@ -574,18 +628,18 @@ struct HsWave {
         for (int t = 0; t < NS; ++t) s += c.sGe[t * NY1 + NY] * val[t];
         tnuA += s;
       }
-      // (d) Cholesky of Qqq (identical on every lane), own column of the gains K | kc
-      double Lq[NQ * NQ];
+      // (d) L D L^T of Qqq (identical on every lane), own column of the gains K | kc
+      double Lq[NQ * NQ], dinv[NQ];
 #pragma unroll
       for (int r = 0; r < NQ; ++r)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) Lq[r * NQ + q] = rdlane(col[NW + r], NW + q);
-      nreg += chol_reg<NQ>(Lq, o.reg_floor);
+        for (int q = 0; q <= r; ++q) Lq[r * NQ + q] = rdlane(col[NW + r], NW + q);
+      nreg += ldl_reg<NQ>(Lq, dinv, o.reg_floor);
       if (nreg > 0 && abort_on_reg) return nreg;
       double kk[NQ];
 #pragma unroll
       for (int r = 0; r < NQ; ++r) kk[r] = col[NW + r];
-      chol_solve<NQ, 1>(Lq, kk);
+      ldl_solve<NQ>(Lq, dinv, kk);
       {
         double* Kst = c.kg + (long)k * KST;
         if (isP) {
@@ -596,13 +650,13 @@ struct HsWave {
           for (int r = 0; r < NQ; ++r) Kst[NQ * NW + r * NC + cc] = kk[r];
         }
       }
-      // (e) value function: own column of P = Qss - Qsq K,  pc = qc_s - Qsq kc
+      // (e) value function: own column of P = Qss - Qsq K,  pc = qc_s - Qsq kc   (lanes without a column: unused)
 #pragma unroll
       for (int r = 0; r < NW; ++r) {
         double s = col[r];
 #pragma unroll
         for (int t = 0; t < NQ; ++t) s -= rdlane(col[r], NW + t) * kk[t];
-        val[r] = isVal ? s : 0.0;
+        val[r] = s;
       }
       // terminal-multiplier bookkeeping, part 2 (lane NY+cc holds Tnu[:, cc]): Tnu[i][cc] -= qc_q[:, nu_i]^T kc[:, cc]
 #pragma unroll
@@ -864,6 +918,7 @@ struct HsWave {
       v = fr ? v : l;
       c.z[i] = v; c.zL[i] = hl ? 1.0 : 0.0; c.zU[i] = hu ? 1.0 : 0.0;
     }
+    if (c.lane < ZR) c.zr[c.lane] = 0.0;
   }
 
   // ---- the solve (control flow identical to HsSolver<Sys>::solve) ------------------------------------------------
@@ -1030,6 +1085,7 @@ void hs_solve_wave_kernel(int B, HsSolveOpts o, double* __restrict__ z, const do
   c.hr = s; s += (long)W::HR_N * c.K;
   c.st = s; s += (long)W::SG_N * c.N;
   c.kg = s; s += (long)W::KST * c.N;
+  c.zr = s; s += W::ZR;
   c.lam = lam ? lam + b * (long)(2 * c.N * W::NS) : s;
   c.pp.load(params, b, params_stride);
   double* l = reinterpret_cast<double*>(smem_wave);
