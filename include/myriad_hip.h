@@ -13,6 +13,9 @@
  *                                 nlp_solvers/__init__.py:18-98 (:57-58)      myr_solve
  *   get_state_trajectory_and_cost / get_defect   utils.py:258-324            myr_rollout
  *   Python exceptions / solution['success']      nlp_solvers/__init__.py:59-64  return codes, status[], myr_last_error
+ *   jax.grad(lagrangian, argnums=0)(x, lmbda)    nlp_solvers/extra_gradient.py:21-33,
+ *                                                experiments/e2e_sysid.py:113-125           myr_vjp (add_gradf=1), myr_jvp
+ *   step(x, lmbda) (extragradient iteration)     nlp_solvers/extra_gradient.py:25-33        myr_exgd
  *
  * Conventions
  *   - all floating point is IEEE fp64 (the reference sets jax_enable_x64, run.py:15);
@@ -46,7 +49,7 @@ enum { MYR_MEM_HOST = 0, MYR_MEM_DEVICE = 1 };
 /* per-instance solve status */
 enum { MYR_STATUS_CONVERGED = 0, MYR_STATUS_MAXITER = 1, MYR_STATUS_NAN = 2, MYR_STATUS_STALLED = 3 };
 /* kernel ids for myr_kernel_time */
-enum { MYR_K_EVAL = 0, MYR_K_SOLVE = 1, MYR_K_ROLLOUT = 2, MYR_K_RESID = 3, MYR_K_COUNT = 4 };
+enum { MYR_K_EVAL = 0, MYR_K_SOLVE = 1, MYR_K_ROLLOUT = 2, MYR_K_RESID = 3, MYR_K_PROD = 4, MYR_K_COUNT = 5 };
 /* error codes */
 enum { MYR_OK = 0, MYR_E_ARG = -1, MYR_E_UNSUPPORTED = -2, MYR_E_HIP = -3, MYR_E_CAPACITY = -4 };
 
@@ -135,6 +138,28 @@ int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, const double
  */
 int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u_rows, const double* x0, const double* us,
                 const double* params, int32_t params_stride, double* xs, double* cost, int32_t mem);
+
+/*
+ * Matrix-free products with the constraint Jacobian of the COLLOCATION transcriptions (HERMITE_SIMPSON, TRAPEZOIDAL;
+ * SHOOTING returns MYR_E_UNSUPPORTED) -- what jax.grad(lagrangian) computes through the dense transcription in
+ * nlp_solvers/extra_gradient.py:21-33 and experiments/e2e_sysid.py:113-141.
+ *   myr_vjp:  out[B][n] = J(z)^T lam   (+ grad f(z) when add_gradf != 0: the gradient of the Lagrangian in z)
+ *   myr_jvp:  out[B][m] = J(z) v
+ * z [B][n], lam [B][m], v [B][n]; layouts and row order as in myr_eval.
+ */
+int myr_vjp(myr_handle h, int32_t B, const double* z, const double* lam, const double* params, int32_t params_stride,
+            double* out, int32_t add_gradf, int32_t mem);
+int myr_jvp(myr_handle h, int32_t B, const double* z, const double* v, const double* params, int32_t params_stride,
+            double* out, int32_t mem);
+
+/*
+ * `nsteps` extragradient iterations on B instances, iterate resident on the device (extra_gradient.py:25-33):
+ *   x_bar = clip(x - eta_x dL/dx(x, lam), lb, ub);  x_new = clip(x - eta_x dL/dx(x_bar, lam), lb, ub);
+ *   lam_new = lam + eta_v c(x_new)
+ * z [B][n] and lam [B][m] are updated in place; lb, ub [B][n].
+ */
+int myr_exgd(myr_handle h, int32_t B, double* z, double* lam, const double* lb, const double* ub, const double* params,
+             int32_t params_stride, double eta_x, double eta_v, int32_t nsteps, int32_t mem);
 
 /* Average device time (HIP events on the handle's stream) of the launches of one kernel since the last reset. */
 int myr_kernel_time(myr_handle h, int32_t kernel_id, double* avg_ms, int32_t* launches);

@@ -18,11 +18,12 @@ SYS_IDS = {"CARTPOLE": 0, "VANDERPOL": 1, "CANCERTREATMENT": 2, "SIMPLECASE": 3,
 TR_IDS = {"HERMITE_SIMPSON": 0, "TRAPEZOIDAL": 1, "SHOOTING": 2}
 INT_IDS = {"EULER": 0, "HEUN": 1, "MIDPOINT": 2, "RK4": 3}
 MEM_HOST, MEM_DEVICE = 0, 1
-K_EVAL, K_SOLVE, K_ROLLOUT, K_RESID = 0, 1, 2, 3
+K_EVAL, K_SOLVE, K_ROLLOUT, K_RESID, K_PROD = 0, 1, 2, 3, 4
 STATUS_NAMES = {0: "CONVERGED", 1: "MAXITER", 2: "NAN", 3: "STALLED"}
 
 EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve",
-           "myr_rollout", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error", "myr_version"]
+           "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",
+           "myr_version"]
 
 
 class ProblemDesc(C.Structure):
@@ -73,6 +74,12 @@ def load() -> C.CDLL:
   lib.myr_solve.restype = C.c_int
   lib.myr_rollout.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, dp, dp, C.c_int32]
   lib.myr_rollout.restype = C.c_int
+  lib.myr_vjp.argtypes = [vp, C.c_int32, dp, dp, dp, C.c_int32, dp, C.c_int32, C.c_int32]
+  lib.myr_vjp.restype = C.c_int
+  lib.myr_jvp.argtypes = [vp, C.c_int32, dp, dp, dp, C.c_int32, dp, C.c_int32]
+  lib.myr_jvp.restype = C.c_int
+  lib.myr_exgd.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32]
+  lib.myr_exgd.restype = C.c_int
   lib.myr_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
   lib.myr_kernel_time.restype = C.c_int
   lib.myr_kernel_time_reset.argtypes = [vp]
@@ -214,6 +221,55 @@ class Engine:
     _chk(self.lib.myr_rollout(self._h, B, int(num_steps), int(us.shape[1]), _addr(x0), _addr(us), _addr(p), ps,
                               _addr(xs), _addr(cost), MEM_HOST), "myr_rollout")
     return xs, cost
+
+  # ---- Lagrangian products / extragradient (collocation transcriptions) ------------------------
+  def _batch2(self, a, width, name):
+    a = _f64(a)
+    if a.ndim == 1:
+      a = a[None]
+    if a.shape[1] != width:
+      raise ValueError(f"{name} must be [B,{width}]")
+    return a
+
+  def vjp(self, z, lam, params=None, add_gradf=False):
+    """J(z)^T lam (+ grad f(z) when add_gradf: the gradient of the Lagrangian in z), [B,n]."""
+    z = self._batch2(z, self.n, "z"); lam = self._batch2(lam, self.m, "lam")
+    B = z.shape[0]
+    if lam.shape[0] != B:
+      raise ValueError("z and lam must have the same batch size")
+    p, ps = self._params(params, B)
+    out = np.empty((B, self.n))
+    _chk(self.lib.myr_vjp(self._h, B, _addr(z), _addr(lam), _addr(p), ps, _addr(out), int(bool(add_gradf)), MEM_HOST), "myr_vjp")
+    return out
+
+  def jvp(self, z, v, params=None):
+    """J(z) v, [B,m]."""
+    z = self._batch2(z, self.n, "z"); v = self._batch2(v, self.n, "v")
+    B = z.shape[0]
+    if v.shape[0] != B:
+      raise ValueError("z and v must have the same batch size")
+    p, ps = self._params(params, B)
+    out = np.empty((B, self.m))
+    _chk(self.lib.myr_jvp(self._h, B, _addr(z), _addr(v), _addr(p), ps, _addr(out), MEM_HOST), "myr_jvp")
+    return out
+
+  def exgd(self, z, lam, lb, ub, eta_x, eta_v, nsteps, params=None):
+    """`nsteps` extragradient iterations; returns the new (z, lam)."""
+    z = self._batch2(z, self.n, "z").copy(); lam = self._batch2(lam, self.m, "lam").copy()
+    B = z.shape[0]
+    lb = np.ascontiguousarray(np.broadcast_to(_f64(lb), z.shape))
+    ub = np.ascontiguousarray(np.broadcast_to(_f64(ub), z.shape))
+    p, ps = self._params(params, B)
+    _chk(self.lib.myr_exgd(self._h, B, _addr(z), _addr(lam), _addr(lb), _addr(ub), _addr(p), ps, float(eta_x), float(eta_v),
+                           int(nsteps), MEM_HOST), "myr_exgd")
+    return z, lam
+
+  def products_device(self, op, B, z, w, out, params=None, params_stride=0, add_gradf=0):
+    """Zero-copy vjp ('vjp') / jvp ('jvp') on device tensors."""
+    if op == "vjp":
+      _chk(self.lib.myr_vjp(self._h, int(B), _addr(z), _addr(w), _addr(params), int(params_stride), _addr(out), int(add_gradf), MEM_DEVICE), "myr_vjp")
+    else:
+      _chk(self.lib.myr_jvp(self._h, int(B), _addr(z), _addr(w), _addr(params), int(params_stride), _addr(out), MEM_DEVICE), "myr_jvp")
 
   def kernel_time(self, kernel_id: int):
     ms = C.c_double(); n = C.c_int32()

@@ -9,6 +9,7 @@
 
 #include "../../include/myriad_hip.h"
 #include "hs_eval.h"
+#include "colloc_products.h"
 #include "hs_solver.h"
 #include "hs_solver_wave.h"
 #include "os_solver.h"
@@ -313,6 +314,159 @@ extern "C" int myr_eval(myr_handle h, int32_t B, const double* z, const double* 
   if (ng) HIPCHK(hipMemcpyAsync(gradf, dg, ng * 8, hipMemcpyDeviceToHost, h->stream));
   if (nc) HIPCHK(hipMemcpyAsync(c, dc, nc * 8, hipMemcpyDeviceToHost, h->stream));
   if (nj) HIPCHK(hipMemcpyAsync(jblk, dj, nj * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MYR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lagrangian products and the extragradient step (collocation transcriptions)
+// ------------------------------------------------------------------------------------------------
+enum { PRODOP_VJP = 0, PRODOP_JVP = 1, PRODOP_EXGD = 2 };
+struct ProdArgs {
+  int op, B;
+  const double *z, *w, *params; int pstride;     // w: lam (vjp) or v (jvp)
+  double* out; int add_gradf;
+  double *zio, *lamio; const double *lb, *ub; double eta_x, eta_v; int nsteps;   // exgd
+};
+
+template <class Sys, int SCHEME>
+static int launch_products(myr_handle h, const ProdArgs& a) {
+  const int N = h->d.intervals;
+  const double hstep = h->d.T / N;
+  using P = CollocProducts<Sys, SCHEME>;
+  KTimer& kt = h->kt[MYR_K_PROD];
+  HIPCHK(hipEventRecord(kt.a, h->stream));
+  if (a.op == PRODOP_EXGD) {
+    const size_t lds = colloc_exgd_lds_bytes<Sys, SCHEME>(N);
+    if (lds > 160 * 1024) return fail(MYR_E_CAPACITY, "myr_exgd: intervals too large for the LDS-resident iterate");
+    auto kern = colloc_exgd_kernel<Sys, SCHEME>;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(64), lds, h->stream, a.B, N, hstep, a.zio, a.lamio, a.lb, a.ub,
+                       a.params, a.pstride, a.eta_x, a.eta_v, a.nsteps);
+  } else {
+    const long units = (long)a.B * (a.op == PRODOP_VJP ? P::points(N) : N);
+    long blocks = (units + 255) / 256;
+    if (blocks > 256L * 64) blocks = 256L * 64;       // grid-stride beyond 64 workgroups per CU
+    if (a.op == PRODOP_VJP)
+      hipLaunchKernelGGL((colloc_vjp_kernel<Sys, SCHEME>), dim3((unsigned)blocks), dim3(256), 0, h->stream, a.B, N, hstep, a.z, a.w,
+                         a.params, a.pstride, a.out, a.add_gradf);
+    else
+      hipLaunchKernelGGL((colloc_jvp_kernel<Sys, SCHEME>), dim3((unsigned)blocks), dim3(256), 0, h->stream, a.B, N, hstep, a.z, a.w,
+                         a.params, a.pstride, a.out);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(kt.b, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+  kt.sum_ms += ms;
+  kt.launches += 1;
+  return MYR_OK;
+}
+
+template <class Sys>
+static int products_for_system(myr_handle h, const ProdArgs& a) {
+  if constexpr (Sys::PARAMS_BY_POINTER) {
+    if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "products: NODE systems are built for HERMITE_SIMPSON");
+    return launch_products<Sys, PROD_HS>(h, a);
+  } else {
+    switch (h->d.transcription) {
+      case MYR_TR_HERMITE_SIMPSON: return launch_products<Sys, PROD_HS>(h, a);
+      case MYR_TR_TRAPEZOIDAL: return launch_products<Sys, PROD_TRAP>(h, a);
+      default: return fail(MYR_E_UNSUPPORTED, "products: built for the collocation transcriptions (HERMITE_SIMPSON, TRAPEZOIDAL)");
+    }
+  }
+}
+
+static int dispatch_products(myr_handle h, const ProdArgs& a) {
+  switch (h->d.system_id) {
+    case MYR_SYS_CARTPOLE: return products_for_system<SysCARTPOLE>(h, a);
+    case MYR_SYS_VANDERPOL: return products_for_system<SysVANDERPOL>(h, a);
+    case MYR_SYS_CANCERTREATMENT: return products_for_system<SysCANCERTREATMENT>(h, a);
+    case MYR_SYS_SIMPLECASE: return products_for_system<SysSIMPLECASE>(h, a);
+    case MYR_SYS_NODE_CARTPOLE: return products_for_system<SysNODE_CARTPOLE>(h, a);
+  }
+  return fail(MYR_E_ARG, "products: unknown system");
+}
+
+static int check_products_args(myr_handle h, const char* who, int32_t B, const void* p0, const void* p1, const void* p2,
+                               const double* params, int32_t params_stride) {
+  if (!h || !p0 || !p1 || !p2) return fail(MYR_E_ARG, std::string(who) + ": null handle or array");
+  if (B < 0) return fail(MYR_E_ARG, std::string(who) + ": negative batch");
+  if (params && params_stride != 0 && params_stride != h->dims.np)
+    return fail(MYR_E_ARG, std::string(who) + ": params_stride must be 0 (shared) or np");
+  if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, std::string(who) + ": a NODE system needs its weights in `params`");
+  return MYR_OK;
+}
+
+// one implementation for J^T lam / grad L (in_w = m, out = n) and J v (in_w = n, out = m)
+static int products_call(myr_handle h, int op, const char* who, int32_t B, const double* z, const double* w, const double* params,
+                         int32_t params_stride, double* out, int32_t add_gradf, int32_t mem) {
+  int rc = check_products_args(h, who, B, z, w, out, params, params_stride);
+  if (rc) return rc;
+  if (B == 0) return MYR_OK;
+  HIPCHK(hipSetDevice(h->d.device));
+  const myr_dims& dm = h->dims;
+  ProdArgs a{};
+  a.op = op; a.B = B; a.pstride = params_stride; a.add_gradf = add_gradf;
+  if (mem == MYR_MEM_DEVICE) { a.z = z; a.w = w; a.params = params; a.out = out; return dispatch_products(h, a); }
+  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, std::string(who) + ": bad mem kind");
+  const size_t nz = (size_t)B * dm.n, nw = (size_t)B * (op == PRODOP_VJP ? dm.m : dm.n), no = (size_t)B * (op == PRODOP_VJP ? dm.n : dm.m);
+  const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  rc = ensure_dbuf(h, (al(nz) + al(nw) + al(no) + al(npar)) * 8);
+  if (rc) return rc;
+  double* dz = (double*)h->dbuf; double* dw = dz + al(nz); double* dout = dw + al(nw); double* dp = dout + al(no);
+  HIPCHK(hipMemcpyAsync(dz, z, nz * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dw, w, nw * 8, hipMemcpyHostToDevice, h->stream));
+  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
+  a.z = dz; a.w = dw; a.params = npar ? dp : nullptr; a.out = dout;
+  rc = dispatch_products(h, a);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, dout, no * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MYR_OK;
+}
+
+extern "C" int myr_vjp(myr_handle h, int32_t B, const double* z, const double* lam, const double* params, int32_t params_stride,
+                       double* out, int32_t add_gradf, int32_t mem) {
+  return products_call(h, PRODOP_VJP, "myr_vjp", B, z, lam, params, params_stride, out, add_gradf, mem);
+}
+
+extern "C" int myr_jvp(myr_handle h, int32_t B, const double* z, const double* v, const double* params, int32_t params_stride,
+                       double* out, int32_t mem) {
+  return products_call(h, PRODOP_JVP, "myr_jvp", B, z, v, params, params_stride, out, 0, mem);
+}
+
+extern "C" int myr_exgd(myr_handle h, int32_t B, double* z, double* lam, const double* lb, const double* ub, const double* params,
+                        int32_t params_stride, double eta_x, double eta_v, int32_t nsteps, int32_t mem) {
+  int rc = check_products_args(h, "myr_exgd", B, z, lam, lb, params, params_stride);
+  if (rc) return rc;
+  if (!ub) return fail(MYR_E_ARG, "myr_exgd: null ub");
+  if (nsteps < 0) return fail(MYR_E_ARG, "myr_exgd: negative nsteps");
+  if (B == 0 || nsteps == 0) return MYR_OK;
+  HIPCHK(hipSetDevice(h->d.device));
+  const myr_dims& dm = h->dims;
+  ProdArgs a{};
+  a.op = PRODOP_EXGD; a.B = B; a.pstride = params_stride; a.eta_x = eta_x; a.eta_v = eta_v; a.nsteps = nsteps;
+  if (mem == MYR_MEM_DEVICE) { a.zio = z; a.lamio = lam; a.lb = lb; a.ub = ub; a.params = params; return dispatch_products(h, a); }
+  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_exgd: bad mem kind");
+  const size_t nz = (size_t)B * dm.n, nl = (size_t)B * dm.m;
+  const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  rc = ensure_dbuf(h, (3 * al(nz) + al(nl) + al(npar)) * 8);
+  if (rc) return rc;
+  double* dz = (double*)h->dbuf; double* dlb = dz + al(nz); double* dub = dlb + al(nz); double* dl = dub + al(nz); double* dp = dl + al(nl);
+  HIPCHK(hipMemcpyAsync(dz, z, nz * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dlb, lb, nz * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dub, ub, nz * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dl, lam, nl * 8, hipMemcpyHostToDevice, h->stream));
+  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
+  a.zio = dz; a.lamio = dl; a.lb = dlb; a.ub = dub; a.params = npar ? dp : nullptr;
+  rc = dispatch_products(h, a);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(z, dz, nz * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(lam, dl, nl * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return MYR_OK;
 }

@@ -39,7 +39,15 @@ def solve(hp: HParams, cfg: Config, opt_dict: Dict) -> Dict[str, np.ndarray]:
               'method': 'SLSQP' if hp.nlpsolver == NLPSolverType.SLSQP else 'trust-constr'}
     solution = minimize(**inputs)
   elif hp.nlpsolver == NLPSolverType.EXTRAGRADIENT:
-    raise NotImplementedError("extra_gradient.py is outside the hot path (SURVEY.md section 2, row 13)")
+    # reference branch :45-49; the iteration runs on the device (collocation transcriptions)
+    from myriad_amd.defaults import learning_rates
+    from myriad_amd.nlp_solvers.extra_gradient import extra_gradient
+    options = {'maxiter': hp.max_iter}
+    if hp.system in learning_rates:
+      options = {**options, **learning_rates[hp.system]}
+    solution = extra_gradient(fun=opt_dict['objective'], x0=opt_dict['guess'], method='exgd',
+                              constraints={'type': 'eq', 'fun': opt_dict['constraints']}, bounds=opt_dict['bounds'],
+                              jac=None, options=options, optimizer=opt, params=opt_dict.get('params'))
   else:
     print("Unknown NLP solver. Please choose among", list(NLPSolverType.__members__.keys()))
     raise ValueError
@@ -49,7 +57,7 @@ def solve(hp: HParams, cfg: Config, opt_dict: Dict) -> Dict[str, np.ndarray]:
     print(f'Completed in {_t2 - _t1} seconds.')
     print('Cost given by solver:', solution['fun'])
   lmbda = None
-  if hp.nlpsolver in (NLPSolverType.IPOPT, NLPSolverType.SQP, NLPSolverType.TRUST):
+  if hp.nlpsolver in (NLPSolverType.IPOPT, NLPSolverType.SQP, NLPSolverType.TRUST, NLPSolverType.EXTRAGRADIENT):
     lmbda = solution['v']
     if isinstance(lmbda, list):
       lmbda = lmbda[0]

@@ -125,6 +125,32 @@ class TrajectoryOptimizer(object):
       return trap_dense_from_blocks(blk, N, ns, nu)
     return shoot_dense_from_blocks(blk, N, self.hp.controls_per_interval, ns, nu)
 
+  # ---- Lagrangian products (collocation; experiments/e2e_sysid.py:113-141, nlp_solvers/extra_gradient.py:21-33) ----
+  def lagrangian(self, variables, lmbdas, params=None):
+    """fun(x) + lmbda @ constraint_fun(x)"""
+    p = self.system.device_params() if params is None else self.system.params_from_mapping(params)
+    r = self.engine.eval(variables, params=p, want=("f", "c"))
+    return float(r["f"][0] + np.asarray(lmbdas, dtype=np.float64) @ r["c"][0])
+
+  def lagrangian_grad(self, variables, lmbdas, params=None):
+    """jax.grad(lagrangian, argnums=0): grad f + J^T lmbda, applied matrix-free on the device."""
+    p = self.system.device_params() if params is None else self.system.params_from_mapping(params)
+    return self.engine.vjp(variables, lmbdas, params=p, add_gradf=True)[0]
+
+  def constraints_vjp(self, variables, lmbdas, params=None):
+    p = self.system.device_params() if params is None else self.system.params_from_mapping(params)
+    return self.engine.vjp(variables, lmbdas, params=p, add_gradf=False)[0]
+
+  def constraints_jvp(self, variables, v, params=None):
+    p = self.system.device_params() if params is None else self.system.params_from_mapping(params)
+    return self.engine.jvp(variables, v, params=p)[0]
+
+  def extragradient_step(self, variables, lmbdas, eta_x, eta_v, nsteps=1, params=None):
+    """`nsteps` iterations of the reference's `step(x, lmbda)` (extra_gradient.py:25-33)."""
+    p = self.system.device_params() if params is None else self.system.params_from_mapping(params)
+    z, lam = self.engine.exgd(variables, lmbdas, self.bounds[:, 0], self.bounds[:, 1], eta_x, eta_v, nsteps, params=p)
+    return z[0], lam[0]
+
   # ---- solve ---------------------------------------------------------------------------------------
   def _opt_inputs(self, params=None, guess=None) -> Dict:
     return {'objective': self.objective, 'guess': self.guess if guess is None else np.asarray(guess),

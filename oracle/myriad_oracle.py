@@ -446,6 +446,38 @@ class Callbacks:
     return self._jac(_t(z)).numpy()
 
 
+class Lagrangian:
+  """lagrangian(x, lmbda) = fun(x) + lmbda @ constraint_fun(x) and the extragradient `step` exactly as
+  nlp_solvers/extra_gradient.py:21-33 (and experiments/e2e_sysid.py:113-125) build them: gradients by reverse-mode
+  autodiff through the restated transcription (jax.grad -> torch.func.grad)."""
+
+  def __init__(self, tr: Transcription):
+    self.tr = tr
+    self._L = lambda x, lm: tr.objective(x) + lm @ tr.constraints(x)
+    self._gx = torch.func.grad(self._L, argnums=0)
+    self._gl = torch.func.grad(self._L, argnums=1)
+
+  def value(self, x, lmbda):
+    return float(self._L(_t(x), _t(lmbda)))
+
+  def grad_x(self, x, lmbda):
+    return self._gx(_t(x), _t(lmbda)).numpy()
+
+  def grad_lmbda(self, x, lmbda):
+    return self._gl(_t(x), _t(lmbda)).numpy()
+
+  def jvp(self, x, v):
+    """J(x) v by forward-mode autodiff of the constraints."""
+    return torch.func.jvp(self.tr.constraints, (_t(x),), (_t(v),))[1].numpy()
+
+  def step(self, x, lmbda, eta_x, eta_v):                       # extra_gradient.py:25-33
+    lb, ub = self.tr.bounds[:, 0], self.tr.bounds[:, 1]
+    x_bar = np.clip(x - eta_x * self.grad_x(x, lmbda), lb, ub)
+    x_new = np.clip(x - eta_x * self.grad_x(x_bar, lmbda), lb, ub)
+    lmbda_new = lmbda + eta_v * self.grad_lmbda(x_new, lmbda)
+    return x_new, lmbda_new
+
+
 def solve(tr: Transcription, nlpsolver: str = "SLSQP", max_iter: int = 1000, guess=None,
           extra_options: Optional[dict] = None, cb: Optional[Callbacks] = None):
   """nlp_solvers/__init__.py:18-98 restricted to the SciPy branches (:50-55).

@@ -1,0 +1,132 @@
+"""GPU parity tests of the matrix-free Lagrangian products and the fused extragradient step against
+the oracle's autodiff through the restated transcriptions -- what the reference computes with jax.grad
+(nlp_solvers/extra_gradient.py:21-33, experiments/e2e_sysid.py:113-141)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SYSTEMS = ["CARTPOLE", "VANDERPOL", "CANCERTREATMENT", "SIMPLECASE"]
+
+
+def _oracle(name, tr_name, N):
+  from oracle import myriad_oracle as O
+  s = {"CARTPOLE": O.CartPole, "VANDERPOL": O.VanDerPol, "CANCERTREATMENT": O.CancerTreatment, "SIMPLECASE": O.SimpleCase}[name]()
+  tr = O.hermite_simpson(s, N) if tr_name == "HERMITE_SIMPSON" else O.trapezoidal(s, N)
+  return s, tr, O.Lagrangian(tr)
+
+
+def _point(tr, rng, scale=0.2):
+  z = tr.guess + scale * rng.standard_normal(tr.guess.size)
+  lo = np.where(np.isfinite(tr.bounds[:, 0]), tr.bounds[:, 0], -np.inf)
+  hi = np.where(np.isfinite(tr.bounds[:, 1]), tr.bounds[:, 1], np.inf)
+  return np.clip(z, lo + 1e-3 * (hi > lo), hi - 1e-3 * (hi > lo))
+
+
+@pytest.mark.parametrize("tr_name", ["HERMITE_SIMPSON", "TRAPEZOIDAL"])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_vjp_jvp_match_autodiff(name, tr_name):
+  from myriad_amd import _lib
+  N, B = 7, 5
+  s, tr, L = _oracle(name, tr_name, N)
+  eng = _lib.Engine(name, tr_name, N, s.T, max_batch=B)
+  rng = np.random.default_rng(3)
+  z = np.stack([_point(tr, rng) for _ in range(B)])
+  lam = rng.standard_normal((B, eng.m)); v = rng.standard_normal((B, eng.n))
+  gL = eng.vjp(z, lam, add_gradf=True)
+  jt = eng.vjp(z, lam, add_gradf=False)
+  jv = eng.jvp(z, v)
+  from oracle import myriad_oracle as O
+  cb = O.Callbacks(tr)
+  for b in range(B):
+    ref = L.grad_x(z[b], lam[b])
+    np.testing.assert_allclose(gL[b], ref, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(ref).max()))
+    refjt = ref - cb.grad(z[b])
+    np.testing.assert_allclose(jt[b], refjt, rtol=1e-11, atol=1e-12 * max(1.0, np.abs(ref).max()))
+    refjv = L.jvp(z[b], v[b])
+    np.testing.assert_allclose(jv[b], refjv, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(refjv).max()))
+  eng.close()
+
+
+@pytest.mark.parametrize("name,tr_name", [("CARTPOLE", "HERMITE_SIMPSON"), ("VANDERPOL", "TRAPEZOIDAL"), ("CANCERTREATMENT", "HERMITE_SIMPSON")])
+def test_extragradient_steps_match_reference_iteration(name, tr_name):
+  from myriad_amd import _lib
+  N, steps = 6, 25
+  s, tr, L = _oracle(name, tr_name, N)
+  eng = _lib.Engine(name, tr_name, N, s.T, max_batch=2)
+  rng = np.random.default_rng(5)
+  z0 = np.stack([_point(tr, rng, 0.05) for _ in range(2)])
+  lam0 = np.ones((2, eng.m))                                    # extra_gradient.py:77
+  eta_x, eta_v = 1e-2, 1e-3
+  z, lam = eng.exgd(z0, lam0, tr.bounds[:, 0], tr.bounds[:, 1], eta_x, eta_v, steps)
+  for b in range(2):
+    x, lm = z0[b].copy(), lam0[b].copy()
+    for _ in range(steps):
+      x, lm = L.step(x, lm, eta_x, eta_v)
+    np.testing.assert_allclose(z[b], x, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(lam[b], lm, rtol=1e-10, atol=1e-11)
+  # chunking is exact: 25 steps == 24 + 1
+  z2, lam2 = eng.exgd(z0, lam0, tr.bounds[:, 0], tr.bounds[:, 1], eta_x, eta_v, steps - 1)
+  z2, lam2 = eng.exgd(z2, lam2, tr.bounds[:, 0], tr.bounds[:, 1], eta_x, eta_v, 1)
+  assert np.array_equal(z2, z) and np.array_equal(lam2, lam)
+  eng.close()
+
+
+def test_products_full_size_adjoint_identity_and_linearity():
+  """BASELINE size (CARTPOLE HS N=100, B=4096): <J v, lam> == <v, J^T lam> and J^T is linear in lam -- properties that
+  need no reference values."""
+  import torch
+  torch.cuda.init()
+  from myriad_amd import _lib
+  from bench import build_workload
+  B, N = 4096, 100
+  x0, z0, lb, ub, T = build_workload(B, N, 2019)
+  eng = _lib.Engine("CARTPOLE", "HERMITE_SIMPSON", N, T, max_batch=B)
+  rng = np.random.default_rng(0)
+  z = z0 + 0.05 * rng.standard_normal(z0.shape)
+  lam = rng.standard_normal((B, eng.m)); lam2 = rng.standard_normal((B, eng.m)); v = rng.standard_normal((B, eng.n))
+  jv = eng.jvp(z, v); jtl = eng.vjp(z, lam)
+  lhs = (jv * lam).sum(1); rhs = (v * jtl).sum(1)
+  assert np.abs(lhs - rhs).max() <= 1e-10 * max(1.0, np.abs(lhs).max())
+  comb = eng.vjp(z, 2.0 * lam - 0.5 * lam2)
+  np.testing.assert_allclose(comb, 2.0 * jtl - 0.5 * eng.vjp(z, lam2), rtol=1e-11, atol=1e-11)
+  # grad L = grad f + J^T lam, with grad f from the eval kernel
+  g = eng.eval(z, want=("gradf",))["gradf"]
+  gf = np.zeros((B, eng.n)); gf[:, eng.x_rows * eng.ns:] = g
+  np.testing.assert_allclose(eng.vjp(z, lam, add_gradf=True), gf + jtl, rtol=1e-12, atol=1e-12)
+  eng.close()
+
+
+def test_extragradient_solver_branch_runs_like_the_reference():
+  """hp.nlpsolver = EXTRAGRADIENT through get_optimizer(...).solve(): result keys and the reference's schedule (0.1 %
+  step decay at iterations 0, 1000, ...: extra_gradient.py:52-60).  The iteration is only marginally stable on this
+  problem, so 1200 steps amplify round-off to ~1e-5; the test therefore also runs the schedule WITHOUT the second decay
+  and requires the device result to sit much closer to the reference schedule than that."""
+  from myriad_amd.config import Config, HParams, NLPSolverType, OptimizerType, QuadratureRule
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = HParams(system=SystemType.CANCERTREATMENT, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
+               intervals=10, nlpsolver=NLPSolverType.EXTRAGRADIENT, max_iter=120)
+  assert hp.max_iter == 1200                                    # config.py:99-100: exgd gets 10x the iterations
+  opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+  sol = opt.solve()
+  assert set(sol) == {'x', 'u', 'xs_and_us', 'cost', 'lambda'}
+  assert sol['lambda'].shape == (2 * 10 * 1,)
+  from oracle import myriad_oracle as O
+  tr = O.hermite_simpson(O.CancerTreatment(), 10)
+  L = O.Lagrangian(tr)
+
+  def run(decay_at):
+    x, lm = tr.guess.copy(), np.ones(20)
+    ex, ev = 1e-1, 1e-3
+    for i in range(1200):
+      if i in decay_at:
+        ex *= 0.999; ev *= 0.999
+      x, lm = L.step(x, lm, ex, ev)
+    return x, lm
+
+  x, lm = run({0, 1000})
+  x_wrong, lm_wrong = run({0})
+  err = max(np.abs(sol['xs_and_us'] - x).max(), np.abs(sol['lambda'] - lm).max())
+  gap = max(np.abs(x_wrong - x).max(), np.abs(lm_wrong - lm).max())
+  assert err < 0.01 * gap, (err, gap)

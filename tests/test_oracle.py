@@ -100,3 +100,23 @@ def test_rollout_and_defect_helpers():
   assert O.get_defect(s, xs) is None
   cp = O.CartPole()
   np.testing.assert_allclose(O.get_defect(cp, np.array([[1., np.pi, 0.5, 0.]])), [0., 0., 0.5, 0.])
+
+
+def test_lagrangian_restatement_is_consistent():
+  """extra_gradient.py:21-33: grad_x L = grad f + J^T lam, grad_lam L = c, J v by forward mode, and one `step`."""
+  s = O.VanDerPol()
+  for tr in (O.hermite_simpson(s, 5), O.trapezoidal(s, 5)):
+    L, cb = O.Lagrangian(tr), O.Callbacks(tr)
+    rng = np.random.default_rng(1)
+    z = tr.guess + 0.1 * rng.standard_normal(tr.guess.size)
+    lam = rng.standard_normal(cb.cons(z).size); v = rng.standard_normal(z.size)
+    np.testing.assert_allclose(L.grad_x(z, lam), cb.grad(z) + cb.jac(z).T @ lam, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(L.grad_lmbda(z, lam), cb.cons(z), rtol=0, atol=0)
+    np.testing.assert_allclose(L.jvp(z, v), cb.jac(z) @ v, rtol=1e-12, atol=1e-13)
+    eps = 1e-6
+    fd = (L.value(z + eps * v, lam) - L.value(z - eps * v, lam)) / (2 * eps)
+    assert abs(fd - L.grad_x(z, lam) @ v) < 1e-6 * max(1.0, abs(fd))
+    x1, l1 = L.step(z, lam, 1e-2, 1e-3)
+    lb, ub = tr.bounds[:, 0], tr.bounds[:, 1]
+    assert (x1 >= lb).all() and (x1 <= ub).all()
+    np.testing.assert_allclose(l1, lam + 1e-3 * cb.cons(x1), rtol=1e-14)
