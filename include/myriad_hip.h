@@ -16,6 +16,7 @@
  *   jax.grad(lagrangian, argnums=0)(x, lmbda)    nlp_solvers/extra_gradient.py:21-33,
  *                                                experiments/e2e_sysid.py:113-125           myr_vjp (add_gradf=1), myr_jvp
  *   step(x, lmbda) (extragradient iteration)     nlp_solvers/extra_gradient.py:25-33        myr_exgd
+ *   FBSM(hp,cfg,system).solve()                  trajectory_optimizers/forward_backward_sweep.py:88-116   myr_fbsm
  *
  * Conventions
  *   - all floating point is IEEE fp64 (the reference sets jax_enable_x64, run.py:15);
@@ -49,7 +50,7 @@ enum { MYR_MEM_HOST = 0, MYR_MEM_DEVICE = 1 };
 /* per-instance solve status */
 enum { MYR_STATUS_CONVERGED = 0, MYR_STATUS_MAXITER = 1, MYR_STATUS_NAN = 2, MYR_STATUS_STALLED = 3 };
 /* kernel ids for myr_kernel_time */
-enum { MYR_K_EVAL = 0, MYR_K_SOLVE = 1, MYR_K_ROLLOUT = 2, MYR_K_RESID = 3, MYR_K_PROD = 4, MYR_K_COUNT = 5 };
+enum { MYR_K_EVAL = 0, MYR_K_SOLVE = 1, MYR_K_ROLLOUT = 2, MYR_K_RESID = 3, MYR_K_PROD = 4, MYR_K_FBSM = 5, MYR_K_COUNT = 6 };
 /* error codes */
 enum { MYR_OK = 0, MYR_E_ARG = -1, MYR_E_UNSUPPORTED = -2, MYR_E_HIP = -3, MYR_E_CAPACITY = -4 };
 
@@ -160,6 +161,19 @@ int myr_jvp(myr_handle h, int32_t B, const double* z, const double* v, const dou
  */
 int myr_exgd(myr_handle h, int32_t B, double* z, double* lam, const double* lb, const double* ub, const double* params,
              int32_t params_stride, double eta_x, double eta_v, int32_t nsteps, int32_t mem);
+
+/*
+ * Batched Forward-Backward Sweep, the reference's indirect solver (trajectory_optimizers/forward_backward_sweep.py:20-116;
+ * RK4 sweeps utils.py:138-197; stopping rule trajectory_optimizers/base.py:128-141) for B instances of the handle's
+ * system (IndirectFHCS systems on the path: SIMPLECASE, CANCERTREATMENT; others return MYR_E_UNSUPPORTED; terminal state
+ * conditions -- the reference's secant `sequencesolver` -- are not supported).  The handle's transcription is not used.
+ *   N = hp.fbsm_intervals; x0 [B][ns]; adj_T [ns] or NULL (= 0); params as in myr_eval;
+ *   clip_lo/clip_hi: the bounds the system's optim_characterization clips with; delta: stopping tolerance (0.001)
+ *   xs, adjs [B][N+1][ns], us [B][N+1][nu], sweeps [B] (may be NULL).  Host arrays only.
+ */
+int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, const double* adj_T, const double* params,
+             int32_t params_stride, double clip_lo, double clip_hi, double delta, int32_t max_sweeps, double* xs,
+             double* us, double* adjs, int32_t* sweeps, int32_t mem);
 
 /* Average device time (HIP events on the handle's stream) of the launches of one kernel since the last reset. */
 int myr_kernel_time(myr_handle h, int32_t kernel_id, double* avg_ms, int32_t* launches);

@@ -18,11 +18,11 @@ SYS_IDS = {"CARTPOLE": 0, "VANDERPOL": 1, "CANCERTREATMENT": 2, "SIMPLECASE": 3,
 TR_IDS = {"HERMITE_SIMPSON": 0, "TRAPEZOIDAL": 1, "SHOOTING": 2}
 INT_IDS = {"EULER": 0, "HEUN": 1, "MIDPOINT": 2, "RK4": 3}
 MEM_HOST, MEM_DEVICE = 0, 1
-K_EVAL, K_SOLVE, K_ROLLOUT, K_RESID, K_PROD = 0, 1, 2, 3, 4
+K_EVAL, K_SOLVE, K_ROLLOUT, K_RESID, K_PROD, K_FBSM = 0, 1, 2, 3, 4, 5
 STATUS_NAMES = {0: "CONVERGED", 1: "MAXITER", 2: "NAN", 3: "STALLED"}
 
 EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve",
-           "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",
+           "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_fbsm", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",
            "myr_version"]
 
 
@@ -80,6 +80,9 @@ def load() -> C.CDLL:
   lib.myr_jvp.restype = C.c_int
   lib.myr_exgd.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32]
   lib.myr_exgd.restype = C.c_int
+  lib.myr_fbsm.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
+                           dp, dp, dp, ip, C.c_int32]
+  lib.myr_fbsm.restype = C.c_int
   lib.myr_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
   lib.myr_kernel_time.restype = C.c_int
   lib.myr_kernel_time_reset.argtypes = [vp]
@@ -270,6 +273,20 @@ class Engine:
       _chk(self.lib.myr_vjp(self._h, int(B), _addr(z), _addr(w), _addr(params), int(params_stride), _addr(out), int(add_gradf), MEM_DEVICE), "myr_vjp")
     else:
       _chk(self.lib.myr_jvp(self._h, int(B), _addr(z), _addr(w), _addr(params), int(params_stride), _addr(out), MEM_DEVICE), "myr_jvp")
+
+  def fbsm(self, x0, N, clip_lo, clip_hi, params=None, adj_T=None, delta=0.001, max_sweeps=10000):
+    """Batched Forward-Backward Sweep: returns {'x' [B,N+1,ns], 'u' [B,N+1,nu], 'adj' [B,N+1,ns], 'sweeps' [B]}."""
+    x0 = _f64(x0)
+    if x0.ndim == 1:
+      x0 = x0[None]
+    B = x0.shape[0]
+    p, ps = self._params(params, B)
+    aT = None if adj_T is None else _f64(adj_T)
+    xs = np.empty((B, N + 1, self.ns)); us = np.empty((B, N + 1, self.nu)); adjs = np.empty((B, N + 1, self.ns))
+    sw = np.empty(B, dtype=np.int32)
+    _chk(self.lib.myr_fbsm(self._h, B, int(N), _addr(x0), _addr(aT), _addr(p), ps, float(clip_lo), float(clip_hi), float(delta),
+                           int(max_sweeps), _addr(xs), _addr(us), _addr(adjs), _addr(sw), MEM_HOST), "myr_fbsm")
+    return {"x": xs, "u": us, "adj": adjs, "sweeps": sw}
 
   def kernel_time(self, kernel_id: int):
     ms = C.c_double(); n = C.c_int32()

@@ -15,6 +15,7 @@
 #include "os_solver.h"
 #include "shoot_eval.h"
 #include "rollout.h"
+#include "fbsm.h"
 #include "systems_gen.h"
 #include "node_system.h"
 
@@ -812,3 +813,81 @@ extern "C" int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u
   HIPCHK(hipStreamSynchronize(h->stream));
   return MYR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// batched Forward-Backward Sweep (indirect method)
+// ------------------------------------------------------------------------------------------------
+template <class Sys>
+static int launch_fbsm(myr_handle h, int B, long Bp, int N, const double* x0, const double* adjT, const double* params, int pstride,
+                       double lo, double hi, double delta, int max_sweeps, double* X, double* U, double* A, int32_t* sweeps) {
+  if constexpr (!Indirect<Sys>::SUPPORTED) {
+    return fail(MYR_E_UNSUPPORTED, "myr_fbsm: this system has no adjoint dynamics (not an IndirectFHCS on the path)");
+  } else {
+    KTimer& kt = h->kt[MYR_K_FBSM];
+    HIPCHK(hipEventRecord(kt.a, h->stream));
+    hipLaunchKernelGGL(fbsm_kernel<Sys>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, Bp, N, h->d.T, x0, adjT, params,
+                       pstride, lo, hi, delta, max_sweeps, X, U, A, sweeps);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(kt.b, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+    kt.sum_ms += ms;
+    kt.launches += 1;
+    return MYR_OK;
+  }
+}
+
+extern "C" int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, const double* adj_T, const double* params,
+                        int32_t params_stride, double clip_lo, double clip_hi, double delta, int32_t max_sweeps, double* xs,
+                        double* us, double* adjs, int32_t* sweeps, int32_t mem) {
+  if (!h || !x0 || !xs || !us || !adjs) return fail(MYR_E_ARG, "myr_fbsm: null handle or array");
+  if (B < 0 || N < 1 || max_sweeps < 1) return fail(MYR_E_ARG, "myr_fbsm: bad sizes");
+  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_fbsm: host arrays only");
+  if (params && params_stride != 0 && params_stride != h->dims.np)
+    return fail(MYR_E_ARG, "myr_fbsm: params_stride must be 0 (shared) or np");
+  if (B == 0) return MYR_OK;
+  HIPCHK(hipSetDevice(h->d.device));
+  const myr_dims& dm = h->dims;
+  long Bp = ((long)B + 63) / 64 * 64;
+  if (((Bp / 64) & 1) == 0) Bp += 64;                 // odd multiple of 64 lanes: rotate points over HBM channels
+  const size_t rows_x = (size_t)(N + 1) * dm.ns, rows_u = (size_t)(N + 1) * dm.nu;
+  const size_t nx0 = (size_t)B * dm.ns, npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  // batch-minor working arrays + instance-major staging for the transposes + sweeps
+  const size_t work = (2 * rows_x + rows_u) * (size_t)Bp, stage = (size_t)B * (rows_x > rows_u ? rows_x : rows_u);
+  int rc = ensure_dbuf(h, (al(nx0) + al(npar) + al((size_t)dm.ns) + al(work) + al(stage) + al((size_t)B)) * 8);
+  if (rc) return rc;
+  double* dx0 = (double*)h->dbuf;
+  double* dp = dx0 + al(nx0);
+  double* dadj = dp + al(npar);
+  double* X = dadj + al((size_t)dm.ns);
+  double* A = X + rows_x * Bp;
+  double* U = A + rows_x * Bp;
+  double* st = X + al(work);
+  int32_t* dsw = reinterpret_cast<int32_t*>(st + al(stage));
+  HIPCHK(hipMemcpyAsync(dx0, x0, nx0 * 8, hipMemcpyHostToDevice, h->stream));
+  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
+  if (adj_T) HIPCHK(hipMemcpyAsync(dadj, adj_T, (size_t)dm.ns * 8, hipMemcpyHostToDevice, h->stream));
+#define MYR_FBSM(S) rc = launch_fbsm<S>(h, B, Bp, N, dx0, adj_T ? dadj : nullptr, npar ? dp : nullptr, params_stride, clip_lo, clip_hi, delta, max_sweeps, X, U, A, dsw)
+  switch (h->d.system_id) {
+    case MYR_SYS_CARTPOLE: MYR_FBSM(SysCARTPOLE); break;
+    case MYR_SYS_VANDERPOL: MYR_FBSM(SysVANDERPOL); break;
+    case MYR_SYS_CANCERTREATMENT: MYR_FBSM(SysCANCERTREATMENT); break;
+    case MYR_SYS_SIMPLECASE: MYR_FBSM(SysSIMPLECASE); break;
+    default: rc = fail(MYR_E_UNSUPPORTED, "myr_fbsm: this system has no adjoint dynamics");
+  }
+#undef MYR_FBSM
+  if (rc) return rc;
+  struct { double* src; double* dst; size_t cols; } outs[3] = {{X, xs, rows_x}, {U, us, rows_u}, {A, adjs, rows_x}};
+  for (auto& o : outs) {
+    dim3 grid((unsigned)((o.cols + 31) / 32), (unsigned)((B + 31) / 32));
+    hipLaunchKernelGGL(transpose_back_kernel, grid, dim3(256), 0, h->stream, o.src, st, B, (int)o.cols, Bp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(o.dst, st, (size_t)B * o.cols * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  if (sweeps) HIPCHK(hipMemcpy(sweeps, dsw, (size_t)B * 4, hipMemcpyDeviceToHost));
+  return MYR_OK;
+}
+

@@ -58,8 +58,11 @@ class FiniteHorizonControlSystem:
 
 
 class IndirectFHCS(FiniteHorizonControlSystem):
-  """systems/base.py:125-182 (fields only; FBSM is out of scope of the hot path)."""
+  """systems/base.py:125-182: adjoint terminal value and secant guesses; adj_ODE / optim_characterization live on the
+  device (csrc/fbsm.h) for the systems on the path."""
   adj_T = None
+  guess_a = None
+  guess_b = None
 
 
 class CartPole(FiniteHorizonControlSystem):

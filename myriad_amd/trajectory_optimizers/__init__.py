@@ -309,7 +309,8 @@ def get_optimizer(hp: HParams, cfg: Config, system):
   elif hp.optimizer == OptimizerType.SHOOTING:
     optimizer = MultipleShootingOptimizer(hp, cfg, system)
   elif hp.optimizer == OptimizerType.FBSM:
-    raise NotImplementedError("FBSM (forward_backward_sweep.py) is outside the hot path (SURVEY.md section 2, row 14)")
+    from myriad_amd.trajectory_optimizers.forward_backward_sweep import FBSM
+    optimizer = FBSM(hp, cfg, system)
   else:
     raise KeyError
   return optimizer

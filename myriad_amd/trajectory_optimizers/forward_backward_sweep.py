@@ -1,0 +1,100 @@
+"""Host mirror of /root/reference/myriad/trajectory_optimizers/forward_backward_sweep.py:20-116 (class FBSM) and of
+IndirectMethodOptimizer (trajectory_optimizers/base.py:106-141): same constructor, attributes and `solve()` result
+({'x','u','adj'}), with the sweeps on the GPU (`myr_fbsm`, csrc/fbsm.h).  EXTENSION: `solve_batch` runs B instances
+(parameter / start-state sweeps) in one call.
+
+Out of scope here, as in csrc/fbsm.h: systems with terminal state conditions (the secant `sequencesolver`, :118-158)
+and discrete systems (:33-35)."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from myriad_amd import _lib
+from myriad_amd.config import Config, HParams
+from myriad_amd.systems import IndirectFHCS
+
+
+class IndirectMethodOptimizer(object):
+  """trajectory_optimizers/base.py:106-141."""
+  require_adj: bool = True
+
+  def __init__(self, hp: HParams, cfg: Config, bounds, guess, unravel):
+    self.hp, self.cfg, self.bounds, self.guess, self.unravel = hp, cfg, bounds, guess, unravel
+
+  def solve(self):
+    raise NotImplementedError
+
+  def stopping_criterion(self, x_iter, u_iter, adj_iter, delta: float = 0.001) -> bool:
+    """base.py:128-141 (kept for callers; the device applies the same rule inside the sweep loop)."""
+    (x, old_x), (u, old_u), (adj, old_adj) = x_iter, u_iter, adj_iter
+    stop_x = np.abs(x).sum(axis=0) * delta - np.abs(x - old_x).sum(axis=0)
+    stop_u = np.abs(u).sum(axis=0) * delta - np.abs(u - old_u).sum(axis=0)
+    stop_adj = np.abs(adj).sum(axis=0) * delta - np.abs(adj - old_adj).sum(axis=0)
+    return bool(np.min(np.hstack((stop_u, stop_x, stop_adj))) < 0)
+
+
+class FBSM(IndirectMethodOptimizer):
+  """Forward-Backward Sweep Method (Lenhart & Workman), forward_backward_sweep.py:20-116."""
+
+  def __init__(self, hp: HParams, cfg: Config, system: IndirectFHCS):
+    if not isinstance(system, IndirectFHCS):
+      raise NotImplementedError("FBSM needs adjoint dynamics: an IndirectFHCS system (tests/test_smoke.py:34-37)")
+    if getattr(system, "discrete", False):
+      raise NotImplementedError("discrete systems are not on the device path")
+    self.system = system
+    self.N = hp.fbsm_intervals                                   # :31
+    self.h = system.T / self.N
+    state_shape = system.x_0.shape[0]
+    control_shape = system.bounds.shape[0] - state_shape
+    self.x_guess = np.vstack((system.x_0, np.zeros((self.N, state_shape))))        # :38
+    self.u_guess = np.zeros((self.N + 1, control_shape))                           # :42
+    if system.adj_T is not None:
+      self.adj_guess = np.vstack((np.zeros((self.N, state_shape)), system.adj_T))  # :44
+    else:
+      self.adj_guess = np.zeros((self.N + 1, state_shape))
+    self.t_interval = np.linspace(0, system.T, num=self.N + 1).reshape(-1, 1)
+    sizes = (self.x_guess.size, self.u_guess.size, self.adj_guess.size)
+    guess = np.concatenate([self.x_guess.ravel(), self.u_guess.ravel(), self.adj_guess.ravel()])
+
+    def unravel(v):
+      a, b = sizes[0], sizes[0] + sizes[1]
+      return (v[:a].reshape(self.x_guess.shape), v[a:b].reshape(self.u_guess.shape), v[b:].reshape(self.adj_guess.shape))
+
+    self.x_bounds = system.bounds[:-1]                           # :52-55
+    self.u_bounds = system.bounds[-1:]
+    bounds = np.vstack((self.x_bounds, self.u_bounds))
+    self.terminal_cdtion = False
+    if system.x_T is not None and any(v is not None for v in system.x_T):
+      raise NotImplementedError("terminal state conditions (sequencesolver, :118-158) are not on the device path")
+    super().__init__(hp, cfg, bounds, guess, unravel)
+    self._engine: Optional[_lib.Engine] = None
+
+  @property
+  def engine(self) -> _lib.Engine:
+    if self._engine is None:
+      # the handle's transcription is irrelevant for myr_fbsm; any valid one creates the system slot
+      self._engine = _lib.Engine(self.system.name, "HERMITE_SIMPSON", 1, self.system.T, max_batch=1)
+    return self._engine
+
+  def _clip_bounds(self):
+    """The bounds the system's optim_characterization clips with: the CONTROL row for CANCERTREATMENT
+    (cancer_treatment.py:88-91), bounds[0] -- the state row, a reference quirk -- for SIMPLECASE (simple_case.py:59-62)."""
+    row = self.system.bounds[0] if self.system.name == "SIMPLECASE" else self.system.bounds[-1]
+    return float(row[0]), float(row[1])
+
+  def solve_batch(self, x0s=None, params=None, max_sweeps: int = 10000) -> Dict[str, np.ndarray]:
+    if x0s is None:
+      B = 1 if params is None or np.ndim(params) == 1 else np.shape(params)[0]
+      x0s = np.tile(self.system.x_0, (B, 1))
+    p = self.system.device_params() if params is None else np.asarray(params, dtype=np.float64)
+    lo, hi = self._clip_bounds()
+    r = self.engine.fbsm(np.asarray(x0s, dtype=np.float64), self.N, lo, hi, params=p, adj_T=self.system.adj_T, max_sweeps=max_sweeps)
+    return {'x': r['x'], 'u': r['u'], 'adj': r['adj'], 'sweeps': r['sweeps']}
+
+  def solve(self) -> Dict[str, np.ndarray]:
+    """:88-116 -- {'x': [N+1,ns], 'u': [N+1,nu], 'adj': [N+1,ns]}; the guesses are updated like the reference's."""
+    r = self.solve_batch()
+    self.x_guess, self.u_guess, self.adj_guess = r['x'][0], r['u'][0], r['adj'][0]
+    return {'x': self.x_guess, 'u': self.u_guess, 'adj': self.adj_guess}

@@ -148,6 +148,18 @@ class CancerTreatment(System):
   def cost(self, x, u, t=None):                              # cancer_treatment.py:75-76
     return (self.a * x ** 2 + u ** 2)[..., 0]
 
+  # IndirectFHCS members (numpy; used by fbsm())
+  adj_T = None
+
+  def np_dynamics(self, x, u):                               # cancer_treatment.py:62-65
+    return self.r * x * np.log(1 / x) - u * self.delta * x
+
+  def adj_ODE(self, adj, x, u):                              # cancer_treatment.py:84-86
+    return adj * (self.r + self.delta * u - self.r * np.log(1 / x)) - 2 * self.a * x
+
+  def optim_characterization(self, adj, x):                  # cancer_treatment.py:88-91 (clips with the CONTROL bounds)
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], 0.5 * adj * self.delta * x))
+
 
 class SimpleCase(System):
   """myriad/systems/lenhart/simple_case.py:25-62."""
@@ -169,6 +181,18 @@ class SimpleCase(System):
 
   def cost(self, x, u, t=None):                              # simple_case.py:52-53
     return (-self.A * x + self.B * u ** 2)[..., 0]
+
+  # IndirectFHCS members (numpy; used by fbsm())
+  adj_T = None
+
+  def np_dynamics(self, x, u):                               # simple_case.py:46-50
+    return -0.5 * x ** 2 + self.C * u
+
+  def adj_ODE(self, adj, x, u):                              # simple_case.py:55-57 (maximisation-convention adjoint)
+    return -self.A + x * adj
+
+  def optim_characterization(self, adj, x):                  # simple_case.py:59-62 (clips with bounds[0], the STATE row)
+    return np.minimum(self.bounds[0, 1], np.maximum(self.bounds[0, 0], (self.C * adj) / (2 * self.B)))
 
 
 class NodeCartPole(CartPole):
@@ -444,6 +468,55 @@ class Callbacks:
 
   def jac(self, z):
     return self._jac(_t(z)).numpy()
+
+
+def _rk4_fbsm(dyn, x_t1, u, u_next, v, v_next, h):
+  """utils.py:166-175: RK4 step with the costates averaged at the half step."""
+  um, vm = (u + u_next) / 2, (v + v_next) / 2
+  k1 = dyn(x_t1, u, v)
+  k2 = dyn(x_t1 + h * k1 / 2, um, vm)
+  k3 = dyn(x_t1 + h * k2 / 2, um, vm)
+  k4 = dyn(x_t1 + h * k3, u_next, v_next)
+  return x_t1 + (h / 6) * (k1 + 2 * k2 + 2 * k3 + k4)
+
+
+def integrate_fbsm(dyn, x_0, u, h, N, v=None):
+  """utils.py:138-197, continuous systems: forward (h > 0) from index 0, backward (h < 0) from index N."""
+  if v is None:
+    v = np.zeros_like(u)
+  out = np.zeros((N + 1,) + np.shape(x_0))
+  if h >= 0:
+    out[0] = x_0
+    for i in range(N):
+      out[i + 1] = _rk4_fbsm(dyn, out[i], u[i], u[i + 1], v[i], v[i + 1], h)
+  else:
+    out[N] = x_0
+    for i in range(N, 0, -1):
+      out[i - 1] = _rk4_fbsm(dyn, out[i], u[i], u[i - 1], v[i], v[i - 1], h)
+  return out
+
+
+def fbsm(system, N: int = 1000, delta: float = 0.001, max_sweeps: int = 10000):
+  """Forward-Backward Sweep (trajectory_optimizers/forward_backward_sweep.py:20-116) for systems without terminal
+  state conditions; stopping rule of trajectory_optimizers/base.py:128-141.  Returns {'x','u','adj','sweeps'}."""
+  ns = system.x_0.shape[0]
+  h = system.T / N
+  x = np.vstack([system.x_0, np.zeros((N, ns))])               # :38
+  u = np.zeros((N + 1, 1))                                     # :42
+  adj = np.zeros((N + 1, ns))                                  # :46 (adj_T None)
+  f = lambda x_, u_, v_: system.np_dynamics(x_, u_)
+  a = lambda adj_, x_, u_: system.adj_ODE(adj_, x_, u_)
+  n = 0
+  while True:
+    old_u, old_x, old_adj = u.copy(), x.copy(), adj.copy()
+    x = integrate_fbsm(f, x[0], u, h, N)                                   # :95-96
+    adj = integrate_fbsm(a, adj[-1], x, -h, N, u)                          # :97-98
+    u = 0.5 * (system.optim_characterization(adj, x) + old_u)              # :100-102
+    n += 1
+    stop = np.hstack([np.abs(v).sum(0) * delta - np.abs(v - o).sum(0) for v, o in ((u, old_u), (x, old_x), (adj, old_adj))])
+    if not (stop.min() < 0) or n >= max_sweeps:                            # base.py:141
+      break
+  return {"x": x, "u": u, "adj": adj, "sweeps": n}
 
 
 class Lagrangian:

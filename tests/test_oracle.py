@@ -120,3 +120,20 @@ def test_lagrangian_restatement_is_consistent():
     lb, ub = tr.bounds[:, 0], tr.bounds[:, 1]
     assert (x1 >= lb).all() and (x1 <= ub).all()
     np.testing.assert_allclose(l1, lam + 1e-3 * cb.cons(x1), rtol=1e-14)
+
+
+def test_fbsm_restatement_is_a_pontryagin_fixed_point():
+  """forward_backward_sweep.py:88-116: at the returned iterate the control equals its optimality characterisation
+  (to the sweep's own 1e-3 stopping tolerance) and the state/adjoint satisfy their ODEs (RK4 residual)."""
+  for S in (O.SimpleCase, O.CancerTreatment):
+    s = S()
+    r = O.fbsm(s, 400)
+    assert 2 <= r["sweeps"] < 50
+    u_star = s.optim_characterization(r["adj"], r["x"])
+    assert np.abs(u_star - r["u"]).max() < 2e-2 * max(1.0, np.abs(r["u"]).max())
+    h = s.T / 400
+    xdot = (r["x"][2:] - r["x"][:-2]) / (2 * h)
+    assert np.abs(xdot - s.np_dynamics(r["x"][1:-1], r["u"][1:-1])).max() < 5e-2 * max(1.0, np.abs(xdot).max())
+    adot = (r["adj"][2:] - r["adj"][:-2]) / (2 * h)
+    assert np.abs(adot - s.adj_ODE(r["adj"][1:-1], r["x"][1:-1], r["u"][1:-1])).max() < 5e-2 * max(1.0, np.abs(adot).max())
+    assert r["adj"][-1, 0] == 0.0                                # transversality: adj(T) = adj_T = 0
