@@ -41,7 +41,10 @@ extern "C" {
 enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2, MYR_SYS_SIMPLECASE = 3,
        /* NodeSystem over CARTPOLE with a (64,64) sigmoid MLP (systems/neural_ode/node_system.py:14-42,
           neural_ode/create_node.py:110-117): params = the 4804 weights, see csrc/node_system.h for the order */
-       MYR_SYS_NODE_CARTPOLE = 4 };
+       MYR_SYS_NODE_CARTPOLE = 4,
+       /* further autonomous systems without terminal cost (systems/lenhart/*.py, miscellaneous/seir.py) */
+       MYR_SYS_BIOREACTOR = 5, MYR_SYS_GLUCOSE = 6, MYR_SYS_MOULDFUNGICIDE = 7, MYR_SYS_SIMPLECASEWITHBOUNDS = 8,
+       MYR_SYS_HIVTREATMENT = 9, MYR_SYS_EPIDEMICSEIRN = 10, MYR_SYS_SEIR = 11, MYR_SYS_BEARPOPULATIONS = 12 };
 /* transcription: OptimizerType x QuadratureRule (config.py:12-57) */
 enum { MYR_TR_HERMITE_SIMPSON = 0, MYR_TR_TRAPEZOIDAL = 1, MYR_TR_SHOOTING = 2 };
 /* IntegrationMethod (config.py:46-50) */

@@ -19,6 +19,12 @@
 #include "systems_gen.h"
 #include "node_system.h"
 
+// closed-form systems (tools/gen_systems.py): X(NAME) expands once per system; the enum values are MYR_SYS_<NAME>
+#define MYR_CLOSED_FORM_SYSTEMS(X)                                                                               \
+  X(CARTPOLE) X(VANDERPOL) X(CANCERTREATMENT) X(SIMPLECASE) X(BIOREACTOR) X(GLUCOSE) X(MOULDFUNGICIDE)           \
+  X(SIMPLECASEWITHBOUNDS) X(HIVTREATMENT) X(EPIDEMICSEIRN) X(SEIR) X(BEARPOPULATIONS)
+
+
 using namespace myriad;
 
 static thread_local std::string g_err;
@@ -36,10 +42,9 @@ static int fail(int code, const std::string& msg) {
 struct SysInfo { int ns, nu, np; bool cost_dep_x; };
 static bool sys_info(int id, SysInfo* s) {
   switch (id) {
-    case MYR_SYS_CARTPOLE: *s = {SysCARTPOLE::NS, SysCARTPOLE::NU, SysCARTPOLE::NP, SysCARTPOLE::COST_DEP_X}; return true;
-    case MYR_SYS_VANDERPOL: *s = {SysVANDERPOL::NS, SysVANDERPOL::NU, SysVANDERPOL::NP, SysVANDERPOL::COST_DEP_X}; return true;
-    case MYR_SYS_CANCERTREATMENT: *s = {SysCANCERTREATMENT::NS, SysCANCERTREATMENT::NU, SysCANCERTREATMENT::NP, SysCANCERTREATMENT::COST_DEP_X}; return true;
-    case MYR_SYS_SIMPLECASE: *s = {SysSIMPLECASE::NS, SysSIMPLECASE::NU, SysSIMPLECASE::NP, SysSIMPLECASE::COST_DEP_X}; return true;
+#define X(N) case MYR_SYS_##N: *s = {Sys##N::NS, Sys##N::NU, Sys##N::NP, Sys##N::COST_DEP_X}; return true;
+    MYR_CLOSED_FORM_SYSTEMS(X)
+#undef X
     case MYR_SYS_NODE_CARTPOLE: *s = {SysNODE_CARTPOLE::NS, SysNODE_CARTPOLE::NU, SysNODE_CARTPOLE::NP, SysNODE_CARTPOLE::COST_DEP_X}; return true;
   }
   return false;
@@ -271,10 +276,9 @@ static int eval_for_system(myr_handle h, int B, const double* z, const double* p
 static int dispatch_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
                          double* f, double* g, double* c, double* j) {
   switch (h->d.system_id) {
-    case MYR_SYS_CARTPOLE: return eval_for_system<SysCARTPOLE>(h, B, z, params, pstride, f, g, c, j);
-    case MYR_SYS_VANDERPOL: return eval_for_system<SysVANDERPOL>(h, B, z, params, pstride, f, g, c, j);
-    case MYR_SYS_CANCERTREATMENT: return eval_for_system<SysCANCERTREATMENT>(h, B, z, params, pstride, f, g, c, j);
-    case MYR_SYS_SIMPLECASE: return eval_for_system<SysSIMPLECASE>(h, B, z, params, pstride, f, g, c, j);
+#define X(N) case MYR_SYS_##N: return eval_for_system<Sys##N>(h, B, z, params, pstride, f, g, c, j);
+    MYR_CLOSED_FORM_SYSTEMS(X)
+#undef X
     case MYR_SYS_NODE_CARTPOLE: return eval_for_system<SysNODE_CARTPOLE>(h, B, z, params, pstride, f, g, c, j);
   }
   return fail(MYR_E_ARG, "eval: unknown system");
@@ -381,10 +385,9 @@ static int products_for_system(myr_handle h, const ProdArgs& a) {
 
 static int dispatch_products(myr_handle h, const ProdArgs& a) {
   switch (h->d.system_id) {
-    case MYR_SYS_CARTPOLE: return products_for_system<SysCARTPOLE>(h, a);
-    case MYR_SYS_VANDERPOL: return products_for_system<SysVANDERPOL>(h, a);
-    case MYR_SYS_CANCERTREATMENT: return products_for_system<SysCANCERTREATMENT>(h, a);
-    case MYR_SYS_SIMPLECASE: return products_for_system<SysSIMPLECASE>(h, a);
+#define X(N) case MYR_SYS_##N: return products_for_system<Sys##N>(h, a);
+    MYR_CLOSED_FORM_SYSTEMS(X)
+#undef X
     case MYR_SYS_NODE_CARTPOLE: return products_for_system<SysNODE_CARTPOLE>(h, a);
   }
   return fail(MYR_E_ARG, "products: unknown system");
@@ -678,10 +681,9 @@ static int dispatch_solve(myr_handle h, int B, double* z, const double* lb, cons
                           int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                           int32_t* iters, double* kkt) {
   switch (h->d.system_id) {
-    case MYR_SYS_CARTPOLE: return solve_for_system<SysCARTPOLE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-    case MYR_SYS_VANDERPOL: return solve_for_system<SysVANDERPOL>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-    case MYR_SYS_CANCERTREATMENT: return solve_for_system<SysCANCERTREATMENT>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-    case MYR_SYS_SIMPLECASE: return solve_for_system<SysSIMPLECASE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+#define X(N) case MYR_SYS_##N: return solve_for_system<Sys##N>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    MYR_CLOSED_FORM_SYSTEMS(X)
+#undef X
     case MYR_SYS_NODE_CARTPOLE: return solve_for_system<SysNODE_CARTPOLE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   return fail(MYR_E_ARG, "solve: unknown system");
@@ -763,10 +765,9 @@ static int dispatch_rollout(myr_handle h, int B, int num_steps, int u_rows, cons
   dim3 g((unsigned)((B + 63) / 64)), t(64);
 #define RO(S) hipLaunchKernelGGL(rollout_kernel<S>, g, t, 0, h->stream, B, method, num_steps, hs, u_rows, x0, us, params, pstride, xs, cost)
   switch (h->d.system_id) {
-    case MYR_SYS_CARTPOLE: RO(SysCARTPOLE); break;
-    case MYR_SYS_VANDERPOL: RO(SysVANDERPOL); break;
-    case MYR_SYS_CANCERTREATMENT: RO(SysCANCERTREATMENT); break;
-    case MYR_SYS_SIMPLECASE: RO(SysSIMPLECASE); break;
+#define X(N) case MYR_SYS_##N: RO(Sys##N); break;
+    MYR_CLOSED_FORM_SYSTEMS(X)
+#undef X
     case MYR_SYS_NODE_CARTPOLE: RO(SysNODE_CARTPOLE); break;
     default: return fail(MYR_E_ARG, "rollout: unknown system");
   }
@@ -871,10 +872,9 @@ extern "C" int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, co
   if (adj_T) HIPCHK(hipMemcpyAsync(dadj, adj_T, (size_t)dm.ns * 8, hipMemcpyHostToDevice, h->stream));
 #define MYR_FBSM(S) rc = launch_fbsm<S>(h, B, Bp, N, dx0, adj_T ? dadj : nullptr, npar ? dp : nullptr, params_stride, clip_lo, clip_hi, delta, max_sweeps, X, U, A, dsw)
   switch (h->d.system_id) {
-    case MYR_SYS_CARTPOLE: MYR_FBSM(SysCARTPOLE); break;
-    case MYR_SYS_VANDERPOL: MYR_FBSM(SysVANDERPOL); break;
-    case MYR_SYS_CANCERTREATMENT: MYR_FBSM(SysCANCERTREATMENT); break;
-    case MYR_SYS_SIMPLECASE: MYR_FBSM(SysSIMPLECASE); break;
+#define X(N) case MYR_SYS_##N: MYR_FBSM(Sys##N); break;
+    MYR_CLOSED_FORM_SYSTEMS(X)
+#undef X
     default: rc = fail(MYR_E_UNSUPPORTED, "myr_fbsm: this system has no adjoint dynamics");
   }
 #undef MYR_FBSM

@@ -144,13 +144,173 @@ class SimpleCase(IndirectFHCS):
     return float(np.squeeze(-self.A * np.asarray(x_t) + self.B * np.squeeze(u_t) ** 2))
 
 
+# ---- further autonomous systems without terminal cost.  Constructor signatures, x_0 / x_T / T / bounds
+# and parameter names are the reference's; dynamics and cost are numpy restatements for host-side use (plots, checks),
+# the device has its own generated code (tools/gen_systems.py).
+class Bioreactor(IndirectFHCS):
+  """systems/lenhart/bioreactor.py:37-83."""
+  name = "BIOREACTOR"
+  param_names = ("K", "G", "D")
+
+  def __init__(self, K=2., G=1., D=1., M=1., x_0=(.5, .1), T=2.):
+    super().__init__(x_0=[x_0[0]], x_T=None, T=T, bounds=[[0., 1.], [0., M]])
+    self.K, self.G, self.D, self.M = K, G, D, M
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    x = np.asarray(x_t, dtype=np.float64); u = float(np.squeeze(u_t))
+    return np.array([self.G * u * x[0] - self.D * x[0] ** 2])
+
+  def cost(self, x_t, u_t, t=None):
+    return float(-self.K * np.asarray(x_t)[0] + np.squeeze(u_t))
+
+
+class Glucose(IndirectFHCS):
+  """systems/lenhart/glucose.py:41-104."""
+  name = "GLUCOSE"
+  param_names = ("a", "b", "c", "A", "l")
+
+  def __init__(self, a=1., b=1., c=1., A=2., l=.5, x_0=(.75, 0.), T=.2):
+    super().__init__(x_0=[x_0[0], x_0[1]], x_T=None, T=T, bounds=[[0., 1.], [0., 1.], [0., 0.01]])
+    self.a, self.b, self.c, self.A, self.l = a, b, c, A, l
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    x0, x1 = x_t
+    return np.array([-self.a * x0 - self.b * x1, -self.c * x1 + float(np.squeeze(u_t))])
+
+  def cost(self, x_t, u_t, t=None):
+    return float(100_000 * (self.A * (x_t[0] - self.l) ** 2 + np.squeeze(u_t) ** 2))
+
+
+class MouldFungicide(IndirectFHCS):
+  """systems/lenhart/mould_fungicide.py:26-70."""
+  name = "MOULDFUNGICIDE"
+  param_names = ("r", "M", "A")
+
+  def __init__(self, r=0.3, M=10., A=10., x_0=1.0, T=5):
+    super().__init__(x_0=[x_0], x_T=None, T=T, bounds=[[0., 5.], [0., 5.]])
+    self.r, self.M, self.A = r, M, A
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    x = np.asarray(x_t, dtype=np.float64)
+    return self.r * (self.M - x) - np.squeeze(u_t) * x
+
+  def cost(self, x_t, u_t, t=None):
+    return float(np.squeeze(self.A * np.asarray(x_t) ** 2 + np.squeeze(u_t) ** 2))
+
+
+class SimpleCaseWithBounds(IndirectFHCS):
+  """systems/lenhart/simple_case_with_bounds.py:24-55."""
+  name = "SIMPLECASEWITHBOUNDS"
+  param_names = ("A", "C")
+
+  def __init__(self, A=1., C=4., M_1=-1., M_2=2., x_0=1., T=1.):
+    super().__init__(x_0=[x_0], x_T=None, T=T, bounds=[[0., 3.], [M_1, M_2]])
+    self.A, self.C, self.M_1, self.M_2 = A, C, M_1, M_2
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    return -0.5 * np.asarray(x_t, dtype=np.float64) ** 2 + self.C * np.squeeze(u_t)
+
+  def cost(self, x_t, u_t, t=None):
+    return float(np.squeeze(-self.A * np.asarray(x_t) + np.squeeze(u_t) ** 2))
+
+
+class HIVTreatment(IndirectFHCS):
+  """systems/lenhart/hiv_treatment.py:33-111."""
+  name = "HIVTREATMENT"
+  param_names = ("s", "m_1", "m_2", "m_3", "r", "T_max", "k", "N", "A")
+
+  def __init__(self, s=10., m_1=.02, m_2=.5, m_3=4.4, r=.03, T_max=1500., k=.000024, N=300., x_0=(800., .04, 1.5), A=.05, T=20.):
+    super().__init__(x_0=[x_0[0], x_0[1], x_0[2]], x_T=None, T=T, bounds=[[0., 1600.], [0., 100.], [0., 100.], [0., 1.]])
+    self.s, self.m_1, self.m_2, self.m_3, self.r, self.T_max, self.k, self.N, self.A = s, m_1, m_2, m_3, r, T_max, k, N, A
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    x0, x1, x2 = x_t
+    u = float(np.squeeze(u_t))
+    return np.array([self.s / (1 + x2) - self.m_1 * x0 + self.r * x0 * (1 - (x0 + x1) / self.T_max) - u * self.k * x0 * x2,
+                     u * self.k * x0 * x2 - self.m_2 * x1,
+                     self.N * self.m_2 * x1 - self.m_3 * x2])
+
+  def cost(self, x_t, u_t, t=None):
+    return float(-self.A * x_t[0] + (1 - np.squeeze(u_t)) ** 2)
+
+
+class EpidemicSEIRN(IndirectFHCS):
+  """systems/lenhart/epidemic_seirn.py:41-95."""
+  name = "EPIDEMICSEIRN"
+  param_names = ("A", "b", "d", "c", "e", "g", "a")
+
+  def __init__(self, A=.1, b=.525, d=.5, c=.0001, e=.5, g=.1, a=.2, x_0=(1000., 100., 50., 15.), T=20.):
+    super().__init__(x_0=[x_0[0], x_0[1], x_0[2], float(np.sum(x_0))], x_T=None, T=T,
+                     bounds=[[-np.inf, np.inf]] * 4 + [[0., 0.9]])
+    self.A, self.b, self.d, self.c, self.e, self.g, self.a = A, b, d, c, e, g, a
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    x0, x1, x2, x3 = x_t
+    u = float(np.squeeze(u_t))
+    return np.array([self.b * x3 - self.d * x0 - self.c * x0 * x2 - u * x0,
+                     self.c * x0 * x2 - (self.e + self.d) * x1,
+                     self.e * x1 - (self.g + self.a + self.d) * x2,
+                     (self.b - self.d) * x3 - self.a * x2])
+
+  def cost(self, x_t, u_t, t=None):
+    return float(self.A * x_t[2] + np.squeeze(u_t) ** 2)
+
+
+class SEIR(FiniteHorizonControlSystem):
+  """systems/miscellaneous/seir.py:44-95 (constants fixed in the constructor, box bounds on the states)."""
+  name = "SEIR"
+  param_names = ("A", "b", "d", "c", "e", "g", "a")
+
+  def __init__(self):
+    self.b, self.d, self.c, self.e, self.g, self.a = 0.525, 0.5, 0.0001, 0.5, 0.1, 0.2
+    self.S_0, self.E_0, self.I_0, self.R_0 = 1000.0, 100.0, 50.0, 15.0
+    self.N_0 = self.S_0 + self.E_0 + self.I_0 + self.R_0
+    self.A, self.M = 0.1, 1000
+    super().__init__(x_0=[self.S_0, self.E_0, self.I_0, self.N_0], x_T=None, T=20,
+                     bounds=[[0., 2000.], [0., 250.], [0., 250.], [0., 3000.], [0., 1.]])
+
+  dynamics = EpidemicSEIRN.dynamics
+  cost = EpidemicSEIRN.cost
+
+
+class BearPopulations(IndirectFHCS):
+  """systems/lenhart/bear_populations.py:38-110 (two controls)."""
+  name = "BEARPOPULATIONS"
+  param_names = ("r", "K", "m_p", "m_f", "c_p", "c_f")
+
+  def __init__(self, r=.1, K=.75, m_p=.5, m_f=.5, c_p=10_000, c_f=10, x_0=(.4, .2, 0.), T=25):
+    super().__init__(x_0=[x_0[0], x_0[1], x_0[2]], x_T=None, T=T, bounds=[[0., 2.], [0., 2.], [0., 2.], [0., .2], [0., .2]])
+    self.r, self.K, self.m_p, self.m_f, self.c_p, self.c_f = r, K, m_p, m_f, float(c_p), float(c_f)
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    k, k2 = self.r / self.K, self.r / self.K ** 2
+    x0, x1, _ = x_t
+    u0, u1 = u_t
+    return np.array([self.r * x0 - k * x0 ** 2 + k * self.m_f * (1 - x0 / self.K) * x1 ** 2 - u0 * x0,
+                     self.r * x1 - k * x1 ** 2 + k * self.m_p * (1 - x1 / self.K) * x0 ** 2 - u1 * x1,
+                     k * (1 - self.m_p) * x0 ** 2 + k * (1 - self.m_f) * x1 ** 2 + k2 * self.m_f * x0 * x1 ** 2 + k2 * self.m_p * x0 ** 2 * x1])
+
+  def cost(self, x_t, u_t, t=None):
+    return float(x_t[2] + self.c_p * u_t[0] ** 2 + self.c_f * u_t[1] ** 2)
+
+
 class SystemType(Enum):
   """systems/__init__.py:29-53: an enum of system classes; calling a member instantiates the system.
-  Members outside the hot path (17 further systems) are listed in DESIGN.md as out of scope."""
+  Members not built here (time-dependent cost, terminal cost, discrete or clipped gym-style dynamics: TUMOUR,
+  MOUNTAINCAR, PENDULUM, BACTERIA, HARVEST, TIMBERHARVEST, PREDATORPREY, INVASIVEPLANT, ROCKETLANDING) are listed in
+  DESIGN.md."""
   CARTPOLE = CartPole
   VANDERPOL = VanDerPol
+  SEIR = SEIR
   SIMPLECASE = SimpleCase
+  MOULDFUNGICIDE = MouldFungicide
+  SIMPLECASEWITHBOUNDS = SimpleCaseWithBounds
   CANCERTREATMENT = CancerTreatment
+  EPIDEMICSEIRN = EpidemicSEIRN
+  HIVTREATMENT = HIVTreatment
+  BEARPOPULATIONS = BearPopulations
+  GLUCOSE = Glucose
+  BIOREACTOR = Bioreactor
 
   def __call__(self, *args, **kwargs):
     return self.value(*args, **kwargs)

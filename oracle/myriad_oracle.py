@@ -195,6 +195,172 @@ class SimpleCase(System):
     return np.minimum(self.bounds[0, 1], np.maximum(self.bounds[0, 0], (self.C * adj) / (2 * self.B)))
 
 
+# ---- further autonomous systems without terminal cost ------------------------------------------
+class Bioreactor(System):
+  """myriad/systems/lenhart/bioreactor.py:37-83."""
+  name = "BIOREACTOR"
+  param_names = ("K", "G", "D")
+
+  def __init__(self, K=2., G=1., D=1., M=1., x_0=(.5, .1), T=2.):
+    self.K, self.G, self.D, self.M = K, G, D, M
+    self.x_0 = np.array([x_0[0]]); self.x_T = None; self.T = float(T)
+    self.bounds = np.array([[0., 1.], [0., M]])
+
+  def params(self):
+    return np.array([self.K, self.G, self.D])
+
+  def dynamics(self, x, u):                                  # bioreactor.py:60-69
+    return torch.stack([self.G * u[..., 0] * x[..., 0] - self.D * x[..., 0] ** 2], dim=-1)
+
+  def cost(self, x, u, t=None):                              # bioreactor.py:82-83
+    return -self.K * x[..., 0] + u[..., 0]
+
+
+class Glucose(System):
+  """myriad/systems/lenhart/glucose.py:41-104."""
+  name = "GLUCOSE"
+  param_names = ("a", "b", "c", "A", "l")
+
+  def __init__(self, a=1., b=1., c=1., A=2., l=.5, x_0=(.75, 0.), T=.2):
+    self.a, self.b, self.c, self.A, self.l = a, b, c, A, l
+    self.x_0 = np.array([x_0[0], x_0[1]]); self.x_T = None; self.T = float(T)
+    self.bounds = np.array([[0., 1.], [0., 1.], [0., 0.01]])
+
+  def params(self):
+    return np.array([self.a, self.b, self.c, self.A, self.l])
+
+  def dynamics(self, x, u):                                  # glucose.py:74-84
+    return torch.stack([-self.a * x[..., 0] - self.b * x[..., 1], -self.c * x[..., 1] + u[..., 0]], dim=-1)
+
+  def cost(self, x, u, t=None):                              # glucose.py:103-104
+    return 100_000 * (self.A * (x[..., 0] - self.l) ** 2 + u[..., 0] ** 2)
+
+
+class MouldFungicide(System):
+  """myriad/systems/lenhart/mould_fungicide.py:26-70."""
+  name = "MOULDFUNGICIDE"
+  param_names = ("r", "M", "A")
+
+  def __init__(self, r=0.3, M=10., A=10., x_0=1.0, T=5):
+    self.r, self.M, self.A = r, M, A
+    self.x_0 = np.array([x_0]); self.x_T = None; self.T = float(T)
+    self.bounds = np.array([[0., 5.], [0., 5.]])
+
+  def params(self):
+    return np.array([self.r, self.M, self.A])
+
+  def dynamics(self, x, u):                                  # mould_fungicide.py:54-58
+    return self.r * (self.M - x) - u * x
+
+  def cost(self, x, u, t=None):                              # mould_fungicide.py:69-70
+    return (self.A * x ** 2 + u ** 2)[..., 0]
+
+
+class SimpleCaseWithBounds(System):
+  """myriad/systems/lenhart/simple_case_with_bounds.py:24-55."""
+  name = "SIMPLECASEWITHBOUNDS"
+  param_names = ("A", "C")
+
+  def __init__(self, A=1., C=4., M_1=-1., M_2=2., x_0=1., T=1.):
+    self.A, self.C, self.M_1, self.M_2 = A, C, M_1, M_2
+    self.x_0 = np.array([x_0]); self.x_T = None; self.T = float(T)
+    self.bounds = np.array([[0., 3.], [M_1, M_2]])
+
+  def params(self):
+    return np.array([self.A, self.C])
+
+  def dynamics(self, x, u):                                  # simple_case_with_bounds.py:47-51
+    return -0.5 * x ** 2 + self.C * u
+
+  def cost(self, x, u, t=None):                              # simple_case_with_bounds.py:53-55
+    return (-self.A * x + u ** 2)[..., 0]
+
+
+class HIVTreatment(System):
+  """myriad/systems/lenhart/hiv_treatment.py:33-111."""
+  name = "HIVTREATMENT"
+  param_names = ("s", "m_1", "m_2", "m_3", "r", "T_max", "k", "N", "A")
+
+  def __init__(self, s=10., m_1=.02, m_2=.5, m_3=4.4, r=.03, T_max=1500., k=.000024, N=300., x_0=(800., .04, 1.5), A=.05, T=20.):
+    self.s, self.m_1, self.m_2, self.m_3, self.r, self.T_max, self.k, self.N, self.A = s, m_1, m_2, m_3, r, T_max, k, N, A
+    self.x_0 = np.array([x_0[0], x_0[1], x_0[2]]); self.x_T = None; self.T = float(T)
+    self.bounds = np.array([[0., 1600.], [0., 100.], [0., 100.], [0., 1.]])
+
+  def params(self):
+    return np.array([self.s, self.m_1, self.m_2, self.m_3, self.r, self.T_max, self.k, self.N, self.A])
+
+  def dynamics(self, x, u):                                  # hiv_treatment.py:72-84
+    x0, x1, x2, u0 = x[..., 0], x[..., 1], x[..., 2], u[..., 0]
+    return torch.stack([
+      self.s / (1 + x2) - self.m_1 * x0 + self.r * x0 * (1 - (x0 + x1) / self.T_max) - u0 * self.k * x0 * x2,
+      u0 * self.k * x0 * x2 - self.m_2 * x1,
+      self.N * self.m_2 * x1 - self.m_3 * x2], dim=-1)
+
+  def cost(self, x, u, t=None):                              # hiv_treatment.py:110-111
+    return -self.A * x[..., 0] + (1 - u[..., 0]) ** 2
+
+
+class EpidemicSEIRN(System):
+  """myriad/systems/lenhart/epidemic_seirn.py:41-95."""
+  name = "EPIDEMICSEIRN"
+  param_names = ("A", "b", "d", "c", "e", "g", "a")
+
+  def __init__(self, A=.1, b=.525, d=.5, c=.0001, e=.5, g=.1, a=.2, x_0=(1000., 100., 50., 15.), T=20.):
+    self.A, self.b, self.d, self.c, self.e, self.g, self.a = A, b, d, c, e, g, a
+    self.x_0 = np.array([x_0[0], x_0[1], x_0[2], float(np.sum(x_0))]); self.x_T = None; self.T = float(T)   # :45-50
+    self.bounds = np.array([[-np.inf, np.inf]] * 4 + [[0., 0.9]])
+
+  def params(self):
+    return np.array([self.A, self.b, self.d, self.c, self.e, self.g, self.a])
+
+  def dynamics(self, x, u):                                  # epidemic_seirn.py:78-92
+    x0, x1, x2, x3, u0 = x[..., 0], x[..., 1], x[..., 2], x[..., 3], u[..., 0]
+    return torch.stack([
+      self.b * x3 - self.d * x0 - self.c * x0 * x2 - u0 * x0,
+      self.c * x0 * x2 - (self.e + self.d) * x1,
+      self.e * x1 - (self.g + self.a + self.d) * x2,
+      (self.b - self.d) * x3 - self.a * x2], dim=-1)
+
+  def cost(self, x, u, t=None):                              # epidemic_seirn.py:94-95
+    return self.A * x[..., 2] + u[..., 0] ** 2
+
+
+class SEIR(EpidemicSEIRN):
+  """myriad/systems/miscellaneous/seir.py:44-95: the same field with fixed constants and box bounds on the states."""
+  name = "SEIR"
+
+  def __init__(self):
+    super().__init__()                                        # constants of seir.py:46-58 equal the SEIRN defaults
+    self.x_0 = np.array([1000.0, 100.0, 50.0, 1165.0])        # S_0, E_0, I_0, N_0 = S+E+I+R (:52-56)
+    self.bounds = np.array([[0., 2000.], [0., 250.], [0., 250.], [0., 3000.], [0., 1.]])   # :72-78
+
+
+class BearPopulations(System):
+  """myriad/systems/lenhart/bear_populations.py:38-110 (two controls)."""
+  name = "BEARPOPULATIONS"
+  param_names = ("r", "K", "m_p", "m_f", "c_p", "c_f")
+
+  def __init__(self, r=.1, K=.75, m_p=.5, m_f=.5, c_p=10_000, c_f=10, x_0=(.4, .2, 0.), T=25):
+    self.r, self.K, self.m_p, self.m_f, self.c_p, self.c_f = r, K, m_p, m_f, float(c_p), float(c_f)
+    self.x_0 = np.array([x_0[0], x_0[1], x_0[2]]); self.x_T = None; self.T = float(T)
+    self.bounds = np.array([[0., 2.], [0., 2.], [0., 2.], [0., .2], [0., .2]])
+
+  def params(self):
+    return np.array([self.r, self.K, self.m_p, self.m_f, self.c_p, self.c_f])
+
+  def dynamics(self, x, u):                                  # bear_populations.py:72-86
+    k, k2 = self.r / self.K, self.r / self.K ** 2
+    x0, x1, u0, u1 = x[..., 0], x[..., 1], u[..., 0], u[..., 1]
+    return torch.stack([
+      self.r * x0 - k * x0 ** 2 + k * self.m_f * (1 - x0 / self.K) * x1 ** 2 - u0 * x0,
+      self.r * x1 - k * x1 ** 2 + k * self.m_p * (1 - x1 / self.K) * x0 ** 2 - u1 * x1,
+      k * (1 - self.m_p) * x0 ** 2 + k * (1 - self.m_f) * x1 ** 2 + k2 * self.m_f * x0 * x1 ** 2 + k2 * self.m_p * (x0 ** 2) * x1],
+      dim=-1)
+
+  def cost(self, x, u, t=None):                              # bear_populations.py:109-110
+    return x[..., 2] + self.c_p * u[..., 0] ** 2 + self.c_f * u[..., 1] ** 2
+
+
 class NodeCartPole(CartPole):
   """myriad/systems/neural_ode/node_system.py:14-42 over CARTPOLE: dynamics = net.apply(params, [x;u]) with the MLP of
   myriad/neural_ode/create_node.py:110-117 (Linear+sigmoid per hidden layer, Linear out; Haiku y = x @ w + b);
@@ -213,7 +379,8 @@ class NodeCartPole(CartPole):
     return h @ w + b
 
 
-SYSTEMS = {c.name: c for c in (CartPole, VanDerPol, CancerTreatment, SimpleCase)}
+SYSTEMS = {c.name: c for c in (CartPole, VanDerPol, CancerTreatment, SimpleCase, Bioreactor, Glucose, MouldFungicide,
+                                SimpleCaseWithBounds, HIVTreatment, EpidemicSEIRN, SEIR, BearPopulations)}
 
 
 # --------------------------------------------------------------------------------------

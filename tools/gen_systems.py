@@ -69,6 +69,71 @@ def systems():
   out.append(dict(name="SIMPLECASE", id=3, x=x, u=u, p=p,
                   f=[-sp.Rational(1, 2) * x[0] ** 2 + p[2] * u[0]],
                   g=-p[0] * x[0] + p[1] * u[0] ** 2, pdefault=[1.0, 1.0, 4.0], pnames=["A", "B", "C"]))
+  # ==== SURVEY.md 8(f4): further autonomous systems without terminal cost =====================================
+  # ---- BIOREACTOR: myriad/systems/lenhart/bioreactor.py:60-69 (dynamics), :82-83 (cost) ----
+  x = sp.symbols("x0:1", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:3", real=True)   # K, G, D
+  out.append(dict(name="BIOREACTOR", id=5, x=x, u=u, p=p,
+                  f=[p[1] * u[0] * x[0] - p[2] * x[0] ** 2], g=-p[0] * x[0] + u[0],
+                  pdefault=[2.0, 1.0, 1.0], pnames=["K", "G", "D"]))
+  # ---- GLUCOSE: myriad/systems/lenhart/glucose.py:74-84, :103-104 ----
+  x = sp.symbols("x0:2", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:5", real=True)   # a, b, c, A, l
+  out.append(dict(name="GLUCOSE", id=6, x=x, u=u, p=p,
+                  f=[-p[0] * x[0] - p[1] * x[1], -p[2] * x[1] + u[0]],
+                  g=100000 * (p[3] * (x[0] - p[4]) ** 2 + u[0] ** 2),
+                  pdefault=[1.0, 1.0, 1.0, 2.0, 0.5], pnames=["a", "b", "c", "A", "l"]))
+  # ---- MOULDFUNGICIDE: myriad/systems/lenhart/mould_fungicide.py:54-58, :69-70 ----
+  x = sp.symbols("x0:1", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:3", real=True)   # r, M, A
+  out.append(dict(name="MOULDFUNGICIDE", id=7, x=x, u=u, p=p,
+                  f=[p[0] * (p[1] - x[0]) - u[0] * x[0]], g=p[2] * x[0] ** 2 + u[0] ** 2,
+                  pdefault=[0.3, 10.0, 10.0], pnames=["r", "M", "A"]))
+  # ---- SIMPLECASEWITHBOUNDS: myriad/systems/lenhart/simple_case_with_bounds.py:47-55 ----
+  x = sp.symbols("x0:1", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:2", real=True)   # A, C
+  out.append(dict(name="SIMPLECASEWITHBOUNDS", id=8, x=x, u=u, p=p,
+                  f=[-sp.Rational(1, 2) * x[0] ** 2 + p[1] * u[0]], g=-p[0] * x[0] + u[0] ** 2,
+                  pdefault=[1.0, 4.0], pnames=["A", "C"]))
+  # ---- HIVTREATMENT: myriad/systems/lenhart/hiv_treatment.py:72-84, :110-111 ----
+  x = sp.symbols("x0:3", real=True)
+  u = sp.symbols("u0:1", real=True)
+  s_, m1_, m2_, m3_, r_, Tm_, k_, N_, A_ = p = sp.symbols("p0:9", real=True)   # s, m_1, m_2, m_3, r, T_max, k, N, A
+  out.append(dict(name="HIVTREATMENT", id=9, x=x, u=u, p=p,
+                  f=[s_ / (1 + x[2]) - m1_ * x[0] + r_ * x[0] * (1 - (x[0] + x[1]) / Tm_) - u[0] * k_ * x[0] * x[2],
+                     u[0] * k_ * x[0] * x[2] - m2_ * x[1],
+                     N_ * m2_ * x[1] - m3_ * x[2]],
+                  g=-A_ * x[0] + (1 - u[0]) ** 2,
+                  pdefault=[10.0, 0.02, 0.5, 4.4, 0.03, 1500.0, 0.000024, 300.0, 0.05],
+                  pnames=["s", "m_1", "m_2", "m_3", "r", "T_max", "k", "N", "A"]))
+  # ---- EPIDEMICSEIRN: myriad/systems/lenhart/epidemic_seirn.py:78-92, :94-95 ----
+  x = sp.symbols("x0:4", real=True)
+  u = sp.symbols("u0:1", real=True)
+  A_, b_, d_, c_, e_, g_, a_ = p = sp.symbols("p0:7", real=True)   # A, b, d, c, e, g, a
+  seirn_f = [b_ * x[3] - d_ * x[0] - c_ * x[0] * x[2] - u[0] * x[0],
+             c_ * x[0] * x[2] - (e_ + d_) * x[1],
+             e_ * x[1] - (g_ + a_ + d_) * x[2],
+             (b_ - d_) * x[3] - a_ * x[2]]
+  out.append(dict(name="EPIDEMICSEIRN", id=10, x=x, u=u, p=p, f=seirn_f, g=A_ * x[2] + u[0] ** 2,
+                  pdefault=[0.1, 0.525, 0.5, 0.0001, 0.5, 0.1, 0.2], pnames=["A", "b", "d", "c", "e", "g", "a"]))
+  # ---- SEIR: myriad/systems/miscellaneous/seir.py:83-95 (same field, fixed constants of :46-58) ----
+  out.append(dict(name="SEIR", id=11, x=x, u=u, p=p, f=seirn_f, g=A_ * x[2] + u[0] ** 2,
+                  pdefault=[0.1, 0.525, 0.5, 0.0001, 0.5, 0.1, 0.2], pnames=["A", "b", "d", "c", "e", "g", "a"]))
+  # ---- BEARPOPULATIONS: myriad/systems/lenhart/bear_populations.py:72-86, :109-110 (two controls) ----
+  x = sp.symbols("x0:3", real=True)
+  u = sp.symbols("u0:2", real=True)
+  r_, K_, mp_, mf_, cp_, cf_ = p = sp.symbols("p0:6", real=True)   # r, K, m_p, m_f, c_p, c_f
+  k1, k2 = r_ / K_, r_ / K_ ** 2
+  out.append(dict(name="BEARPOPULATIONS", id=12, x=x, u=u, p=p,
+                  f=[r_ * x[0] - k1 * x[0] ** 2 + k1 * mf_ * (1 - x[0] / K_) * x[1] ** 2 - u[0] * x[0],
+                     r_ * x[1] - k1 * x[1] ** 2 + k1 * mp_ * (1 - x[1] / K_) * x[0] ** 2 - u[1] * x[1],
+                     k1 * (1 - mp_) * x[0] ** 2 + k1 * (1 - mf_) * x[1] ** 2 + k2 * mf_ * x[0] * x[1] ** 2 + k2 * mp_ * x[0] ** 2 * x[1]],
+                  g=x[2] + cp_ * u[0] ** 2 + cf_ * u[1] ** 2,
+                  pdefault=[0.1, 0.75, 0.5, 0.5, 10000.0, 10.0], pnames=["r", "K", "m_p", "m_f", "c_p", "c_f"]))
   return out
 
 
