@@ -115,8 +115,8 @@ def cpu_same_algorithm(z0, lb, ub, N, T, nsample):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=5)
-  ap.add_argument("--warmup", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
   ap.add_argument("--intervals", type=int, default=100)
   ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline sample (0 = skip)")
