@@ -137,3 +137,27 @@ def test_fbsm_restatement_is_a_pontryagin_fixed_point():
     adot = (r["adj"][2:] - r["adj"][:-2]) / (2 * h)
     assert np.abs(adot - s.adj_ODE(r["adj"][1:-1], r["x"][1:-1], r["u"][1:-1])).max() < 5e-2 * max(1.0, np.abs(adot).max())
     assert r["adj"][-1, 0] == 0.0                                # transversality: adj(T) = adj_T = 0
+
+
+def test_golden_shooting_solutions_are_feasible_optima_of_the_oracle_problem(golden_dir):
+  """tests/golden/solve_shoot_*.npz: recomputed feasibility / cost, bounds, and first-order optimality in the
+  null space of the constraints at the stored optimum (projected gradient on the inactive variables)."""
+  cases = {"simplecase_10x100": O.SimpleCase, "vanderpol_1x50": O.VanDerPol, "cancertreatment_1x100": O.CancerTreatment}
+  for tag, S in cases.items():
+    d = np.load(os.path.join(golden_dir, f"solve_shoot_{tag}.npz"))
+    for b in range(d["z"].shape[0]):
+      kw = dict(zip(S.param_names, d["params"][b])) if S is O.CancerTreatment else {}
+      s = S(**kw) if kw else S()
+      s.x_0 = d["x0"][b].copy()
+      tr = O.shooting(s, int(d["intervals"]), int(d["cpi"]), "HEUN")
+      cb = O.Callbacks(tr)
+      z = d["z"][b]
+      np.testing.assert_array_equal(tr.bounds[:, 0], d["lb"][b])
+      assert np.abs(cb.cons(z)).max() <= 1e-10
+      assert cb.fun(z) == pytest.approx(float(d["cost"][b]), rel=1e-13)
+      assert (z >= d["lb"][b] - 1e-12).all() and (z <= d["ub"][b] + 1e-12).all()
+      if b == 0 and tag != "simplecase_10x100":
+        J, g = cb.jac(z), cb.grad(z)
+        free = (d["lb"][b] < d["ub"][b]) & (z - d["lb"][b] > 1e-6) & (d["ub"][b] - z > 1e-6)
+        lam = np.linalg.lstsq(J[:, free].T, -g[free], rcond=None)[0]
+        assert np.abs(g[free] + J[:, free].T @ lam).max() < 1e-5 * max(1.0, np.abs(g).max())
