@@ -26,7 +26,14 @@ def gather_solutions(local: Dict[str, "torch.Tensor"], counts: Sequence[int], gr
   assert len(counts) == world and local[next(iter(local))].shape[0] == counts[rank]
   mx = max(counts)
   out = {}
+  equal = all(c == mx for c in counts)
+  fused = equal and dist.get_backend(group) == "nccl"      # RCCL: one flat all-gather straight into the result
   for k, t in local.items():
+    if fused:
+      res = t.new_empty((world * mx,) + tuple(t.shape[1:]))
+      dist.all_gather_into_tensor(res, t.contiguous(), group=group)
+      out[k] = res
+      continue
     pad = t
     if t.shape[0] < mx:   # all_gather needs equal shapes: pad the short ranks
       pad = torch.cat([t, t.new_zeros((mx - t.shape[0],) + tuple(t.shape[1:]))], dim=0)

@@ -99,3 +99,21 @@ def test_rollout_kernel_matches_oracle(method):
       np.testing.assert_allclose(xs[b], oxs, rtol=1e-12, atol=1e-13)
       assert cost[b] == pytest.approx(oc, rel=1e-12, abs=1e-14)
     eng.close()
+
+
+def test_gather_solutions_over_rccl_single_rank():
+  """The N>1 bench path's only collective, on the RCCL backend (a 1-rank group is all a 1-GPU box allows; the
+  world-2 logic is covered on gloo in tests/test_host_api.py)."""
+  import os
+  import torch
+  import torch.distributed as dist
+  from myriad_amd.batched import gather_solutions
+  os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29617")
+  dist.init_process_group("nccl", rank=0, world_size=1)
+  try:
+    z = torch.arange(12, dtype=torch.float64, device="cuda").reshape(4, 3)
+    st = torch.tensor([0, 1, 0, 3], dtype=torch.int32, device="cuda")
+    out = gather_solutions({"z": z, "status": st}, [4])
+    assert torch.equal(out["z"], z) and torch.equal(out["status"], st)
+  finally:
+    dist.destroy_process_group()
