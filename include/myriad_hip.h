@@ -136,6 +136,15 @@ int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, const double
               double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt, int32_t mem);
 
 /*
+ * Variable scaling of the SOLVE path.  scale [ns+nu] (states, then controls; NULL = all 1): myr_solve then works on
+ * z/s, lb/s, ub/s with the dynamics f(s x)/s -- the same optimisation problem in better-conditioned variables (IPOPT's
+ * user scaling, which the reference reaches through `nlp_scaling_method`); inputs and outputs of myr_solve stay in the
+ * ORIGINAL variables (z, lam) except kkt[][0], the constraint violation, which is measured in scaled states.
+ * Not available for NODE systems.  Power-of-two scales make the change of variables exact in floating point.
+ */
+int myr_set_var_scale(myr_handle h, const double* scale);
+
+/*
  * True-dynamics rollout under given controls (utils.py:258-298) + terminal state.
  *   x0 [B][ns], us [B][u_rows_rollout][nu]  ->  xs [B][num_steps+1][ns] (may be NULL), cost [B]
  *   u_rows_rollout = (RK4 ? 2 : 1)*num_steps + 1 consumed entries (reference indexing utils.py:57-65).

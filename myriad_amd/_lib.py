@@ -24,7 +24,7 @@ K_EVAL, K_SOLVE, K_ROLLOUT, K_RESID, K_PROD, K_FBSM = 0, 1, 2, 3, 4, 5
 STATUS_NAMES = {0: "CONVERGED", 1: "MAXITER", 2: "NAN", 3: "STALLED"}
 
 EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve",
-           "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_fbsm", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",
+           "myr_set_var_scale", "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_fbsm", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",
            "myr_version"]
 
 
@@ -76,6 +76,8 @@ def load() -> C.CDLL:
   lib.myr_solve.restype = C.c_int
   lib.myr_rollout.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, dp, dp, C.c_int32]
   lib.myr_rollout.restype = C.c_int
+  lib.myr_set_var_scale.argtypes = [vp, dp]
+  lib.myr_set_var_scale.restype = C.c_int
   lib.myr_vjp.argtypes = [vp, C.c_int32, dp, dp, dp, C.c_int32, dp, C.c_int32, C.c_int32]
   lib.myr_vjp.restype = C.c_int
   lib.myr_jvp.argtypes = [vp, C.c_int32, dp, dp, dp, C.c_int32, dp, C.c_int32]
@@ -191,6 +193,16 @@ class Engine:
     o = SolveOpts()
     self.lib.myr_default_solve_opts(C.byref(o))
     return o
+
+  def set_var_scale(self, scale=None):
+    """Variable scales [ns+nu] of the solve path (None = unscaled); see include/myriad_hip.h, myr_set_var_scale."""
+    if scale is None:
+      _chk(self.lib.myr_set_var_scale(self._h, None), "myr_set_var_scale")
+      return
+    s = _f64(scale)
+    if s.shape != (self.ns + self.nu,):
+      raise ValueError(f"scale must have ns+nu = {self.ns + self.nu} entries")
+    _chk(self.lib.myr_set_var_scale(self._h, _addr(s)), "myr_set_var_scale")
 
   def solve(self, z0, lb, ub, params=None, opts: Optional[SolveOpts] = None):
     z = _f64(z0).copy()

@@ -30,6 +30,10 @@
 
 namespace myriad {
 
+// variable scales of the scaled problem the solver kernels work on (by-value kernel argument; closed-form systems have
+// at most 8 variables per point)
+struct VarScale { double s[8]; };
+
 struct HsSolveOpts {
   int N;
   double h;

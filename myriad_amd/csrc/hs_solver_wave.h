@@ -1067,7 +1067,7 @@ struct HsWave {
 // grid = B wavefronts (one 64-thread workgroup per trajectory); dynamic LDS = HsWave<Sys>::lds_bytes(N)
 template <class Sys>
 __global__ __launch_bounds__(64, MYR_WAVE_MIN_WAVES)
-void hs_solve_wave_kernel(int B, HsSolveOpts o, double* __restrict__ z, const double* __restrict__ lb,
+void hs_solve_wave_kernel(int B, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                           const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                           const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
                           int32_t* iters, double* kkt) {
@@ -1088,6 +1088,7 @@ void hs_solve_wave_kernel(int B, HsSolveOpts o, double* __restrict__ z, const do
   c.zr = s; s += W::ZR;
   c.lam = lam ? lam + b * (long)(2 * c.N * W::NS) : s;
   c.pp.load(params, b, params_stride);
+  c.pp.set_scale(vs.s);
   double* l = reinterpret_cast<double*>(smem_wave);
   c.r0 = l; l += W::r0_doubles(c.N);
   c.sPi = l; l += c.N * W::NS;

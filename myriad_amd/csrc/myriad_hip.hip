@@ -72,6 +72,11 @@ struct myr_handle_s {
   // solver scratch (batch-minor / SoA)
   void* sbuf = nullptr;
   size_t sbuf_bytes = 0;
+  // variable scaling of the solve path (myr_set_var_scale): the solver kernels see z/s, lb/s, ub/s
+  VarScale vscale{{1, 1, 1, 1, 1, 1, 1, 1}};
+  bool vscale_on = false;
+  void* vbuf = nullptr;       // scaled copies of lb, ub
+  size_t vbuf_bytes = 0;
 };
 
 static int ensure_dbuf(myr_handle h, size_t bytes) {
@@ -165,6 +170,7 @@ extern "C" int myr_destroy(myr_handle h) {
   (void)hipSetDevice(h->d.device);
   if (h->dbuf) (void)hipFree(h->dbuf);
   if (h->sbuf) (void)hipFree(h->sbuf);
+  if (h->vbuf) (void)hipFree(h->vbuf);
   for (int i = 0; i < MYR_K_COUNT; ++i) {
     if (h->kt[i].a) (void)hipEventDestroy(h->kt[i].a);
     if (h->kt[i].b) (void)hipEventDestroy(h->kt[i].b);
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(256) void transpose_back_kernel(const double* __res
 // so the 64 lanes of a wavefront always touch 64 consecutive doubles (one 512-byte coalesced access).
 template <class Core, class Sys>
 __global__ __launch_bounds__(64, 1)
-void lane_solve_kernel(int B, long Bp, int lanes_per_wave, HsSolveOpts o, double* z, double* lb, double* ub, double* zL, double* zU,
+void lane_solve_kernel(int B, long Bp, int lanes_per_wave, HsSolveOpts o, VarScale vs, double* z, double* lb, double* ub, double* zL, double* zU,
                      double* lam, double* dz, double* st, const double* __restrict__ params, int params_stride,
                      double* cost, int32_t* status, int32_t* iters, double* kkt) {
   // The kernel is latency-bound (long dependent fp64 chains, one wave per SIMD at best), so a wavefront may be
@@ -530,6 +536,7 @@ void lane_solve_kernel(int B, long Bp, int lanes_per_wave, HsSolveOpts o, double
   if (b >= B) return;
   SysParams<Sys> pp;
   pp.load(params, b, params_stride);
+  pp.set_scale(vs.s);
   const double* p = pp.get();
   HsWork w{{z + b, Bp}, {lb + b, Bp}, {ub + b, Bp}, {zL + b, Bp}, {zU + b, Bp}, {lam + b, Bp}, {dz + b, Bp}, {st + b, Bp}};
   HsSolveResult r;
@@ -586,7 +593,7 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KTimer& kt = h->kt[MYR_K_SOLVE];
     HIPCHK(hipEventRecord(kt.a, h->stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, h->stream, B, o, z, lb, ub, lam, (double*)h->sbuf, stride,
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, h->stream, B, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
                        params, pstride, cost, status, iters, kkt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(kt.b, h->stream));
@@ -636,7 +643,7 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
   KTimer& kt = h->kt[MYR_K_SOLVE];
   HIPCHK(hipEventRecord(kt.a, h->stream));
   const int lpw = h->solve_lpw;
-  hipLaunchKernelGGL((lane_solve_kernel<Core, Sys>), dim3((unsigned)((B + lpw - 1) / lpw)), dim3(64), 0, h->stream, B, Bp, lpw, o, sz, slb, sub, szL,
+  hipLaunchKernelGGL((lane_solve_kernel<Core, Sys>), dim3((unsigned)((B + lpw - 1) / lpw)), dim3(64), 0, h->stream, B, Bp, lpw, o, h->vscale, sz, slb, sub, szL,
                      szU, slam, sdz, sst, params, pstride, cost, status, iters, kkt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
@@ -689,6 +696,76 @@ static int dispatch_solve(myr_handle h, int B, double* z, const double* lb, cons
   return fail(MYR_E_ARG, "solve: unknown system");
 }
 
+// ---- variable scaling of the solve path ----------------------------------------------------------------------
+// z / lb / ub -> scaled variables (z in place, bounds into handle scratch); afterwards z back and lam / s_state
+__global__ __launch_bounds__(256)
+void scale_in_kernel(long total, int n, int xcount, int ns, int nu, VarScale vs, double* z, const double* __restrict__ lb,
+                     const double* __restrict__ ub, double* lbs, double* ubs) {
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(g % n);
+    const double inv = 1.0 / vs.s[i < xcount ? i % ns : ns + (i - xcount) % nu];
+    z[g] *= inv; lbs[g] = lb[g] * inv; ubs[g] = ub[g] * inv;
+  }
+}
+__global__ __launch_bounds__(256)
+void scale_out_kernel(long total_z, long total_l, int n, int xcount, int ns, int nu, int m, VarScale vs, double* z, double* lam) {
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total_z + total_l; g += (long)gridDim.x * blockDim.x) {
+    if (g < total_z) {
+      const int i = (int)(g % n);
+      z[g] *= vs.s[i < xcount ? i % ns : ns + (i - xcount) % nu];
+    } else if (lam) {
+      const long q = g - total_z;
+      lam[q] /= vs.s[(int)((q % m) % ns)];       // every constraint row is a state-component row (defect / interpolation)
+    }
+  }
+}
+
+static int dispatch_solve_scaled(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
+                                 int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
+                                 int32_t* iters, double* kkt) {
+  if (!h->vscale_on) return dispatch_solve(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  const myr_dims& dm = h->dims;
+  const size_t need = 2 * (size_t)B * dm.n * 8;
+  if (need > h->vbuf_bytes) {
+    if (h->vbuf) HIPCHK(hipFree(h->vbuf));
+    h->vbuf = nullptr; h->vbuf_bytes = 0;
+    HIPCHK(hipMalloc(&h->vbuf, need));
+    h->vbuf_bytes = need;
+  }
+  double* lbs = (double*)h->vbuf;
+  double* ubs = lbs + (size_t)B * dm.n;
+  const long tz = (long)B * dm.n, tl = lam ? (long)B * dm.m : 0;
+  const int xcount = dm.x_rows * dm.ns;
+  long blocks = (tz + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(scale_in_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, tz, dm.n, xcount, dm.ns, dm.nu, h->vscale, z, lb, ub, lbs, ubs);
+  HIPCHK(hipGetLastError());
+  int rc = dispatch_solve(h, B, z, lbs, ubs, params, pstride, so, lam, cost, status, iters, kkt);
+  // unscale even after a failed launch sequence is pointless: return the error as is
+  if (rc) return rc;
+  hipLaunchKernelGGL(scale_out_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, tz, tl, dm.n, xcount, dm.ns, dm.nu, dm.m, h->vscale, z, lam);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MYR_OK;
+}
+
+extern "C" int myr_set_var_scale(myr_handle h, const double* scale) {
+  if (!h) return fail(MYR_E_ARG, "myr_set_var_scale: null handle");
+  if (h->d.system_id == MYR_SYS_NODE_CARTPOLE && scale) return fail(MYR_E_UNSUPPORTED, "myr_set_var_scale: not available for NODE systems");
+  const int nw = h->dims.ns + h->dims.nu;
+  if (nw > 8) return fail(MYR_E_CAPACITY, "myr_set_var_scale: more than 8 variables per point");
+  bool on = false;
+  for (int i = 0; i < 8; ++i) h->vscale.s[i] = 1.0;
+  if (scale) {
+    for (int i = 0; i < nw; ++i) {
+      if (!(scale[i] > 0.0) || !(scale[i] < 1e300)) return fail(MYR_E_ARG, "myr_set_var_scale: scales must be positive and finite");
+      h->vscale.s[i] = scale[i];
+      on = on || scale[i] != 1.0;
+    }
+  }
+  h->vscale_on = on;
+  return MYR_OK;
+}
+
 extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, const double* ub,
                          const double* params, int32_t params_stride, const myr_solve_opts* opts,
                          double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt, int32_t mem) {
@@ -705,7 +782,7 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
   HIPCHK(hipSetDevice(h->d.device));
   const myr_dims& dm = h->dims;
   if (mem == MYR_MEM_DEVICE)
-    return dispatch_solve(h, B, z, lb, ub, params, params_stride, so, lam, cost, status, iters, kkt);
+    return dispatch_solve_scaled(h, B, z, lb, ub, params, params_stride, so, lam, cost, status, iters, kkt);
   if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_solve: bad mem kind");
   const size_t nz = (size_t)B * dm.n, nl = lam ? (size_t)B * dm.m : 0;
   const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
@@ -726,7 +803,7 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
   HIPCHK(hipMemcpyAsync(dlb, lb, nz * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(dub, ub, nz * 8, hipMemcpyHostToDevice, h->stream));
   if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
-  rc = dispatch_solve(h, B, dz, dlb, dub, npar ? dp : nullptr, params_stride, so, nl ? dlam : nullptr, dcost, dstat, dit, dkkt);
+  rc = dispatch_solve_scaled(h, B, dz, dlb, dub, npar ? dp : nullptr, params_stride, so, nl ? dlam : nullptr, dcost, dstat, dit, dkkt);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(z, dz, nz * 8, hipMemcpyDeviceToHost, h->stream));
   if (nl) HIPCHK(hipMemcpyAsync(lam, dlam, nl * 8, hipMemcpyDeviceToHost, h->stream));

@@ -71,13 +71,13 @@ struct SysNODE {
   // the cost is the TRUE system's (node_system.py:41-42); its parameters are the true defaults
   MYR_HD static inline double g(const double* x, const double* u, const double* p) {
     (void)p;
-    double tp[True::NP > 0 ? True::NP : 1];
+    double tp[True::NPX];
     True::default_params(tp);
     return True::g(x, u, tp);
   }
   MYR_HD static inline void cost_grad(const double* x, const double* u, const double* p, double* go, double* gw) {
     (void)p;
-    double tp[True::NP > 0 ? True::NP : 1];
+    double tp[True::NPX];
     True::default_params(tp);
     True::cost_grad(x, u, tp, go, gw);
   }
@@ -160,7 +160,7 @@ struct SysNODE {
         for (int b = a; b < NW; ++b) Wacc[a * NW + b] += c2[j] * m[a] * m[b];
     }
     // true cost's second derivative
-    double tp[True::NP > 0 ? True::NP : 1], tf[NS], tA[NS * NS], tB[NS * NU], tg, tgw[NW], tD2[True::NNZ2], Wg[NW * NW], zero[NS];
+    double tp[True::NPX], tf[NS], tA[NS * NS], tB[NS * NU], tg, tgw[NW], tD2[True::NNZ2], Wg[NW * NW], zero[NS];
     True::default_params(tp);
 #pragma unroll
     for (int r = 0; r < NS; ++r) zero[r] = 0.0;

@@ -48,6 +48,21 @@ class FiniteHorizonControlSystem:
     """Parameter vector in the order the generated device code expects (csrc/systems_gen.h)."""
     return np.array([getattr(self, k) for k in self.param_names], dtype=np.float64)
 
+  def var_scale(self) -> np.ndarray:
+    """Variable scales [ns+nu] for the device solver (myr_set_var_scale): each state by the magnitude of its start /
+    terminal value when that is at least 8, rounded to a power of two so that the change of variables is exact in floating
+    point; controls unscaled.  All ones for the BASELINE systems.  (The reference leaves scaling to IPOPT's
+    gradient-based `nlp_scaling_method`; the batched SQP has no such pass.)"""
+    ns = self.x_0.shape[0]
+    s = np.ones(self.bounds.shape[0])
+    for i in range(ns):
+      a = abs(float(self.x_0[i]))
+      if self.x_T is not None and self.x_T[i] is not None and np.isfinite(float(self.x_T[i])):
+        a = max(a, abs(float(self.x_T[i])))
+      if a >= 8.0:
+        s[i] = 2.0 ** np.round(np.log2(a))
+    return s
+
   def params_from_mapping(self, params) -> np.ndarray:
     """`params` mapping of the reference's parametrized_dynamics -> device parameter vector."""
     p = self.device_params()

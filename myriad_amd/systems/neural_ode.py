@@ -41,6 +41,9 @@ class NodeSystem(FiniteHorizonControlSystem):
   """node_system.py:14-42."""
   param_names = ()
 
+  def var_scale(self):
+    return None          # network dynamics take their inputs as trained: no variable scaling on the device
+
   def __init__(self, node: NeuralODE, true_system: FiniteHorizonControlSystem):
     self.node = node
     self.true_system = true_system

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Optional
 
+import os
+
 import numpy as np
 
 from myriad_amd import _lib
@@ -82,6 +84,11 @@ class TrajectoryOptimizer(object):
       self._engine = _lib.Engine(self.system.name, self.transcription, self.hp.intervals, self.system.T,
                                  controls_per_interval=self.hp.controls_per_interval,
                                  integration_method=self.hp.integration_method.name)
+      scale = getattr(self.system, "var_scale", None)
+      if scale is not None and os.environ.get("MYRIAD_VAR_SCALE", "1") != "0":
+        s = scale()
+        if s is not None and np.any(s != 1.0):
+          self._engine.set_var_scale(s)
     return self._engine
 
   def unravel(self, z):

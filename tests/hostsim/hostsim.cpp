@@ -66,7 +66,7 @@ static void one_step(int N, double T, double* z, const double* lb, const double*
   if (getenv("RHO")) o.rho_term = atof(getenv("RHO"));
   if (getenv("REGF")) o.reg_floor = atof(getenv("REGF"));
   std::vector<double> st(HsSol<Sys>::stage_doubles(N)), lbv(lb, lb + n), ubv(ub, ub + n);
-  double p[Sys::NP > 0 ? Sys::NP : 1];
+  double p[Sys::NPX];
   Sys::default_params(p);
   HsWork w{{z, 1}, {lbv.data(), 1}, {ubv.data(), 1}, {zL, 1}, {zU, 1}, {lam, 1}, {dz, 1}, {st.data(), 1}};
   typename S::SweepOut so;
@@ -107,7 +107,7 @@ extern "C" int hostsim_step(int system_id, int N, double T, double* z, const dou
 
 extern "C" double hostsim_rollout(int system_id, int method, int num_steps, double h, int u_rows, const double* x0,
                                   const double* us, const double* params, double* xs) {
-#define RL(S) { double p[S::NP > 0 ? S::NP : 1]; if (params) for (int i = 0; i < S::NP; ++i) p[i] = params[i]; else S::default_params(p); \
+#define RL(S) { double p[S::NPX]; S::default_params(p); if (params) for (int i = 0; i < S::NP; ++i) p[i] = params[i]; \
                 return Rollout<S>::run(method, num_steps, h, u_rows, x0, us, p, xs); }
   switch (system_id) {
     case 0: RL(SysCARTPOLE)

@@ -65,17 +65,10 @@ def test_hs_solve_is_a_kkt_point_of_the_oracle_problem(sysname):
   O, s, tr, cb = _oracle(sysname, "COLLOCATION", hp)
   opt = get_optimizer(hp, CFG, hp.system())
   r = opt.solve_batch()
-  if sysname in ("EPIDEMICSEIRN", "SEIR"):
-    # KNOWN LIMIT: the solver has no variable scaling; with states O(1e3) next to a control O(1) and a
-    # curvature of 1e-4 these two do not reach the ABSOLUTE tolerances within max_iter.  What is required here is the
-    # reference's contract: non-convergence is reported (status MAXITER), not raised, and the iterate is near-feasible.
-    assert r['status'][0] in (0, 1)
-    assert r['kkt'][0, 0] <= 1e-3 and np.isfinite(r['cost'][0])
-    return
   assert r['status'][0] == 0, (sysname, r['status'], r['iters'], r['kkt'])
   z, lam = r['xs_and_us'][0], r['lambda'][0]
   c = cb.cons(z)
-  scale = max(1.0, np.abs(z).max())
+  scale = max(1.0, np.abs(z).max())          # the solver's 1e-8 is in scaled states (myr_set_var_scale)
   assert np.abs(c).max() <= 1e-8 * scale
   assert cb.fun(z) == pytest.approx(r['cost'][0], rel=1e-11)
   lb, ub = tr.bounds[:, 0], tr.bounds[:, 1]
@@ -97,3 +90,17 @@ def test_hs_solve_cost_matches_oracle_slsqp(sysname):
   r = O.solve(tr, "SLSQP", max_iter=500, extra_options={"ftol": 1e-14}, cb=cb)
   assert sol['cost'] <= r['cost'] + 1e-6 * max(1.0, abs(r['cost']))
   assert sol['cost'] == pytest.approx(r['cost'], rel=1e-5)
+
+
+def test_variable_scaling_is_what_makes_the_large_state_systems_converge(monkeypatch):
+  """EPIDEMICSEIRN has states O(1e3) next to a control O(1): unscaled, the absolute regularisation constants of the
+  solver stall it (status MAXITER, reported not raised); with the power-of-two state scales of system.var_scale() it
+  converges, to the same optimum the unscaled run was approaching."""
+  hp = HParams(system=SystemType.EPIDEMICSEIRN, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
+               intervals=20, nlpsolver=NLPSolverType.SQP)
+  scaled = get_optimizer(hp, CFG, hp.system()).solve_batch()
+  monkeypatch.setenv("MYRIAD_VAR_SCALE", "0")
+  unscaled = get_optimizer(hp, CFG, hp.system()).solve_batch(max_iter=300)
+  assert scaled['status'][0] == 0 and scaled['iters'][0] < 100
+  assert unscaled['status'][0] == 1 and unscaled['iters'][0] == 300
+  assert scaled['cost'][0] == pytest.approx(unscaled['cost'][0], rel=2e-2)      # 13.3967 vs ~13.49 after 300 stalled iterations

@@ -8,7 +8,7 @@
 using namespace myriad;
 using Sys = SysCARTPOLE;
 __global__ void k(HsSolveOpts o, double* z, double* lb, double* ub, double* zL, double* zU, double* lam, double* dz, double* st, HsSolveResult* r) {
-  double p[4]; Sys::default_params(p);
+  double p[Sys::NPX]; Sys::default_params(p);
   HsWork w{{z, 1}, {lb, 1}, {ub, 1}, {zL, 1}, {zU, 1}, {lam, 1}, {dz, 1}, {st, 1}};
   HsSolver<Sys>::solve(w, o, p, *r);
 }

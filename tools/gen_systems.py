@@ -154,8 +154,16 @@ def gen_system(S):
   ns, nu, npar = len(x), len(u), len(p)
   w = x + u
   nw = ns + nu
-  f = [sp.sympify(e) for e in S["f"]]
-  g = sp.sympify(S["g"])
+  # Variable scaling (solver-side conditioning): the generated functions take SCALED variables
+  # xt = x / sc, ut = u / sc and return the scaled field ft_i = f_i(sc xt, sc ut) / sc_i and the unchanged cost; the NW
+  # scale factors follow the NP model parameters in the parameter vector (all 1 unless the solver sets them, in which
+  # case every product below is exact and the functions are the reference's).  Derivatives are taken AFTER the
+  # substitution, so A, B and the second derivatives are those of the scaled problem.
+  sc = list(sp.symbols(f"sc0:{nw}", positive=True))
+  isc = list(sp.symbols(f"isc0:{ns}", positive=True))      # 1 / sc_i, precomputed by SysParams::set_scale (no divisions here)
+  smap = {v: sc[i] * v for i, v in enumerate(w)}
+  f = [sp.sympify(e).subs(smap, simultaneous=True) * isc[i] for i, e in enumerate(S["f"])]
+  g = sp.sympify(S["g"]).subs(smap, simultaneous=True)
   A = [[sp.diff(f[i], x[j]) for j in range(ns)] for i in range(ns)]
   Bm = [[sp.diff(f[i], u[j]) for j in range(nu)] for i in range(ns)]
   gw = [sp.diff(g, v) for v in w]
@@ -173,12 +181,17 @@ def gen_system(S):
       s.append(f"{indent}const double {v} = u[{i}];")
     for i, v in enumerate(p):
       s.append(f"{indent}const double {v} = p[{i}];")
-    return "\n".join(s) + "\n" + "\n".join(f"{indent}(void){v};" for v in (x + u + p))
+    for i, v in enumerate(sc):
+      s.append(f"{indent}const double {v} = p[{npar + i}];")
+    for i, v in enumerate(isc):
+      s.append(f"{indent}const double {v} = p[{npar + nw + i}];")
+    return "\n".join(s) + "\n" + "\n".join(f"{indent}(void){v};" for v in (x + u + p + sc + isc))
 
   o = []
   o.append(f"// ===== {name} (id {S['id']}): ns={ns} nu={nu} np={npar} =====")
   o.append(f"struct Sys{name} {{")
   o.append(f"  static constexpr int ID = {S['id']}, NS = {ns}, NU = {nu}, NP = {npar}, NW = {nw};")
+  o.append(f"  static constexpr int NPX = NP + NW + NS;   // model parameters, the NW variable scales, the NS inverse state scales")
   o.append(f"  static constexpr bool COST_DEP_X = {'true' if cost_dep_x else 'false'};")
   o.append(f"  static constexpr const char* NAME = \"{name}\";")
   o.append("  static constexpr bool PARAMS_BY_POINTER = false;   // parameters are a handful of scalars: copied to registers")
@@ -260,6 +273,7 @@ def gen_system(S):
   o.append("  MYR_HD static inline void default_params(double* p) {")
   for i, v in enumerate(S["pdefault"]):
     o.append(f"    p[{i}] = {v!r};  // {S['pnames'][i]}")
+  o.append(f"    for (int i = NP; i < NPX; ++i) p[i] = 1.0;   // unit variable scales")
   o.append("  }")
   o.append("};")
   return "\n".join(o)
@@ -287,16 +301,24 @@ def main():
 // weights of a neural-ODE system) are used in place through a pointer.
 template <class Sys>
 struct SysParams {
-  double buf[Sys::PARAMS_BY_POINTER ? 1 : (Sys::NP > 0 ? Sys::NP : 1)];
+  double buf[Sys::PARAMS_BY_POINTER ? 1 : Sys::NP + Sys::NW + Sys::NS];
   const double* ptr;
   MYR_HD inline void load(const double* params, long b, int stride) {
     if constexpr (Sys::PARAMS_BY_POINTER) {
       ptr = params + b * (long)stride;
     } else {
       ptr = nullptr;
+      Sys::default_params(buf);
       if (params) { for (int i = 0; i < Sys::NP; ++i) buf[i] = params[b * (long)stride + i]; }
-      else Sys::default_params(buf);
     }
+  }
+  // variable scales of the scaled problem the solver works on (closed-form systems only; scale[NW])
+  MYR_HD inline void set_scale(const double* scale) {
+    if constexpr (!Sys::PARAMS_BY_POINTER) {
+      for (int i = 0; i < Sys::NW; ++i) buf[Sys::NP + i] = scale[i];
+      for (int i = 0; i < Sys::NS; ++i) buf[Sys::NP + Sys::NW + i] = 1.0 / scale[i];
+    }
+    else (void)scale;
   }
   MYR_HD inline const double* get() const { if constexpr (Sys::PARAMS_BY_POINTER) return ptr; else return buf; }
 };
