@@ -22,7 +22,8 @@
 // closed-form systems (tools/gen_systems.py): X(NAME) expands once per system; the enum values are MYR_SYS_<NAME>
 #define MYR_CLOSED_FORM_SYSTEMS(X)                                                                               \
   X(CARTPOLE) X(VANDERPOL) X(CANCERTREATMENT) X(SIMPLECASE) X(BIOREACTOR) X(GLUCOSE) X(MOULDFUNGICIDE)           \
-  X(SIMPLECASEWITHBOUNDS) X(HIVTREATMENT) X(EPIDEMICSEIRN) X(SEIR) X(BEARPOPULATIONS)
+  X(SIMPLECASEWITHBOUNDS) X(HIVTREATMENT) X(EPIDEMICSEIRN) X(SEIR) X(BEARPOPULATIONS) X(PENDULUM) X(MOUNTAINCAR)     \
+  X(ROCKETLANDING)
 
 
 using namespace myriad;

@@ -309,14 +309,96 @@ class BearPopulations(IndirectFHCS):
     return float(x_t[2] + self.c_p * u_t[0] ** 2 + self.c_f * u_t[1] ** 2)
 
 
+class Pendulum(FiniteHorizonControlSystem):
+  """systems/classical_control/pendulum.py:51-120."""
+  name = "PENDULUM"
+  param_names = ("g", "m", "length")
+
+  def __init__(self, g: float = 10., m: float = 1., length: float = 1.):
+    self.g, self.m, self.length = g, m, length
+    self.max_speed, self.max_torque, self.ctrl_penalty = 8., 2., 0.001
+    super().__init__(x_0=[0., 0.], x_T=[np.pi, 0.], T=15,
+                     bounds=[[-np.pi, np.pi], [-self.max_speed, self.max_speed], [-self.max_torque, self.max_torque]])
+
+  def dynamics(self, x_t, u_t, t=None):
+    u = float(np.clip(np.squeeze(u_t), -self.max_torque, self.max_torque))
+    theta = ((x_t[0] + np.pi) % (2 * np.pi)) - np.pi
+    dot_theta = float(np.clip(x_t[1], -self.max_speed, self.max_speed))
+    return np.array([dot_theta, (-3. * self.g / (2. * self.length) * np.sin(theta) + 3. * u / (self.m * self.length ** 2)) * 0.05])
+
+  def cost(self, x_t, u_t, t=None):
+    theta = ((x_t[0] + np.pi) % (2 * np.pi)) - np.pi
+    return float(theta ** 2 + 0.1 * x_t[1] ** 2 + self.ctrl_penalty * np.squeeze(u_t) ** 2)
+
+
+class MountainCar(FiniteHorizonControlSystem):
+  """systems/classical_control/mountain_car.py:55-101."""
+  name = "MOUNTAINCAR"
+  param_names = ("power", "gravity")
+
+  def __init__(self, power=0.0015, gravity=0.0025):
+    self.min_action, self.max_action = -1.0, 1.0
+    self.min_position, self.max_position, self.max_speed = -1.2, 0.6, 0.07
+    self.power, self.gravity = power, gravity
+    super().__init__(x_0=[-0.1, 0.], x_T=[0.45, 0.], T=300.,
+                     bounds=[[self.min_position, self.max_position], [-self.max_speed, self.max_speed], [self.min_action, self.max_action]])
+
+  def dynamics(self, x_t, u_t, t=None):
+    force = float(np.clip(np.squeeze(u_t), self.min_action, self.max_action))
+    return np.array([x_t[1], force * self.power - self.gravity * x_t[0]])
+
+  def cost(self, x_t, u_t, t=None):
+    return float(10. * np.squeeze(u_t) ** 2)
+
+
+class RocketLanding(FiniteHorizonControlSystem):
+  """systems/miscellaneous/rocket_landing.py:55-120."""
+  name = "ROCKETLANDING"
+  param_names = ("g", "m", "length")
+
+  def __init__(self, g: float = 9.8, m: float = 100_000, length: float = 50, width: float = 10):
+    self.g, self.m, self.length, self.width = g, float(m), float(length), width
+    self.min_thrust, self.max_thrust = 880 * 1000, 1 * 2210 * 1000
+    self.I = 1 / 12 * self.m * self.length ** 2
+    self.max_gimble = 20 * 0.01745329
+    self.min_gimble = -self.max_gimble
+    self.min_percent_thrust, self.max_percent_thrust = 0.4, 1.
+    super().__init__(x_0=[0., 0., 1000., -80., -np.pi / 2., 0.], x_T=[0.] * 6, T=16.,
+                     bounds=[[-250., 150.], [-250., 150.], [0., 1000.], [-250., 150.], [-2 * np.pi, 2 * np.pi], [-250., 150.],
+                             [self.min_percent_thrust, self.max_percent_thrust], [self.min_gimble, self.max_gimble]])
+
+  def dynamics(self, x_t, u_t, t=None):
+    theta, thrust, ang = x_t[4], u_t[0], u_t[1]
+    F_x = self.max_thrust * thrust * np.sin(ang + theta)
+    F_y = self.max_thrust * thrust * np.cos(ang + theta)
+    Tq = -self.length / 2 * self.max_thrust * thrust * np.sin(ang)
+    return np.array([x_t[1], F_x / self.m, x_t[3], F_y / self.m - self.g, x_t[5], Tq / self.I])
+
+  def cost(self, x_t, u_t, t=None):
+    return float(u_t[0] ** 2 + u_t[1] ** 2 + 2 * x_t[5] ** 2)
+
+
+class InvasivePlant(IndirectFHCS):
+  """systems/lenhart/invasive_plant.py: a DISCRETE-time system.  Kept as a SystemType member for the reference's error
+  behaviour: the direct optimisers refuse discrete systems with NotImplementedError (trajectory_optimizers/base.py:66-67);
+  its discrete FBSM variant is not on the device path."""
+  name = "INVASIVEPLANT"
+  param_names = ("B", "k", "eps")
+
+  def __init__(self, B=1., k=1., eps=.01, x_0=(.5, 1., 1.5, 2., 10.), T=10.):
+    super().__init__(x_0=list(x_0), x_T=None, T=T, bounds=[[-np.inf, np.inf]] * 5 + [[0., 1.]] * 5, discrete=True)
+    self.B, self.k, self.eps = B, k, eps
+
+
 class SystemType(Enum):
   """systems/__init__.py:29-53: an enum of system classes; calling a member instantiates the system.
-  Members not built here (time-dependent cost, terminal cost, discrete or clipped gym-style dynamics: TUMOUR,
-  MOUNTAINCAR, PENDULUM, BACTERIA, HARVEST, TIMBERHARVEST, PREDATORPREY, INVASIVEPLANT, ROCKETLANDING) are listed in
-  DESIGN.md."""
+  Members not built here (time-dependent cost or terminal cost: TUMOUR, BACTERIA, HARVEST, TIMBERHARVEST, PREDATORPREY)
+  are listed in DESIGN.md."""
   CARTPOLE = CartPole
   VANDERPOL = VanDerPol
   SEIR = SEIR
+  MOUNTAINCAR = MountainCar
+  PENDULUM = Pendulum
   SIMPLECASE = SimpleCase
   MOULDFUNGICIDE = MouldFungicide
   SIMPLECASEWITHBOUNDS = SimpleCaseWithBounds
@@ -326,6 +408,8 @@ class SystemType(Enum):
   BEARPOPULATIONS = BearPopulations
   GLUCOSE = Glucose
   BIOREACTOR = Bioreactor
+  INVASIVEPLANT = InvasivePlant
+  ROCKETLANDING = RocketLanding
 
   def __call__(self, *args, **kwargs):
     return self.value(*args, **kwargs)

@@ -361,6 +361,85 @@ class BearPopulations(System):
     return x[..., 2] + self.c_p * u[..., 0] ** 2 + self.c_f * u[..., 1] ** 2
 
 
+def _angle_normalize(x):
+  """pendulum.py:17-18 (Python / jnp `%`: result has the sign of the divisor -> torch.remainder)."""
+  return torch.remainder(x + math.pi, 2 * math.pi) - math.pi
+
+
+class Pendulum(System):
+  """myriad/systems/classical_control/pendulum.py:51-120 (gym-style clips and angle normalisation kept)."""
+  name = "PENDULUM"
+  param_names = ("g", "m", "length")
+
+  def __init__(self, g=10., m=1., length=1.):
+    self.g, self.m, self.length = g, m, length
+    self.max_speed, self.max_torque, self.ctrl_penalty = 8., 2., 0.001
+    self.x_0 = np.array([0., 0.]); self.x_T = np.array([np.pi, 0.]); self.T = 15.0
+    self.bounds = np.array([[-np.pi, np.pi], [-self.max_speed, self.max_speed], [-self.max_torque, self.max_torque]])
+
+  def params(self):
+    return np.array([self.g, self.m, self.length])
+
+  def dynamics(self, x, u):                                  # pendulum.py:94-108
+    uu = torch.clamp(u[..., 0], -self.max_torque, self.max_torque)
+    theta = _angle_normalize(x[..., 0])
+    dot_theta = torch.clamp(x[..., 1], -self.max_speed, self.max_speed)
+    ddt = (-3. * self.g / (2. * self.length) * torch.sin(theta) + 3. * uu / (self.m * self.length ** 2)) * 0.05
+    return torch.stack([dot_theta, ddt], dim=-1)
+
+  def cost(self, x, u, t=None):                              # pendulum.py:114-120
+    return _angle_normalize(x[..., 0]) ** 2 + 0.1 * x[..., 1] ** 2 + self.ctrl_penalty * u[..., 0] ** 2
+
+
+class MountainCar(System):
+  """myriad/systems/classical_control/mountain_car.py:55-101 (hill_function(x) = x^2/2, :11-13)."""
+  name = "MOUNTAINCAR"
+  param_names = ("power", "gravity")
+
+  def __init__(self, power=0.0015, gravity=0.0025):
+    self.power, self.gravity = power, gravity
+    self.x_0 = np.array([-0.1, 0.]); self.x_T = np.array([0.45, 0.]); self.T = 300.0
+    self.bounds = np.array([[-1.2, 0.6], [-0.07, 0.07], [-1.0, 1.0]])
+
+  def params(self):
+    return np.array([self.power, self.gravity])
+
+  def dynamics(self, x, u):                                  # mountain_car.py:83-89; d/dx (x^2/2) = x
+    force = torch.clamp(u[..., 0], -1.0, 1.0)
+    return torch.stack([x[..., 1], force * self.power - self.gravity * x[..., 0]], dim=-1)
+
+  def cost(self, x, u, t=None):                              # mountain_car.py:100-101
+    return 10. * u[..., 0] ** 2
+
+
+class RocketLanding(System):
+  """myriad/systems/miscellaneous/rocket_landing.py:55-120 (six states, two controls)."""
+  name = "ROCKETLANDING"
+  param_names = ("g", "m", "length")
+
+  def __init__(self, g=9.8, m=100_000, length=50, width=10):
+    self.g, self.m, self.length, self.width = g, float(m), float(length), width
+    self.max_thrust = 1 * 2210 * 1000
+    self.I = 1 / 12 * self.m * self.length ** 2
+    mg = 20 * 0.01745329
+    self.x_0 = np.array([0., 0., 1000., -80., -np.pi / 2., 0.]); self.x_T = np.zeros(6); self.T = 16.0
+    self.bounds = np.array([[-250., 150.], [-250., 150.], [0., 1000.], [-250., 150.], [-2 * np.pi, 2 * np.pi], [-250., 150.],
+                            [0.4, 1.], [-mg, mg]])
+
+  def params(self):
+    return np.array([self.g, self.m, self.length])
+
+  def dynamics(self, x, u):                                  # rocket_landing.py:99-117
+    theta, thrust, ang = x[..., 4], u[..., 0], u[..., 1]
+    F_x = self.max_thrust * thrust * torch.sin(ang + theta)
+    F_y = self.max_thrust * thrust * torch.cos(ang + theta)
+    Tq = -self.length / 2 * self.max_thrust * thrust * torch.sin(ang)
+    return torch.stack([x[..., 1], F_x / self.m, x[..., 3], F_y / self.m - self.g, x[..., 5], Tq / self.I], dim=-1)
+
+  def cost(self, x, u, t=None):                              # rocket_landing.py:119-120
+    return u[..., 0] ** 2 + u[..., 1] ** 2 + 2 * x[..., 5] ** 2
+
+
 class NodeCartPole(CartPole):
   """myriad/systems/neural_ode/node_system.py:14-42 over CARTPOLE: dynamics = net.apply(params, [x;u]) with the MLP of
   myriad/neural_ode/create_node.py:110-117 (Linear+sigmoid per hidden layer, Linear out; Haiku y = x @ w + b);
@@ -380,7 +459,8 @@ class NodeCartPole(CartPole):
 
 
 SYSTEMS = {c.name: c for c in (CartPole, VanDerPol, CancerTreatment, SimpleCase, Bioreactor, Glucose, MouldFungicide,
-                                SimpleCaseWithBounds, HIVTreatment, EpidemicSEIRN, SEIR, BearPopulations)}
+                                SimpleCaseWithBounds, HIVTreatment, EpidemicSEIRN, SEIR, BearPopulations, Pendulum, MountainCar,
+                                RocketLanding)}
 
 
 # --------------------------------------------------------------------------------------

@@ -89,6 +89,8 @@ extern "C" int hostsim_solve(int system_id, int N, double T, int B, double* z, c
     case 1: GO(SysVANDERPOL); return 0;
     case 2: GO(SysCANCERTREATMENT); return 0;
     case 3: GO(SysSIMPLECASE); return 0;
+    case 13: GO(SysPENDULUM); return 0;     // dev: solver traces of the later systems
+    case 10: GO(SysEPIDEMICSEIRN); return 0;
   }
   return -1;
 }

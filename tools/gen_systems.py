@@ -16,7 +16,38 @@ from sympy.printing.c import C99CodePrinter
 OUT = os.path.join(os.path.dirname(__file__), "..", "myriad_amd", "csrc", "systems_gen.h")
 
 
+class inboxf(sp.Function):
+  """1 where lo <= x <= hi else 0 (the derivative of clip inside the box); piecewise constant."""
+  nargs = 3
+  def fdiff(self, argindex=1):
+    return sp.S.Zero
+
+
+class clipf(sp.Function):
+  """jnp.clip(x, lo, hi)"""
+  nargs = 3
+  def fdiff(self, argindex=1):
+    x, lo, hi = self.args
+    return inboxf(x, lo, hi) if argindex == 1 else sp.S.Zero
+
+
+class angnormf(sp.Function):
+  """angle_normalize(x) = ((x + pi) % (2 pi)) - pi  (pendulum.py:17-18); derivative 1 almost everywhere"""
+  nargs = 1
+  def fdiff(self, argindex=1):
+    return sp.S.One
+
+
 class Printer(C99CodePrinter):
+  def _print_clipf(self, e):
+    return "myr_clip(%s, %s, %s)" % tuple(self._print(a) for a in e.args)
+
+  def _print_inboxf(self, e):
+    return "myr_inbox(%s, %s, %s)" % tuple(self._print(a) for a in e.args)
+
+  def _print_angnormf(self, e):
+    return "myr_angnorm(%s)" % self._print(e.args[0])
+
   def _print_Pow(self, expr):
     b, e = expr.as_base_exp()
     if e == 2:
@@ -134,6 +165,36 @@ def systems():
                      k1 * (1 - mp_) * x[0] ** 2 + k1 * (1 - mf_) * x[1] ** 2 + k2 * mf_ * x[0] * x[1] ** 2 + k2 * mp_ * x[0] ** 2 * x[1]],
                   g=x[2] + cp_ * u[0] ** 2 + cf_ * u[1] ** 2,
                   pdefault=[0.1, 0.75, 0.5, 0.5, 10000.0, 10.0], pnames=["r", "K", "m_p", "m_f", "c_p", "c_f"]))
+  # ---- PENDULUM: myriad/systems/classical_control/pendulum.py:94-108 (dynamics), :114-120 (cost); gym-style clips kept ----
+  x = sp.symbols("x0:2", real=True)
+  u = sp.symbols("u0:1", real=True)
+  g_, m_, L_ = p = sp.symbols("p0:3", real=True)   # g, m, length
+  uc = clipf(u[0], -2.0, 2.0)                       # max_torque (:58)
+  th = angnormf(x[0])
+  dth = clipf(x[1], -8.0, 8.0)                      # max_speed (:57)
+  out.append(dict(name="PENDULUM", id=13, x=x, u=u, p=p,
+                  f=[dth, (-3 * g_ / (2 * L_) * sp.sin(th) + 3 * uc / (m_ * L_ ** 2)) * sp.Rational(1, 20)],
+                  g=angnormf(x[0]) ** 2 + sp.Rational(1, 10) * x[1] ** 2 + sp.Rational(1, 1000) * u[0] ** 2,
+                  pdefault=[10.0, 1.0, 1.0], pnames=["g", "m", "length"]))
+  # ---- MOUNTAINCAR: myriad/systems/classical_control/mountain_car.py:83-89 (hill_function = x^2/2, :11-13), :100-101 ----
+  x = sp.symbols("x0:2", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:2", real=True)   # power, gravity
+  out.append(dict(name="MOUNTAINCAR", id=14, x=x, u=u, p=p,
+                  f=[x[1], clipf(u[0], -1.0, 1.0) * p[0] - p[1] * x[0]], g=10 * u[0] ** 2,
+                  pdefault=[0.0015, 0.0025], pnames=["power", "gravity"]))
+  # ---- ROCKETLANDING: myriad/systems/miscellaneous/rocket_landing.py:99-120 (two controls, six states) ----
+  x = sp.symbols("x0:6", real=True)
+  u = sp.symbols("u0:2", real=True)
+  g_, m_, L_ = p = sp.symbols("p0:3", real=True)   # g, m, length
+  Fmax = 2210 * 1000                                # max_thrust (:61)
+  I_ = m_ * L_ ** 2 / 12                            # :62
+  out.append(dict(name="ROCKETLANDING", id=15, x=x, u=u, p=p,
+                  f=[x[1], Fmax * u[0] * sp.sin(u[1] + x[4]) / m_,
+                     x[3], Fmax * u[0] * sp.cos(u[1] + x[4]) / m_ - g_,
+                     x[5], -L_ / 2 * Fmax * u[0] * sp.sin(u[1]) / I_],
+                  g=u[0] ** 2 + u[1] ** 2 + 2 * x[5] ** 2,
+                  pdefault=[9.8, 100000.0, 50.0], pnames=["g", "m", "length"]))
   return out
 
 
@@ -293,7 +354,16 @@ def main():
            "#define MYR_HD",
            "#endif",
            "#endif",
-           "namespace myriad {", ""]
+           "namespace myriad {",
+           "// gym-style helpers of the PENDULUM / MOUNTAINCAR fields (jnp.clip, angle_normalize with Python's % semantics)",
+           "MYR_HD inline double myr_clip(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }",
+           "MYR_HD inline double myr_inbox(double x, double lo, double hi) { return (x >= lo && x <= hi) ? 1.0 : 0.0; }",
+           "MYR_HD inline double myr_angnorm(double x) {",
+           "  const double two_pi = 6.283185307179586476925286766559, pi = 3.141592653589793238462643383279;",
+           "  double t = fmod(x + pi, two_pi);",
+           "  if (t < 0.0) t += two_pi;",
+           "  return t - pi;",
+           "}", ""]
   for S in systems():
     parts.append(gen_system(S))
     parts.append("")
