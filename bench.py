@@ -167,14 +167,19 @@ def main():
     torch.cuda.synchronize()
 
   for _ in range(a.warmup):
-    step()
+    int(step().sum().item())        # the same work as a timed step, including the count read-back
   eng.kernel_time_reset()
   fence()
   t0 = time.perf_counter()
   nconv = 0
+  trace = []
   for _ in range(a.steps):
+    ts = time.perf_counter()
     ok = step()
     nconv += int(ok.sum().item())
+    trace.append(time.perf_counter() - ts)
+  if os.environ.get("MYRIAD_BENCH_TRACE") and rank == 0:
+    print("per-step ms:", " ".join("%.1f" % (1e3 * t) for t in trace), file=sys.stderr)
   fence()
   dt = time.perf_counter() - t0
   tt = torch.tensor([dt, float(nconv)], **f64)
