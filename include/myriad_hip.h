@@ -46,7 +46,11 @@ enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2,
        MYR_SYS_BIOREACTOR = 5, MYR_SYS_GLUCOSE = 6, MYR_SYS_MOULDFUNGICIDE = 7, MYR_SYS_SIMPLECASEWITHBOUNDS = 8,
        MYR_SYS_HIVTREATMENT = 9, MYR_SYS_EPIDEMICSEIRN = 10, MYR_SYS_SEIR = 11, MYR_SYS_BEARPOPULATIONS = 12,
        /* classical_control/{pendulum,mountain_car}.py (gym-style clips kept), miscellaneous/rocket_landing.py */
-       MYR_SYS_PENDULUM = 13, MYR_SYS_MOUNTAINCAR = 14, MYR_SYS_ROCKETLANDING = 15 };
+       MYR_SYS_PENDULUM = 13, MYR_SYS_MOUNTAINCAR = 14, MYR_SYS_ROCKETLANDING = 15,
+       /* systems with a (linear) terminal cost: lenhart/bacteria.py, miscellaneous/tumour.py.  The terminal
+          term is applied where the reference applies it for collocation -- the TRAPEZOIDAL objective (trapezoidal.py:126-127)
+          and the rollout (utils.py:295-296), not the Hermite-Simpson objective; SHOOTING returns MYR_E_UNSUPPORTED */
+       MYR_SYS_BACTERIA = 16, MYR_SYS_TUMOUR = 17 };
 /* transcription: OptimizerType x QuadratureRule (config.py:12-57) */
 enum { MYR_TR_HERMITE_SIMPSON = 0, MYR_TR_TRAPEZOIDAL = 1, MYR_TR_SHOOTING = 2 };
 /* IntegrationMethod (config.py:46-50) */

@@ -142,6 +142,7 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
     // Simpson weight of point j in  sum_k h/6 (g_s + 4 g_m + g_e)   (hermite_simpson.py:212-214)
     const double w = SCHEME == EVAL_HS ? ((j & 1) ? 4.0 * h6 : ((j == 0 || j == K - 1) ? h6 : 2.0 * h6))
                                        : ((j == 0 || j == K - 1) ? 0.5 * h : h);      // trapezoidal.py:80-94
+    if (SCHEME == EVAL_TRAP && j == K - 1) fold_terminal<Sys>(x, u, p, w, g, gw);   // trapezoidal.py:126-127 (not in the HS objective)
     facc += w * g;
     if (gout) {
       double* gb = gout + b * (long)(K * L::NGRAD_PER_PT);

@@ -25,6 +25,9 @@ struct SysNODE {
   static constexpr int O_W1 = 0, O_B1 = O_W1 + NW * H1, O_W2 = O_B1 + H1, O_B2 = O_W2 + H1 * H2, O_W3 = O_B2 + H2, O_B3 = O_W3 + H2 * NS;
   static constexpr bool COST_DEP_X = True::COST_DEP_X;
   static constexpr bool PARAMS_BY_POINTER = true;
+  static constexpr bool HAS_TERMINAL = false;           // NodeSystem is built over systems without a terminal cost
+  MYR_HD static inline double term(const double*, const double*, const double*) { return 0.0; }
+  MYR_HD static inline void term_grad(const double*, const double*, const double*, double* gw) { for (int i = 0; i < NW; ++i) gw[i] = 0.0; }
   static constexpr int NNZ2 = 1;                      // no stored second derivatives: hessian() recomputes
   static constexpr const char* NAME = "NODE";
 

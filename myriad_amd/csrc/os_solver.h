@@ -207,6 +207,7 @@ struct TrapCore {
     VarBlk Ve, Vs;
     load_vars(w, Kp, Kp - 1, Ve);
     H::lin_point(Ve, p, Pe);
+    fold_terminal<Sys>(Pe.x, Pe.u, p, wtrap(Kp, Kp - 1, h), Pe.g, Pe.gw);    // trapezoidal.py:126-127
     double pi_c[NS], ru_c[NU], mu_c[NS];
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
@@ -368,6 +369,7 @@ struct TrapCore {
       load_vars(w, Kp, j, V);
       Sys::cost_grad(V.z, V.z + NS, p, &gg, gw);
       const double wj = wtrap(Kp, j, h);
+      if (j == Kp - 1) fold_terminal<Sys>(V.z, V.z + NS, p, wj, gg, gw);
 #pragma unroll
       for (int c = 0; c < NW; ++c) {
         w.dz[zi(Kp, j, c)] = d[c];
@@ -424,7 +426,9 @@ struct TrapCore {
         if (c < NS) x[c] = v; else u[c - NS] = v;
       }
       Sys::f(x, u, p, ff);
-      f += wtrap(Kp, j, h) * Sys::g(x, u, p);
+      double gj = Sys::g(x, u, p);
+      if (j == Kp - 1) fold_terminal<Sys>(x, u, p, wtrap(Kp, j, h), gj, nullptr);
+      f += wtrap(Kp, j, h) * gj;
     };
     get(0, xs, us, fs);
     for (int j = 0; j < N; ++j) {

@@ -75,6 +75,7 @@ struct Rollout {
         for (int i = 0; i < NS; ++i) xs[(long)(s + 1) * NS + i] = x[i];
       }
     }
+    if constexpr (Sys::HAS_TERMINAL) c += Sys::term(x, us + (long)(u_rows - 1) * NU, p);   // utils.py:295-296: terminal_cost_fn(x_end, us[-1])
     return c;
   }
 };

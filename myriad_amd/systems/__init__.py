@@ -378,6 +378,49 @@ class RocketLanding(FiniteHorizonControlSystem):
     return float(u_t[0] ** 2 + u_t[1] ** 2 + 2 * x_t[5] ** 2)
 
 
+class Bacteria(IndirectFHCS):
+  """systems/lenhart/bacteria.py:33-86 (terminal cost -C x(T))."""
+  name = "BACTERIA"
+  param_names = ("r", "A", "B", "C")
+
+  def __init__(self, r=1., A=1., B=12., C=1., x_0=1.):
+    super().__init__(x_0=[x_0], x_T=None, T=1, bounds=[[0., 10.], [0., 2.]], terminal_cost=True)
+    self.adj_T = np.array([C])
+    self.r, self.A, self.B, self.C = r, A, B, C
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    x = np.asarray(x_t, dtype=np.float64); u = np.squeeze(u_t)
+    return self.r * x + self.A * u * x - self.B * u ** 2 * np.exp(-x)
+
+  def cost(self, x_t, u_t, t=None):
+    return float(np.squeeze(u_t) ** 2)
+
+  def terminal_cost_fn(self, x_T, u_T, T=None):
+    return float(-self.C * np.squeeze(x_T))
+
+
+class Tumour(FiniteHorizonControlSystem):
+  """systems/miscellaneous/tumour.py:52-108 (zero running cost, terminal cost p(T))."""
+  name = "TUMOUR"
+  param_names = ("xi", "b", "d", "G", "mu")
+
+  def __init__(self, xi=0.084, b=5.85, d=0.00873, G=0.15, mu=0.02):
+    self.xi, self.b, self.d, self.G, self.mu = xi, b, d, G, mu
+    p_ = ((b - mu) / d) ** (3 / 2)
+    super().__init__(x_0=[p_ / 2, p_ / 4, 0.], x_T=None, T=1.2, bounds=[[0., p_], [0., p_], [0., 15.], [0., 75.]], terminal_cost=True)
+
+  def dynamics(self, x_t, u_t, t=None):
+    p, q, y = x_t
+    u = float(np.squeeze(u_t))
+    return np.array([-self.xi * p * np.log(p / q), q * (self.b - (self.mu + self.d * p ** (2 / 3) + self.G * u)), u])
+
+  def cost(self, x_t, u_t, t=None):
+    return 0.
+
+  def terminal_cost_fn(self, x_T, u_T, T=None):
+    return float(x_T[0])
+
+
 class InvasivePlant(IndirectFHCS):
   """systems/lenhart/invasive_plant.py: a DISCRETE-time system.  Kept as a SystemType member for the reference's error
   behaviour: the direct optimisers refuse discrete systems with NotImplementedError (trajectory_optimizers/base.py:66-67);
@@ -392,15 +435,17 @@ class InvasivePlant(IndirectFHCS):
 
 class SystemType(Enum):
   """systems/__init__.py:29-53: an enum of system classes; calling a member instantiates the system.
-  Members not built here (time-dependent cost or terminal cost: TUMOUR, BACTERIA, HARVEST, TIMBERHARVEST, PREDATORPREY)
-  are listed in DESIGN.md."""
+  Members not built here (HARVEST, TIMBERHARVEST: time-dependent cost; PREDATORPREY: partially pinned terminal state that
+  only the reference's shooting path accepts) are listed in DESIGN.md."""
   CARTPOLE = CartPole
   VANDERPOL = VanDerPol
   SEIR = SEIR
+  TUMOUR = Tumour
   MOUNTAINCAR = MountainCar
   PENDULUM = Pendulum
   SIMPLECASE = SimpleCase
   MOULDFUNGICIDE = MouldFungicide
+  BACTERIA = Bacteria
   SIMPLECASEWITHBOUNDS = SimpleCaseWithBounds
   CANCERTREATMENT = CancerTreatment
   EPIDEMICSEIRN = EpidemicSEIRN

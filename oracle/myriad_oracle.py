@@ -58,6 +58,9 @@ class System:
   def cost(self, x, u, t=None):
     raise NotImplementedError
 
+  def terminal_cost_fn(self, x_T, u_T, T=None):                # systems/base.py:101-111
+    return 0.0
+
   def params(self) -> np.ndarray:
     return np.zeros(0)
 
@@ -440,6 +443,57 @@ class RocketLanding(System):
     return u[..., 0] ** 2 + u[..., 1] ** 2 + 2 * x[..., 5] ** 2
 
 
+# ---- systems with a (linear) terminal cost ---------------------------------------------------------------------------
+class Bacteria(System):
+  """myriad/systems/lenhart/bacteria.py:33-86."""
+  name = "BACTERIA"
+  param_names = ("r", "A", "B", "C")
+  terminal_cost = True
+
+  def __init__(self, r=1., A=1., B=12., C=1., x_0=1.):
+    self.r, self.A, self.B, self.C = r, A, B, C
+    self.x_0 = np.array([x_0]); self.x_T = None; self.T = 1.0
+    self.bounds = np.array([[0., 10.], [0., 2.]])
+
+  def params(self):
+    return np.array([self.r, self.A, self.B, self.C])
+
+  def dynamics(self, x, u):                                  # bacteria.py:59-63
+    return self.r * x + self.A * u * x - self.B * u ** 2 * torch.exp(-x)
+
+  def cost(self, x, u, t=None):                              # bacteria.py:77-78
+    return (u ** 2)[..., 0]
+
+  def terminal_cost_fn(self, x_T, u_T, T=None):              # bacteria.py:84-86
+    return -self.C * x_T.squeeze()
+
+
+class Tumour(System):
+  """myriad/systems/miscellaneous/tumour.py:52-108 (zero running cost; the objective is the terminal tumour volume)."""
+  name = "TUMOUR"
+  param_names = ("xi", "b", "d", "G", "mu")
+  terminal_cost = True
+
+  def __init__(self, xi=0.084, b=5.85, d=0.00873, G=0.15, mu=0.02):
+    self.xi, self.b, self.d, self.G, self.mu = xi, b, d, G, mu
+    p_ = ((b - mu) / d) ** (3 / 2)                           # :62 asymptotically stable focus
+    self.x_0 = np.array([p_ / 2, p_ / 4, 0.]); self.x_T = None; self.T = 1.2
+    self.bounds = np.array([[0., p_], [0., p_], [0., 15.], [0., 75.]])
+
+  def params(self):
+    return np.array([self.xi, self.b, self.d, self.G, self.mu])
+
+  def dynamics(self, x, u):                                  # tumour.py:80-86
+    pp, q, u0 = x[..., 0], x[..., 1], u[..., 0]
+    return torch.stack([-self.xi * pp * torch.log(pp / q), q * (self.b - (self.mu + self.d * pp ** (2 / 3) + self.G * u0)), u0], dim=-1)
+
+  def cost(self, x, u, t=None):                              # tumour.py:100-101
+    return torch.zeros_like(u[..., 0])
+
+  def terminal_cost_fn(self, x_T, u_T, T=None):              # tumour.py:106-108
+    return x_T[..., 0]
+
+
 class NodeCartPole(CartPole):
   """myriad/systems/neural_ode/node_system.py:14-42 over CARTPOLE: dynamics = net.apply(params, [x;u]) with the MLP of
   myriad/neural_ode/create_node.py:110-117 (Linear+sigmoid per hidden layer, Linear out; Haiku y = x @ w + b);
@@ -460,7 +514,7 @@ class NodeCartPole(CartPole):
 
 SYSTEMS = {c.name: c for c in (CartPole, VanDerPol, CancerTreatment, SimpleCase, Bioreactor, Glucose, MouldFungicide,
                                 SimpleCaseWithBounds, HIVTreatment, EpidemicSEIRN, SEIR, BearPopulations, Pendulum, MountainCar,
-                                RocketLanding)}
+                                RocketLanding, Bacteria, Tumour)}
 
 
 # --------------------------------------------------------------------------------------
@@ -606,6 +660,8 @@ def trapezoidal(system: System, intervals: int, method: str = "HEUN") -> Transcr
   def objective(z):                                            # :115-128
     x, u = split(z)
     c = ((h / 2) * (system.cost(x[:-1], u[:-1]) + system.cost(x[1:], u[1:]))).sum()
+    if system.terminal_cost:                                   # :126-127
+      c = c + system.terminal_cost_fn(x[-1], u[-1])
     return c
 
   def constraints(z):                                          # :183-192, trapezoid_defect :151-163
@@ -673,7 +729,10 @@ def shooting(system: System, intervals: int, controls_per_interval: int, method:
       return torch.cat([system.dynamics(x, u), system.cost(x, u)[..., None]], dim=-1)
     start = torch.cat([xs[:-1], torch.zeros(I, 1, dtype=DT)], dim=1)      # :198
     end, _ = integrate_time_independent(aug, start, ru, step, cpi, method)
-    return end[:, -1].sum()                                    # :205 (no terminal cost in the 4 systems)
+    total = end[:, -1].sum()                                   # :205
+    if system.terminal_cost:                                   # :206-208: on the INTEGRATED end state of the last interval
+      total = total + system.terminal_cost_fn(end[-1, :-1], us[-1])
+    return total
 
   return Transcription(objective, constraints, bounds, guess, I + 1, R_u, ns, nu, x_guess, u_guess)
 
@@ -831,7 +890,10 @@ def get_state_trajectory_and_cost(system: System, num_steps: int, method: str, s
   times = torch.linspace(0., system.T, num_steps + 1, dtype=DT)
   start = torch.cat([_t(start_state), torch.zeros(1, dtype=DT)])
   _, sc = integrate(aug, start, us, step, num_steps, times, method)
-  return sc[:, :-1].numpy(), float(sc[-1, -1])
+  cost = float(sc[-1, -1])
+  if system.terminal_cost:                                     # utils.py:295-296
+    cost += float(system.terminal_cost_fn(sc[-1, :-1], us[-1]))
+  return sc[:, :-1].numpy(), cost
 
 
 def get_defect(system: System, xs):

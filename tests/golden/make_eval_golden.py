@@ -16,7 +16,7 @@ CASES = [("CARTPOLE", 5, 3), ("CARTPOLE", 100, 1), ("VANDERPOL", 4, 2), ("CANCER
          # SURVEY.md 8(f4) systems
          ("BIOREACTOR", 3, 2), ("GLUCOSE", 3, 2), ("MOULDFUNGICIDE", 3, 2), ("SIMPLECASEWITHBOUNDS", 3, 2), ("HIVTREATMENT", 3, 2),
          ("EPIDEMICSEIRN", 3, 2), ("SEIR", 3, 2), ("BEARPOPULATIONS", 3, 2),
-         ("PENDULUM", 3, 3), ("MOUNTAINCAR", 3, 3), ("ROCKETLANDING", 3, 2)]
+         ("PENDULUM", 3, 3), ("MOUNTAINCAR", 3, 3), ("ROCKETLANDING", 3, 2), ("BACTERIA", 3, 2), ("TUMOUR", 3, 2)]
 ONLY = set(a.upper() for a in sys.argv[1:])
 
 for name, N, B in CASES:
@@ -31,6 +31,8 @@ for name, N, B in CASES:
       if scale == 0.05 else tr.guess[None] + 0.25 * rng.standard_normal((B, tr.guess.size))
   if name in ("PENDULUM", "MOUNTAINCAR"):
     z[2] = 3.0 * tr.guess + 2.5 * rng.standard_normal(tr.guess.size)   # outside the box: clip / angle_normalize branches
+  if name == "TUMOUR":
+    z = np.abs(z) + 1.0                                       # log(p / q): keep the states positive
   if name == "CANCERTREATMENT":
     z[:, :tr.x_rows] = np.abs(z[:, :tr.x_rows]) + 0.05      # keep x > 0 (log(1/x), cancer_treatment.py:25-29)
   f = np.array([cb.fun(zb) for zb in z])

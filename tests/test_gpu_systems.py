@@ -135,3 +135,49 @@ def test_discrete_system_is_refused_like_the_reference():
   hp = HParams(system=SystemType.INVASIVEPLANT, optimizer=OptimizerType.SHOOTING)
   with pytest.raises(NotImplementedError):                       # trajectory_optimizers/base.py:66-67
     get_optimizer(hp, CFG, hp.system())
+
+
+@pytest.mark.parametrize("sysname", ["BACTERIA", "TUMOUR"])
+def test_terminal_cost_systems_follow_the_reference_rule(sysname):
+  """Linear terminal costs (bacteria.py:84-86, tumour.py:106-108): applied by the TRAPEZOIDAL objective
+  (trapezoidal.py:126-127) and the rollout (utils.py:295-296), NOT by the Hermite-Simpson objective
+  (hermite_simpson.py:243-257 has no terminal term); shooting is refused."""
+  from myriad_amd.utils import get_state_trajectory_and_cost
+  for quad, N in (("TRAPEZOIDAL", 7), ("HERMITE_SIMPSON", 5)):
+    hp = HParams(system=SystemType[sysname], optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule[quad], intervals=N,
+                 nlpsolver=NLPSolverType.SQP)
+    O, s, tr, cb = _oracle(sysname, "COLLOCATION", hp)
+    o = get_optimizer(hp, CFG, hp.system())
+    rng = np.random.default_rng(3)
+    z = np.abs(tr.guess * (1.0 + 0.05 * rng.standard_normal(tr.guess.size))) + 0.05
+    np.testing.assert_allclose(o.constraints(z), cb.cons(z), rtol=1e-11, atol=1e-10)
+    assert o.objective(z) == pytest.approx(cb.fun(z), rel=1e-12, abs=1e-12)
+    np.testing.assert_allclose(o.objective_grad(z), cb.grad(z), rtol=1e-10, atol=1e-11)
+    lam = rng.standard_normal(cb.cons(z).size)
+    ref = cb.grad(z) + cb.jac(z).T @ lam
+    np.testing.assert_allclose(o.lagrangian_grad(z, lam), ref, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(ref).max()))
+  # solve (trapezoidal): KKT of the oracle problem, terminal gradient included
+  hp = HParams(system=SystemType[sysname], optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.TRAPEZOIDAL, intervals=20,
+               nlpsolver=NLPSolverType.SQP)
+  O, s, tr, cb = _oracle(sysname, "COLLOCATION", hp)
+  opt = get_optimizer(hp, CFG, hp.system())
+  r = opt.solve_batch()
+  assert r['status'][0] == 0, (r['status'], r['iters'], r['kkt'])
+  z, lam = r['xs_and_us'][0], r['lambda'][0]
+  assert np.abs(cb.cons(z)).max() <= 1e-8 * max(1.0, np.abs(z).max())
+  assert cb.fun(z) == pytest.approx(r['cost'][0], rel=1e-11)
+  lb, ub = tr.bounds[:, 0], tr.bounds[:, 1]
+  rr = cb.grad(z) + cb.jac(z).T @ lam
+  width = np.where(np.isfinite(ub - lb), ub - lb, 1.0)
+  inact = (lb < ub) & (z - lb > 1e-3 * width) & (ub - z > 1e-3 * width)
+  assert np.abs(rr[inact]).max() < 1e-4 * max(1.0, np.abs(cb.grad(z)).max())
+  # rollout cost includes the terminal term
+  hp2 = HParams(system=SystemType[sysname], optimizer=OptimizerType.COLLOCATION, intervals=20)
+  us = r['u'][0]
+  _, c = get_state_trajectory_and_cost(hp2, hp2.system(), hp2.system().x_0, us)
+  _, c_ref = O.get_state_trajectory_and_cost(s, hp2.num_steps, hp2.integration_method.name, s.x_0, us)
+  assert c == pytest.approx(c_ref, rel=1e-11)
+  # shooting: refused, loudly
+  hp3 = HParams(system=SystemType[sysname], optimizer=OptimizerType.SHOOTING, intervals=2, controls_per_interval=5, nlpsolver=NLPSolverType.SQP)
+  with pytest.raises(NotImplementedError):
+    get_optimizer(hp3, CFG, hp3.system()).solve()

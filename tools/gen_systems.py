@@ -195,6 +195,26 @@ def systems():
                      x[5], -L_ / 2 * Fmax * u[0] * sp.sin(u[1]) / I_],
                   g=u[0] ** 2 + u[1] ** 2 + 2 * x[5] ** 2,
                   pdefault=[9.8, 100000.0, 50.0], pnames=["g", "m", "length"]))
+  # ==== systems with a (linear) terminal cost: applied by the trapezoidal transcription (trapezoidal.py:126-127) and the
+  # post-solve rollout (utils.py:295-296); NOT by the reference's Hermite-Simpson objective (hermite_simpson.py:243-257)
+  # ---- BACTERIA: myriad/systems/lenhart/bacteria.py:59-63, :77-78, terminal :84-86 ----
+  x = sp.symbols("x0:1", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:4", real=True)   # r, A, B, C
+  out.append(dict(name="BACTERIA", id=16, x=x, u=u, p=p,
+                  f=[p[0] * x[0] + p[1] * u[0] * x[0] - p[2] * u[0] ** 2 * sp.exp(-x[0])], g=u[0] ** 2, gT=-p[3] * x[0],
+                  pdefault=[1.0, 1.0, 12.0, 1.0], pnames=["r", "A", "B", "C"]))
+  # (PREDATORPREY, the third terminal-cost system, pins only one terminal state: x_T = [None, None, B]; the reference's
+  #  collocation optimisers fail on that (np.expand_dims / linspace over None) and only its shooting path handles it, which is
+  #  not built for terminal costs here -- so it has no direct path to mirror and is left out.)
+  # ---- TUMOUR: myriad/systems/miscellaneous/tumour.py:80-86, cost 0 :100-101, terminal :106-108 ----
+  x = sp.symbols("x0:3", positive=True)
+  u = sp.symbols("u0:1", real=True)
+  xi_, b_, d_, G_, mu_ = p = sp.symbols("p0:5", real=True)   # xi, b, d, G, mu
+  out.append(dict(name="TUMOUR", id=17, x=x, u=u, p=p,
+                  f=[-xi_ * x[0] * sp.log(x[0] / x[1]), x[1] * (b_ - (mu_ + d_ * x[0] ** sp.Rational(2, 3) + G_ * u[0])), u[0]],
+                  g=sp.S.Zero, gT=x[0],
+                  pdefault=[0.084, 5.85, 0.00873, 0.15, 0.02], pnames=["xi", "b", "d", "G", "mu"]))
   return out
 
 
@@ -225,6 +245,10 @@ def gen_system(S):
   smap = {v: sc[i] * v for i, v in enumerate(w)}
   f = [sp.sympify(e).subs(smap, simultaneous=True) * isc[i] for i, e in enumerate(S["f"])]
   g = sp.sympify(S["g"]).subs(smap, simultaneous=True)
+  gT = sp.sympify(S.get("gT", 0)).subs(smap, simultaneous=True)      # terminal cost (systems/base.py:101-111), in scaled variables
+  has_term = gT != 0
+  gTw = [sp.diff(gT, v) for v in (x + u)]
+  assert all(sp.simplify(sp.diff(e, v)) == 0 for e in gTw for v in (x + u)), "terminal cost must be linear (no Hessian term is generated)"
   A = [[sp.diff(f[i], x[j]) for j in range(ns)] for i in range(ns)]
   Bm = [[sp.diff(f[i], u[j]) for j in range(nu)] for i in range(ns)]
   gw = [sp.diff(g, v) for v in w]
@@ -232,7 +256,7 @@ def gen_system(S):
   wg = sp.Symbol("wg", real=True)
   lag = wg * g + sum(mu[i] * f[i] for i in range(ns))
   H = [[sp.diff(lag, w[i], w[j]) for j in range(nw)] for i in range(nw)]
-  cost_dep_x = any(sp.diff(g, v) != 0 for v in x)
+  cost_dep_x = any(sp.diff(g, v) != 0 for v in x) or any(sp.diff(gT, v) != 0 for v in x)
 
   def unpack(indent="  "):
     s = []
@@ -331,6 +355,17 @@ def gen_system(S):
   o.append("    (void)x; (void)u; (void)p;")
   o.append("    contract(D2, mu, wg, W);")
   o.append("  }")
+  o.append(f"  static constexpr bool HAS_TERMINAL = {'true' if has_term else 'false'};   // linear terminal cost (applied by the trapezoidal transcription and the rollout)")
+  o.append("  MYR_HD static inline double term(const double* x, const double* u, const double* p) {")
+  o.append(unpack("    "))
+  o.append("    double r;")
+  o.append(emit_block([("r", gT)], "    "))
+  o.append("    return r;")
+  o.append("  }")
+  o.append("  MYR_HD static inline void term_grad(const double* x, const double* u, const double* p, double* gw) {")
+  o.append(unpack("    "))
+  o.append(emit_block([(f"gw[{i}]", gTw[i]) for i in range(nw)], "    "))
+  o.append("  }")
   o.append("  MYR_HD static inline void default_params(double* p) {")
   for i, v in enumerate(S["pdefault"]):
     o.append(f"    p[{i}] = {v!r};  // {S['pnames'][i]}")
@@ -392,6 +427,20 @@ struct SysParams {
   }
   MYR_HD inline const double* get() const { if constexpr (Sys::PARAMS_BY_POINTER) return ptr; else return buf; }
 };
+""")
+  parts.append("""// Fold a (linear) terminal cost into the running cost of the LAST point of a quadrature with weight w_last:
+// w_last (g + gT / w_last) = w_last g + gT, and likewise for the gradient -- every consumer of (g, gw) at that point then
+// sees the terminal term without further changes (second derivatives are zero for a linear gT).
+template <class Sys>
+MYR_HD inline void fold_terminal(const double* x, const double* u, const double* p, double w_last, double& g, double* gw) {
+  if constexpr (Sys::HAS_TERMINAL) {
+    double tg[Sys::NW];
+    Sys::term_grad(x, u, p, tg);
+    const double iw = 1.0 / w_last;
+    g += Sys::term(x, u, p) * iw;
+    if (gw) { for (int c = 0; c < Sys::NW; ++c) gw[c] += tg[c] * iw; }
+  } else { (void)x; (void)u; (void)p; (void)w_last; (void)g; (void)gw; }
+}
 """)
   parts.append("}  // namespace myriad")
   with open(OUT, "w") as fh:
