@@ -66,7 +66,7 @@ struct myr_handle_s {
   // staging for MYR_MEM_HOST calls
   void* dbuf = nullptr;
   size_t dbuf_bytes = 0;
-  int eval_wpt = 4;
+  int eval_wpt = 8;
   int eval_nt = 1;      // non-temporal stores for the c / J-block streams
   int solve_mode = 1;   // 1: one trajectory per wavefront (hs_solver_wave.h); 0: one trajectory per lane (hs_solver.h)
   int solve_lpw = 16;   // trajectories (active lanes) per wavefront in the solve kernel
