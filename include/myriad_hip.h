@@ -42,7 +42,7 @@ enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2,
        /* NodeSystem over CARTPOLE with a (64,64) sigmoid MLP (systems/neural_ode/node_system.py:14-42,
           neural_ode/create_node.py:110-117): params = the 4804 weights, see csrc/node_system.h for the order */
        MYR_SYS_NODE_CARTPOLE = 4,
-       /* further autonomous systems without terminal cost (systems/lenhart/*.py, miscellaneous/seir.py) */
+       /* further autonomous systems without terminal cost (systems/lenhart/<name>.py, miscellaneous/seir.py) */
        MYR_SYS_BIOREACTOR = 5, MYR_SYS_GLUCOSE = 6, MYR_SYS_MOULDFUNGICIDE = 7, MYR_SYS_SIMPLECASEWITHBOUNDS = 8,
        MYR_SYS_HIVTREATMENT = 9, MYR_SYS_EPIDEMICSEIRN = 10, MYR_SYS_SEIR = 11, MYR_SYS_BEARPOPULATIONS = 12,
        /* classical_control/{pendulum,mountain_car}.py (gym-style clips kept), miscellaneous/rocket_landing.py */
@@ -50,7 +50,10 @@ enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2,
        /* systems with a (linear) terminal cost: lenhart/bacteria.py, miscellaneous/tumour.py.  The terminal
           term is applied where the reference applies it for collocation -- the TRAPEZOIDAL objective (trapezoidal.py:126-127)
           and the rollout (utils.py:295-296), not the Hermite-Simpson objective; SHOOTING returns MYR_E_UNSUPPORTED */
-       MYR_SYS_BACTERIA = 16, MYR_SYS_TUMOUR = 17 };
+       MYR_SYS_BACTERIA = 16, MYR_SYS_TUMOUR = 17,
+       /* running cost g(x,u,t) with explicit time (lenhart/harvest.py:61-62, timber_harvest.py:84-85): collocation
+          transcriptions and the rollout; SHOOTING returns MYR_E_UNSUPPORTED */
+       MYR_SYS_HARVEST = 18, MYR_SYS_TIMBERHARVEST = 19 };
 /* transcription: OptimizerType x QuadratureRule (config.py:12-57) */
 enum { MYR_TR_HERMITE_SIMPSON = 0, MYR_TR_TRAPEZOIDAL = 1, MYR_TR_SHOOTING = 2 };
 /* IntegrationMethod (config.py:46-50) */

@@ -70,8 +70,9 @@ struct CollocProducts {
   }
   // (grad f +) J^T lam restricted to point j, from the point's own (x, u)
   __device__ static inline void vjp_point(const double* x, const double* u, const double* p, const double* a, const double* e,
-                                          double wj, bool add_gradf, double* gx, double* gu, bool last = false) {
+                                          double wj, bool add_gradf, double* gx, double* gu, bool last = false, double t = 0.0) {
     double f[NS], A[NS * NS], Bm[NS * NU], g, gw[NW];
+    set_time<Sys>(p, t);
     Sys::lin(x, u, p, f, A, Bm, &g, gw);
     if (SCHEME == PROD_TRAP && last) fold_terminal<Sys>(x, u, p, wj, g, gw);     // trapezoidal.py:126-127
 #pragma unroll
@@ -126,7 +127,7 @@ void colloc_vjp_kernel(int B, int N, double h, const double* __restrict__ z, con
 #pragma unroll
     for (int c = 0; c < NU; ++c) u[c] = zb[(long)K * NS + (long)j * NU + c];
     P::combine(lam + b * m, N, j, h, a, e);
-    P::vjp_point(x, u, pp.get(), a, e, P::wq(K, j, h), add_gradf != 0, gx, gu, j == K - 1);
+    P::vjp_point(x, u, pp.get(), a, e, P::wq(K, j, h), add_gradf != 0, gx, gu, j == K - 1, (SCHEME == PROD_HS ? 0.5 * h : h) * j);
     double* ob = out + b * n;
 #pragma unroll
     for (int q = 0; q < NS; ++q) ob[(long)j * NS + q] = gx[q];
@@ -222,7 +223,7 @@ void colloc_exgd_kernel(int B, int N, double h, double* z, double* lam, const do
 #pragma unroll
         for (int c = 0; c < NU; ++c) u[c] = src[K * NS + j * NU + c];
         P::combine(sl, N, j, h, a, e);
-        P::vjp_point(x, u, p, a, e, P::wq(K, j, h), true, gx, gu, j == K - 1);
+        P::vjp_point(x, u, p, a, e, P::wq(K, j, h), true, gx, gu, j == K - 1, (SCHEME == PROD_HS ? 0.5 * h : h) * j);
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
           const int i = j * NS + q;

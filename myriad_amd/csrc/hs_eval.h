@@ -131,6 +131,7 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
     for (int i = 0; i < NS; ++i) x[i] = zb[j * NS + i];
 #pragma unroll
     for (int i = 0; i < NU; ++i) u[i] = zb[K * NS + j * NU + i];
+    set_time<Sys>(p, (SCHEME == EVAL_HS ? 0.5 * h : h) * j);      // t_j of linspace(0, T, K) (hermite_simpson.py:252, trapezoidal.py:124)
     Sys::lin(x, u, p, f, A, Bm, &g, gw);
     double* r = rec + j * REC;
 #pragma unroll

@@ -290,6 +290,7 @@ struct HsSolver {
     HsPoint<Sys> Pe, Pm, Ps;
     VarBlk Ve, Vm, Vs;
     load_vars(w, K, K - 1, Ve);
+    set_time<Sys>(p, 0.5 * h * (K - 1));
     lin_point(Ve, p, Pe);
     // adjoint carries from the later stage: costate on x_e rows, control-row partial residual, Hessian multiplier part
     double pi_c[NS], ru_c[NU], mu_c[NS];
@@ -310,7 +311,9 @@ struct HsSolver {
       const int jm = 2 * k + 1, js = 2 * k;
       load_vars(w, K, jm, Vm);
       load_vars(w, K, js, Vs);
+      set_time<Sys>(p, 0.5 * h * jm);
       lin_point(Vm, p, Pm);
+      set_time<Sys>(p, 0.5 * h * js);
       lin_point(Vs, p, Ps);
       const double we = wsimp(K, 2 * k + 2, h), wm = wsimp(K, jm, h);
       so.f += we * Pe.g + wm * Pm.g;
@@ -749,6 +752,7 @@ struct HsSolver {
     auto apply = [&](int j, const double* dx, const double* du) {
       // objective gradient of point j (cheap closed form), then step limits / merit slope for its NW variables
       load_vars(w, K, j, V);
+      set_time<Sys>(p, 0.5 * h * j);
       Sys::cost_grad(V.z, V.z + NS, p, &gg, gw);
       const double wj = wsimp(K, j, h);
 #pragma unroll
@@ -830,6 +834,7 @@ struct HsSolver {
         if (c < NS) x[c] = v; else u[c - NS] = v;
       }
       Sys::f(x, u, p, ff);
+      set_time<Sys>(p, 0.5 * h * j);
       f += wsimp(K, j, h) * Sys::g(x, u, p);
     };
     get(0, xs, us, fs);

@@ -153,6 +153,7 @@ struct HsWave {
         V.z[q] = c.z[i]; V.l[q] = c.lb[i]; V.u[q] = c.ub[i]; V.zl[q] = c.zL[i]; V.zu[q] = c.zU[i];
       }
       HsPoint<Sys> P;
+      set_time<Sys>(c.pp.get(), 0.5 * c.h * j);
       S::lin_point(V, c.pp.get(), P);
       double* pt = c.pt + j;
       const int K = c.K;
@@ -863,6 +864,7 @@ struct HsWave {
         if (q < NS) x[q] = v; else u[q - NS] = v;
       }
       Sys::f(x, u, c.pp.get(), ff);
+      set_time<Sys>(c.pp.get(), 0.5 * c.h * j);
       fa += S::wsimp(K, j, c.h) * Sys::g(x, u, c.pp.get());
 #pragma unroll
       for (int q = 0; q < NS; ++q) { sX[j * NS + q] = x[q]; sF[j * NS + q] = ff[q]; }

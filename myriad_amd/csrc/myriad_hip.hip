@@ -23,7 +23,7 @@
 #define MYR_CLOSED_FORM_SYSTEMS(X)                                                                               \
   X(CARTPOLE) X(VANDERPOL) X(CANCERTREATMENT) X(SIMPLECASE) X(BIOREACTOR) X(GLUCOSE) X(MOULDFUNGICIDE)           \
   X(SIMPLECASEWITHBOUNDS) X(HIVTREATMENT) X(EPIDEMICSEIRN) X(SEIR) X(BEARPOPULATIONS) X(PENDULUM) X(MOUNTAINCAR)     \
-  X(ROCKETLANDING) X(BACTERIA) X(TUMOUR)
+  X(ROCKETLANDING) X(BACTERIA) X(TUMOUR) X(HARVEST) X(TIMBERHARVEST)
 
 
 using namespace myriad;
@@ -275,7 +275,7 @@ static int eval_for_system(myr_handle h, int B, const double* z, const double* p
       case MYR_TR_HERMITE_SIMPSON: return launch_hs_eval<Sys, EVAL_HS>(h, B, z, params, pstride, f, g, c, j);
       case MYR_TR_TRAPEZOIDAL: return launch_hs_eval<Sys, EVAL_TRAP>(h, B, z, params, pstride, f, g, c, j);
       case MYR_TR_SHOOTING:
-        if constexpr (Sys::HAS_TERMINAL) return fail(MYR_E_UNSUPPORTED, "shooting with a terminal cost (shooting.py:163-165) is not built: use a collocation transcription");
+        if constexpr (Sys::HAS_TERMINAL || Sys::TIME_DEP) return fail(MYR_E_UNSUPPORTED, "shooting with a terminal or time-dependent cost is not built: use a collocation transcription");
         else return launch_shoot_eval<Sys>(h, B, z, params, pstride, f, g, c, j);
     }
   }
@@ -682,8 +682,8 @@ static int solve_for_system(myr_handle h, int B, double* z, const double* lb, co
     case MYR_TR_SHOOTING:
       if (h->d.integration_method != MYR_INT_EULER && h->d.integration_method != MYR_INT_HEUN)
         return fail(MYR_E_UNSUPPORTED, "myr_solve: shooting solve is built for EULER and HEUN steps (RK4 / MIDPOINT: rollout only)");
-      if constexpr (Sys::HAS_TERMINAL)
-        return fail(MYR_E_UNSUPPORTED, "shooting with a terminal cost (shooting.py:163-165) is not built: use a collocation transcription");
+      if constexpr (Sys::HAS_TERMINAL || Sys::TIME_DEP)
+        return fail(MYR_E_UNSUPPORTED, "shooting with a terminal or time-dependent cost is not built: use a collocation transcription");
       else
         return launch_lane_solve<ShootCore<Sys>, Sys>(h, B, ShootCore<Sys>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }

@@ -26,6 +26,8 @@ struct SysNODE {
   static constexpr bool COST_DEP_X = True::COST_DEP_X;
   static constexpr bool PARAMS_BY_POINTER = true;
   static constexpr bool HAS_TERMINAL = false;           // NodeSystem is built over systems without a terminal cost
+  static constexpr bool TIME_DEP = false;               // ... and with time-independent cost
+  static constexpr int T_SLOT = 0;
   MYR_HD static inline double term(const double*, const double*, const double*) { return 0.0; }
   MYR_HD static inline void term_grad(const double*, const double*, const double*, double* gw) { for (int i = 0; i < NW; ++i) gw[i] = 0.0; }
   static constexpr int NNZ2 = 1;                      // no stored second derivatives: hessian() recomputes

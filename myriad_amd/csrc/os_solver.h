@@ -206,6 +206,7 @@ struct TrapCore {
     HsPoint<Sys> Pe, Ps;
     VarBlk Ve, Vs;
     load_vars(w, Kp, Kp - 1, Ve);
+    set_time<Sys>(p, h * (Kp - 1));
     H::lin_point(Ve, p, Pe);
     fold_terminal<Sys>(Pe.x, Pe.u, p, wtrap(Kp, Kp - 1, h), Pe.g, Pe.gw);    // trapezoidal.py:126-127
     double pi_c[NS], ru_c[NU], mu_c[NS];
@@ -221,6 +222,7 @@ struct TrapCore {
 
     for (int j = N - 1; j >= 0; --j) {
       load_vars(w, Kp, j, Vs);
+      set_time<Sys>(p, h * j);
       H::lin_point(Vs, p, Ps);
       const double we = wtrap(Kp, j + 1, h);
       so.f += we * Pe.g;
@@ -367,6 +369,7 @@ struct TrapCore {
     double gg, gw[NW];
     auto apply = [&](int j, const double* d) {
       load_vars(w, Kp, j, V);
+      set_time<Sys>(p, h * j);
       Sys::cost_grad(V.z, V.z + NS, p, &gg, gw);
       const double wj = wtrap(Kp, j, h);
       if (j == Kp - 1) fold_terminal<Sys>(V.z, V.z + NS, p, wj, gg, gw);
@@ -426,6 +429,7 @@ struct TrapCore {
         if (c < NS) x[c] = v; else u[c - NS] = v;
       }
       Sys::f(x, u, p, ff);
+      set_time<Sys>(p, h * j);
       double gj = Sys::g(x, u, p);
       if (j == Kp - 1) fold_terminal<Sys>(x, u, p, wtrap(Kp, j, h), gj, nullptr);
       f += wtrap(Kp, j, h) * gj;

@@ -12,7 +12,8 @@ template <class Sys>
 struct Rollout {
   static constexpr int NS = Sys::NS, NU = Sys::NU;
 
-  MYR_HD static inline void aug(const double* x, const double* u, const double* p, double* dx, double* dc) {
+  MYR_HD static inline void aug(const double* x, const double* u, const double* p, double* dx, double* dc, double t = 0.0) {
+    set_time<Sys>(p, t);
     Sys::f(x, u, p, dx);
     *dc = Sys::g(x, u, p);
   }
@@ -30,42 +31,43 @@ struct Rollout {
     auto U = [&](int i) { return us + (long)(i < u_rows ? i : u_rows - 1) * NU; };
     for (int s = 0; s < num_steps; ++s) {
       double k1[NS], c1, k2[NS], c2, xt[NS];
+      const double t = h * s;                  // ts[idx] of linspace(0, T, num_steps+1) (utils.py:273-281); stage times as utils.py:31-54
       if (method == 0) {                       // Euler: x + h f(x, u_i)
-        aug(x, U(s), p, k1, &c1);
+        aug(x, U(s), p, k1, &c1, t);
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] += h * k1[i];
         c += h * c1;
       } else if (method == 1) {                // Heun: x + h/2 (k1 + k2), k2 at (x + h k1, u_{i+1})
-        aug(x, U(s), p, k1, &c1);
+        aug(x, U(s), p, k1, &c1, t);
 #pragma unroll
         for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * k1[i];
-        aug(xt, U(s + 1), p, k2, &c2);
+        aug(xt, U(s + 1), p, k2, &c2, t + h);
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] += 0.5 * h * (k1[i] + k2[i]);
         c += 0.5 * h * (c1 + c2);
       } else if (method == 2) {                // reference "midpoint": x + h f(x + h f(x,u_i), (u_i+u_{i+1})/2)
-        aug(x, U(s), p, k1, &c1);
+        aug(x, U(s), p, k1, &c1, t);
         double um[NU];
 #pragma unroll
         for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * k1[i];
 #pragma unroll
         for (int i = 0; i < NU; ++i) um[i] = 0.5 * (U(s)[i] + U(s + 1)[i]);
-        aug(xt, um, p, k2, &c2);
+        aug(xt, um, p, k2, &c2, t + 0.5 * h);
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] += h * k2[i];
         c += h * c2;
       } else {                                 // RK4 with controls u[2s], u[2s+1] (k2 and k3), u[2s+2]
         double k3[NS], c3, k4[NS], c4;
-        aug(x, U(2 * s), p, k1, &c1);
+        aug(x, U(2 * s), p, k1, &c1, t);
 #pragma unroll
         for (int i = 0; i < NS; ++i) xt[i] = x[i] + 0.5 * h * k1[i];
-        aug(xt, U(2 * s + 1), p, k2, &c2);
+        aug(xt, U(2 * s + 1), p, k2, &c2, t + 0.5 * h);
 #pragma unroll
         for (int i = 0; i < NS; ++i) xt[i] = x[i] + 0.5 * h * k2[i];
-        aug(xt, U(2 * s + 1), p, k3, &c3);
+        aug(xt, U(2 * s + 1), p, k3, &c3, t + 0.5 * h);
 #pragma unroll
         for (int i = 0; i < NS; ++i) xt[i] = x[i] + h * k3[i];
-        aug(xt, U(2 * s + 2), p, k4, &c4);
+        aug(xt, U(2 * s + 2), p, k4, &c4, t + h);
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] += h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
         c += h / 6.0 * (c1 + 2.0 * c2 + 2.0 * c3 + c4);

@@ -421,6 +421,40 @@ class Tumour(FiniteHorizonControlSystem):
     return float(x_T[0])
 
 
+class Harvest(IndirectFHCS):
+  """systems/lenhart/harvest.py:27-62 (running cost with explicit time)."""
+  name = "HARVEST"
+  param_names = ("A", "k", "m")
+
+  def __init__(self, A=5., k=10., m=.2, M=1., x_0=.4, T=10.):
+    super().__init__(x_0=[x_0], x_T=None, T=T, bounds=[[-np.inf, np.inf], [0., M]])
+    self.A, self.k, self.m, self.M = A, k, m, M
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    return -(self.m + np.squeeze(u_t)) * np.asarray(x_t, dtype=np.float64)
+
+  def cost(self, x_t, u_t, t=None):
+    t = 0.0 if t is None else float(t)
+    return float(np.squeeze(-1 * self.A * (self.k * t / (t + 1)) * np.asarray(x_t) * np.squeeze(u_t) + np.squeeze(u_t) ** 2))
+
+
+class TimberHarvest(IndirectFHCS):
+  """systems/lenhart/timber_harvest.py:36-85 (discounted running cost)."""
+  name = "TIMBERHARVEST"
+  param_names = ("r", "k")
+
+  def __init__(self, r=0., k=1., x_0=100., T=5.):
+    super().__init__(x_0=[x_0], x_T=None, T=T, bounds=[[0., 20_000.], [0., 1.]])
+    self.r, self.k = r, k
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    return np.array([self.k * x_t[0] * float(np.squeeze(u_t))])
+
+  def cost(self, x_t, u_t, t=None):
+    t = 0.0 if t is None else float(t)
+    return float(-np.exp(-self.r * t) * x_t[0] * (1 - np.squeeze(u_t)))
+
+
 class InvasivePlant(IndirectFHCS):
   """systems/lenhart/invasive_plant.py: a DISCRETE-time system.  Kept as a SystemType member for the reference's error
   behaviour: the direct optimisers refuse discrete systems with NotImplementedError (trajectory_optimizers/base.py:66-67);
@@ -435,8 +469,7 @@ class InvasivePlant(IndirectFHCS):
 
 class SystemType(Enum):
   """systems/__init__.py:29-53: an enum of system classes; calling a member instantiates the system.
-  Members not built here (HARVEST, TIMBERHARVEST: time-dependent cost; PREDATORPREY: partially pinned terminal state that
-  only the reference's shooting path accepts) are listed in DESIGN.md."""
+  Not built: PREDATORPREY (partially pinned terminal state that only the reference's shooting path accepts)."""
   CARTPOLE = CartPole
   VANDERPOL = VanDerPol
   SEIR = SEIR
@@ -449,9 +482,11 @@ class SystemType(Enum):
   SIMPLECASEWITHBOUNDS = SimpleCaseWithBounds
   CANCERTREATMENT = CancerTreatment
   EPIDEMICSEIRN = EpidemicSEIRN
+  HARVEST = Harvest
   HIVTREATMENT = HIVTreatment
   BEARPOPULATIONS = BearPopulations
   GLUCOSE = Glucose
+  TIMBERHARVEST = TimberHarvest
   BIOREACTOR = Bioreactor
   INVASIVEPLANT = InvasivePlant
   ROCKETLANDING = RocketLanding

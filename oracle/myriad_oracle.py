@@ -494,6 +494,49 @@ class Tumour(System):
     return x_T[..., 0]
 
 
+# ---- systems whose running cost depends on time ------------------------------------------------------------------------
+class Harvest(System):
+  """myriad/systems/lenhart/harvest.py:27-62."""
+  name = "HARVEST"
+  param_names = ("A", "k", "m")
+
+  def __init__(self, A=5., k=10., m=.2, M=1., x_0=.4, T=10.):
+    self.A, self.k, self.m, self.M = A, k, m, M
+    self.x_0 = np.array([x_0]); self.x_T = None; self.T = float(T)
+    self.bounds = np.array([[-np.inf, np.inf], [0., M]])
+
+  def params(self):
+    return np.array([self.A, self.k, self.m])
+
+  def dynamics(self, x, u):                                  # harvest.py:54-58
+    return -(self.m + u) * x
+
+  def cost(self, x, u, t=None):                              # harvest.py:61-62
+    t = torch.zeros((), dtype=DT) if t is None else t
+    return -1 * self.A * (self.k * t / (t + 1)) * x[..., 0] * u[..., 0] + u[..., 0] ** 2
+
+
+class TimberHarvest(System):
+  """myriad/systems/lenhart/timber_harvest.py:36-85."""
+  name = "TIMBERHARVEST"
+  param_names = ("r", "k")
+
+  def __init__(self, r=0., k=1., x_0=100., T=5.):
+    self.r, self.k = r, k
+    self.x_0 = np.array([x_0]); self.x_T = None; self.T = float(T)
+    self.bounds = np.array([[0., 20_000.], [0., 1.]])
+
+  def params(self):
+    return np.array([self.r, self.k])
+
+  def dynamics(self, x, u):                                  # timber_harvest.py:62-69
+    return torch.stack([self.k * x[..., 0] * u[..., 0]], dim=-1)
+
+  def cost(self, x, u, t=None):                              # timber_harvest.py:84-85
+    t = torch.zeros((), dtype=DT) if t is None else t
+    return -torch.exp(-self.r * t) * x[..., 0] * (1 - u[..., 0])
+
+
 class NodeCartPole(CartPole):
   """myriad/systems/neural_ode/node_system.py:14-42 over CARTPOLE: dynamics = net.apply(params, [x;u]) with the MLP of
   myriad/neural_ode/create_node.py:110-117 (Linear+sigmoid per hidden layer, Linear out; Haiku y = x @ w + b);
@@ -514,7 +557,7 @@ class NodeCartPole(CartPole):
 
 SYSTEMS = {c.name: c for c in (CartPole, VanDerPol, CancerTreatment, SimpleCase, Bioreactor, Glucose, MouldFungicide,
                                 SimpleCaseWithBounds, HIVTreatment, EpidemicSEIRN, SEIR, BearPopulations, Pendulum, MountainCar,
-                                RocketLanding, Bacteria, Tumour)}
+                                RocketLanding, Bacteria, Tumour, Harvest, TimberHarvest)}
 
 
 # --------------------------------------------------------------------------------------
@@ -630,7 +673,8 @@ def hermite_simpson(system: System, intervals: int) -> Transcription:
 
   def objective(z):                                            # :243-257 with hs_cost :194-214
     xs_, xm, xe, us_, um, ue = split(z)
-    return ((h / 6) * (system.cost(xs_, us_) + 4 * system.cost(xm, um) + system.cost(xe, ue))).sum()
+    t = torch.linspace(0., system.T, 2 * N + 1, dtype=DT)      # :252-256: times of the points (cost functions with t)
+    return ((h / 6) * (system.cost(xs_, us_, t[0:-1:2]) + 4 * system.cost(xm, um, t[1::2]) + system.cost(xe, ue, t[2::2]))).sum()
 
   def constraints(z):                                          # :325-335
     xs_, xm, xe, us_, um, ue = split(z)
@@ -659,7 +703,8 @@ def trapezoidal(system: System, intervals: int, method: str = "HEUN") -> Transcr
 
   def objective(z):                                            # :115-128
     x, u = split(z)
-    c = ((h / 2) * (system.cost(x[:-1], u[:-1]) + system.cost(x[1:], u[1:]))).sum()
+    t = torch.linspace(0., system.T, N + 1, dtype=DT)          # :124
+    c = ((h / 2) * (system.cost(x[:-1], u[:-1], t[:-1]) + system.cost(x[1:], u[1:], t[1:]))).sum()
     if system.terminal_cost:                                   # :126-127
       c = c + system.terminal_cost_fn(x[-1], u[-1])
     return c

@@ -16,7 +16,8 @@ CASES = [("CARTPOLE", 5, 3), ("CARTPOLE", 100, 1), ("VANDERPOL", 4, 2), ("CANCER
          # SURVEY.md 8(f4) systems
          ("BIOREACTOR", 3, 2), ("GLUCOSE", 3, 2), ("MOULDFUNGICIDE", 3, 2), ("SIMPLECASEWITHBOUNDS", 3, 2), ("HIVTREATMENT", 3, 2),
          ("EPIDEMICSEIRN", 3, 2), ("SEIR", 3, 2), ("BEARPOPULATIONS", 3, 2),
-         ("PENDULUM", 3, 3), ("MOUNTAINCAR", 3, 3), ("ROCKETLANDING", 3, 2), ("BACTERIA", 3, 2), ("TUMOUR", 3, 2)]
+         ("PENDULUM", 3, 3), ("MOUNTAINCAR", 3, 3), ("ROCKETLANDING", 3, 2), ("BACTERIA", 3, 2), ("TUMOUR", 3, 2),
+         ("HARVEST", 3, 2), ("TIMBERHARVEST", 3, 2)]
 ONLY = set(a.upper() for a in sys.argv[1:])
 
 for name, N, B in CASES:

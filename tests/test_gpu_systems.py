@@ -181,3 +181,50 @@ def test_terminal_cost_systems_follow_the_reference_rule(sysname):
   hp3 = HParams(system=SystemType[sysname], optimizer=OptimizerType.SHOOTING, intervals=2, controls_per_interval=5, nlpsolver=NLPSolverType.SQP)
   with pytest.raises(NotImplementedError):
     get_optimizer(hp3, CFG, hp3.system()).solve()
+
+
+@pytest.mark.parametrize("sysname,kw", [("HARVEST", {}), ("TIMBERHARVEST", {"r": 0.3})])
+def test_time_dependent_cost_systems(sysname, kw):
+  """g(x, u, t) with explicit time (harvest.py:61-62, timber_harvest.py:84-85): the point's time -- linspace(0, T, K) of
+  hermite_simpson.py:252 / trapezoidal.py:124, the stage times of utils.py:31-54 in the rollout -- reaches the generated
+  cost through a slot of the parameter vector."""
+  from oracle import myriad_oracle as O
+  from myriad_amd import systems as HS_
+  from myriad_amd.utils import get_state_trajectory_and_cost
+  so = O.SYSTEMS[sysname](**kw)
+  sh = getattr(HS_, type(so).__name__)(**kw)
+  for quad, N in (("HERMITE_SIMPSON", 6), ("TRAPEZOIDAL", 7)):
+    hp = HParams(system=SystemType[sysname], optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule[quad], intervals=N,
+                 nlpsolver=NLPSolverType.SQP)
+    tr = O.make_transcription(so, "COLLOCATION", N, 1, quad, "HEUN")
+    cb = O.Callbacks(tr)
+    o = get_optimizer(hp, CFG, sh)
+    rng = np.random.default_rng(4)
+    z = np.abs(tr.guess * (1.0 + 0.05 * rng.standard_normal(tr.guess.size))) + 0.05
+    np.testing.assert_allclose(o.constraints(z), cb.cons(z), rtol=1e-11, atol=1e-11)
+    assert o.objective(z) == pytest.approx(cb.fun(z), rel=1e-12)
+    np.testing.assert_allclose(o.objective_grad(z), cb.grad(z), rtol=1e-10, atol=1e-11)
+    lam = rng.standard_normal(cb.cons(z).size)
+    ref = cb.grad(z) + cb.jac(z).T @ lam
+    np.testing.assert_allclose(o.lagrangian_grad(z, lam), ref, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(ref).max()))
+    r = o.solve_batch()
+    assert r['status'][0] == 0, (quad, r['status'], r['iters'], r['kkt'])
+    zs, lm = r['xs_and_us'][0], r['lambda'][0]
+    assert np.abs(cb.cons(zs)).max() <= 1e-8 * max(1.0, np.abs(zs).max())
+    assert cb.fun(zs) == pytest.approx(r['cost'][0], rel=1e-11)
+    lb, ub = tr.bounds[:, 0], tr.bounds[:, 1]
+    rr = cb.grad(zs) + cb.jac(zs).T @ lm
+    width = np.where(np.isfinite(ub - lb), ub - lb, 1.0)
+    inact = (lb < ub) & (zs - lb > 1e-3 * width) & (ub - zs > 1e-3 * width)
+    if inact.any():
+      assert np.abs(rr[inact]).max() < 1e-4 * max(1.0, np.abs(cb.grad(zs)).max())
+  hp2 = HParams(system=SystemType[sysname], optimizer=OptimizerType.COLLOCATION, intervals=20)
+  us = 0.3 * np.ones((21, 1))
+  for method in ("EULER", "HEUN", "MIDPOINT"):
+    hp2.integration_method = IntegrationMethod[method]
+    _, c = get_state_trajectory_and_cost(hp2, sh, sh.x_0, us)
+    _, c_ref = O.get_state_trajectory_and_cost(so, hp2.num_steps, method, so.x_0, us)
+    assert c == pytest.approx(c_ref, rel=1e-11), method
+  hp3 = HParams(system=SystemType[sysname], optimizer=OptimizerType.SHOOTING, intervals=2, controls_per_interval=5, nlpsolver=NLPSolverType.SQP)
+  with pytest.raises(NotImplementedError):
+    get_optimizer(hp3, CFG, sh).solve()

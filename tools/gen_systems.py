@@ -215,6 +215,22 @@ def systems():
                   f=[-xi_ * x[0] * sp.log(x[0] / x[1]), x[1] * (b_ - (mu_ + d_ * x[0] ** sp.Rational(2, 3) + G_ * u[0])), u[0]],
                   g=sp.S.Zero, gT=x[0],
                   pdefault=[0.084, 5.85, 0.00873, 0.15, 0.02], pnames=["xi", "b", "d", "G", "mu"]))
+  # ==== systems whose running cost depends on time: the point's time sits in a slot of the parameter vector ====
+  tt = sp.Symbol("tt", nonnegative=True)
+  # ---- HARVEST: myriad/systems/lenhart/harvest.py:54-62 ----
+  x = sp.symbols("x0:1", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:3", real=True)   # A, k, m
+  out.append(dict(name="HARVEST", id=18, x=x, u=u, p=p,
+                  f=[-(p[2] + u[0]) * x[0]], g=-p[0] * (p[1] * tt / (tt + 1)) * x[0] * u[0] + u[0] ** 2,
+                  pdefault=[5.0, 10.0, 0.2], pnames=["A", "k", "m"]))
+  # ---- TIMBERHARVEST: myriad/systems/lenhart/timber_harvest.py:62-69, :84-85 ----
+  x = sp.symbols("x0:1", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:2", real=True)   # r, k
+  out.append(dict(name="TIMBERHARVEST", id=19, x=x, u=u, p=p,
+                  f=[p[1] * x[0] * u[0]], g=-sp.exp(-p[0] * tt) * x[0] * (1 - u[0]),
+                  pdefault=[0.0, 1.0], pnames=["r", "k"]))
   return out
 
 
@@ -245,6 +261,9 @@ def gen_system(S):
   smap = {v: sc[i] * v for i, v in enumerate(w)}
   f = [sp.sympify(e).subs(smap, simultaneous=True) * isc[i] for i, e in enumerate(S["f"])]
   g = sp.sympify(S["g"]).subs(smap, simultaneous=True)
+  tt = sp.Symbol("tt", nonnegative=True)                              # time of the point (cost only; the dynamics of all systems are autonomous)
+  time_dep = g.has(tt)
+  assert not any(e.has(tt) for e in f), "time-dependent dynamics are not generated"
   gT = sp.sympify(S.get("gT", 0)).subs(smap, simultaneous=True)      # terminal cost (systems/base.py:101-111), in scaled variables
   has_term = gT != 0
   gTw = [sp.diff(gT, v) for v in (x + u)]
@@ -270,13 +289,16 @@ def gen_system(S):
       s.append(f"{indent}const double {v} = p[{npar + i}];")
     for i, v in enumerate(isc):
       s.append(f"{indent}const double {v} = p[{npar + nw + i}];")
-    return "\n".join(s) + "\n" + "\n".join(f"{indent}(void){v};" for v in (x + u + p + sc + isc))
+    s.append(f"{indent}const double tt = p[{npar + nw + ns}];")
+    return "\n".join(s) + "\n" + "\n".join(f"{indent}(void){v};" for v in (x + u + p + sc + isc + [tt]))
 
   o = []
   o.append(f"// ===== {name} (id {S['id']}): ns={ns} nu={nu} np={npar} =====")
   o.append(f"struct Sys{name} {{")
   o.append(f"  static constexpr int ID = {S['id']}, NS = {ns}, NU = {nu}, NP = {npar}, NW = {nw};")
-  o.append(f"  static constexpr int NPX = NP + NW + NS;   // model parameters, the NW variable scales, the NS inverse state scales")
+  o.append(f"  static constexpr int NPX = NP + NW + NS + 1;   // model parameters, the NW variable scales, the NS inverse state scales, the time slot")
+  o.append(f"  static constexpr int T_SLOT = NP + NW + NS;     // p[T_SLOT]: time of the point being evaluated (set_time(); cost only)")
+  o.append(f"  static constexpr bool TIME_DEP = {'true' if time_dep else 'false'};   // running cost g(x,u,t) depends on t")
   o.append(f"  static constexpr bool COST_DEP_X = {'true' if cost_dep_x else 'false'};")
   o.append(f"  static constexpr const char* NAME = \"{name}\";")
   o.append("  static constexpr bool PARAMS_BY_POINTER = false;   // parameters are a handful of scalars: copied to registers")
@@ -369,7 +391,8 @@ def gen_system(S):
   o.append("  MYR_HD static inline void default_params(double* p) {")
   for i, v in enumerate(S["pdefault"]):
     o.append(f"    p[{i}] = {v!r};  // {S['pnames'][i]}")
-  o.append(f"    for (int i = NP; i < NPX; ++i) p[i] = 1.0;   // unit variable scales")
+  o.append(f"    for (int i = NP; i < T_SLOT; ++i) p[i] = 1.0;   // unit variable scales")
+  o.append(f"    p[T_SLOT] = 0.0;")
   o.append("  }")
   o.append("};")
   return "\n".join(o)
@@ -406,7 +429,7 @@ def main():
 // weights of a neural-ODE system) are used in place through a pointer.
 template <class Sys>
 struct SysParams {
-  double buf[Sys::PARAMS_BY_POINTER ? 1 : Sys::NP + Sys::NW + Sys::NS];
+  double buf[Sys::PARAMS_BY_POINTER ? 1 : Sys::NP + Sys::NW + Sys::NS + 1];
   const double* ptr;
   MYR_HD inline void load(const double* params, long b, int stride) {
     if constexpr (Sys::PARAMS_BY_POINTER) {
@@ -428,7 +451,15 @@ struct SysParams {
   MYR_HD inline const double* get() const { if constexpr (Sys::PARAMS_BY_POINTER) return ptr; else return buf; }
 };
 """)
-  parts.append("""// Fold a (linear) terminal cost into the running cost of the LAST point of a quadrature with weight w_last:
+  parts.append("""// Time of the point whose cost is evaluated next (systems with g(x,u,t): harvest.py:61-62, timber_harvest.py:84-85).  `p`
+// is the thread's own parameter buffer (SysParams::buf), so the slot is written through the const view the solver cores hold.
+template <class Sys>
+MYR_HD inline void set_time(const double* p, double t) {
+  if constexpr (Sys::TIME_DEP) const_cast<double*>(p)[Sys::T_SLOT] = t;
+  else { (void)p; (void)t; }
+}
+
+// Fold a (linear) terminal cost into the running cost of the LAST point of a quadrature with weight w_last:
 // w_last (g + gT / w_last) = w_last g + gT, and likewise for the gradient -- every consumer of (g, gw) at that point then
 // sees the terminal term without further changes (second derivatives are zero for a linear gT).
 template <class Sys>
