@@ -186,15 +186,18 @@ int myr_exgd(myr_handle h, int32_t B, double* z, double* lam, const double* lb, 
 /*
  * Batched Forward-Backward Sweep, the reference's indirect solver (trajectory_optimizers/forward_backward_sweep.py:20-116;
  * RK4 sweeps utils.py:138-197; stopping rule trajectory_optimizers/base.py:128-141) for B instances of the handle's
- * system (IndirectFHCS systems on the path: SIMPLECASE, CANCERTREATMENT; others return MYR_E_UNSUPPORTED; terminal state
- * conditions -- the reference's secant `sequencesolver` -- are not supported).  The handle's transcription is not used.
+ * system.  Built for the continuous-time IndirectFHCS systems without terminal STATE conditions: SIMPLECASE,
+ * CANCERTREATMENT, BACTERIA, BEARPOPULATIONS, BIOREACTOR, EPIDEMICSEIRN, GLUCOSE, HARVEST, HIVTREATMENT, MOULDFUNGICIDE,
+ * SIMPLECASEWITHBOUNDS, TIMBERHARVEST (others return MYR_E_UNSUPPORTED; the secant `sequencesolver` for terminal state
+ * conditions and the discrete variant are not built).  The handle's transcription is not used.
  *   N = hp.fbsm_intervals; x0 [B][ns]; adj_T [ns] or NULL (= 0); params as in myr_eval;
- *   clip_lo/clip_hi: the bounds the system's optim_characterization clips with; delta: stopping tolerance (0.001)
+ *   clip_lo / clip_hi [nu]: the bounds each control's optim_characterization is clipped with (+-inf = not clipped);
+ *   bang: max|bounds[-1]| for the bang-bang characterisations; delta: stopping tolerance (0.001)
  *   xs, adjs [B][N+1][ns], us [B][N+1][nu], sweeps [B] (may be NULL).  Host arrays only.
  */
 int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, const double* adj_T, const double* params,
-             int32_t params_stride, double clip_lo, double clip_hi, double delta, int32_t max_sweeps, double* xs,
-             double* us, double* adjs, int32_t* sweeps, int32_t mem);
+             int32_t params_stride, const double* clip_lo, const double* clip_hi, double bang, double delta,
+             int32_t max_sweeps, double* xs, double* us, double* adjs, int32_t* sweeps, int32_t mem);
 
 /* Average device time (HIP events on the handle's stream) of the launches of one kernel since the last reset. */
 int myr_kernel_time(myr_handle h, int32_t kernel_id, double* avg_ms, int32_t* launches);

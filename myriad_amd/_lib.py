@@ -85,7 +85,7 @@ def load() -> C.CDLL:
   lib.myr_jvp.restype = C.c_int
   lib.myr_exgd.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32]
   lib.myr_exgd.restype = C.c_int
-  lib.myr_fbsm.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
+  lib.myr_fbsm.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, dp, dp, C.c_double, C.c_double, C.c_int32,
                            dp, dp, dp, ip, C.c_int32]
   lib.myr_fbsm.restype = C.c_int
   lib.myr_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
@@ -289,7 +289,7 @@ class Engine:
     else:
       _chk(self.lib.myr_jvp(self._h, int(B), _addr(z), _addr(w), _addr(params), int(params_stride), _addr(out), MEM_DEVICE), "myr_jvp")
 
-  def fbsm(self, x0, N, clip_lo, clip_hi, params=None, adj_T=None, delta=0.001, max_sweeps=10000):
+  def fbsm(self, x0, N, clip_lo, clip_hi, params=None, adj_T=None, delta=0.001, max_sweeps=10000, bang=0.0):
     """Batched Forward-Backward Sweep: returns {'x' [B,N+1,ns], 'u' [B,N+1,nu], 'adj' [B,N+1,ns], 'sweeps' [B]}."""
     x0 = _f64(x0)
     if x0.ndim == 1:
@@ -297,9 +297,10 @@ class Engine:
     B = x0.shape[0]
     p, ps = self._params(params, B)
     aT = None if adj_T is None else _f64(adj_T)
+    lo = np.ascontiguousarray(np.broadcast_to(_f64(clip_lo), (self.nu,))); hi = np.ascontiguousarray(np.broadcast_to(_f64(clip_hi), (self.nu,)))
     xs = np.empty((B, N + 1, self.ns)); us = np.empty((B, N + 1, self.nu)); adjs = np.empty((B, N + 1, self.ns))
     sw = np.empty(B, dtype=np.int32)
-    _chk(self.lib.myr_fbsm(self._h, B, int(N), _addr(x0), _addr(aT), _addr(p), ps, float(clip_lo), float(clip_hi), float(delta),
+    _chk(self.lib.myr_fbsm(self._h, B, int(N), _addr(x0), _addr(aT), _addr(p), ps, _addr(lo), _addr(hi), float(bang), float(delta),
                            int(max_sweeps), _addr(xs), _addr(us), _addr(adjs), _addr(sw), MEM_HOST), "myr_fbsm")
     return {"x": xs, "u": us, "adj": adjs, "sweeps": sw}
 

@@ -15,40 +15,77 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "systems_gen.h"
+#include "hs_solver.h"   // VarScale (8 doubles by value)
 
 namespace myriad {
 
-// adjoint ODE and optimality characterisation per system (the IndirectFHCS members of the reference)
+// adjoint ODE and (unclipped) optimality characterisation per system -- the IndirectFHCS members of the reference,
+// restated from the cited lines.  `t` is the time of the point (only HARVEST / TIMBERHARVEST use it); `bang` is
+// max|bounds[-1]| for the bang-bang characterisations (sign(.) * 2 bang + bang, then clipped by the caller).
 template <class Sys> struct Indirect { static constexpr bool SUPPORTED = false; };
 
-// myriad/systems/lenhart/simple_case.py:55-62 (maximisation-convention adjoint; the characterisation is clipped with
-// bounds[0], the state row -- reference quirk kept: the host passes those bounds)
-template <> struct Indirect<SysSIMPLECASE> {
-  static constexpr bool SUPPORTED = true;
-  __device__ static inline void adj_ode(const double* adj, const double* x, const double* u, const double* p, double* out) {
-    (void)u;
-    out[0] = -p[0] + x[0] * adj[0];
-  }
-  __device__ static inline void characterize(const double* adj, const double* x, const double* p, double* u) {
-    (void)x;
-    u[0] = (p[2] * adj[0]) / (2.0 * p[1]);
-  }
-};
-// myriad/systems/lenhart/cancer_treatment.py:84-91
-template <> struct Indirect<SysCANCERTREATMENT> {
-  static constexpr bool SUPPORTED = true;
-  __device__ static inline void adj_ode(const double* adj, const double* x, const double* u, const double* p, double* out) {
-    out[0] = adj[0] * (p[0] + p[2] * u[0] - p[0] * log(1.0 / x[0])) - 2.0 * p[1] * x[0];
-  }
-  __device__ static inline void characterize(const double* adj, const double* x, const double* p, double* u) {
-    u[0] = 0.5 * adj[0] * p[2] * x[0];
-  }
-};
+#define MYR_INDIRECT(SYS, ADJ_BODY, CHAR_BODY)                                                                         \
+  template <> struct Indirect<SYS> {                                                                                   \
+    static constexpr bool SUPPORTED = true;                                                                            \
+    __device__ static inline void adj_ode(const double* adj, const double* x, const double* u, const double* p,        \
+                                          double t, double* out) { (void)adj; (void)x; (void)u; (void)p; (void)t; ADJ_BODY }  \
+    __device__ static inline void characterize(const double* adj, const double* x, const double* p, double t,           \
+                                               double bang, double* u) { (void)adj; (void)x; (void)p; (void)t; (void)bang; CHAR_BODY } \
+  };
+__device__ inline double myr_sign(double v) { return (v > 0.0) - (v < 0.0); }      // jnp.sign
+
+// lenhart/simple_case.py:55-62 (maximisation-convention adjoint; clipped with bounds[0], the state row -- quirk kept by the host)
+MYR_INDIRECT(SysSIMPLECASE, out[0] = -p[0] + x[0] * adj[0];, u[0] = (p[2] * adj[0]) / (2.0 * p[1]);)
+// lenhart/cancer_treatment.py:84-91      p = (r, a, delta)
+MYR_INDIRECT(SysCANCERTREATMENT, out[0] = adj[0] * (p[0] + p[2] * u[0] - p[0] * log(1.0 / x[0])) - 2.0 * p[1] * x[0];,
+             u[0] = 0.5 * adj[0] * p[2] * x[0];)
+// lenhart/bacteria.py:88-95              p = (r, A, B, C); adj_T = [C] (:50)
+MYR_INDIRECT(SysBACTERIA, out[0] = -adj[0] * (p[0] + p[1] * u[0] + p[2] * u[0] * u[0] * exp(-x[0]));,
+             u[0] = adj[0] * p[1] * x[0] / (2.0 * (1.0 + p[2] * adj[0] * exp(-x[0])));)
+// lenhart/bear_populations.py:117-142    p = (r, K, m_p, m_f, c_p, c_f); two controls
+MYR_INDIRECT(SysBEARPOPULATIONS,
+             const double k = p[0] / p[1]; const double k2 = p[0] / (p[1] * p[1]);
+             out[0] = adj[0] * (2 * k * x[0] + k2 * p[3] * x[1] * x[1] + u[0] - p[0]) - adj[1] * (2 * k * p[2] * (1 - x[1] / p[1]) * x[0])
+                      + adj[2] * (2 * k * (p[2] - 1) * x[0] - k2 * p[3] * x[1] * x[1] - 2 * k2 * p[2] * x[0] * x[1]);
+             out[1] = adj[1] * (2 * k * x[1] + k2 * p[2] * x[0] * x[0] + u[1] - p[0]) - adj[0] * (2 * k * p[3] * (1 - x[0] / p[1]) * x[1])
+                      + adj[2] * (2 * k * (p[3] - 1) * x[1] - 2 * k2 * p[3] * x[0] * x[1] - k2 * p[2] * x[0] * x[0]);
+             out[2] = -1.0;,
+             u[0] = adj[0] * x[0] / (2.0 * p[4]); u[1] = adj[1] * x[1] / (2.0 * p[5]);)
+// lenhart/bioreactor.py:90-101           p = (K, G, D); bang-bang
+MYR_INDIRECT(SysBIOREACTOR, out[0] = -p[0] - p[1] * u[0] * adj[0] + 2.0 * p[2] * x[0] * adj[0];,
+             u[0] = myr_sign(-1.0 + p[1] * adj[0] * x[0]) * 2.0 * bang + bang;)
+// lenhart/epidemic_seirn.py:97-111       p = (A, b, d, c, e, g, a); the last row's (d - d) factor is the reference's
+MYR_INDIRECT(SysEPIDEMICSEIRN,
+             out[0] = adj[0] * (p[2] + p[3] * x[2] + u[0]) - adj[1] * p[3] * x[2];
+             out[1] = adj[1] * (p[4] + p[2]) - adj[2] * p[4];
+             out[2] = -p[0] + adj[0] * p[3] * x[0] - adj[1] * p[3] * x[0] + adj[2] * (p[5] + p[6] + p[2]) + adj[3] * p[6];
+             out[3] = -p[1] * adj[0] + adj[3] * (p[2] - p[2]);,
+             u[0] = adj[0] * x[0] / 2.0;)
+// lenhart/glucose.py:114-126             p = (a, b, c, A, l); the characterisation is NOT clipped by the reference
+MYR_INDIRECT(SysGLUCOSE, out[0] = -2.0 * p[3] * (x[0] - p[4]) + adj[0] * p[0]; out[1] = adj[0] * p[1] + adj[1] * p[2];,
+             u[0] = -adj[1] / 2.0;)
+// lenhart/harvest.py:64-71               p = (A, k, m); explicit time
+MYR_INDIRECT(SysHARVEST, out[0] = adj[0] * (p[2] + u[0]) - p[0] * (p[1] * t / (t + 1.0)) * u[0];,
+             u[0] = 0.5 * x[0] * (p[0] * (p[1] * t / (t + 1.0)) - adj[0]);)
+// lenhart/hiv_treatment.py:117-131       p = (s, m_1, m_2, m_3, r, T_max, k, N, A)
+MYR_INDIRECT(SysHIVTREATMENT,
+             out[0] = -p[8] + adj[0] * (p[1] - p[4] * (1 - (x[0] + x[1]) / p[5]) + p[4] * x[0] / p[5] + u[0] * p[6] * x[2]) - adj[1] * u[0] * p[6] * x[2];
+             out[1] = adj[0] * p[4] * x[0] / p[5] + adj[1] * p[2] - adj[2] * p[7] * p[2];
+             out[2] = adj[0] * (p[0] / ((1 + x[2]) * (1 + x[2])) + u[0] * p[6] * x[0]) - adj[1] * u[0] * p[6] * x[0] + adj[2] * p[3];,
+             u[0] = 1.0 + 0.5 * p[6] * x[0] * x[2] * (adj[1] - adj[0]);)
+// lenhart/mould_fungicide.py:72-79       p = (r, M, A)
+MYR_INDIRECT(SysMOULDFUNGICIDE, out[0] = adj[0] * (p[0] + u[0]) - 2.0 * p[2] * x[0];, u[0] = 0.5 * adj[0] * x[0];)
+// lenhart/simple_case_with_bounds.py:57-65   p = (A, C)
+MYR_INDIRECT(SysSIMPLECASEWITHBOUNDS, out[0] = -p[0] + x[0] * adj[0];, u[0] = (p[1] * adj[0]) / 2.0;)
+// lenhart/timber_harvest.py:87-103       p = (r, k); explicit time; bang-bang
+MYR_INDIRECT(SysTIMBERHARVEST, out[0] = u[0] * (exp(-p[0] * t) - p[1] * adj[0]) - exp(-p[0] * t);,
+             u[0] = myr_sign(x[0] * (p[1] * adj[0] - exp(-p[0] * t))) * 2.0 * bang + bang;)
+#undef MYR_INDIRECT
 
 template <class Sys>
 __global__ __launch_bounds__(64)
 void fbsm_kernel(int B, long Bp, int N, double T, const double* __restrict__ x0, const double* __restrict__ adjT,
-                 const double* __restrict__ params, int params_stride, double clip_lo, double clip_hi, double delta,
+                 const double* __restrict__ params, int params_stride, VarScale clip_lo, VarScale clip_hi, double bang, double delta,
                  int max_sweeps, double* xs, double* us, double* adjs, int32_t* sweeps) {
   constexpr int NS = Sys::NS, NU = Sys::NU;
   using I = Indirect<Sys>;
@@ -115,10 +152,10 @@ void fbsm_kernel(int B, long Bp, int N, double T, const double* __restrict__ x0,
       // control update at point i from the NEW adj_i, x_i and the OLD u_i
       {
         double ue[NU];
-        I::characterize(a, xi, p, ue);
+        I::characterize(a, xi, p, h * i, bang, ue);
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
-          const double est = fmin(clip_hi, fmax(clip_lo, ue[c]));
+          const double est = fmin(clip_hi.s[c], fmax(clip_lo.s[c], ue[c]));
           const double nu_ = 0.5 * (est + ui[c]);
           su[c] += fabs(nu_); du[c] += fabs(nu_ - ui[c]);
           at(U, i, c, NU) = nu_;
@@ -134,17 +171,17 @@ void fbsm_kernel(int B, long Bp, int N, double T, const double* __restrict__ x0,
       for (int c = 0; c < NS; ++c) xm[c] = (xi[c] + xj[c]) / 2;
 #pragma unroll
       for (int c = 0; c < NU; ++c) um[c] = (ui[c] + uj[c]) / 2;
-      const double hm = -h;
-      I::adj_ode(a, xi, ui, p, k1);
+      const double hm = -h, ti = h * i;        // utils.py:166-175 with h < 0: stage times t, t + h/2, t + h
+      I::adj_ode(a, xi, ui, p, ti, k1);
 #pragma unroll
       for (int c = 0; c < NS; ++c) t[c] = a[c] + hm * k1[c] / 2;
-      I::adj_ode(t, xm, um, p, k2);
+      I::adj_ode(t, xm, um, p, ti + 0.5 * hm, k2);
 #pragma unroll
       for (int c = 0; c < NS; ++c) t[c] = a[c] + hm * k2[c] / 2;
-      I::adj_ode(t, xm, um, p, k3);
+      I::adj_ode(t, xm, um, p, ti + 0.5 * hm, k3);
 #pragma unroll
       for (int c = 0; c < NS; ++c) t[c] = a[c] + hm * k3[c];
-      I::adj_ode(t, xj, uj, p, k4);
+      I::adj_ode(t, xj, uj, p, ti + hm, k4);
 #pragma unroll
       for (int c = 0; c < NS; ++c) {
         a[c] = a[c] + (hm / 6) * (k1[c] + 2 * k2[c] + 2 * k3[c] + k4[c]);

@@ -903,14 +903,14 @@ extern "C" int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u
 // ------------------------------------------------------------------------------------------------
 template <class Sys>
 static int launch_fbsm(myr_handle h, int B, long Bp, int N, const double* x0, const double* adjT, const double* params, int pstride,
-                       double lo, double hi, double delta, int max_sweeps, double* X, double* U, double* A, int32_t* sweeps) {
+                       const VarScale& lo, const VarScale& hi, double bang, double delta, int max_sweeps, double* X, double* U, double* A, int32_t* sweeps) {
   if constexpr (!Indirect<Sys>::SUPPORTED) {
     return fail(MYR_E_UNSUPPORTED, "myr_fbsm: this system has no adjoint dynamics (not an IndirectFHCS on the path)");
   } else {
     KTimer& kt = h->kt[MYR_K_FBSM];
     HIPCHK(hipEventRecord(kt.a, h->stream));
     hipLaunchKernelGGL(fbsm_kernel<Sys>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, Bp, N, h->d.T, x0, adjT, params,
-                       pstride, lo, hi, delta, max_sweeps, X, U, A, sweeps);
+                       pstride, lo, hi, bang, delta, max_sweeps, X, U, A, sweeps);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(kt.b, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -923,9 +923,12 @@ static int launch_fbsm(myr_handle h, int B, long Bp, int N, const double* x0, co
 }
 
 extern "C" int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, const double* adj_T, const double* params,
-                        int32_t params_stride, double clip_lo, double clip_hi, double delta, int32_t max_sweeps, double* xs,
-                        double* us, double* adjs, int32_t* sweeps, int32_t mem) {
-  if (!h || !x0 || !xs || !us || !adjs) return fail(MYR_E_ARG, "myr_fbsm: null handle or array");
+                        int32_t params_stride, const double* clip_lo, const double* clip_hi, double bang, double delta,
+                        int32_t max_sweeps, double* xs, double* us, double* adjs, int32_t* sweeps, int32_t mem) {
+  if (!h || !x0 || !xs || !us || !adjs || !clip_lo || !clip_hi) return fail(MYR_E_ARG, "myr_fbsm: null handle or array");
+  if (h->dims.nu > 8) return fail(MYR_E_CAPACITY, "myr_fbsm: more than 8 controls");
+  VarScale vlo{}, vhi{};
+  for (int c = 0; c < h->dims.nu; ++c) { vlo.s[c] = clip_lo[c]; vhi.s[c] = clip_hi[c]; }
   if (B < 0 || N < 1 || max_sweeps < 1) return fail(MYR_E_ARG, "myr_fbsm: bad sizes");
   if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_fbsm: host arrays only");
   if (params && params_stride != 0 && params_stride != h->dims.np)
@@ -953,7 +956,7 @@ extern "C" int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, co
   HIPCHK(hipMemcpyAsync(dx0, x0, nx0 * 8, hipMemcpyHostToDevice, h->stream));
   if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
   if (adj_T) HIPCHK(hipMemcpyAsync(dadj, adj_T, (size_t)dm.ns * 8, hipMemcpyHostToDevice, h->stream));
-#define MYR_FBSM(S) rc = launch_fbsm<S>(h, B, Bp, N, dx0, adj_T ? dadj : nullptr, npar ? dp : nullptr, params_stride, clip_lo, clip_hi, delta, max_sweeps, X, U, A, dsw)
+#define MYR_FBSM(S) rc = launch_fbsm<S>(h, B, Bp, N, dx0, adj_T ? dadj : nullptr, npar ? dp : nullptr, params_stride, vlo, vhi, bang, delta, max_sweeps, X, U, A, dsw)
   switch (h->d.system_id) {
 #define X(N) case MYR_SYS_##N: MYR_FBSM(Sys##N); break;
     MYR_CLOSED_FORM_SYSTEMS(X)

@@ -79,18 +79,28 @@ class FBSM(IndirectMethodOptimizer):
     return self._engine
 
   def _clip_bounds(self):
-    """The bounds the system's optim_characterization clips with: the CONTROL row for CANCERTREATMENT
-    (cancer_treatment.py:88-91), bounds[0] -- the state row, a reference quirk -- for SIMPLECASE (simple_case.py:59-62)."""
-    row = self.system.bounds[0] if self.system.name == "SIMPLECASE" else self.system.bounds[-1]
-    return float(row[0]), float(row[1])
+    """Per control: the bounds row the system's optim_characterization clips with, and max|bounds[-1]| for the bang-bang
+    ones.  Reference rules: bounds[-1] for all single-control systems except SIMPLECASE, which uses bounds[0] -- the
+    STATE row, a quirk (simple_case.py:59-62) -- and GLUCOSE, which does not clip (glucose.py:122-126); BEARPOPULATIONS
+    clips its two controls with bounds[-2] and bounds[-1] (bear_populations.py:133-142)."""
+    b = self.system.bounds
+    nu = b.shape[0] - self.system.x_0.shape[0]
+    name = self.system.name
+    if name == "SIMPLECASE":
+      lo, hi = [b[0, 0]], [b[0, 1]]
+    elif name == "GLUCOSE":
+      lo, hi = [-np.inf], [np.inf]
+    else:
+      lo, hi = [b[-nu + c, 0] for c in range(nu)], [b[-nu + c, 1] for c in range(nu)]
+    return np.array(lo, dtype=np.float64), np.array(hi, dtype=np.float64), float(np.max(np.abs(b[-1])))
 
   def solve_batch(self, x0s=None, params=None, max_sweeps: int = 10000) -> Dict[str, np.ndarray]:
     if x0s is None:
       B = 1 if params is None or np.ndim(params) == 1 else np.shape(params)[0]
       x0s = np.tile(self.system.x_0, (B, 1))
     p = self.system.device_params() if params is None else np.asarray(params, dtype=np.float64)
-    lo, hi = self._clip_bounds()
-    r = self.engine.fbsm(np.asarray(x0s, dtype=np.float64), self.N, lo, hi, params=p, adj_T=self.system.adj_T, max_sweeps=max_sweeps)
+    lo, hi, bang = self._clip_bounds()
+    r = self.engine.fbsm(np.asarray(x0s, dtype=np.float64), self.N, lo, hi, params=p, adj_T=self.system.adj_T, max_sweeps=max_sweeps, bang=bang)
     return {'x': r['x'], 'u': r['u'], 'adj': r['adj'], 'sweeps': r['sweeps']}
 
   def solve(self) -> Dict[str, np.ndarray]:

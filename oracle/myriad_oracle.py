@@ -157,10 +157,10 @@ class CancerTreatment(System):
   def np_dynamics(self, x, u):                               # cancer_treatment.py:62-65
     return self.r * x * np.log(1 / x) - u * self.delta * x
 
-  def adj_ODE(self, adj, x, u):                              # cancer_treatment.py:84-86
+  def adj_ODE(self, adj, x, u, t=None):                      # cancer_treatment.py:84-86
     return adj * (self.r + self.delta * u - self.r * np.log(1 / x)) - 2 * self.a * x
 
-  def optim_characterization(self, adj, x):                  # cancer_treatment.py:88-91 (clips with the CONTROL bounds)
+  def optim_characterization(self, adj, x, t=None):          # cancer_treatment.py:88-91 (clips with the CONTROL bounds)
     return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], 0.5 * adj * self.delta * x))
 
 
@@ -191,10 +191,10 @@ class SimpleCase(System):
   def np_dynamics(self, x, u):                               # simple_case.py:46-50
     return -0.5 * x ** 2 + self.C * u
 
-  def adj_ODE(self, adj, x, u):                              # simple_case.py:55-57 (maximisation-convention adjoint)
+  def adj_ODE(self, adj, x, u, t=None):                      # simple_case.py:55-57 (maximisation-convention adjoint)
     return -self.A + x * adj
 
-  def optim_characterization(self, adj, x):                  # simple_case.py:59-62 (clips with bounds[0], the STATE row)
+  def optim_characterization(self, adj, x, t=None):          # simple_case.py:59-62 (clips with bounds[0], the STATE row)
     return np.minimum(self.bounds[0, 1], np.maximum(self.bounds[0, 0], (self.C * adj) / (2 * self.B)))
 
 
@@ -219,6 +219,21 @@ class Bioreactor(System):
     return -self.K * x[..., 0] + u[..., 0]
 
 
+  # IndirectFHCS members (numpy; used by fbsm()); x, adj: [..., ns], u: [..., nu]
+  adj_T = None
+
+  def np_dynamics(self, x, u):
+    return self.G * u * x - self.D * x ** 2
+
+  def adj_ODE(self, adj, x, u, t=None):                      # bioreactor.py:90-94
+    return -self.K - self.G * u * adj + 2 * self.D * x * adj
+
+  def optim_characterization(self, adj, x, t=None):          # bioreactor.py:96-101 (bang-bang)
+    temp = -1 + self.G * adj[:, :1] * x[:, :1]
+    bmax = np.max(np.abs(self.bounds[-1]))
+    char = np.sign(temp) * 2 * bmax + bmax
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], char))
+
 class Glucose(System):
   """myriad/systems/lenhart/glucose.py:41-104."""
   name = "GLUCOSE"
@@ -238,6 +253,17 @@ class Glucose(System):
   def cost(self, x, u, t=None):                              # glucose.py:103-104
     return 100_000 * (self.A * (x[..., 0] - self.l) ** 2 + u[..., 0] ** 2)
 
+
+  adj_T = None
+
+  def np_dynamics(self, x, u):
+    return np.stack([-self.a * x[..., 0] - self.b * x[..., 1], -self.c * x[..., 1] + u[..., 0]], axis=-1)
+
+  def adj_ODE(self, adj, x, u, t=None):                      # glucose.py:114-120
+    return np.stack([-2 * self.A * (x[..., 0] - self.l) + adj[..., 0] * self.a, adj[..., 0] * self.b + adj[..., 1] * self.c], axis=-1)
+
+  def optim_characterization(self, adj, x, t=None):          # glucose.py:122-126 (not clipped)
+    return (-adj[:, 1] / 2).reshape(-1, 1)
 
 class MouldFungicide(System):
   """myriad/systems/lenhart/mould_fungicide.py:26-70."""
@@ -259,6 +285,17 @@ class MouldFungicide(System):
     return (self.A * x ** 2 + u ** 2)[..., 0]
 
 
+  adj_T = None
+
+  def np_dynamics(self, x, u):
+    return self.r * (self.M - x) - u * x
+
+  def adj_ODE(self, adj, x, u, t=None):                      # mould_fungicide.py:72-74
+    return adj * (self.r + u) - 2 * self.A * x
+
+  def optim_characterization(self, adj, x, t=None):          # mould_fungicide.py:76-79
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], 0.5 * adj * x))
+
 class SimpleCaseWithBounds(System):
   """myriad/systems/lenhart/simple_case_with_bounds.py:24-55."""
   name = "SIMPLECASEWITHBOUNDS"
@@ -278,6 +315,17 @@ class SimpleCaseWithBounds(System):
   def cost(self, x, u, t=None):                              # simple_case_with_bounds.py:53-55
     return (-self.A * x + u ** 2)[..., 0]
 
+
+  adj_T = None
+
+  def np_dynamics(self, x, u):
+    return -0.5 * x ** 2 + self.C * u
+
+  def adj_ODE(self, adj, x, u, t=None):                      # simple_case_with_bounds.py:57-59
+    return -self.A + x * adj
+
+  def optim_characterization(self, adj, x, t=None):          # simple_case_with_bounds.py:61-65
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], (self.C * adj) / 2))
 
 class HIVTreatment(System):
   """myriad/systems/lenhart/hiv_treatment.py:33-111."""
@@ -303,6 +351,24 @@ class HIVTreatment(System):
     return -self.A * x[..., 0] + (1 - u[..., 0]) ** 2
 
 
+  adj_T = None
+
+  def np_dynamics(self, x, u):
+    x0, x1, x2, u0 = x[..., 0], x[..., 1], x[..., 2], u[..., 0]
+    return np.stack([self.s / (1 + x2) - self.m_1 * x0 + self.r * x0 * (1 - (x0 + x1) / self.T_max) - u0 * self.k * x0 * x2,
+                     u0 * self.k * x0 * x2 - self.m_2 * x1, self.N * self.m_2 * x1 - self.m_3 * x2], axis=-1)
+
+  def adj_ODE(self, adj, x, u, t=None):                      # hiv_treatment.py:117-125
+    x0, x1, x2, u0, a0, a1, a2 = x[..., 0], x[..., 1], x[..., 2], u[..., 0], adj[..., 0], adj[..., 1], adj[..., 2]
+    return np.stack([
+      -self.A + a0 * (self.m_1 - self.r * (1 - (x0 + x1) / self.T_max) + self.r * x0 / self.T_max + u0 * self.k * x2) - a1 * u0 * self.k * x2,
+      a0 * self.r * x0 / self.T_max + a1 * self.m_2 - a2 * self.N * self.m_2,
+      a0 * (self.s / (1 + x2) ** 2 + u0 * self.k * x0) - a1 * u0 * self.k * x0 + a2 * self.m_3], axis=-1)
+
+  def optim_characterization(self, adj, x, t=None):          # hiv_treatment.py:127-131
+    char = (1 + 0.5 * self.k * x[:, 0] * x[:, 2] * (adj[:, 1] - adj[:, 0])).reshape(-1, 1)
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], char))
+
 class EpidemicSEIRN(System):
   """myriad/systems/lenhart/epidemic_seirn.py:41-95."""
   name = "EPIDEMICSEIRN"
@@ -327,6 +393,23 @@ class EpidemicSEIRN(System):
   def cost(self, x, u, t=None):                              # epidemic_seirn.py:94-95
     return self.A * x[..., 2] + u[..., 0] ** 2
 
+
+  adj_T = None
+
+  def np_dynamics(self, x, u):
+    x0, x1, x2, x3, u0 = x[..., 0], x[..., 1], x[..., 2], x[..., 3], u[..., 0]
+    return np.stack([self.b * x3 - self.d * x0 - self.c * x0 * x2 - u0 * x0, self.c * x0 * x2 - (self.e + self.d) * x1,
+                     self.e * x1 - (self.g + self.a + self.d) * x2, (self.b - self.d) * x3 - self.a * x2], axis=-1)
+
+  def adj_ODE(self, adj, x, u, t=None):                      # epidemic_seirn.py:97-105 (the (d - d) factor is the reference's)
+    x0, x2, u0, a0, a1, a2, a3 = x[..., 0], x[..., 2], u[..., 0], adj[..., 0], adj[..., 1], adj[..., 2], adj[..., 3]
+    return np.stack([a0 * (self.d + self.c * x2 + u0) - a1 * self.c * x2, a1 * (self.e + self.d) - a2 * self.e,
+                     -self.A + a0 * self.c * x0 - a1 * self.c * x0 + a2 * (self.g + self.a + self.d) + a3 * self.a,
+                     -self.b * a0 + a3 * (self.d - self.d)], axis=-1)
+
+  def optim_characterization(self, adj, x, t=None):          # epidemic_seirn.py:107-111
+    char = (adj[:, 0] * x[:, 0] / 2).reshape(-1, 1)
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], char))
 
 class SEIR(EpidemicSEIRN):
   """myriad/systems/miscellaneous/seir.py:44-95: the same field with fixed constants and box bounds on the states."""
@@ -363,10 +446,36 @@ class BearPopulations(System):
   def cost(self, x, u, t=None):                              # bear_populations.py:109-110
     return x[..., 2] + self.c_p * u[..., 0] ** 2 + self.c_f * u[..., 1] ** 2
 
+  adj_T = None
+
+  def np_dynamics(self, x, u):
+    k, k2 = self.r / self.K, self.r / self.K ** 2
+    x0, x1, u0, u1 = x[..., 0], x[..., 1], u[..., 0], u[..., 1]
+    return np.stack([self.r * x0 - k * x0 ** 2 + k * self.m_f * (1 - x0 / self.K) * x1 ** 2 - u0 * x0,
+                     self.r * x1 - k * x1 ** 2 + k * self.m_p * (1 - x1 / self.K) * x0 ** 2 - u1 * x1,
+                     k * (1 - self.m_p) * x0 ** 2 + k * (1 - self.m_f) * x1 ** 2 + k2 * self.m_f * x0 * x1 ** 2 + k2 * self.m_p * (x0 ** 2) * x1], axis=-1)
+
+  def adj_ODE(self, adj, x, u, t=None):                      # bear_populations.py:117-131
+    k, k2 = self.r / self.K, self.r / self.K ** 2
+    x0, x1, u0, u1, a0, a1, a2 = x[..., 0], x[..., 1], u[..., 0], u[..., 1], adj[..., 0], adj[..., 1], adj[..., 2]
+    return np.stack([
+      a0 * (2 * k * x0 + k2 * self.m_f * x1 ** 2 + u0 - self.r) - a1 * (2 * k * self.m_p * (1 - x1 / self.K) * x0)
+      + a2 * (2 * k * (self.m_p - 1) * x0 - k2 * self.m_f * x1 ** 2 - 2 * k2 * self.m_p * x0 * x1),
+      a1 * (2 * k * x1 + k2 * self.m_p * x0 ** 2 + u1 - self.r) - a0 * (2 * k * self.m_f * (1 - x0 / self.K) * x1)
+      + a2 * (2 * k * (self.m_f - 1) * x1 - 2 * k2 * self.m_f * x0 * x1 - k2 * self.m_p * x0 ** 2),
+      -np.ones_like(a0)], axis=-1)
+
+  def optim_characterization(self, adj, x, t=None):          # bear_populations.py:133-142
+    c0 = np.minimum(self.bounds[-2, 1], np.maximum(self.bounds[-2, 0], (adj[:, 0] * x[:, 0] / (2 * self.c_p)).reshape(-1, 1)))
+    c1 = np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], (adj[:, 1] * x[:, 1] / (2 * self.c_f)).reshape(-1, 1)))
+    return np.hstack((c0, c1))
+
 
 def _angle_normalize(x):
   """pendulum.py:17-18 (Python / jnp `%`: result has the sign of the divisor -> torch.remainder)."""
   return torch.remainder(x + math.pi, 2 * math.pi) - math.pi
+
+
 
 
 class Pendulum(System):
@@ -468,6 +577,20 @@ class Bacteria(System):
     return -self.C * x_T.squeeze()
 
 
+  def np_dynamics(self, x, u):
+    return self.r * x + self.A * u * x - self.B * u ** 2 * np.exp(-x)
+
+  @property
+  def adj_T(self):                                           # bacteria.py:50
+    return np.array([self.C])
+
+  def adj_ODE(self, adj, x, u, t=None):                      # bacteria.py:88-90
+    return -adj * (self.r + self.A * u + self.B * u ** 2 * np.exp(-x))
+
+  def optim_characterization(self, adj, x, t=None):          # bacteria.py:92-95
+    char = adj * self.A * x / (2 * (1 + self.B * adj * np.exp(-x)))
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], char))
+
 class Tumour(System):
   """myriad/systems/miscellaneous/tumour.py:52-108 (zero running cost; the objective is the terminal tumour volume)."""
   name = "TUMOUR"
@@ -516,6 +639,18 @@ class Harvest(System):
     return -1 * self.A * (self.k * t / (t + 1)) * x[..., 0] * u[..., 0] + u[..., 0] ** 2
 
 
+  adj_T = None
+
+  def np_dynamics(self, x, u):
+    return -(self.m + u) * x
+
+  def adj_ODE(self, adj, x, u, t=None):                      # harvest.py:64-66
+    return adj * (self.m + u) - self.A * (self.k * t / (t + 1)) * u
+
+  def optim_characterization(self, adj, x, t=None):          # harvest.py:68-71
+    char = 0.5 * x * (self.A * (self.k * t / (t + 1)) - adj)
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], char))
+
 class TimberHarvest(System):
   """myriad/systems/lenhart/timber_harvest.py:36-85."""
   name = "TIMBERHARVEST"
@@ -536,6 +671,20 @@ class TimberHarvest(System):
     t = torch.zeros((), dtype=DT) if t is None else t
     return -torch.exp(-self.r * t) * x[..., 0] * (1 - u[..., 0])
 
+
+  adj_T = None
+
+  def np_dynamics(self, x, u):
+    return self.k * x * u
+
+  def adj_ODE(self, adj, x, u, t=None):                      # timber_harvest.py:87-92
+    return u * (np.exp(-self.r * t) - self.k * adj) - np.exp(-self.r * t)
+
+  def optim_characterization(self, adj, x, t=None):          # timber_harvest.py:94-103 (bang-bang)
+    temp = x[:, :1] * (self.k * adj[:, :1] - np.exp(-self.r * t[:, :1]))
+    bmax = np.max(np.abs(self.bounds[-1]))
+    char = np.sign(temp) * 2 * bmax + bmax
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], char))
 
 class NodeCartPole(CartPole):
   """myriad/systems/neural_ode/node_system.py:14-42 over CARTPOLE: dynamics = net.apply(params, [x;u]) with the MLP of
@@ -821,48 +970,54 @@ class Callbacks:
     return self._jac(_t(z)).numpy()
 
 
-def _rk4_fbsm(dyn, x_t1, u, u_next, v, v_next, h):
-  """utils.py:166-175: RK4 step with the costates averaged at the half step."""
+def _rk4_fbsm(dyn, x_t1, u, u_next, v, v_next, h, t):
+  """utils.py:166-175: RK4 step with the costates averaged at the half step (stage times t, t + h/2, t + h)."""
   um, vm = (u + u_next) / 2, (v + v_next) / 2
-  k1 = dyn(x_t1, u, v)
-  k2 = dyn(x_t1 + h * k1 / 2, um, vm)
-  k3 = dyn(x_t1 + h * k2 / 2, um, vm)
-  k4 = dyn(x_t1 + h * k3, u_next, v_next)
+  k1 = dyn(x_t1, u, v, t)
+  k2 = dyn(x_t1 + h * k1 / 2, um, vm, t + h / 2)
+  k3 = dyn(x_t1 + h * k2 / 2, um, vm, t + h / 2)
+  k4 = dyn(x_t1 + h * k3, u_next, v_next, t + h)
   return x_t1 + (h / 6) * (k1 + 2 * k2 + 2 * k3 + k4)
 
 
-def integrate_fbsm(dyn, x_0, u, h, N, v=None):
+def integrate_fbsm(dyn, x_0, u, h, N, v=None, t=None):
   """utils.py:138-197, continuous systems: forward (h > 0) from index 0, backward (h < 0) from index N."""
   if v is None:
     v = np.zeros_like(u)
+  if t is None:
+    t = np.zeros(N + 1)
   out = np.zeros((N + 1,) + np.shape(x_0))
   if h >= 0:
     out[0] = x_0
     for i in range(N):
-      out[i + 1] = _rk4_fbsm(dyn, out[i], u[i], u[i + 1], v[i], v[i + 1], h)
+      out[i + 1] = _rk4_fbsm(dyn, out[i], u[i], u[i + 1], v[i], v[i + 1], h, t[i])
   else:
     out[N] = x_0
     for i in range(N, 0, -1):
-      out[i - 1] = _rk4_fbsm(dyn, out[i], u[i], u[i - 1], v[i], v[i - 1], h)
+      out[i - 1] = _rk4_fbsm(dyn, out[i], u[i], u[i - 1], v[i], v[i - 1], h, t[i])
   return out
 
 
 def fbsm(system, N: int = 1000, delta: float = 0.001, max_sweeps: int = 10000):
   """Forward-Backward Sweep (trajectory_optimizers/forward_backward_sweep.py:20-116) for systems without terminal
-  state conditions; stopping rule of trajectory_optimizers/base.py:128-141.  Returns {'x','u','adj','sweeps'}."""
+  state conditions; stopping rule of trajectory_optimizers/base.py:128-141.  Returns {'x','u','adj','sweeps'}.
+  Systems provide np_dynamics(x, u), adj_ODE(adj, x, u, t) and optim_characterization(adj, x, t) on [N+1, .] arrays."""
   ns = system.x_0.shape[0]
+  nu = system.bounds.shape[0] - ns
   h = system.T / N
+  t = np.linspace(0, system.T, N + 1)                          # :48
   x = np.vstack([system.x_0, np.zeros((N, ns))])               # :38
-  u = np.zeros((N + 1, 1))                                     # :42
-  adj = np.zeros((N + 1, ns))                                  # :46 (adj_T None)
-  f = lambda x_, u_, v_: system.np_dynamics(x_, u_)
-  a = lambda adj_, x_, u_: system.adj_ODE(adj_, x_, u_)
+  u = np.zeros((N + 1, nu))                                    # :42
+  adj_T = getattr(system, "adj_T", None)
+  adj = np.zeros((N + 1, ns)) if adj_T is None else np.vstack([np.zeros((N, ns)), np.asarray(adj_T, dtype=np.float64)])   # :44-47
+  f = lambda x_, u_, v_, t_: system.np_dynamics(x_, u_)
+  a = lambda adj_, x_, u_, t_: system.adj_ODE(adj_, x_, u_, t_)
   n = 0
   while True:
     old_u, old_x, old_adj = u.copy(), x.copy(), adj.copy()
-    x = integrate_fbsm(f, x[0], u, h, N)                                   # :95-96
-    adj = integrate_fbsm(a, adj[-1], x, -h, N, u)                          # :97-98
-    u = 0.5 * (system.optim_characterization(adj, x) + old_u)              # :100-102
+    x = integrate_fbsm(f, x[0], u, h, N, t=t)                              # :95-96
+    adj = integrate_fbsm(a, adj[-1], x, -h, N, u, t=t)                     # :97-98
+    u = 0.5 * (system.optim_characterization(adj, x, t[:, None]) + old_u)  # :100-102
     n += 1
     stop = np.hstack([np.abs(v).sum(0) * delta - np.abs(v - o).sum(0) for v, o in ((u, old_u), (x, old_x), (adj, old_adj))])
     if not (stop.min() < 0) or n >= max_sweeps:                            # base.py:141

@@ -27,6 +27,27 @@ def test_fbsm_matches_oracle_restatement(st):
     np.testing.assert_allclose(sol[k], ref[k], rtol=1e-11, atol=1e-12, err_msg=k)
 
 
+ALL12 = ["SIMPLECASE", "CANCERTREATMENT", "BACTERIA", "BEARPOPULATIONS", "BIOREACTOR", "EPIDEMICSEIRN", "GLUCOSE", "HARVEST", "HIVTREATMENT",
+         "MOULDFUNGICIDE", "SIMPLECASEWITHBOUNDS", "TIMBERHARVEST"]
+
+
+@pytest.mark.parametrize("name", ALL12)
+def test_fbsm_all_indirect_systems_match_oracle(name):
+  """adj_ODE / optim_characterization of every continuous IndirectFHCS system without terminal state conditions (device:
+  csrc/fbsm.h; oracle: numpy restatement of the same reference lines), incl. adj_T (BACTERIA), two controls
+  (BEARPOPULATIONS), explicit time (HARVEST, TIMBERHARVEST), bang-bang characterisations (BIOREACTOR, TIMBERHARVEST) and
+  the unclipped one (GLUCOSE)."""
+  from oracle import myriad_oracle as O
+  hp = HParams(system=SystemType[name], optimizer=OptimizerType.FBSM, fbsm_intervals=200)
+  opt = get_optimizer(hp, CFG, hp.system())
+  r = opt.solve_batch(max_sweeps=300)
+  ref = O.fbsm(O.SYSTEMS[name](), 200, max_sweeps=300)
+  assert int(r['sweeps'][0]) == ref['sweeps']
+  for k in ('x', 'u', 'adj'):
+    sc = max(1.0, np.abs(ref[k]).max())
+    np.testing.assert_allclose(r[k][0], ref[k], rtol=1e-9, atol=1e-11 * sc, err_msg=k)
+
+
 def test_fbsm_parameter_sweep_matches_per_instance_oracle():
   from oracle import myriad_oracle as O
   hp = HParams(system=SystemType.CANCERTREATMENT, optimizer=OptimizerType.FBSM, fbsm_intervals=200)
@@ -66,6 +87,7 @@ def test_direct_sqp_solution_agrees_with_pontryagin_solution(st):
 
 
 def test_fbsm_rejects_systems_without_adjoint():
-  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.FBSM)
-  with pytest.raises(NotImplementedError):
-    get_optimizer(hp, CFG, hp.system())
+  for st in (SystemType.CARTPOLE, SystemType.SEIR, SystemType.INVASIVEPLANT):     # no adjoint / no adjoint / discrete
+    hp = HParams(system=st, optimizer=OptimizerType.FBSM)
+    with pytest.raises(NotImplementedError):
+      get_optimizer(hp, CFG, hp.system())
