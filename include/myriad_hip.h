@@ -49,10 +49,11 @@ enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2,
        MYR_SYS_PENDULUM = 13, MYR_SYS_MOUNTAINCAR = 14, MYR_SYS_ROCKETLANDING = 15,
        /* systems with a (linear) terminal cost: lenhart/bacteria.py, miscellaneous/tumour.py.  The terminal
           term is applied where the reference applies it for collocation -- the TRAPEZOIDAL objective (trapezoidal.py:126-127)
-          and the rollout (utils.py:295-296), not the Hermite-Simpson objective; SHOOTING returns MYR_E_UNSUPPORTED */
+          the rollout (utils.py:295-296) and, on the integrated end state of the last interval, the SHOOTING objective
+          (shooting.py:206-208); not the Hermite-Simpson objective */
        MYR_SYS_BACTERIA = 16, MYR_SYS_TUMOUR = 17,
-       /* running cost g(x,u,t) with explicit time (lenhart/harvest.py:61-62, timber_harvest.py:84-85): collocation
-          transcriptions and the rollout; SHOOTING returns MYR_E_UNSUPPORTED */
+       /* running cost g(x,u,t) with explicit time (lenhart/harvest.py:61-62, timber_harvest.py:84-85): every transcription
+          evaluates it at the reference's point / step times */
        MYR_SYS_HARVEST = 18, MYR_SYS_TIMBERHARVEST = 19 };
 /* transcription: OptimizerType x QuadratureRule (config.py:12-57) */
 enum { MYR_TR_HERMITE_SIMPSON = 0, MYR_TR_TRAPEZOIDAL = 1, MYR_TR_SHOOTING = 2 };

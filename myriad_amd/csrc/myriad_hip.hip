@@ -274,9 +274,7 @@ static int eval_for_system(myr_handle h, int B, const double* z, const double* p
     switch (h->d.transcription) {
       case MYR_TR_HERMITE_SIMPSON: return launch_hs_eval<Sys, EVAL_HS>(h, B, z, params, pstride, f, g, c, j);
       case MYR_TR_TRAPEZOIDAL: return launch_hs_eval<Sys, EVAL_TRAP>(h, B, z, params, pstride, f, g, c, j);
-      case MYR_TR_SHOOTING:
-        if constexpr (Sys::HAS_TERMINAL || Sys::TIME_DEP) return fail(MYR_E_UNSUPPORTED, "shooting with a terminal or time-dependent cost is not built: use a collocation transcription");
-        else return launch_shoot_eval<Sys>(h, B, z, params, pstride, f, g, c, j);
+      case MYR_TR_SHOOTING: return launch_shoot_eval<Sys>(h, B, z, params, pstride, f, g, c, j);
     }
   }
   return fail(MYR_E_ARG, "eval: unknown transcription");
@@ -682,10 +680,7 @@ static int solve_for_system(myr_handle h, int B, double* z, const double* lb, co
     case MYR_TR_SHOOTING:
       if (h->d.integration_method != MYR_INT_EULER && h->d.integration_method != MYR_INT_HEUN)
         return fail(MYR_E_UNSUPPORTED, "myr_solve: shooting solve is built for EULER and HEUN steps (RK4 / MIDPOINT: rollout only)");
-      if constexpr (Sys::HAS_TERMINAL || Sys::TIME_DEP)
-        return fail(MYR_E_UNSUPPORTED, "shooting with a terminal or time-dependent cost is not built: use a collocation transcription");
-      else
-        return launch_lane_solve<ShootCore<Sys>, Sys>(h, B, ShootCore<Sys>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+      return launch_lane_solve<ShootCore<Sys>, Sys>(h, B, ShootCore<Sys>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   return fail(MYR_E_ARG, "solve: unknown transcription");
 }

@@ -478,36 +478,66 @@ struct ShootCore {
   MYR_HD static void solve_nu(const SweepOut& so, double mu, double* nu) { H::solve_nu(so, mu, nu); }
 
   // one integration step of [x; integral of g]  (utils.py:41-44 Heun, :52-54 Euler), plain values
+  // t0: time at the start of the step (cost functions with explicit time, shooting.py:196-203 integrates with the global
+  // step times); last: the final step of the final interval, whose end state carries the terminal cost (shooting.py:206-208)
   MYR_HD static inline void step_val(int method, double h, const double* x, const double* u, const double* un, const double* p,
-                                     double* xn, double& dc) {
+                                     double* xn, double& dc, double t0 = 0.0, bool last = false) {
     double f1[NS];
     Sys::f(x, u, p, f1);
+    set_time<Sys>(p, t0);
     const double g1 = Sys::g(x, u, p);
     if (method == 0) {
 #pragma unroll
       for (int c = 0; c < NS; ++c) xn[c] = x[c] + h * f1[c];
       dc = h * g1;
+      if constexpr (Sys::HAS_TERMINAL) { if (last) dc += Sys::term(xn, un, p); }
       return;
     }
     double xt[NS], f2[NS];
 #pragma unroll
     for (int c = 0; c < NS; ++c) xt[c] = x[c] + h * f1[c];
     Sys::f(xt, un, p, f2);
+    set_time<Sys>(p, t0 + h);
     const double g2 = Sys::g(xt, un, p);
 #pragma unroll
     for (int c = 0; c < NS; ++c) xn[c] = x[c] + 0.5 * h * (f1[c] + f2[c]);
     dc = 0.5 * h * (g1 + g2);
+    if constexpr (Sys::HAS_TERMINAL) { if (last) dc += Sys::term(xn, un, p); }
   }
 
   // step linearisation: Fy (NS x NY) = d x_next / d (x, u, u_next), gy = d dc / dy, and, for costate pin of x_next,
   // Hs = d2 (dc + pin^T x_next) / dy2
+  // A (linear) terminal cost on x_next is folded into the last step: its gradient joins the costate for the Hessian term
+  // and is pulled back through Fy into gy.
   MYR_HD static inline void step_lin(int method, double h, const double* x, const double* u, const double* un, const double* p,
-                                     const double* pin, double* Fy, double* gy, double* Hs) {
+                                     const double* pin_in, double* Fy, double* gy, double* Hs, double t0 = 0.0, bool last = false) {
+    double pin[NS], tg[NW];
+#pragma unroll
+    for (int c = 0; c < NW; ++c) tg[c] = 0.0;
+    if constexpr (Sys::HAS_TERMINAL) { if (last) Sys::term_grad(x, un, p, tg); }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) pin[c] = pin_in[c] + tg[c];
+    auto fold = [&]() {
+      if constexpr (Sys::HAS_TERMINAL) {
+        if (last) {
+#pragma unroll
+          for (int c = 0; c < NY; ++c) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int t = 0; t < NS; ++t) s2 += tg[t] * Fy[t * NY + c];
+            gy[c] += s2;
+          }
+#pragma unroll
+          for (int a = 0; a < NU; ++a) gy[NW + a] += tg[NS + a];
+        }
+      }
+    };
     HsPoint<Sys> P1;
 #pragma unroll
     for (int c = 0; c < NS; ++c) P1.x[c] = x[c];
 #pragma unroll
     for (int a = 0; a < NU; ++a) P1.u[a] = u[a];
+    set_time<Sys>(p, t0);
     Sys::lin_d2(P1.x, P1.u, p, P1.f, P1.A, P1.B, &P1.g, P1.gw, P1.D2);
 #pragma unroll
     for (int i = 0; i < NY * NY; ++i) Hs[i] = 0.0;
@@ -531,6 +561,7 @@ struct ShootCore {
       for (int r = 0; r < NW; ++r)
 #pragma unroll
         for (int c = 0; c < NW; ++c) Hs[r * NY + c] = W1[r * NW + c];
+      fold();
       return;
     }
     const double hh = 0.5 * h;
@@ -539,6 +570,7 @@ struct ShootCore {
     for (int c = 0; c < NS; ++c) P2.x[c] = x[c] + h * P1.f[c];
 #pragma unroll
     for (int a = 0; a < NU; ++a) P2.u[a] = un[a];
+    set_time<Sys>(p, t0 + h);
     Sys::lin_d2(P2.x, P2.u, p, P2.f, P2.A, P2.B, &P2.g, P2.gw, P2.D2);
     // J2 = d w2 / dy (NW x NY): x~ rows [I + h A1, h B1, 0], u_next rows [0, 0, I]
     double J2[NW * NY];
@@ -603,6 +635,7 @@ struct ShootCore {
         for (int t = 0; t < NW; ++t) s += J2[t * NY + r] * T[t * NY + c];
         Hs[r * NY + c] = s;
       }
+    fold();
   }
 
   // own (bound) terms of one decision variable
@@ -632,7 +665,7 @@ struct ShootCore {
         for (int c = 0; c < NS; ++c) w.st[xs0 + (long)i * NS + c] = x[c];
 #pragma unroll
         for (int a = 0; a < NU; ++a) { u[a] = w.z[ui(o, i, a)]; un[a] = w.z[ui(o, i + 1, a)]; }
-        step_val(method, h, x, u, un, p, xn, dc);
+        step_val(method, h, x, u, un, p, xn, dc, h * i, i == S - 1);
         so.f += dc;
 #pragma unroll
         for (int c = 0; c < NS; ++c) x[c] = xn[c];
@@ -690,7 +723,7 @@ struct ShootCore {
       for (int c = 0; c < NS; ++c) x[c] = w.st[xs0 + (long)i * NS + c];
 #pragma unroll
       for (int a = 0; a < NU; ++a) { u[a] = w.z[ui(o, i, a)]; un[a] = w.z[ui(o, i + 1, a)]; }
-      step_lin(method, h, x, u, un, p, pin, Fy, gy, Hs);
+      step_lin(method, h, x, u, un, p, pin, Fy, gy, Hs, h * i, i == S - 1);
       // control-row stationarity of u_{i+1}
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
@@ -854,7 +887,7 @@ struct ShootCore {
         double u[NU], xn[NS], dc;
 #pragma unroll
         for (int a = 0; a < NU; ++a) { u[a] = un[a]; un[a] = val(ui(o, i + 1, a)); }
-        step_val(method, h, x, u, un, p, xn, dc);
+        step_val(method, h, x, u, un, p, xn, dc, h * i, i == I * cpi - 1);
         f += dc;
 #pragma unroll
         for (int c = 0; c < NS; ++c) x[c] = xn[c];

@@ -49,7 +49,7 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
       double xn[NS], dc;
 #pragma unroll
       for (int c = 0; c < NS; ++c) xs[(long)j * NS + c] = x[c];
-      SC::step_val(method, h, x, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, xn, dc);
+      SC::step_val(method, h, x, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, xn, dc, h * i, i == S - 1);
       ftot += dc;
 #pragma unroll
       for (int c = 0; c < NS; ++c) x[c] = xn[c];
@@ -78,7 +78,7 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
       double xi[NS], Fy[NS * NY], gy[NY], Hs[NY * NY];
 #pragma unroll
       for (int c = 0; c < NS; ++c) xi[c] = xs[(long)j * NS + c];
-      SC::step_lin(method, h, xi, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, zero, Fy, gy, Hs);
+      SC::step_lin(method, h, xi, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, zero, Fy, gy, Hs, h * i, i == S - 1);
       // column block of u_{i+1}: this step's d/du_next + what step i+1 contributed as its own d/du
 #pragma unroll
       for (int u = 0; u < NU; ++u) {

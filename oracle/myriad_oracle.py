@@ -918,11 +918,13 @@ def shooting(system: System, intervals: int, controls_per_interval: int, method:
   def objective(z):                                            # :169-210, augmented_dynamics :80-92
     xs, us = split(z)
     ru = reorganize_controls(us).transpose(0, 1)
-    def aug(x_and_c, u):
+    def aug(x_and_c, u, t):
       x = x_and_c[..., :-1]
-      return torch.cat([system.dynamics(x, u), system.cost(x, u)[..., None]], dim=-1)
+      return torch.cat([system.dynamics(x, u), system.cost(x, u, t)[..., None]], dim=-1)
+    t = torch.linspace(0., system.T, S + 1, dtype=DT)          # :196
+    ts = torch.cat([t[:-1].reshape(I, cpi), t[::cpi][1:].reshape(I, 1)], dim=1).transpose(0, 1)   # reorganize_times :132-142
     start = torch.cat([xs[:-1], torch.zeros(I, 1, dtype=DT)], dim=1)      # :198
-    end, _ = integrate_time_independent(aug, start, ru, step, cpi, method)
+    end, _ = integrate(aug, start, ru, step, cpi, ts, method)             # :199-203 (integrate_in_parallel with the step times)
     total = end[:, -1].sum()                                   # :205
     if system.terminal_cost:                                   # :206-208: on the INTEGRATED end state of the last interval
       total = total + system.terminal_cost_fn(end[-1, :-1], us[-1])

@@ -136,12 +136,43 @@ def test_discrete_system_is_refused_like_the_reference():
   with pytest.raises(NotImplementedError):                       # trajectory_optimizers/base.py:66-67
     get_optimizer(hp, CFG, hp.system())
 
+def _shooting_checks(sysname, sys_host, sys_oracle):
+  from oracle import myriad_oracle as O
+  for method in ("HEUN", "EULER"):
+    hp = HParams(system=SystemType[sysname], optimizer=OptimizerType.SHOOTING, intervals=2, controls_per_interval=6,
+                 integration_method=IntegrationMethod[method], nlpsolver=NLPSolverType.SQP, max_iter=500)
+    tr = O.shooting(sys_oracle, 2, 6, method)
+    cb = O.Callbacks(tr)
+    o = get_optimizer(hp, CFG, sys_host)
+    rng = np.random.default_rng(8)
+    z = np.abs(tr.guess * (1.0 + 0.05 * rng.standard_normal(tr.guess.size))) + 0.05
+    np.testing.assert_allclose(o.constraints(z), cb.cons(z), rtol=1e-11, atol=1e-11 * max(1.0, np.abs(z).max()))
+    assert o.objective(z) == pytest.approx(cb.fun(z), rel=1e-12)
+    g_ref = cb.grad(z)
+    np.testing.assert_allclose(o.objective_grad(z), g_ref, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(g_ref).max()))
+    np.testing.assert_allclose(o.constraints_jac(z), cb.jac(z), rtol=1e-10, atol=1e-11)
+  # solve (Heun, 1 x 20 as the reference's default shape)
+  hp = HParams(system=SystemType[sysname], optimizer=OptimizerType.SHOOTING, intervals=1, controls_per_interval=20, nlpsolver=NLPSolverType.SQP, max_iter=500)
+  tr = O.shooting(sys_oracle, 1, 20, "HEUN")
+  cb = O.Callbacks(tr)
+  r = get_optimizer(hp, CFG, sys_host).solve_batch()
+  assert r['status'][0] == 0, (sysname, r['status'], r['iters'], r['kkt'])
+  z, lam = r['xs_and_us'][0], r['lambda'][0]
+  assert np.abs(cb.cons(z)).max() <= 1e-8 * max(1.0, np.abs(z).max())
+  assert cb.fun(z) == pytest.approx(r['cost'][0], rel=1e-10)
+  lb, ub = tr.bounds[:, 0], tr.bounds[:, 1]
+  rr = cb.grad(z) + cb.jac(z).T @ lam
+  width = np.where(np.isfinite(ub - lb), ub - lb, 1.0)
+  inact = (lb < ub) & (z - lb > 1e-3 * width) & (ub - z > 1e-3 * width)
+  if inact.any():
+    assert np.abs(rr[inact]).max() < 1e-4 * max(1.0, np.abs(cb.grad(z)).max())
+
 
 @pytest.mark.parametrize("sysname", ["BACTERIA", "TUMOUR"])
 def test_terminal_cost_systems_follow_the_reference_rule(sysname):
   """Linear terminal costs (bacteria.py:84-86, tumour.py:106-108): applied by the TRAPEZOIDAL objective
   (trapezoidal.py:126-127) and the rollout (utils.py:295-296), NOT by the Hermite-Simpson objective
-  (hermite_simpson.py:243-257 has no terminal term); shooting is refused."""
+  (hermite_simpson.py:243-257 has no terminal term); shooting applies it to the integrated end state."""
   from myriad_amd.utils import get_state_trajectory_and_cost
   for quad, N in (("TRAPEZOIDAL", 7), ("HERMITE_SIMPSON", 5)):
     hp = HParams(system=SystemType[sysname], optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule[quad], intervals=N,
@@ -177,10 +208,9 @@ def test_terminal_cost_systems_follow_the_reference_rule(sysname):
   _, c = get_state_trajectory_and_cost(hp2, hp2.system(), hp2.system().x_0, us)
   _, c_ref = O.get_state_trajectory_and_cost(s, hp2.num_steps, hp2.integration_method.name, s.x_0, us)
   assert c == pytest.approx(c_ref, rel=1e-11)
-  # shooting: refused, loudly
-  hp3 = HParams(system=SystemType[sysname], optimizer=OptimizerType.SHOOTING, intervals=2, controls_per_interval=5, nlpsolver=NLPSolverType.SQP)
-  with pytest.raises(NotImplementedError):
-    get_optimizer(hp3, CFG, hp3.system()).solve()
+  # shooting (the reference's default optimiser): the terminal cost sits on the INTEGRATED end state of the last interval
+  # (shooting.py:206-208); callbacks against the oracle's autodiff, then a solve checked against the oracle's KKT conditions
+  _shooting_checks(sysname, hp.system(), O.SYSTEMS[sysname]())
 
 
 @pytest.mark.parametrize("sysname,kw", [("HARVEST", {}), ("TIMBERHARVEST", {"r": 0.3})])
@@ -225,6 +255,4 @@ def test_time_dependent_cost_systems(sysname, kw):
     _, c = get_state_trajectory_and_cost(hp2, sh, sh.x_0, us)
     _, c_ref = O.get_state_trajectory_and_cost(so, hp2.num_steps, method, so.x_0, us)
     assert c == pytest.approx(c_ref, rel=1e-11), method
-  hp3 = HParams(system=SystemType[sysname], optimizer=OptimizerType.SHOOTING, intervals=2, controls_per_interval=5, nlpsolver=NLPSolverType.SQP)
-  with pytest.raises(NotImplementedError):
-    get_optimizer(hp3, CFG, sh).solve()
+  _shooting_checks(sysname, sh, so)
