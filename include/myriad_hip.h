@@ -54,7 +54,9 @@ enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2,
        MYR_SYS_BACTERIA = 16, MYR_SYS_TUMOUR = 17,
        /* running cost g(x,u,t) with explicit time (lenhart/harvest.py:61-62, timber_harvest.py:84-85): every transcription
           evaluates it at the reference's point / step times */
-       MYR_SYS_HARVEST = 18, MYR_SYS_TIMBERHARVEST = 19 };
+       MYR_SYS_HARVEST = 18, MYR_SYS_TIMBERHARVEST = 19,
+       /* lenhart/predator_prey.py: terminal cost and ONE pinned terminal state (x_T = [None, None, B]) */
+       MYR_SYS_PREDATORPREY = 20 };
 /* transcription: OptimizerType x QuadratureRule (config.py:12-57) */
 enum { MYR_TR_HERMITE_SIMPSON = 0, MYR_TR_TRAPEZOIDAL = 1, MYR_TR_SHOOTING = 2 };
 /* IntegrationMethod (config.py:46-50) */
@@ -189,8 +191,9 @@ int myr_exgd(myr_handle h, int32_t B, double* z, double* lam, const double* lb, 
  * RK4 sweeps utils.py:138-197; stopping rule trajectory_optimizers/base.py:128-141) for B instances of the handle's
  * system.  Built for the continuous-time IndirectFHCS systems without terminal STATE conditions: SIMPLECASE,
  * CANCERTREATMENT, BACTERIA, BEARPOPULATIONS, BIOREACTOR, EPIDEMICSEIRN, GLUCOSE, HARVEST, HIVTREATMENT, MOULDFUNGICIDE,
- * SIMPLECASEWITHBOUNDS, TIMBERHARVEST (others return MYR_E_UNSUPPORTED; the secant `sequencesolver` for terminal state
- * conditions and the discrete variant are not built).  The handle's transcription is not used.
+ * SIMPLECASEWITHBOUNDS, TIMBERHARVEST, PREDATORPREY (others return MYR_E_UNSUPPORTED).  The secant `sequencesolver` for a
+ * terminal state condition (PREDATORPREY) is a host loop over this call with different adj_T; the discrete variant is
+ * not built.  The handle's transcription is not used.
  *   N = hp.fbsm_intervals; x0 [B][ns]; adj_T [ns] or NULL (= 0); params as in myr_eval;
  *   clip_lo / clip_hi [nu]: the bounds each control's optim_characterization is clipped with (+-inf = not clipped);
  *   bang: max|bounds[-1]| for the bang-bang characterisations; delta: stopping tolerance (0.001)

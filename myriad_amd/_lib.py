@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmyriad_hip.so")
 SYS_IDS = {"CARTPOLE": 0, "VANDERPOL": 1, "CANCERTREATMENT": 2, "SIMPLECASE": 3, "NODE_CARTPOLE": 4, "BIOREACTOR": 5,
            "GLUCOSE": 6, "MOULDFUNGICIDE": 7, "SIMPLECASEWITHBOUNDS": 8, "HIVTREATMENT": 9, "EPIDEMICSEIRN": 10, "SEIR": 11,
            "BEARPOPULATIONS": 12, "PENDULUM": 13, "MOUNTAINCAR": 14, "ROCKETLANDING": 15,
-           "BACTERIA": 16, "TUMOUR": 17, "HARVEST": 18, "TIMBERHARVEST": 19}
+           "BACTERIA": 16, "TUMOUR": 17, "HARVEST": 18, "TIMBERHARVEST": 19, "PREDATORPREY": 20}
 TR_IDS = {"HERMITE_SIMPSON": 0, "TRAPEZOIDAL": 1, "SHOOTING": 2}
 INT_IDS = {"EULER": 0, "HEUN": 1, "MIDPOINT": 2, "RK4": 3}
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -80,6 +80,12 @@ MYR_INDIRECT(SysSIMPLECASEWITHBOUNDS, out[0] = -p[0] + x[0] * adj[0];, u[0] = (p
 // lenhart/timber_harvest.py:87-103       p = (r, k); explicit time; bang-bang
 MYR_INDIRECT(SysTIMBERHARVEST, out[0] = u[0] * (exp(-p[0] * t) - p[1] * adj[0]) - exp(-p[0] * t);,
              u[0] = myr_sign(x[0] * (p[1] * adj[0] - exp(-p[0] * t))) * 2.0 * bang + bang;)
+// lenhart/predator_prey.py:124-137      p = (d_1, d_2, A); adj_T = [1, 0, 0] with the third component set by the secant solver
+MYR_INDIRECT(SysPREDATORPREY,
+             out[0] = adj[0] * (x[1] - 1 + p[0] * u[0]) - adj[1] * x[1];
+             out[1] = adj[0] * x[0] + adj[1] * (1 - x[0] + p[1] * u[0]);
+             out[2] = 0.0;,
+             u[0] = (adj[0] * p[0] * x[0] + adj[1] * p[1] * x[1] - adj[2]) / p[2];)
 #undef MYR_INDIRECT
 
 template <class Sys>

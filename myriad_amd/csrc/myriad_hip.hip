@@ -23,7 +23,7 @@
 #define MYR_CLOSED_FORM_SYSTEMS(X)                                                                               \
   X(CARTPOLE) X(VANDERPOL) X(CANCERTREATMENT) X(SIMPLECASE) X(BIOREACTOR) X(GLUCOSE) X(MOULDFUNGICIDE)           \
   X(SIMPLECASEWITHBOUNDS) X(HIVTREATMENT) X(EPIDEMICSEIRN) X(SEIR) X(BEARPOPULATIONS) X(PENDULUM) X(MOUNTAINCAR)     \
-  X(ROCKETLANDING) X(BACTERIA) X(TUMOUR) X(HARVEST) X(TIMBERHARVEST)
+  X(ROCKETLANDING) X(BACTERIA) X(TUMOUR) X(HARVEST) X(TIMBERHARVEST) X(PREDATORPREY)
 
 
 using namespace myriad;

@@ -22,7 +22,8 @@ class FiniteHorizonControlSystem:
 
   def __init__(self, x_0, x_T, T, bounds, terminal_cost=False, discrete=False):
     self.x_0 = np.asarray(x_0, dtype=np.float64)
-    self.x_T = None if x_T is None else np.asarray(x_T, dtype=np.float64)
+    # a terminal state with unpinned components stays a list with None entries (predator_prey.py:47), as in the reference
+    self.x_T = None if x_T is None else (list(x_T) if any(v is None for v in x_T) else np.asarray(x_T, dtype=np.float64))
     self.T = float(T)
     self.bounds = np.asarray(bounds, dtype=np.float64)
     self.terminal_cost = terminal_cost
@@ -455,6 +456,31 @@ class TimberHarvest(IndirectFHCS):
     return float(-np.exp(-self.r * t) * x_t[0] * (1 - np.squeeze(u_t)))
 
 
+class PredatorPrey(IndirectFHCS):
+  """systems/lenhart/predator_prey.py:40-137: terminal cost x_0(T) and ONE pinned terminal state (x_T = [None, None, B]).  As in
+  the reference only the shooting optimiser and the FBSM secant solver accept it; the collocation optimisers raise
+  TypeError on the None entries (trapezoidal.py:71, hermite_simpson.py:41)."""
+  name = "PREDATORPREY"
+  param_names = ("d_1", "d_2", "A")
+
+  def __init__(self, d_1=.1, d_2=.1, A=1., B=5., guess_a=-.52, guess_b=.5, M=1., x_0=(10., 1., 0.), T=10.):
+    super().__init__(x_0=[x_0[0], x_0[1], x_0[2]], x_T=[None, None, B], T=T, bounds=[[0., 11.], [0., 11.], [0., 5.], [0, M]],
+                     terminal_cost=True)
+    self.adj_T = np.array([1., 0., 0.])
+    self.d_1, self.d_2, self.A, self.guess_a, self.guess_b, self.M = d_1, d_2, A, guess_a, guess_b, M
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):
+    x0, x1, _ = x_t
+    u = float(np.squeeze(u_t))
+    return np.array([(1 - x1) * x0 - self.d_1 * x0 * u, (x0 - 1) * x1 - self.d_2 * x1 * u, u])
+
+  def cost(self, x_t, u_t, t=None):
+    return float(self.A * 0.5 * np.squeeze(u_t) ** 2)
+
+  def terminal_cost_fn(self, x_T, u_T, T=None):
+    return float(x_T[0])
+
+
 class InvasivePlant(IndirectFHCS):
   """systems/lenhart/invasive_plant.py: a DISCRETE-time system.  Kept as a SystemType member for the reference's error
   behaviour: the direct optimisers refuse discrete systems with NotImplementedError (trajectory_optimizers/base.py:66-67);
@@ -469,7 +495,7 @@ class InvasivePlant(IndirectFHCS):
 
 class SystemType(Enum):
   """systems/__init__.py:29-53: an enum of system classes; calling a member instantiates the system.
-  Not built: PREDATORPREY (partially pinned terminal state that only the reference's shooting path accepts)."""
+  All 21 members of the reference's enum are present."""
   CARTPOLE = CartPole
   VANDERPOL = VanDerPol
   SEIR = SEIR
@@ -488,6 +514,7 @@ class SystemType(Enum):
   GLUCOSE = Glucose
   TIMBERHARVEST = TimberHarvest
   BIOREACTOR = Bioreactor
+  PREDATORPREY = PredatorPrey
   INVASIVEPLANT = InvasivePlant
   ROCKETLANDING = RocketLanding
 

@@ -65,9 +65,18 @@ class FBSM(IndirectMethodOptimizer):
     self.x_bounds = system.bounds[:-1]                           # :52-55
     self.u_bounds = system.bounds[-1:]
     bounds = np.vstack((self.x_bounds, self.u_bounds))
+    # additional condition if a terminal state is pinned (:58-70): solved by the secant method over adj(T) of that state
     self.terminal_cdtion = False
-    if system.x_T is not None and any(v is not None for v in system.x_T):
-      raise NotImplementedError("terminal state conditions (sequencesolver, :118-158) are not on the device path")
+    if system.x_T is not None:
+      num_term_state = 0
+      for idx, x_Ti in enumerate(system.x_T):
+        if x_Ti is not None:
+          self.terminal_cdtion = True
+          self.term_cdtion_state = idx
+          self.term_value = float(x_Ti)
+          num_term_state += 1
+        if num_term_state > 1:
+          raise NotImplementedError("Multiple states with terminal condition not supported yet")
     super().__init__(hp, cfg, bounds, guess, unravel)
     self._engine: Optional[_lib.Engine] = None
 
@@ -103,8 +112,44 @@ class FBSM(IndirectMethodOptimizer):
     r = self.engine.fbsm(np.asarray(x0s, dtype=np.float64), self.N, lo, hi, params=p, adj_T=self.system.adj_T, max_sweeps=max_sweeps, bang=bang)
     return {'x': r['x'], 'u': r['u'], 'adj': r['adj'], 'sweeps': r['sweeps']}
 
+  def _solve_with_adj_T(self, adj_T, max_sweeps):
+    lo, hi, bang = self._clip_bounds()
+    r = self.engine.fbsm(self.system.x_0[None], self.N, lo, hi, params=self.system.device_params(), adj_T=adj_T,
+                         max_sweeps=max_sweeps, bang=bang)
+    return r['x'][0], r['u'][0], r['adj'][0]
+
+  def sequencesolver(self, max_sweeps: int = 10000, max_secant: int = 100) -> Dict[str, np.ndarray]:
+    """:118-158: secant method on a = adj(T)[term_cdtion_state] until the terminal state hits its value (|V| <= 1e-10).
+    `reinitiate(a)` (:72-86) resets all guesses, so every evaluation is one fresh device sweep sequence with that adj_T.
+    `max_secant` guards the reference's uncapped loop."""
+    base = np.zeros(self.system.x_0.shape[0]) if self.system.adj_T is None else np.asarray(self.system.adj_T, dtype=np.float64)
+
+    def V(a):
+      aT = base.copy(); aT[self.term_cdtion_state] = a
+      x, u, adj = self._solve_with_adj_T(aT, max_sweeps)
+      return x[-1, self.term_cdtion_state] - self.term_value, (x, u, adj)
+
+    a, b = self.system.guess_a, self.system.guess_b
+    Va, sol = V(a)
+    Vb, _ = V(b)
+    count = 0
+    while abs(Va) > 1e-10 and count < max_secant:
+      if abs(Va) > abs(Vb):
+        a, b = b, a
+        Va, Vb = Vb, Va
+      d = Va * (b - a) / (Vb - Va)
+      b, Vb = a, Va
+      a = a - d
+      Va, sol = V(a)
+      count += 1
+    self.x_guess, self.u_guess, self.adj_guess = sol
+    self.secant_iterations = count
+    return {'x': self.x_guess, 'u': self.u_guess, 'adj': self.adj_guess}
+
   def solve(self) -> Dict[str, np.ndarray]:
     """:88-116 -- {'x': [N+1,ns], 'u': [N+1,nu], 'adj': [N+1,ns]}; the guesses are updated like the reference's."""
+    if self.terminal_cdtion:
+      return self.sequencesolver()
     r = self.solve_batch()
     self.x_guess, self.u_guess, self.adj_guess = r['x'][0], r['u'][0], r['adj'][0]
     return {'x': self.x_guess, 'u': self.u_guess, 'adj': self.adj_guess}

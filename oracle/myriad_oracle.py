@@ -591,6 +591,44 @@ class Bacteria(System):
     char = adj * self.A * x / (2 * (1 + self.B * adj * np.exp(-x)))
     return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], char))
 
+class PredatorPrey(System):
+  """myriad/systems/lenhart/predator_prey.py:40-137 (x_T = [None, None, B]: only the third state is pinned)."""
+  name = "PREDATORPREY"
+  param_names = ("d_1", "d_2", "A")
+  terminal_cost = True
+
+  def __init__(self, d_1=.1, d_2=.1, A=1., B=5., guess_a=-.52, guess_b=.5, M=1., x_0=(10., 1., 0.), T=10.):
+    self.d_1, self.d_2, self.A, self.M, self.guess_a, self.guess_b = d_1, d_2, A, M, guess_a, guess_b
+    self.x_0 = np.array([x_0[0], x_0[1], x_0[2]]); self.x_T = [None, None, B]; self.T = float(T)
+    self.bounds = np.array([[0., 11.], [0., 11.], [0., 5.], [0., M]])
+    self.adj_T = np.array([1., 0., 0.])                        # :66
+
+  def params(self):
+    return np.array([self.d_1, self.d_2, self.A])
+
+  def dynamics(self, x, u):                                  # predator_prey.py:85-96
+    x0, x1, u0 = x[..., 0], x[..., 1], u[..., 0]
+    return torch.stack([(1 - x1) * x0 - self.d_1 * x0 * u0, (x0 - 1) * x1 - self.d_2 * x1 * u0, u0], dim=-1)
+
+  def cost(self, x, u, t=None):                              # predator_prey.py:113-114
+    return self.A * 0.5 * u[..., 0] ** 2
+
+  def terminal_cost_fn(self, x_T, u_T, T=None):              # predator_prey.py:120-122
+    return x_T[..., 0]
+
+  def np_dynamics(self, x, u):
+    x0, x1, u0 = x[..., 0], x[..., 1], u[..., 0]
+    return np.stack([(1 - x1) * x0 - self.d_1 * x0 * u0, (x0 - 1) * x1 - self.d_2 * x1 * u0, u0], axis=-1)
+
+  def adj_ODE(self, adj, x, u, t=None):                      # predator_prey.py:124-130
+    a0, a1, x0, x1, u0 = adj[..., 0], adj[..., 1], x[..., 0], x[..., 1], u[..., 0]
+    return np.stack([a0 * (x1 - 1 + self.d_1 * u0) - a1 * x1, a0 * x0 + a1 * (1 - x0 + self.d_2 * u0), np.zeros_like(a0)], axis=-1)
+
+  def optim_characterization(self, adj, x, t=None):          # predator_prey.py:132-137
+    char = ((adj[:, 0] * self.d_1 * x[:, 0] + adj[:, 1] * self.d_2 * x[:, 1] - adj[:, 2]) / self.A).reshape(-1, 1)
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], char))
+
+
 class Tumour(System):
   """myriad/systems/miscellaneous/tumour.py:52-108 (zero running cost; the objective is the terminal tumour volume)."""
   name = "TUMOUR"
@@ -706,7 +744,7 @@ class NodeCartPole(CartPole):
 
 SYSTEMS = {c.name: c for c in (CartPole, VanDerPol, CancerTreatment, SimpleCase, Bioreactor, Glucose, MouldFungicide,
                                 SimpleCaseWithBounds, HIVTreatment, EpidemicSEIRN, SEIR, BearPopulations, Pendulum, MountainCar,
-                                RocketLanding, Bacteria, Tumour, Harvest, TimberHarvest)}
+                                RocketLanding, Bacteria, Tumour, Harvest, TimberHarvest, PredatorPrey)}
 
 
 # --------------------------------------------------------------------------------------
@@ -1025,6 +1063,46 @@ def fbsm(system, N: int = 1000, delta: float = 0.001, max_sweeps: int = 10000):
     if not (stop.min() < 0) or n >= max_sweeps:                            # base.py:141
       break
   return {"x": x, "u": u, "adj": adj, "sweeps": n}
+
+
+def fbsm_secant(system, N: int = 1000, max_sweeps: int = 10000, max_secant: int = 100):
+  """FBSM.sequencesolver (forward_backward_sweep.py:118-158): secant method on the terminal adjoint of the pinned state."""
+  idx = [i for i, v in enumerate(system.x_T) if v is not None]
+  assert len(idx) == 1
+  idx, val = idx[0], float(system.x_T[idx[0]])
+  base = np.asarray(system.adj_T, dtype=np.float64).copy()
+
+  def V(a):
+    aT = base.copy(); aT[idx] = a                              # reinitiate(a) :72-86
+    s2 = _With(system, adj_T=aT)
+    r = fbsm(s2, N, max_sweeps=max_sweeps)
+    return r["x"][-1, idx] - val, r
+
+  a, b = system.guess_a, system.guess_b
+  Va, sol = V(a)
+  Vb, _ = V(b)
+  count = 0
+  while abs(Va) > 1e-10 and count < max_secant:
+    if abs(Va) > abs(Vb):
+      a, b = b, a
+      Va, Vb = Vb, Va
+    d = Va * (b - a) / (Vb - Va)
+    b, Vb = a, Va
+    a = a - d
+    Va, sol = V(a)
+    count += 1
+  sol["secant_iterations"] = count
+  return sol
+
+
+class _With:
+  """view of a system with some attributes replaced (used to vary adj_T without mutating the system)"""
+  def __init__(self, base, **kw):
+    self.__dict__["_b"] = base
+    self.__dict__["_kw"] = kw
+  def __getattr__(self, k):
+    kw = self.__dict__["_kw"]
+    return kw[k] if k in kw else getattr(self.__dict__["_b"], k)
 
 
 class Lagrangian:

@@ -91,3 +91,17 @@ def test_fbsm_rejects_systems_without_adjoint():
     hp = HParams(system=st, optimizer=OptimizerType.FBSM)
     with pytest.raises(NotImplementedError):
       get_optimizer(hp, CFG, hp.system())
+
+
+def test_fbsm_secant_solver_for_a_terminal_state_condition():
+  """FBSM.sequencesolver (forward_backward_sweep.py:118-158) on PREDATORPREY: secant iterations on adj(T) of the pinned
+  state, each one a device sweep sequence; same iterates as the oracle's restatement."""
+  from oracle import myriad_oracle as O
+  hp = HParams(system=SystemType.PREDATORPREY, optimizer=OptimizerType.FBSM, fbsm_intervals=200)
+  opt = get_optimizer(hp, CFG, hp.system())
+  sol = opt.solve()
+  ref = O.fbsm_secant(O.PredatorPrey(), 200)
+  assert opt.secant_iterations == ref["secant_iterations"]
+  assert abs(sol['x'][-1, 2] - 5.0) <= 1e-10
+  for k in ('x', 'u', 'adj'):
+    np.testing.assert_allclose(sol[k], ref[k], rtol=1e-8, atol=1e-10, err_msg=k)

@@ -256,3 +256,32 @@ def test_time_dependent_cost_systems(sysname, kw):
     _, c_ref = O.get_state_trajectory_and_cost(so, hp2.num_steps, method, so.x_0, us)
     assert c == pytest.approx(c_ref, rel=1e-11), method
   _shooting_checks(sysname, sh, so)
+
+
+def test_predator_prey_shooting_and_collocation_refusal():
+  """PREDATORPREY (terminal cost + ONE pinned terminal state, predator_prey.py:47): shooting works (shooting.py:255-258 loops
+  over the non-None entries), the collocation optimisers fail on the None entries as the reference's do."""
+  from oracle import myriad_oracle as O
+  so = O.PredatorPrey()
+  hp = HParams(system=SystemType.PREDATORPREY, optimizer=OptimizerType.SHOOTING, intervals=40, controls_per_interval=1,
+               nlpsolver=NLPSolverType.SQP, max_iter=500)
+  tr = O.shooting(so, 40, 1, "HEUN")
+  cb = O.Callbacks(tr)
+  o = get_optimizer(hp, CFG, hp.system())
+  np.testing.assert_array_equal(o.bounds, tr.bounds)
+  np.testing.assert_allclose(o.guess, tr.guess, rtol=1e-12, atol=1e-12)
+  rng = np.random.default_rng(2)
+  z = np.abs(tr.guess * (1.0 + 0.02 * rng.standard_normal(tr.guess.size))) + 0.02
+  np.testing.assert_allclose(o.constraints(z), cb.cons(z), rtol=1e-11, atol=1e-11)
+  assert o.objective(z) == pytest.approx(cb.fun(z), rel=1e-12)
+  np.testing.assert_allclose(o.objective_grad(z), cb.grad(z), rtol=1e-10, atol=1e-11)
+  np.testing.assert_allclose(o.constraints_jac(z), cb.jac(z), rtol=1e-10, atol=1e-11)
+  r = o.solve_batch()
+  assert r['status'][0] == 0, (r['status'], r['iters'], r['kkt'])
+  zs = r['xs_and_us'][0]
+  assert np.abs(cb.cons(zs)).max() <= 1e-8 and cb.fun(zs) == pytest.approx(r['cost'][0], rel=1e-10)
+  assert zs[40 * 3 + 2] == pytest.approx(5.0, abs=1e-9)        # the pinned terminal state x_2(T) = B
+  for quad in (QuadratureRule.TRAPEZOIDAL, QuadratureRule.HERMITE_SIMPSON):
+    hpc = HParams(system=SystemType.PREDATORPREY, optimizer=OptimizerType.COLLOCATION, quadrature_rule=quad, intervals=10)
+    with pytest.raises(TypeError):
+      get_optimizer(hpc, CFG, hpc.system())

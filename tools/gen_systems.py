@@ -204,9 +204,6 @@ def systems():
   out.append(dict(name="BACTERIA", id=16, x=x, u=u, p=p,
                   f=[p[0] * x[0] + p[1] * u[0] * x[0] - p[2] * u[0] ** 2 * sp.exp(-x[0])], g=u[0] ** 2, gT=-p[3] * x[0],
                   pdefault=[1.0, 1.0, 12.0, 1.0], pnames=["r", "A", "B", "C"]))
-  # (PREDATORPREY, the third terminal-cost system, pins only one terminal state: x_T = [None, None, B]; the reference's
-  #  collocation optimisers fail on that (np.expand_dims / linspace over None) and only its shooting path handles it, which is
-  #  not built for terminal costs here -- so it has no direct path to mirror and is left out.)
   # ---- TUMOUR: myriad/systems/miscellaneous/tumour.py:80-86, cost 0 :100-101, terminal :106-108 ----
   x = sp.symbols("x0:3", positive=True)
   u = sp.symbols("u0:1", real=True)
@@ -231,6 +228,16 @@ def systems():
   out.append(dict(name="TIMBERHARVEST", id=19, x=x, u=u, p=p,
                   f=[p[1] * x[0] * u[0]], g=-sp.exp(-p[0] * tt) * x[0] * (1 - u[0]),
                   pdefault=[0.0, 1.0], pnames=["r", "k"]))
+  # ---- PREDATORPREY: myriad/systems/lenhart/predator_prey.py:85-96, cost :113-114, terminal :120-122.  x_T = [None, None, B]
+  # pins one terminal state only: the reference's collocation optimisers cannot build that (np.expand_dims / linspace over
+  # None), its shooting optimiser and the FBSM secant solver can -- same here (host side).
+  x = sp.symbols("x0:3", real=True)
+  u = sp.symbols("u0:1", real=True)
+  p = sp.symbols("p0:3", real=True)   # d_1, d_2, A
+  out.append(dict(name="PREDATORPREY", id=20, x=x, u=u, p=p,
+                  f=[(1 - x[1]) * x[0] - p[0] * x[0] * u[0], (x[0] - 1) * x[1] - p[1] * x[1] * u[0], u[0]],
+                  g=p[2] * sp.Rational(1, 2) * u[0] ** 2, gT=x[0],
+                  pdefault=[0.1, 0.1, 1.0], pnames=["d_1", "d_2", "A"]))
   return out
 
 
