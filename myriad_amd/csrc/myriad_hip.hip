@@ -241,8 +241,8 @@ template <class Sys>
 static int launch_shoot_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
                              double* f, double* g, double* c, double* j) {
   const int I = h->d.intervals, cpi = h->d.controls_per_interval, method = h->d.integration_method;
-  if (method != MYR_INT_EULER && method != MYR_INT_HEUN)
-    return fail(MYR_E_UNSUPPORTED, "myr_eval: shooting eval is built for EULER and HEUN steps");
+  if (method == MYR_INT_RK4)
+    return fail(MYR_E_UNSUPPORTED, "myr_eval: shooting eval is built for EULER, HEUN and MIDPOINT steps (RK4: rollout only)");
   const size_t need = (size_t)B * (size_t)(cpi + 1) * Sys::NS * 8;
   if (need > h->sbuf_bytes) {
     if (h->sbuf) HIPCHK(hipFree(h->sbuf));
@@ -678,8 +678,8 @@ static int solve_for_system(myr_handle h, int B, double* z, const double* lb, co
     case MYR_TR_TRAPEZOIDAL:
       return launch_lane_solve<TrapCore<Sys>, Sys>(h, B, TrapCore<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     case MYR_TR_SHOOTING:
-      if (h->d.integration_method != MYR_INT_EULER && h->d.integration_method != MYR_INT_HEUN)
-        return fail(MYR_E_UNSUPPORTED, "myr_solve: shooting solve is built for EULER and HEUN steps (RK4 / MIDPOINT: rollout only)");
+      if (h->d.integration_method == MYR_INT_RK4)
+        return fail(MYR_E_UNSUPPORTED, "myr_solve: shooting solve is built for EULER, HEUN and MIDPOINT steps (RK4: rollout only)");
       return launch_lane_solve<ShootCore<Sys>, Sys>(h, B, ShootCore<Sys>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   return fail(MYR_E_ARG, "solve: unknown transcription");

@@ -496,6 +496,19 @@ struct ShootCore {
     double xt[NS], f2[NS];
 #pragma unroll
     for (int c = 0; c < NS; ++c) xt[c] = x[c] + h * f1[c];
+    if (method == 2) {      // the reference's "midpoint" rule (utils.py:47-50): full Euler predictor, averaged control, time t + h/2
+      double um[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) um[a] = 0.5 * (u[a] + un[a]);
+      Sys::f(xt, um, p, f2);
+      set_time<Sys>(p, t0 + 0.5 * h);
+      const double gm = Sys::g(xt, um, p);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) xn[c] = x[c] + h * f2[c];
+      dc = h * gm;
+      if constexpr (Sys::HAS_TERMINAL) { if (last) dc += Sys::term(xn, un, p); }
+      return;
+    }
     Sys::f(xt, un, p, f2);
     set_time<Sys>(p, t0 + h);
     const double g2 = Sys::g(xt, un, p);
@@ -564,15 +577,21 @@ struct ShootCore {
       fold();
       return;
     }
-    const double hh = 0.5 * h;
+    // Two-stage rules share one derivation: stage 2 is evaluated at w2 = (x + h f1, u2) and
+    //   x_next = x + a1 h f1 + a2 h f2(w2),   dc = a1 h g1 + a2 h g2(w2)
+    //   Heun     (utils.py:41-44): u2 = u_next,            a1 = a2 = 1/2, time t + h
+    //   midpoint (utils.py:47-50): u2 = (u + u_next) / 2,  a1 = 0, a2 = 1, time t + h/2
+    const bool mid = (method == 2);
+    const double a1 = mid ? 0.0 : 0.5, a2 = mid ? 1.0 : 0.5, cu = mid ? 0.5 : 0.0, cun = mid ? 0.5 : 1.0;
+    const double h1 = a1 * h, h2 = a2 * h;
     HsPoint<Sys> P2;
 #pragma unroll
     for (int c = 0; c < NS; ++c) P2.x[c] = x[c] + h * P1.f[c];
 #pragma unroll
-    for (int a = 0; a < NU; ++a) P2.u[a] = un[a];
-    set_time<Sys>(p, t0 + h);
+    for (int a = 0; a < NU; ++a) P2.u[a] = cu * u[a] + cun * un[a];
+    set_time<Sys>(p, t0 + (mid ? 0.5 * h : h));
     Sys::lin_d2(P2.x, P2.u, p, P2.f, P2.A, P2.B, &P2.g, P2.gw, P2.D2);
-    // J2 = d w2 / dy (NW x NY): x~ rows [I + h A1, h B1, 0], u_next rows [0, 0, I]
+    // J2 = d w2 / dy (NW x NY): x~ rows [I + h A1, h B1, 0], u2 rows [0, cu I, cun I]
     double J2[NW * NY];
 #pragma unroll
     for (int i = 0; i < NW * NY; ++i) J2[i] = 0.0;
@@ -584,38 +603,39 @@ struct ShootCore {
       for (int a = 0; a < NU; ++a) J2[r * NY + NS + a] = h * P1.B[r * NU + a];
     }
 #pragma unroll
-    for (int a = 0; a < NU; ++a) J2[(NS + a) * NY + NW + a] = 1.0;
-    // Fy = [I 0 0] + h/2 ([A1 B1 0] + [A2 B2] J2)
+    for (int a = 0; a < NU; ++a) { J2[(NS + a) * NY + NS + a] = cu; J2[(NS + a) * NY + NW + a] = cun; }
+    // Fy = [I 0 0] + h1 [A1 B1 0] + h2 [A2 B2] J2
 #pragma unroll
     for (int r = 0; r < NS; ++r)
 #pragma unroll
       for (int c = 0; c < NY; ++c) {
-        double s = (c < NS) ? (((r == c) ? 1.0 : 0.0) + hh * P1.A[r * NS + c]) : ((c < NW) ? hh * P1.B[r * NU + (c - NS)] : 0.0);
+        double s = (c < NS) ? (((r == c) ? 1.0 : 0.0) + h1 * P1.A[r * NS + c]) : ((c < NW) ? h1 * P1.B[r * NU + (c - NS)] : 0.0);
 #pragma unroll
-        for (int t = 0; t < NS; ++t) s += hh * P2.A[r * NS + t] * J2[t * NY + c];
+        for (int t = 0; t < NS; ++t) s += h2 * P2.A[r * NS + t] * J2[t * NY + c];
 #pragma unroll
-        for (int a = 0; a < NU; ++a) s += hh * P2.B[r * NU + a] * J2[(NS + a) * NY + c];
+        for (int a = 0; a < NU; ++a) s += h2 * P2.B[r * NU + a] * J2[(NS + a) * NY + c];
         Fy[r * NY + c] = s;
       }
-    // gy = h/2 (gw1 E1 + gw2 J2)
+    // gy = h1 gw1 E1 + h2 gw2 J2
 #pragma unroll
     for (int c = 0; c < NY; ++c) {
-      double s = (c < NW) ? hh * P1.gw[c] : 0.0;
+      double s = (c < NW) ? h1 * P1.gw[c] : 0.0;
 #pragma unroll
-      for (int t = 0; t < NW; ++t) s += hh * P2.gw[t] * J2[t * NY + c];
+      for (int t = 0; t < NW; ++t) s += h2 * P2.gw[t] * J2[t * NY + c];
       gy[c] = s;
     }
-    // Hessians
-    double mu1[NS], W1[NW * NW], W2[NW * NW];
+    // Hessians: stage 1 carries its own weight h1 (pin, g) plus what flows back through the predictor x~ = x + h f1
+    double mu1[NS], mu2[NS], W1[NW * NW], W2[NW * NW];
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
       double s = P2.gw[c];
 #pragma unroll
       for (int t = 0; t < NS; ++t) s += P2.A[t * NS + c] * pin[t];
-      mu1[c] = hh * pin[c] + h * hh * s;
+      mu1[c] = h1 * pin[c] + h * h2 * s;
+      mu2[c] = h2 * pin[c];
     }
-    Sys::hessian(P1.x, P1.u, p, P1.D2, mu1, hh, W1);
-    Sys::hessian(P2.x, P2.u, p, P2.D2, pin, 1.0, W2);
+    Sys::hessian(P1.x, P1.u, p, P1.D2, mu1, h1, W1);
+    Sys::hessian(P2.x, P2.u, p, P2.D2, mu2, h2, W2);
     double T[NW * NY];
 #pragma unroll
     for (int r = 0; r < NW; ++r)
@@ -624,7 +644,7 @@ struct ShootCore {
         double s = 0.0;
 #pragma unroll
         for (int t = 0; t < NW; ++t) s += W2[r * NW + t] * J2[t * NY + c];
-        T[r * NY + c] = hh * s;
+        T[r * NY + c] = s;
       }
 #pragma unroll
     for (int r = 0; r < NY; ++r)

@@ -43,6 +43,8 @@ def test_trapezoidal_solve_matches_oracle_slsqp(sysname, N):
   ("CANCERTREATMENT", dict(intervals=1, controls_per_interval=100), "HEUN"),   # config 4 shape
   ("CARTPOLE", dict(intervals=10, controls_per_interval=5), "HEUN"),
   ("SIMPLECASE", dict(intervals=4, controls_per_interval=10), "EULER"),
+  ("VANDERPOL", dict(intervals=2, controls_per_interval=20), "MIDPOINT"),        # the reference's "midpoint" rule (quirk Q11)
+  ("CANCERTREATMENT", dict(intervals=1, controls_per_interval=40), "MIDPOINT"),
 ])
 def test_shooting_solve_matches_oracle_slsqp(sysname, kw, method):
   hp = HParams(system=SystemType[sysname], optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod[method],
@@ -118,6 +120,9 @@ def test_cancertreatment_parameter_sweep_config4_shape():
   ("CANCERTREATMENT", "SHOOTING", "TRAPEZOIDAL", "HEUN", dict(intervals=1, controls_per_interval=100)),
   ("SIMPLECASE", "SHOOTING", "TRAPEZOIDAL", "HEUN", dict(intervals=10, controls_per_interval=100)),
   ("VANDERPOL", "SHOOTING", "TRAPEZOIDAL", "EULER", dict(intervals=3, controls_per_interval=4)),
+  ("VANDERPOL", "SHOOTING", "TRAPEZOIDAL", "MIDPOINT", dict(intervals=3, controls_per_interval=4)),
+  ("CARTPOLE", "SHOOTING", "TRAPEZOIDAL", "MIDPOINT", dict(intervals=2, controls_per_interval=5)),
+  ("CANCERTREATMENT", "SHOOTING", "TRAPEZOIDAL", "MIDPOINT", dict(intervals=1, controls_per_interval=12)),
 ])
 def test_eval_callbacks_match_oracle(sysname, opt, quad, method, kw):
   """objective / grad / constraints / jacobian of the trapezoidal and shooting transcriptions (the four callbacks the
