@@ -165,12 +165,12 @@ int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u_rows, cons
                 const double* params, int32_t params_stride, double* xs, double* cost, int32_t mem);
 
 /*
- * Matrix-free products with the constraint Jacobian of the COLLOCATION transcriptions (HERMITE_SIMPSON, TRAPEZOIDAL;
- * SHOOTING returns MYR_E_UNSUPPORTED) -- what jax.grad(lagrangian) computes through the dense transcription in
+ * Matrix-free products with the constraint Jacobian -- what jax.grad(lagrangian) computes through the dense transcription in
  * nlp_solvers/extra_gradient.py:21-33 and experiments/e2e_sysid.py:113-141.
  *   myr_vjp:  out[B][n] = J(z)^T lam   (+ grad f(z) when add_gradf != 0: the gradient of the Lagrangian in z)
  *   myr_jvp:  out[B][m] = J(z) v
- * z [B][n], lam [B][m], v [B][n]; layouts and row order as in myr_eval.
+ * z [B][n], lam [B][m], v [B][n]; layouts and row order as in myr_eval.  Collocation: pointwise / intervalwise kernels;
+ * SHOOTING (EULER, HEUN, MIDPOINT): reverse sweep seeded with lam / forward tangents through the steps.
  */
 int myr_vjp(myr_handle h, int32_t B, const double* z, const double* lam, const double* params, int32_t params_stride,
             double* out, int32_t add_gradf, int32_t mem);

@@ -376,6 +376,56 @@ static int launch_products(myr_handle h, const ProdArgs& a) {
   return MYR_OK;
 }
 
+// shooting: J^T lam / grad L by the reverse sweep of shoot_eval_kernel seeded with lam, J v by forward tangents, and the
+// extragradient step as a launch sequence (the iterate of a shooting problem is small: no LDS-resident variant)
+template <class Sys>
+static int launch_shoot_products(myr_handle h, const ProdArgs& a) {
+  const int I = h->d.intervals, cpi = h->d.controls_per_interval, method = h->d.integration_method;
+  if (method == MYR_INT_RK4) return fail(MYR_E_UNSUPPORTED, "products: shooting is built for EULER, HEUN and MIDPOINT steps");
+  const myr_dims& dm = h->dims;
+  const size_t sweep = (size_t)a.B * (size_t)(cpi + 1) * Sys::NS * 8;
+  const size_t extra = a.op == PRODOP_EXGD ? ((size_t)2 * a.B * dm.n + (size_t)a.B * dm.m) * 8 : 0;   // g, zbar, c
+  if (sweep + extra > h->sbuf_bytes) {
+    if (h->sbuf) HIPCHK(hipFree(h->sbuf));
+    h->sbuf = nullptr; h->sbuf_bytes = 0;
+    HIPCHK(hipMalloc(&h->sbuf, sweep + extra));
+    h->sbuf_bytes = sweep + extra;
+  }
+  double* scr = (double*)h->sbuf;
+  const dim3 grid((unsigned)((a.B + 63) / 64)), blk(64);
+  KTimer& kt = h->kt[MYR_K_PROD];
+  HIPCHK(hipEventRecord(kt.a, h->stream));
+  if (a.op == PRODOP_VJP) {
+    hipLaunchKernelGGL(shoot_eval_kernel<Sys>, grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, a.z, a.params, a.pstride,
+                       (double*)nullptr, a.out, (double*)nullptr, (double*)nullptr, scr, a.w, a.add_gradf);
+  } else if (a.op == PRODOP_JVP) {
+    hipLaunchKernelGGL(shoot_jvp_kernel<Sys>, grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, a.z, a.w, a.params, a.pstride, a.out);
+  } else {
+    double* g = scr + sweep / 8; double* zbar = g + (size_t)a.B * dm.n; double* cbuf = zbar + (size_t)a.B * dm.n;
+    const long tz = (long)a.B * dm.n, tl = (long)a.B * dm.m;
+    long ub_ = (tz + 255) / 256; if (ub_ > 16384) ub_ = 16384;
+    for (int s = 0; s < a.nsteps; ++s) {
+      hipLaunchKernelGGL(shoot_eval_kernel<Sys>, grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, (const double*)a.zio, a.params, a.pstride,
+                         (double*)nullptr, g, (double*)nullptr, (double*)nullptr, scr, (const double*)a.lamio, 1);
+      hipLaunchKernelGGL(exgd_update_kernel, dim3((unsigned)ub_), dim3(256), 0, h->stream, tz, (const double*)a.zio, (const double*)g, a.lb, a.ub, a.eta_x, zbar);
+      hipLaunchKernelGGL(shoot_eval_kernel<Sys>, grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, (const double*)zbar, a.params, a.pstride,
+                         (double*)nullptr, g, (double*)nullptr, (double*)nullptr, scr, (const double*)a.lamio, 1);
+      hipLaunchKernelGGL(exgd_update_kernel, dim3((unsigned)ub_), dim3(256), 0, h->stream, tz, (const double*)a.zio, (const double*)g, a.lb, a.ub, a.eta_x, a.zio);
+      hipLaunchKernelGGL(shoot_eval_kernel<Sys>, grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, (const double*)a.zio, a.params, a.pstride,
+                         (double*)nullptr, (double*)nullptr, cbuf, (double*)nullptr, scr, (const double*)nullptr, 1);
+      hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, h->stream, tl, a.eta_v, (const double*)cbuf, a.lamio);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(kt.b, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+  kt.sum_ms += ms;
+  kt.launches += 1;
+  return MYR_OK;
+}
+
 template <class Sys>
 static int products_for_system(myr_handle h, const ProdArgs& a) {
   if constexpr (Sys::PARAMS_BY_POINTER) {
@@ -385,7 +435,8 @@ static int products_for_system(myr_handle h, const ProdArgs& a) {
     switch (h->d.transcription) {
       case MYR_TR_HERMITE_SIMPSON: return launch_products<Sys, PROD_HS>(h, a);
       case MYR_TR_TRAPEZOIDAL: return launch_products<Sys, PROD_TRAP>(h, a);
-      default: return fail(MYR_E_UNSUPPORTED, "products: built for the collocation transcriptions (HERMITE_SIMPSON, TRAPEZOIDAL)");
+      case MYR_TR_SHOOTING: return launch_shoot_products<Sys>(h, a);
+      default: return fail(MYR_E_ARG, "products: unknown transcription");
     }
   }
 }

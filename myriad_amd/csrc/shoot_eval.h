@@ -22,7 +22,9 @@ __global__ __launch_bounds__(64)
 void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double* __restrict__ z,
                        const double* __restrict__ params, int params_stride, double* __restrict__ fout,
                        double* __restrict__ gout, double* __restrict__ cout, double* __restrict__ jout,
-                       double* __restrict__ scratch) {
+                       double* __restrict__ scratch, const double* __restrict__ lamin = nullptr, int with_cost = 1) {
+  // lamin [B][I*NS] (optional): gout becomes (with_cost ? grad f : 0) + J^T lam -- the gradient of the Lagrangian in z
+  // (nlp_solvers/extra_gradient.py:21-33) by the same reverse sweep, seeded with lam_k at the end of interval k
   using SC = ShootCore<Sys>;
   constexpr int NS = Sys::NS, NU = Sys::NU, NW = Sys::NW, NY = NW + NU;
   const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,6 +61,8 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
       for (int c = 0; c < NS; ++c) cout[b * (long)I * NS + (long)k * NS + c] = x[c] - zb[(long)(k + 1) * NS + c];   // shooting.py:239-241
     }
     if (!jout && !gb) continue;
+    const double* lk = lamin ? lamin + b * (long)I * NS + (long)k * NS : nullptr;
+    const double cw = with_cost ? 1.0 : 0.0;
     // reverse sweep: Lam = d x_end / d x_{j+1} (ns x ns), a = d (cost of the rest of the interval) / d x_{j+1}
     double Lam[NS * NS], a[NS], pendJ[NS * NU], pendg[NU];
 #pragma unroll
@@ -66,7 +70,10 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
 #pragma unroll
       for (int c = 0; c < NS; ++c) Lam[r * NS + c] = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-    for (int c = 0; c < NS; ++c) a[c] = 0.0;
+    for (int c = 0; c < NS; ++c) {
+      a[c] = lk ? lk[c] : 0.0;                                   // d (lam_k^T c_k) / d x_end = lam_k
+      if (lk && gb) gb[(long)(k + 1) * NS + c] -= lk[c];         // d (lam_k^T c_k) / d x_{k+1} = -lam_k
+    }
 #pragma unroll
     for (int q = 0; q < NS * NU; ++q) pendJ[q] = 0.0;
 #pragma unroll
@@ -82,7 +89,7 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
       // column block of u_{i+1}: this step's d/du_next + what step i+1 contributed as its own d/du
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        double gsum = pendg[u] + gy[NW + u];
+        double gsum = pendg[u] + cw * gy[NW + u];
 #pragma unroll
         for (int t = 0; t < NS; ++t) gsum += a[t] * Fy[t * NY + NW + u];
         if (gb) gb[(long)(I + 1) * NS + (long)(i + 1) * NU + u] += gsum;
@@ -98,7 +105,7 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
       double nL[NS * NS], na[NS];
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        double g2 = gy[NS + u];
+        double g2 = cw * gy[NS + u];
 #pragma unroll
         for (int t = 0; t < NS; ++t) g2 += a[t] * Fy[t * NY + NS + u];
         pendg[u] = g2;
@@ -112,7 +119,7 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
       }
 #pragma unroll
       for (int c = 0; c < NS; ++c) {
-        double s = gy[c];
+        double s = cw * gy[c];
 #pragma unroll
         for (int t = 0; t < NS; ++t) s += a[t] * Fy[t * NY + c];
         na[c] = s;
@@ -144,6 +151,65 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
     }
   }
   if (fout) fout[b] = ftot;
+}
+
+// out[b] = J(z_b) v_b for the shooting constraints c_k = x_end(x_k, u_{k cpi .. (k+1) cpi}) - x_{k+1}: forward tangent
+// propagation through the steps of each interval (one trajectory per lane)
+template <class Sys>
+__global__ __launch_bounds__(64)
+void shoot_jvp_kernel(int B, int I, int cpi, int method, double T, const double* __restrict__ z, const double* __restrict__ v,
+                      const double* __restrict__ params, int params_stride, double* __restrict__ out) {
+  using SC = ShootCore<Sys>;
+  constexpr int NS = Sys::NS, NU = Sys::NU, NW = Sys::NW, NY = NW + NU;
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int S = I * cpi;
+  const long n = (long)(I + 1) * NS + (long)(S + 1) * NU;
+  const double h = T / S;
+  const double* zb = z + b * n; const double* vb = v + b * n;
+  const double* ub = zb + (long)(I + 1) * NS; const double* vu = vb + (long)(I + 1) * NS;
+  SysParams<Sys> pp;
+  pp.load(params, b, params_stride);
+  const double* p = pp.get();
+  const double zero[NS] = {0};
+  for (int k = 0; k < I; ++k) {
+    double x[NS], dx[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { x[c] = zb[(long)k * NS + c]; dx[c] = vb[(long)k * NS + c]; }
+    for (int j = 0; j < cpi; ++j) {
+      const int i = k * cpi + j;
+      double xn[NS], dc, Fy[NS * NY], gy[NY], Hs[NY * NY], dn[NS];
+      SC::step_lin(method, h, x, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, zero, Fy, gy, Hs, h * i, false);
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) s += Fy[r * NY + c] * dx[c];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) s += Fy[r * NY + NS + a] * vu[(long)i * NU + a] + Fy[r * NY + NW + a] * vu[(long)(i + 1) * NU + a];
+        dn[r] = s;
+      }
+      SC::step_val(method, h, x, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, xn, dc, h * i, false);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) { x[c] = xn[c]; dx[c] = dn[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) out[b * (long)I * NS + (long)k * NS + c] = dx[c] - vb[(long)(k + 1) * NS + c];
+  }
+}
+
+// z <- clip(zref - eta g, lb, ub) (out may alias zref); lam += eta_v c
+__global__ __launch_bounds__(256)
+void exgd_update_kernel(long total, const double* __restrict__ zref, const double* __restrict__ g, const double* __restrict__ lb,
+                        const double* __restrict__ ub, double eta, double* out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const double v = zref[i] - eta * g[i];
+    out[i] = v < lb[i] ? lb[i] : (v > ub[i] ? ub[i] : v);
+  }
+}
+__global__ __launch_bounds__(256)
+void axpy_kernel(long total, double a, const double* __restrict__ x, double* y) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) y[i] += a * x[i];
 }
 
 }  // namespace myriad

@@ -130,3 +130,63 @@ def test_extragradient_solver_branch_runs_like_the_reference():
   err = max(np.abs(sol['xs_and_us'] - x).max(), np.abs(sol['lambda'] - lm).max())
   gap = max(np.abs(x_wrong - x).max(), np.abs(lm_wrong - lm).max())
   assert err < 0.01 * gap, (err, gap)
+
+
+@pytest.mark.parametrize("name,method,kw", [("VANDERPOL", "HEUN", dict(I=2, cpi=6)), ("CANCERTREATMENT", "HEUN", dict(I=1, cpi=12)),
+                                            ("SIMPLECASE", "EULER", dict(I=3, cpi=4)), ("CARTPOLE", "MIDPOINT", dict(I=2, cpi=5)),
+                                            ("BACTERIA", "HEUN", dict(I=2, cpi=5)), ("HARVEST", "HEUN", dict(I=2, cpi=5))])
+def test_shooting_products_match_autodiff(name, method, kw):
+  """J^T lam, grad L and J v of the SHOOTING transcription (reverse sweep seeded with lam / forward tangents) against the
+  oracle's autodiff, incl. a terminal-cost and a time-dependent-cost system."""
+  from oracle import myriad_oracle as O
+  from myriad_amd import _lib
+  s = O.SYSTEMS[name]()
+  I, cpi = kw["I"], kw["cpi"]
+  tr = O.shooting(s, I, cpi, method)
+  L, cb = O.Lagrangian(tr), O.Callbacks(tr)
+  B = 3
+  eng = _lib.Engine(name, "SHOOTING", I, s.T, controls_per_interval=cpi, integration_method=method, max_batch=B)
+  rng = np.random.default_rng(9)
+  z = np.stack([np.abs(tr.guess * (1.0 + 0.05 * rng.standard_normal(tr.guess.size))) + 0.05 for _ in range(B)])
+  if name == "CARTPOLE":
+    z = np.stack([tr.guess + 0.1 * rng.standard_normal(tr.guess.size) for _ in range(B)])
+  lam = rng.standard_normal((B, eng.m)); v = rng.standard_normal((B, eng.n))
+  gL = eng.vjp(z, lam, add_gradf=True); jt = eng.vjp(z, lam, add_gradf=False); jv = eng.jvp(z, v)
+  for b in range(B):
+    ref = L.grad_x(z[b], lam[b])
+    sc = max(1.0, np.abs(ref).max())
+    np.testing.assert_allclose(gL[b], ref, rtol=1e-10, atol=1e-12 * sc)
+    np.testing.assert_allclose(jt[b], ref - cb.grad(z[b]), rtol=1e-9, atol=1e-11 * sc)
+    refjv = L.jvp(z[b], v[b])
+    np.testing.assert_allclose(jv[b], refjv, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(refjv).max()))
+  # extragradient steps as a launch sequence == the reference iteration
+  z0 = z[:2]; lam0 = np.ones((2, eng.m))
+  zz, ll = eng.exgd(z0, lam0, tr.bounds[:, 0], tr.bounds[:, 1], 1e-3, 1e-4, 10)
+  for b in range(2):
+    x, lm = z0[b].copy(), lam0[b].copy()
+    for _ in range(10):
+      x, lm = L.step(x, lm, 1e-3, 1e-4)
+    np.testing.assert_allclose(zz[b], x, rtol=1e-9, atol=1e-10 * max(1.0, np.abs(x).max()))
+    np.testing.assert_allclose(ll[b], lm, rtol=1e-9, atol=1e-10)
+  eng.close()
+
+
+def test_extragradient_solver_on_single_shooting_like_the_reference_defaults():
+  """defaults.py:10-13 tunes the extragradient step sizes for CANCERTREATMENT single shooting: run that branch."""
+  from myriad_amd.config import Config, HParams, NLPSolverType, OptimizerType
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = HParams(system=SystemType.CANCERTREATMENT, optimizer=OptimizerType.SHOOTING, intervals=1, controls_per_interval=50,
+               nlpsolver=NLPSolverType.EXTRAGRADIENT, max_iter=50)
+  opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+  sol = opt.solve()
+  assert set(sol) == {'x', 'u', 'xs_and_us', 'cost', 'lambda'} and sol['lambda'].shape == (1,)
+  from oracle import myriad_oracle as O
+  tr = O.shooting(O.CancerTreatment(), 1, 50, "HEUN")
+  L = O.Lagrangian(tr)
+  x, lm = tr.guess.copy(), np.ones(1)
+  ex, ev = 1e-1 * 0.999, 1e-3 * 0.999
+  for i in range(500):
+    x, lm = L.step(x, lm, ex, ev)
+  np.testing.assert_allclose(sol['xs_and_us'], x, rtol=1e-7, atol=1e-8)
+  np.testing.assert_allclose(sol['lambda'], lm, rtol=1e-7, atol=1e-8)
