@@ -28,7 +28,14 @@
 
 using namespace myriad;
 
-static thread_local std::string g_err;
+// Translation units (see __graft_entry__.build): the library is either this one file compiled as is, or -- to build in
+// parallel -- one object with -DMYR_TU_MAIN (C-ABI + dispatch, no per-system kernels) plus one object per system with
+// -DMYR_TU_SYSTEM=<Sys...> (explicit instantiation of that system's entry points, nothing else exported).
+#if defined(MYR_TU_SYSTEM)
+extern thread_local std::string g_err;
+#else
+thread_local std::string g_err;
+#endif
 static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -87,118 +94,6 @@ static int ensure_dbuf(myr_handle h, size_t bytes) {
   HIPCHK(hipMalloc(&h->dbuf, bytes));
   h->dbuf_bytes = bytes;
   return 0;
-}
-
-extern "C" const char* myr_last_error(void) { return g_err.c_str(); }
-extern "C" const char* myr_version(void) { return "myriad_hip 0.1 (gfx950)"; }
-
-extern "C" void myr_default_solve_opts(myr_solve_opts* o) {
-  if (!o) return;
-  o->max_iter = 1000;   // config.py:70
-  o->reserved = 0;
-  o->tol_feas = 1e-8;
-  o->tol_stat = 1e-6;
-  o->tol_compl = 1e-7;
-  o->mu_init = 0.1;
-}
-
-extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
-  if (!desc || !out) return fail(MYR_E_ARG, "myr_create: null argument");
-  SysInfo si;
-  if (!sys_info(desc->system_id, &si)) return fail(MYR_E_ARG, "myr_create: unknown system_id");
-  if (desc->intervals < 1 || desc->controls_per_interval < 1 || !(desc->T > 0.0))
-    return fail(MYR_E_ARG, "myr_create: intervals, controls_per_interval and T must be positive");
-  myr_dims dm;
-  memset(&dm, 0, sizeof(dm));
-  dm.ns = si.ns; dm.nu = si.nu; dm.np = si.np;
-  const int N = desc->intervals;
-  switch (desc->transcription) {
-    case MYR_TR_HERMITE_SIMPSON: {
-      const int K = 2 * N + 1;
-      dm.x_rows = K; dm.u_rows = K;
-      dm.n = K * (si.ns + si.nu);
-      dm.m = 2 * N * si.ns;
-      dm.jblk = N * (5 * si.ns * si.ns + 5 * si.ns * si.nu);
-      dm.ngrad = si.cost_dep_x ? dm.n : K * si.nu;
-      break;
-    }
-    case MYR_TR_TRAPEZOIDAL: {
-      dm.x_rows = N + 1; dm.u_rows = N + 1;
-      dm.n = (N + 1) * (si.ns + si.nu);
-      dm.m = N * si.ns;
-      dm.jblk = N * (2 * si.ns * si.ns + 2 * si.ns * si.nu);
-      dm.ngrad = si.cost_dep_x ? dm.n : (N + 1) * si.nu;
-      break;
-    }
-    case MYR_TR_SHOOTING: {
-      const int mc = desc->integration_method == MYR_INT_RK4 ? 2 : 1;
-      dm.x_rows = N + 1; dm.u_rows = mc * N * desc->controls_per_interval + 1;
-      dm.n = dm.x_rows * si.ns + dm.u_rows * si.nu;
-      dm.m = N * si.ns;
-      dm.jblk = N * (si.ns * si.ns + si.ns * (desc->controls_per_interval + 1) * si.nu);   // EULER / HEUN layout
-      dm.ngrad = dm.n;
-      break;
-    }
-    default:
-      return fail(MYR_E_ARG, "myr_create: unknown transcription");
-  }
-  int ndev = 0;
-  HIPCHK(hipGetDeviceCount(&ndev));
-  if (desc->device < 0 || desc->device >= ndev) return fail(MYR_E_ARG, "myr_create: bad device ordinal");
-  HIPCHK(hipSetDevice(desc->device));
-  myr_handle h = new myr_handle_s();
-  h->d = *desc;
-  h->dims = dm;
-  h->si = si;
-  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  for (int i = 0; i < MYR_K_COUNT; ++i) {
-    HIPCHK(hipEventCreate(&h->kt[i].a));
-    HIPCHK(hipEventCreate(&h->kt[i].b));
-  }
-  const char* w = getenv("MYRIAD_EVAL_WPT");
-  if (w) { int v = atoi(w); if (v == 1 || v == 4 || v == 8) h->eval_wpt = v; }
-  if (const char* e = getenv("MYRIAD_EVAL_NT")) h->eval_nt = atoi(e);
-  const char* md = getenv("MYRIAD_SOLVE_MODE");
-  if (md) h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1;
-  const char* l = getenv("MYRIAD_SOLVE_LPW");
-  if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
-  *out = h;
-  return MYR_OK;
-}
-
-extern "C" int myr_destroy(myr_handle h) {
-  if (!h) return MYR_OK;
-  (void)hipSetDevice(h->d.device);
-  if (h->dbuf) (void)hipFree(h->dbuf);
-  if (h->sbuf) (void)hipFree(h->sbuf);
-  if (h->vbuf) (void)hipFree(h->vbuf);
-  for (int i = 0; i < MYR_K_COUNT; ++i) {
-    if (h->kt[i].a) (void)hipEventDestroy(h->kt[i].a);
-    if (h->kt[i].b) (void)hipEventDestroy(h->kt[i].b);
-  }
-  if (h->stream) (void)hipStreamDestroy(h->stream);
-  delete h;
-  return MYR_OK;
-}
-
-extern "C" int myr_get_dims(myr_handle h, myr_dims* out) {
-  if (!h || !out) return fail(MYR_E_ARG, "myr_get_dims: null argument");
-  *out = h->dims;
-  return MYR_OK;
-}
-
-extern "C" int myr_kernel_time(myr_handle h, int32_t kernel_id, double* avg_ms, int32_t* launches) {
-  if (!h || kernel_id < 0 || kernel_id >= MYR_K_COUNT) return fail(MYR_E_ARG, "myr_kernel_time: bad argument");
-  const KTimer& k = h->kt[kernel_id];
-  if (avg_ms) *avg_ms = k.launches ? k.sum_ms / k.launches : 0.0;
-  if (launches) *launches = k.launches;
-  return MYR_OK;
-}
-
-extern "C" int myr_kernel_time_reset(myr_handle h) {
-  if (!h) return fail(MYR_E_ARG, "myr_kernel_time_reset: null handle");
-  for (int i = 0; i < MYR_K_COUNT; ++i) { h->kt[i].sum_ms = 0.0; h->kt[i].launches = 0; }
-  return MYR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -265,7 +160,7 @@ static int launch_shoot_eval(myr_handle h, int B, const double* z, const double*
 }
 
 template <class Sys>
-static int eval_for_system(myr_handle h, int B, const double* z, const double* params, int pstride,
+int eval_for_system(myr_handle h, int B, const double* z, const double* params, int pstride,
                            double* f, double* g, double* c, double* j) {
   if constexpr (Sys::PARAMS_BY_POINTER) {   // neural-ODE systems: built for the Hermite-Simpson transcription (config 5)
     if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "myr_eval: NODE systems are built for HERMITE_SIMPSON");
@@ -278,56 +173,6 @@ static int eval_for_system(myr_handle h, int B, const double* z, const double* p
     }
   }
   return fail(MYR_E_ARG, "eval: unknown transcription");
-}
-
-static int dispatch_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
-                         double* f, double* g, double* c, double* j) {
-  switch (h->d.system_id) {
-#define X(N) case MYR_SYS_##N: return eval_for_system<Sys##N>(h, B, z, params, pstride, f, g, c, j);
-    MYR_CLOSED_FORM_SYSTEMS(X)
-#undef X
-    case MYR_SYS_NODE_CARTPOLE: return eval_for_system<SysNODE_CARTPOLE>(h, B, z, params, pstride, f, g, c, j);
-  }
-  return fail(MYR_E_ARG, "eval: unknown system");
-}
-
-extern "C" int myr_eval(myr_handle h, int32_t B, const double* z, const double* params, int32_t params_stride,
-                        double* f, double* gradf, double* c, double* jblk, int32_t mem) {
-  if (!h || !z) return fail(MYR_E_ARG, "myr_eval: null handle or z");
-  if (B < 0) return fail(MYR_E_ARG, "myr_eval: negative batch");
-  if (B == 0) return MYR_OK;
-  if (params && params_stride != 0 && params_stride != h->dims.np)
-    return fail(MYR_E_ARG, "myr_eval: params_stride must be 0 (shared) or np");
-  if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, "myr_eval: a NODE system needs its weights in `params`");
-  HIPCHK(hipSetDevice(h->d.device));
-  const myr_dims& dm = h->dims;
-  if (mem == MYR_MEM_DEVICE) return dispatch_eval(h, B, z, params, params_stride, f, gradf, c, jblk);
-  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_eval: bad mem kind");
-  // host pointers: stage through device scratch
-  const size_t nz = (size_t)B * dm.n, npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
-  const size_t nf = f ? (size_t)B : 0, ng = gradf ? (size_t)B * dm.ngrad : 0;
-  const size_t nc = c ? (size_t)B * dm.m : 0, nj = jblk ? (size_t)B * dm.jblk : 0;
-  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };   // keep 16-byte alignment of every carve
-  const size_t total = al(nz) + al(npar) + al(nf) + al(ng) + al(nc) + al(nj);
-  int rc = ensure_dbuf(h, total * 8);
-  if (rc) return rc;
-  double* dz = (double*)h->dbuf;
-  double* dp = dz + al(nz);
-  double* df = dp + al(npar);
-  double* dg = df + al(nf);
-  double* dc = dg + al(ng);
-  double* dj = dc + al(nc);
-  HIPCHK(hipMemcpyAsync(dz, z, nz * 8, hipMemcpyHostToDevice, h->stream));
-  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
-  rc = dispatch_eval(h, B, dz, npar ? dp : nullptr, params_stride, nf ? df : nullptr, ng ? dg : nullptr,
-                     nc ? dc : nullptr, nj ? dj : nullptr);
-  if (rc) return rc;
-  if (nf) HIPCHK(hipMemcpyAsync(f, df, nf * 8, hipMemcpyDeviceToHost, h->stream));
-  if (ng) HIPCHK(hipMemcpyAsync(gradf, dg, ng * 8, hipMemcpyDeviceToHost, h->stream));
-  if (nc) HIPCHK(hipMemcpyAsync(c, dc, nc * 8, hipMemcpyDeviceToHost, h->stream));
-  if (nj) HIPCHK(hipMemcpyAsync(jblk, dj, nj * 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return MYR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,7 +272,7 @@ static int launch_shoot_products(myr_handle h, const ProdArgs& a) {
 }
 
 template <class Sys>
-static int products_for_system(myr_handle h, const ProdArgs& a) {
+int products_for_system(myr_handle h, const ProdArgs& a) {
   if constexpr (Sys::PARAMS_BY_POINTER) {
     if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "products: NODE systems are built for HERMITE_SIMPSON");
     return launch_products<Sys, PROD_HS>(h, a);
@@ -441,103 +286,11 @@ static int products_for_system(myr_handle h, const ProdArgs& a) {
   }
 }
 
-static int dispatch_products(myr_handle h, const ProdArgs& a) {
-  switch (h->d.system_id) {
-#define X(N) case MYR_SYS_##N: return products_for_system<Sys##N>(h, a);
-    MYR_CLOSED_FORM_SYSTEMS(X)
-#undef X
-    case MYR_SYS_NODE_CARTPOLE: return products_for_system<SysNODE_CARTPOLE>(h, a);
-  }
-  return fail(MYR_E_ARG, "products: unknown system");
-}
-
-static int check_products_args(myr_handle h, const char* who, int32_t B, const void* p0, const void* p1, const void* p2,
-                               const double* params, int32_t params_stride) {
-  if (!h || !p0 || !p1 || !p2) return fail(MYR_E_ARG, std::string(who) + ": null handle or array");
-  if (B < 0) return fail(MYR_E_ARG, std::string(who) + ": negative batch");
-  if (params && params_stride != 0 && params_stride != h->dims.np)
-    return fail(MYR_E_ARG, std::string(who) + ": params_stride must be 0 (shared) or np");
-  if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, std::string(who) + ": a NODE system needs its weights in `params`");
-  return MYR_OK;
-}
-
-// one implementation for J^T lam / grad L (in_w = m, out = n) and J v (in_w = n, out = m)
-static int products_call(myr_handle h, int op, const char* who, int32_t B, const double* z, const double* w, const double* params,
-                         int32_t params_stride, double* out, int32_t add_gradf, int32_t mem) {
-  int rc = check_products_args(h, who, B, z, w, out, params, params_stride);
-  if (rc) return rc;
-  if (B == 0) return MYR_OK;
-  HIPCHK(hipSetDevice(h->d.device));
-  const myr_dims& dm = h->dims;
-  ProdArgs a{};
-  a.op = op; a.B = B; a.pstride = params_stride; a.add_gradf = add_gradf;
-  if (mem == MYR_MEM_DEVICE) { a.z = z; a.w = w; a.params = params; a.out = out; return dispatch_products(h, a); }
-  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, std::string(who) + ": bad mem kind");
-  const size_t nz = (size_t)B * dm.n, nw = (size_t)B * (op == PRODOP_VJP ? dm.m : dm.n), no = (size_t)B * (op == PRODOP_VJP ? dm.n : dm.m);
-  const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
-  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
-  rc = ensure_dbuf(h, (al(nz) + al(nw) + al(no) + al(npar)) * 8);
-  if (rc) return rc;
-  double* dz = (double*)h->dbuf; double* dw = dz + al(nz); double* dout = dw + al(nw); double* dp = dout + al(no);
-  HIPCHK(hipMemcpyAsync(dz, z, nz * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(dw, w, nw * 8, hipMemcpyHostToDevice, h->stream));
-  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
-  a.z = dz; a.w = dw; a.params = npar ? dp : nullptr; a.out = dout;
-  rc = dispatch_products(h, a);
-  if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(out, dout, no * 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return MYR_OK;
-}
-
-extern "C" int myr_vjp(myr_handle h, int32_t B, const double* z, const double* lam, const double* params, int32_t params_stride,
-                       double* out, int32_t add_gradf, int32_t mem) {
-  return products_call(h, PRODOP_VJP, "myr_vjp", B, z, lam, params, params_stride, out, add_gradf, mem);
-}
-
-extern "C" int myr_jvp(myr_handle h, int32_t B, const double* z, const double* v, const double* params, int32_t params_stride,
-                       double* out, int32_t mem) {
-  return products_call(h, PRODOP_JVP, "myr_jvp", B, z, v, params, params_stride, out, 0, mem);
-}
-
-extern "C" int myr_exgd(myr_handle h, int32_t B, double* z, double* lam, const double* lb, const double* ub, const double* params,
-                        int32_t params_stride, double eta_x, double eta_v, int32_t nsteps, int32_t mem) {
-  int rc = check_products_args(h, "myr_exgd", B, z, lam, lb, params, params_stride);
-  if (rc) return rc;
-  if (!ub) return fail(MYR_E_ARG, "myr_exgd: null ub");
-  if (nsteps < 0) return fail(MYR_E_ARG, "myr_exgd: negative nsteps");
-  if (B == 0 || nsteps == 0) return MYR_OK;
-  HIPCHK(hipSetDevice(h->d.device));
-  const myr_dims& dm = h->dims;
-  ProdArgs a{};
-  a.op = PRODOP_EXGD; a.B = B; a.pstride = params_stride; a.eta_x = eta_x; a.eta_v = eta_v; a.nsteps = nsteps;
-  if (mem == MYR_MEM_DEVICE) { a.zio = z; a.lamio = lam; a.lb = lb; a.ub = ub; a.params = params; return dispatch_products(h, a); }
-  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_exgd: bad mem kind");
-  const size_t nz = (size_t)B * dm.n, nl = (size_t)B * dm.m;
-  const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
-  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
-  rc = ensure_dbuf(h, (3 * al(nz) + al(nl) + al(npar)) * 8);
-  if (rc) return rc;
-  double* dz = (double*)h->dbuf; double* dlb = dz + al(nz); double* dub = dlb + al(nz); double* dl = dub + al(nz); double* dp = dl + al(nl);
-  HIPCHK(hipMemcpyAsync(dz, z, nz * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(dlb, lb, nz * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(dub, ub, nz * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(dl, lam, nl * 8, hipMemcpyHostToDevice, h->stream));
-  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
-  a.zio = dz; a.lamio = dl; a.lb = dlb; a.ub = dub; a.params = npar ? dp : nullptr;
-  rc = dispatch_products(h, a);
-  if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(z, dz, nz * 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(lam, dl, nl * 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return MYR_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
 // solve
 // ------------------------------------------------------------------------------------------------
 // [rows][cols] row-major  ->  [cols][ld] (ld >= rows): instance-major <-> batch-minor, 32x32 LDS tiles
-__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst,
+static __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst,
                                                         int rows, int cols, long ld) {
   __shared__ double tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -555,7 +308,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
   }
 }
 // [cols][ld] -> [rows][cols]
-__global__ __launch_bounds__(256) void transpose_back_kernel(const double* __restrict__ src, double* __restrict__ dst,
+static __global__ __launch_bounds__(256) void transpose_back_kernel(const double* __restrict__ src, double* __restrict__ dst,
                                                              int rows, int cols, long ld) {
   __shared__ double tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -714,7 +467,7 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
 }
 
 template <class Sys>
-static int solve_for_system(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
+int solve_for_system(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                             int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                             int32_t* iters, double* kkt) {
   const int N = h->d.intervals, cpi = h->d.controls_per_interval;
@@ -734,6 +487,329 @@ static int solve_for_system(myr_handle h, int B, double* z, const double* lb, co
       return launch_lane_solve<ShootCore<Sys>, Sys>(h, B, ShootCore<Sys>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   return fail(MYR_E_ARG, "solve: unknown transcription");
+}
+
+// ------------------------------------------------------------------------------------------------
+// rollout
+// ------------------------------------------------------------------------------------------------
+template <class Sys>
+__global__ __launch_bounds__(64)
+void rollout_kernel(int B, int method, int num_steps, double h, int u_rows, const double* __restrict__ x0,
+                    const double* __restrict__ us, const double* __restrict__ params, int params_stride,
+                    double* __restrict__ xs, double* __restrict__ cost) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  SysParams<Sys> pp;
+  pp.load(params, b, params_stride);
+  const double* p = pp.get();
+  const double c = Rollout<Sys>::run(method, num_steps, h, u_rows, x0 + b * Sys::NS, us + b * (long)u_rows * Sys::NU, p,
+                                     xs ? xs + b * (long)(num_steps + 1) * Sys::NS : nullptr);
+  if (cost) cost[b] = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched Forward-Backward Sweep (indirect method)
+// ------------------------------------------------------------------------------------------------
+template <class Sys>
+int launch_fbsm(myr_handle h, int B, long Bp, int N, const double* x0, const double* adjT, const double* params, int pstride,
+                       const VarScale& lo, const VarScale& hi, double bang, double delta, int max_sweeps, double* X, double* U, double* A, int32_t* sweeps) {
+  if constexpr (!Indirect<Sys>::SUPPORTED) {
+    return fail(MYR_E_UNSUPPORTED, "myr_fbsm: this system has no adjoint dynamics (not an IndirectFHCS on the path)");
+  } else {
+    KTimer& kt = h->kt[MYR_K_FBSM];
+    HIPCHK(hipEventRecord(kt.a, h->stream));
+    hipLaunchKernelGGL(fbsm_kernel<Sys>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, Bp, N, h->d.T, x0, adjT, params,
+                       pstride, lo, hi, bang, delta, max_sweeps, X, U, A, sweeps);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(kt.b, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+    kt.sum_ms += ms;
+    kt.launches += 1;
+    return MYR_OK;
+  }
+}
+
+template <class Sys>
+int rollout_for_system(myr_handle h, int B, int num_steps, int u_rows, const double* x0, const double* us, const double* params,
+                       int pstride, double* xs, double* cost) {
+  hipLaunchKernelGGL(rollout_kernel<Sys>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, (int)h->d.integration_method, num_steps,
+                     h->d.T / num_steps, u_rows, x0, us, params, pstride, xs, cost);
+  return MYR_OK;
+}
+
+// ---- per-system entry points: explicit instantiation (system objects) / extern declaration (main object) -----------------
+#define MYR_SYSTEM_ENTRY_POINTS(LINK, S)                                                                                          \
+  LINK template int eval_for_system<S>(myr_handle, int, const double*, const double*, int, double*, double*, double*, double*);   \
+  LINK template int products_for_system<S>(myr_handle, const ProdArgs&);                                                          \
+  LINK template int solve_for_system<S>(myr_handle, int, double*, const double*, const double*, const double*, int,               \
+                                        const myr_solve_opts&, double*, double*, int32_t*, int32_t*, double*);                    \
+  LINK template int rollout_for_system<S>(myr_handle, int, int, int, const double*, const double*, const double*, int, double*, double*); \
+  LINK template int launch_fbsm<S>(myr_handle, int, long, int, const double*, const double*, const double*, int, const VarScale&,  \
+                                   const VarScale&, double, double, int, double*, double*, double*, int32_t*);
+#if defined(MYR_TU_SYSTEM)
+MYR_SYSTEM_ENTRY_POINTS(, myriad::MYR_TU_SYSTEM)
+#elif defined(MYR_TU_MAIN)
+#define X(N) MYR_SYSTEM_ENTRY_POINTS(extern, Sys##N)
+MYR_CLOSED_FORM_SYSTEMS(X)
+#undef X
+MYR_SYSTEM_ENTRY_POINTS(extern, SysNODE_CARTPOLE)
+#endif
+
+#if !defined(MYR_TU_SYSTEM)   // ===== C-ABI and dispatch: the main object only ============================================
+extern "C" const char* myr_last_error(void) { return g_err.c_str(); }
+extern "C" const char* myr_version(void) { return "myriad_hip 0.1 (gfx950)"; }
+
+extern "C" void myr_default_solve_opts(myr_solve_opts* o) {
+  if (!o) return;
+  o->max_iter = 1000;   // config.py:70
+  o->reserved = 0;
+  o->tol_feas = 1e-8;
+  o->tol_stat = 1e-6;
+  o->tol_compl = 1e-7;
+  o->mu_init = 0.1;
+}
+
+extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
+  if (!desc || !out) return fail(MYR_E_ARG, "myr_create: null argument");
+  SysInfo si;
+  if (!sys_info(desc->system_id, &si)) return fail(MYR_E_ARG, "myr_create: unknown system_id");
+  if (desc->intervals < 1 || desc->controls_per_interval < 1 || !(desc->T > 0.0))
+    return fail(MYR_E_ARG, "myr_create: intervals, controls_per_interval and T must be positive");
+  myr_dims dm;
+  memset(&dm, 0, sizeof(dm));
+  dm.ns = si.ns; dm.nu = si.nu; dm.np = si.np;
+  const int N = desc->intervals;
+  switch (desc->transcription) {
+    case MYR_TR_HERMITE_SIMPSON: {
+      const int K = 2 * N + 1;
+      dm.x_rows = K; dm.u_rows = K;
+      dm.n = K * (si.ns + si.nu);
+      dm.m = 2 * N * si.ns;
+      dm.jblk = N * (5 * si.ns * si.ns + 5 * si.ns * si.nu);
+      dm.ngrad = si.cost_dep_x ? dm.n : K * si.nu;
+      break;
+    }
+    case MYR_TR_TRAPEZOIDAL: {
+      dm.x_rows = N + 1; dm.u_rows = N + 1;
+      dm.n = (N + 1) * (si.ns + si.nu);
+      dm.m = N * si.ns;
+      dm.jblk = N * (2 * si.ns * si.ns + 2 * si.ns * si.nu);
+      dm.ngrad = si.cost_dep_x ? dm.n : (N + 1) * si.nu;
+      break;
+    }
+    case MYR_TR_SHOOTING: {
+      const int mc = desc->integration_method == MYR_INT_RK4 ? 2 : 1;
+      dm.x_rows = N + 1; dm.u_rows = mc * N * desc->controls_per_interval + 1;
+      dm.n = dm.x_rows * si.ns + dm.u_rows * si.nu;
+      dm.m = N * si.ns;
+      dm.jblk = N * (si.ns * si.ns + si.ns * (desc->controls_per_interval + 1) * si.nu);   // EULER / HEUN layout
+      dm.ngrad = dm.n;
+      break;
+    }
+    default:
+      return fail(MYR_E_ARG, "myr_create: unknown transcription");
+  }
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (desc->device < 0 || desc->device >= ndev) return fail(MYR_E_ARG, "myr_create: bad device ordinal");
+  HIPCHK(hipSetDevice(desc->device));
+  myr_handle h = new myr_handle_s();
+  h->d = *desc;
+  h->dims = dm;
+  h->si = si;
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  for (int i = 0; i < MYR_K_COUNT; ++i) {
+    HIPCHK(hipEventCreate(&h->kt[i].a));
+    HIPCHK(hipEventCreate(&h->kt[i].b));
+  }
+  const char* w = getenv("MYRIAD_EVAL_WPT");
+  if (w) { int v = atoi(w); if (v == 1 || v == 4 || v == 8) h->eval_wpt = v; }
+  if (const char* e = getenv("MYRIAD_EVAL_NT")) h->eval_nt = atoi(e);
+  const char* md = getenv("MYRIAD_SOLVE_MODE");
+  if (md) h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1;
+  const char* l = getenv("MYRIAD_SOLVE_LPW");
+  if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
+  *out = h;
+  return MYR_OK;
+}
+
+extern "C" int myr_destroy(myr_handle h) {
+  if (!h) return MYR_OK;
+  (void)hipSetDevice(h->d.device);
+  if (h->dbuf) (void)hipFree(h->dbuf);
+  if (h->sbuf) (void)hipFree(h->sbuf);
+  if (h->vbuf) (void)hipFree(h->vbuf);
+  for (int i = 0; i < MYR_K_COUNT; ++i) {
+    if (h->kt[i].a) (void)hipEventDestroy(h->kt[i].a);
+    if (h->kt[i].b) (void)hipEventDestroy(h->kt[i].b);
+  }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return MYR_OK;
+}
+
+extern "C" int myr_get_dims(myr_handle h, myr_dims* out) {
+  if (!h || !out) return fail(MYR_E_ARG, "myr_get_dims: null argument");
+  *out = h->dims;
+  return MYR_OK;
+}
+
+extern "C" int myr_kernel_time(myr_handle h, int32_t kernel_id, double* avg_ms, int32_t* launches) {
+  if (!h || kernel_id < 0 || kernel_id >= MYR_K_COUNT) return fail(MYR_E_ARG, "myr_kernel_time: bad argument");
+  const KTimer& k = h->kt[kernel_id];
+  if (avg_ms) *avg_ms = k.launches ? k.sum_ms / k.launches : 0.0;
+  if (launches) *launches = k.launches;
+  return MYR_OK;
+}
+
+extern "C" int myr_kernel_time_reset(myr_handle h) {
+  if (!h) return fail(MYR_E_ARG, "myr_kernel_time_reset: null handle");
+  for (int i = 0; i < MYR_K_COUNT; ++i) { h->kt[i].sum_ms = 0.0; h->kt[i].launches = 0; }
+  return MYR_OK;
+}
+
+static int dispatch_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
+                         double* f, double* g, double* c, double* j) {
+  switch (h->d.system_id) {
+#define X(N) case MYR_SYS_##N: return eval_for_system<Sys##N>(h, B, z, params, pstride, f, g, c, j);
+    MYR_CLOSED_FORM_SYSTEMS(X)
+#undef X
+    case MYR_SYS_NODE_CARTPOLE: return eval_for_system<SysNODE_CARTPOLE>(h, B, z, params, pstride, f, g, c, j);
+  }
+  return fail(MYR_E_ARG, "eval: unknown system");
+}
+
+extern "C" int myr_eval(myr_handle h, int32_t B, const double* z, const double* params, int32_t params_stride,
+                        double* f, double* gradf, double* c, double* jblk, int32_t mem) {
+  if (!h || !z) return fail(MYR_E_ARG, "myr_eval: null handle or z");
+  if (B < 0) return fail(MYR_E_ARG, "myr_eval: negative batch");
+  if (B == 0) return MYR_OK;
+  if (params && params_stride != 0 && params_stride != h->dims.np)
+    return fail(MYR_E_ARG, "myr_eval: params_stride must be 0 (shared) or np");
+  if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, "myr_eval: a NODE system needs its weights in `params`");
+  HIPCHK(hipSetDevice(h->d.device));
+  const myr_dims& dm = h->dims;
+  if (mem == MYR_MEM_DEVICE) return dispatch_eval(h, B, z, params, params_stride, f, gradf, c, jblk);
+  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_eval: bad mem kind");
+  // host pointers: stage through device scratch
+  const size_t nz = (size_t)B * dm.n, npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
+  const size_t nf = f ? (size_t)B : 0, ng = gradf ? (size_t)B * dm.ngrad : 0;
+  const size_t nc = c ? (size_t)B * dm.m : 0, nj = jblk ? (size_t)B * dm.jblk : 0;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };   // keep 16-byte alignment of every carve
+  const size_t total = al(nz) + al(npar) + al(nf) + al(ng) + al(nc) + al(nj);
+  int rc = ensure_dbuf(h, total * 8);
+  if (rc) return rc;
+  double* dz = (double*)h->dbuf;
+  double* dp = dz + al(nz);
+  double* df = dp + al(npar);
+  double* dg = df + al(nf);
+  double* dc = dg + al(ng);
+  double* dj = dc + al(nc);
+  HIPCHK(hipMemcpyAsync(dz, z, nz * 8, hipMemcpyHostToDevice, h->stream));
+  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
+  rc = dispatch_eval(h, B, dz, npar ? dp : nullptr, params_stride, nf ? df : nullptr, ng ? dg : nullptr,
+                     nc ? dc : nullptr, nj ? dj : nullptr);
+  if (rc) return rc;
+  if (nf) HIPCHK(hipMemcpyAsync(f, df, nf * 8, hipMemcpyDeviceToHost, h->stream));
+  if (ng) HIPCHK(hipMemcpyAsync(gradf, dg, ng * 8, hipMemcpyDeviceToHost, h->stream));
+  if (nc) HIPCHK(hipMemcpyAsync(c, dc, nc * 8, hipMemcpyDeviceToHost, h->stream));
+  if (nj) HIPCHK(hipMemcpyAsync(jblk, dj, nj * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MYR_OK;
+}
+
+static int dispatch_products(myr_handle h, const ProdArgs& a) {
+  switch (h->d.system_id) {
+#define X(N) case MYR_SYS_##N: return products_for_system<Sys##N>(h, a);
+    MYR_CLOSED_FORM_SYSTEMS(X)
+#undef X
+    case MYR_SYS_NODE_CARTPOLE: return products_for_system<SysNODE_CARTPOLE>(h, a);
+  }
+  return fail(MYR_E_ARG, "products: unknown system");
+}
+
+static int check_products_args(myr_handle h, const char* who, int32_t B, const void* p0, const void* p1, const void* p2,
+                               const double* params, int32_t params_stride) {
+  if (!h || !p0 || !p1 || !p2) return fail(MYR_E_ARG, std::string(who) + ": null handle or array");
+  if (B < 0) return fail(MYR_E_ARG, std::string(who) + ": negative batch");
+  if (params && params_stride != 0 && params_stride != h->dims.np)
+    return fail(MYR_E_ARG, std::string(who) + ": params_stride must be 0 (shared) or np");
+  if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, std::string(who) + ": a NODE system needs its weights in `params`");
+  return MYR_OK;
+}
+
+// one implementation for J^T lam / grad L (in_w = m, out = n) and J v (in_w = n, out = m)
+static int products_call(myr_handle h, int op, const char* who, int32_t B, const double* z, const double* w, const double* params,
+                         int32_t params_stride, double* out, int32_t add_gradf, int32_t mem) {
+  int rc = check_products_args(h, who, B, z, w, out, params, params_stride);
+  if (rc) return rc;
+  if (B == 0) return MYR_OK;
+  HIPCHK(hipSetDevice(h->d.device));
+  const myr_dims& dm = h->dims;
+  ProdArgs a{};
+  a.op = op; a.B = B; a.pstride = params_stride; a.add_gradf = add_gradf;
+  if (mem == MYR_MEM_DEVICE) { a.z = z; a.w = w; a.params = params; a.out = out; return dispatch_products(h, a); }
+  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, std::string(who) + ": bad mem kind");
+  const size_t nz = (size_t)B * dm.n, nw = (size_t)B * (op == PRODOP_VJP ? dm.m : dm.n), no = (size_t)B * (op == PRODOP_VJP ? dm.n : dm.m);
+  const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  rc = ensure_dbuf(h, (al(nz) + al(nw) + al(no) + al(npar)) * 8);
+  if (rc) return rc;
+  double* dz = (double*)h->dbuf; double* dw = dz + al(nz); double* dout = dw + al(nw); double* dp = dout + al(no);
+  HIPCHK(hipMemcpyAsync(dz, z, nz * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dw, w, nw * 8, hipMemcpyHostToDevice, h->stream));
+  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
+  a.z = dz; a.w = dw; a.params = npar ? dp : nullptr; a.out = dout;
+  rc = dispatch_products(h, a);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, dout, no * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MYR_OK;
+}
+
+extern "C" int myr_vjp(myr_handle h, int32_t B, const double* z, const double* lam, const double* params, int32_t params_stride,
+                       double* out, int32_t add_gradf, int32_t mem) {
+  return products_call(h, PRODOP_VJP, "myr_vjp", B, z, lam, params, params_stride, out, add_gradf, mem);
+}
+
+extern "C" int myr_jvp(myr_handle h, int32_t B, const double* z, const double* v, const double* params, int32_t params_stride,
+                       double* out, int32_t mem) {
+  return products_call(h, PRODOP_JVP, "myr_jvp", B, z, v, params, params_stride, out, 0, mem);
+}
+
+extern "C" int myr_exgd(myr_handle h, int32_t B, double* z, double* lam, const double* lb, const double* ub, const double* params,
+                        int32_t params_stride, double eta_x, double eta_v, int32_t nsteps, int32_t mem) {
+  int rc = check_products_args(h, "myr_exgd", B, z, lam, lb, params, params_stride);
+  if (rc) return rc;
+  if (!ub) return fail(MYR_E_ARG, "myr_exgd: null ub");
+  if (nsteps < 0) return fail(MYR_E_ARG, "myr_exgd: negative nsteps");
+  if (B == 0 || nsteps == 0) return MYR_OK;
+  HIPCHK(hipSetDevice(h->d.device));
+  const myr_dims& dm = h->dims;
+  ProdArgs a{};
+  a.op = PRODOP_EXGD; a.B = B; a.pstride = params_stride; a.eta_x = eta_x; a.eta_v = eta_v; a.nsteps = nsteps;
+  if (mem == MYR_MEM_DEVICE) { a.zio = z; a.lamio = lam; a.lb = lb; a.ub = ub; a.params = params; return dispatch_products(h, a); }
+  if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_exgd: bad mem kind");
+  const size_t nz = (size_t)B * dm.n, nl = (size_t)B * dm.m;
+  const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  rc = ensure_dbuf(h, (3 * al(nz) + al(nl) + al(npar)) * 8);
+  if (rc) return rc;
+  double* dz = (double*)h->dbuf; double* dlb = dz + al(nz); double* dub = dlb + al(nz); double* dl = dub + al(nz); double* dp = dl + al(nl);
+  HIPCHK(hipMemcpyAsync(dz, z, nz * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dlb, lb, nz * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dub, ub, nz * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dl, lam, nl * 8, hipMemcpyHostToDevice, h->stream));
+  if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
+  a.zio = dz; a.lamio = dl; a.lb = dlb; a.ub = dub; a.params = npar ? dp : nullptr;
+  rc = dispatch_products(h, a);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(z, dz, nz * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(lam, dl, nl * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MYR_OK;
 }
 
 static int dispatch_solve(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
@@ -867,40 +943,19 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
   return MYR_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// rollout
-// ------------------------------------------------------------------------------------------------
-template <class Sys>
-__global__ __launch_bounds__(64)
-void rollout_kernel(int B, int method, int num_steps, double h, int u_rows, const double* __restrict__ x0,
-                    const double* __restrict__ us, const double* __restrict__ params, int params_stride,
-                    double* __restrict__ xs, double* __restrict__ cost) {
-  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  SysParams<Sys> pp;
-  pp.load(params, b, params_stride);
-  const double* p = pp.get();
-  const double c = Rollout<Sys>::run(method, num_steps, h, u_rows, x0 + b * Sys::NS, us + b * (long)u_rows * Sys::NU, p,
-                                     xs ? xs + b * (long)(num_steps + 1) * Sys::NS : nullptr);
-  if (cost) cost[b] = c;
-}
-
 static int dispatch_rollout(myr_handle h, int B, int num_steps, int u_rows, const double* x0, const double* us,
                             const double* params, int pstride, double* xs, double* cost) {
-  const int method = h->d.integration_method;
-  const double hs = h->d.T / num_steps;
   KTimer& kt = h->kt[MYR_K_ROLLOUT];
   HIPCHK(hipEventRecord(kt.a, h->stream));
-  dim3 g((unsigned)((B + 63) / 64)), t(64);
-#define RO(S) hipLaunchKernelGGL(rollout_kernel<S>, g, t, 0, h->stream, B, method, num_steps, hs, u_rows, x0, us, params, pstride, xs, cost)
+  int rc = MYR_E_ARG;
   switch (h->d.system_id) {
-#define X(N) case MYR_SYS_##N: RO(Sys##N); break;
+#define X(N) case MYR_SYS_##N: rc = rollout_for_system<Sys##N>(h, B, num_steps, u_rows, x0, us, params, pstride, xs, cost); break;
     MYR_CLOSED_FORM_SYSTEMS(X)
 #undef X
-    case MYR_SYS_NODE_CARTPOLE: RO(SysNODE_CARTPOLE); break;
+    case MYR_SYS_NODE_CARTPOLE: rc = rollout_for_system<SysNODE_CARTPOLE>(h, B, num_steps, u_rows, x0, us, params, pstride, xs, cost); break;
     default: return fail(MYR_E_ARG, "rollout: unknown system");
   }
-#undef RO
+  if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -942,30 +997,6 @@ extern "C" int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u
   if (nc) HIPCHK(hipMemcpyAsync(cost, dc, nc * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return MYR_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// batched Forward-Backward Sweep (indirect method)
-// ------------------------------------------------------------------------------------------------
-template <class Sys>
-static int launch_fbsm(myr_handle h, int B, long Bp, int N, const double* x0, const double* adjT, const double* params, int pstride,
-                       const VarScale& lo, const VarScale& hi, double bang, double delta, int max_sweeps, double* X, double* U, double* A, int32_t* sweeps) {
-  if constexpr (!Indirect<Sys>::SUPPORTED) {
-    return fail(MYR_E_UNSUPPORTED, "myr_fbsm: this system has no adjoint dynamics (not an IndirectFHCS on the path)");
-  } else {
-    KTimer& kt = h->kt[MYR_K_FBSM];
-    HIPCHK(hipEventRecord(kt.a, h->stream));
-    hipLaunchKernelGGL(fbsm_kernel<Sys>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, Bp, N, h->d.T, x0, adjT, params,
-                       pstride, lo, hi, bang, delta, max_sweeps, X, U, A, sweeps);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(kt.b, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
-    kt.sum_ms += ms;
-    kt.launches += 1;
-    return MYR_OK;
-  }
 }
 
 extern "C" int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, const double* adj_T, const double* params,
@@ -1022,4 +1053,4 @@ extern "C" int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, co
   if (sweeps) HIPCHK(hipMemcpy(sweeps, dsw, (size_t)B * 4, hipMemcpyDeviceToHost));
   return MYR_OK;
 }
-
+#endif  // !MYR_TU_SYSTEM

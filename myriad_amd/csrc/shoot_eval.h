@@ -199,7 +199,7 @@ void shoot_jvp_kernel(int B, int I, int cpi, int method, double T, const double*
 }
 
 // z <- clip(zref - eta g, lb, ub) (out may alias zref); lam += eta_v c
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void exgd_update_kernel(long total, const double* __restrict__ zref, const double* __restrict__ g, const double* __restrict__ lb,
                         const double* __restrict__ ub, double eta, double* out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -207,7 +207,7 @@ void exgd_update_kernel(long total, const double* __restrict__ zref, const doubl
     out[i] = v < lb[i] ? lb[i] : (v > ub[i] ? ub[i] : v);
   }
 }
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void axpy_kernel(long total, double a, const double* __restrict__ x, double* y) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) y[i] += a * x[i];
 }
