@@ -124,8 +124,8 @@ void myr_default_solve_opts(myr_solve_opts* o);
  *                           (jblk = N*(5 ns^2 + 5 ns nu)).
  *                           TRAPEZOIDAL: per interval  Cxs = h/2 A_s + I, Cxe = h/2 A_e - I (ns x ns),
  *                           Cus = h/2 B_s, Cue = h/2 B_e (ns x nu)   (jblk = N*(2 ns^2 + 2 ns nu)).
- *                           SHOOTING (EULER/HEUN): per interval  Jx = d c_k/d x_k (ns x ns), then
- *                           Ju = d c_k / d u_{k cpi .. (k+1) cpi} (ns x (cpi+1) nu); d c_k/d x_{k+1} = -I implied;
+ *                           SHOOTING: per interval  Jx = d c_k/d x_k (ns x ns), then Ju = d c_k / d (the interval's control
+ *                           rows) (ns x (mc cpi + 1) nu, mc = 2 for RK4 else 1); d c_k/d x_{k+1} = -I implied;
  *                           gradf is the full gradient (ngrad = n).
  * Any output pointer may be NULL to skip it.
  */

@@ -136,8 +136,6 @@ template <class Sys>
 static int launch_shoot_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
                              double* f, double* g, double* c, double* j) {
   const int I = h->d.intervals, cpi = h->d.controls_per_interval, method = h->d.integration_method;
-  if (method == MYR_INT_RK4)
-    return fail(MYR_E_UNSUPPORTED, "myr_eval: shooting eval is built for EULER, HEUN and MIDPOINT steps (RK4: rollout only)");
   const size_t need = (size_t)B * (size_t)(cpi + 1) * Sys::NS * 8;
   if (need > h->sbuf_bytes) {
     if (h->sbuf) HIPCHK(hipFree(h->sbuf));
@@ -147,8 +145,12 @@ static int launch_shoot_eval(myr_handle h, int B, const double* z, const double*
   }
   KTimer& kt = h->kt[MYR_K_EVAL];
   HIPCHK(hipEventRecord(kt.a, h->stream));
-  hipLaunchKernelGGL(shoot_eval_kernel<Sys>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, I, cpi, method, h->d.T,
-                     z, params, pstride, f, g, c, j, (double*)h->sbuf);
+  if (method == MYR_INT_RK4)
+    hipLaunchKernelGGL((shoot_eval_kernel<Sys, 2>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, I, cpi, method, h->d.T,
+                       z, params, pstride, f, g, c, j, (double*)h->sbuf, (const double*)nullptr, 1);
+  else
+    hipLaunchKernelGGL((shoot_eval_kernel<Sys, 1>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, I, cpi, method, h->d.T,
+                       z, params, pstride, f, g, c, j, (double*)h->sbuf, (const double*)nullptr, 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -223,10 +225,9 @@ static int launch_products(myr_handle h, const ProdArgs& a) {
 
 // shooting: J^T lam / grad L by the reverse sweep of shoot_eval_kernel seeded with lam, J v by forward tangents, and the
 // extragradient step as a launch sequence (the iterate of a shooting problem is small: no LDS-resident variant)
-template <class Sys>
-static int launch_shoot_products(myr_handle h, const ProdArgs& a) {
+template <class Sys, int M>
+static int launch_shoot_products_m(myr_handle h, const ProdArgs& a) {
   const int I = h->d.intervals, cpi = h->d.controls_per_interval, method = h->d.integration_method;
-  if (method == MYR_INT_RK4) return fail(MYR_E_UNSUPPORTED, "products: shooting is built for EULER, HEUN and MIDPOINT steps");
   const myr_dims& dm = h->dims;
   const size_t sweep = (size_t)a.B * (size_t)(cpi + 1) * Sys::NS * 8;
   const size_t extra = a.op == PRODOP_EXGD ? ((size_t)2 * a.B * dm.n + (size_t)a.B * dm.m) * 8 : 0;   // g, zbar, c
@@ -241,22 +242,22 @@ static int launch_shoot_products(myr_handle h, const ProdArgs& a) {
   KTimer& kt = h->kt[MYR_K_PROD];
   HIPCHK(hipEventRecord(kt.a, h->stream));
   if (a.op == PRODOP_VJP) {
-    hipLaunchKernelGGL(shoot_eval_kernel<Sys>, grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, a.z, a.params, a.pstride,
+    hipLaunchKernelGGL((shoot_eval_kernel<Sys, M>), grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, a.z, a.params, a.pstride,
                        (double*)nullptr, a.out, (double*)nullptr, (double*)nullptr, scr, a.w, a.add_gradf);
   } else if (a.op == PRODOP_JVP) {
-    hipLaunchKernelGGL(shoot_jvp_kernel<Sys>, grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, a.z, a.w, a.params, a.pstride, a.out);
+    hipLaunchKernelGGL((shoot_jvp_kernel<Sys, M>), grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, a.z, a.w, a.params, a.pstride, a.out);
   } else {
     double* g = scr + sweep / 8; double* zbar = g + (size_t)a.B * dm.n; double* cbuf = zbar + (size_t)a.B * dm.n;
     const long tz = (long)a.B * dm.n, tl = (long)a.B * dm.m;
     long ub_ = (tz + 255) / 256; if (ub_ > 16384) ub_ = 16384;
     for (int s = 0; s < a.nsteps; ++s) {
-      hipLaunchKernelGGL(shoot_eval_kernel<Sys>, grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, (const double*)a.zio, a.params, a.pstride,
+      hipLaunchKernelGGL((shoot_eval_kernel<Sys, M>), grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, (const double*)a.zio, a.params, a.pstride,
                          (double*)nullptr, g, (double*)nullptr, (double*)nullptr, scr, (const double*)a.lamio, 1);
       hipLaunchKernelGGL(exgd_update_kernel, dim3((unsigned)ub_), dim3(256), 0, h->stream, tz, (const double*)a.zio, (const double*)g, a.lb, a.ub, a.eta_x, zbar);
-      hipLaunchKernelGGL(shoot_eval_kernel<Sys>, grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, (const double*)zbar, a.params, a.pstride,
+      hipLaunchKernelGGL((shoot_eval_kernel<Sys, M>), grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, (const double*)zbar, a.params, a.pstride,
                          (double*)nullptr, g, (double*)nullptr, (double*)nullptr, scr, (const double*)a.lamio, 1);
       hipLaunchKernelGGL(exgd_update_kernel, dim3((unsigned)ub_), dim3(256), 0, h->stream, tz, (const double*)a.zio, (const double*)g, a.lb, a.ub, a.eta_x, a.zio);
-      hipLaunchKernelGGL(shoot_eval_kernel<Sys>, grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, (const double*)a.zio, a.params, a.pstride,
+      hipLaunchKernelGGL((shoot_eval_kernel<Sys, M>), grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, (const double*)a.zio, a.params, a.pstride,
                          (double*)nullptr, (double*)nullptr, cbuf, (double*)nullptr, scr, (const double*)nullptr, 1);
       hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, h->stream, tl, a.eta_v, (const double*)cbuf, a.lamio);
     }
@@ -269,6 +270,11 @@ static int launch_shoot_products(myr_handle h, const ProdArgs& a) {
   kt.sum_ms += ms;
   kt.launches += 1;
   return MYR_OK;
+}
+
+template <class Sys>
+static int launch_shoot_products(myr_handle h, const ProdArgs& a) {
+  return h->d.integration_method == MYR_INT_RK4 ? launch_shoot_products_m<Sys, 2>(h, a) : launch_shoot_products_m<Sys, 1>(h, a);
 }
 
 template <class Sys>
@@ -483,7 +489,7 @@ int solve_for_system(myr_handle h, int B, double* z, const double* lb, const dou
       return launch_lane_solve<TrapCore<Sys>, Sys>(h, B, TrapCore<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     case MYR_TR_SHOOTING:
       if (h->d.integration_method == MYR_INT_RK4)
-        return fail(MYR_E_UNSUPPORTED, "myr_solve: shooting solve is built for EULER, HEUN and MIDPOINT steps (RK4: rollout only)");
+        return launch_lane_solve<ShootCore<Sys, 2>, Sys>(h, B, ShootCore<Sys, 2>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
       return launch_lane_solve<ShootCore<Sys>, Sys>(h, B, ShootCore<Sys>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   return fail(MYR_E_ARG, "solve: unknown transcription");
@@ -604,7 +610,7 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
       dm.x_rows = N + 1; dm.u_rows = mc * N * desc->controls_per_interval + 1;
       dm.n = dm.x_rows * si.ns + dm.u_rows * si.nu;
       dm.m = N * si.ns;
-      dm.jblk = N * (si.ns * si.ns + si.ns * (desc->controls_per_interval + 1) * si.nu);   // EULER / HEUN layout
+      dm.jblk = N * (si.ns * si.ns + si.ns * (mc * desc->controls_per_interval + 1) * si.nu);   // Ju spans the interval's mc*cpi+1 control rows
       dm.ngrad = dm.n;
       break;
     }

@@ -18,11 +18,14 @@
 
 namespace myriad {
 
-template <class Sys>
+// M = control rows a stage adds after its own: 1 for trapezoid / Euler / Heun / midpoint steps (du_next), 2 for an RK4
+// step, whose controls are u[2i], u[2i+1], u[2i+2] (utils.py:91-96): the stage then eliminates q = (du_mid, du_next).
+template <class Sys, int M = 1>
 struct OsDims {
   static constexpr int NS = Sys::NS, NU = Sys::NU, NW = Sys::NW;
-  static constexpr int NY = NW + NU;     // stage unknowns: dx, du, du_next
-  static constexpr int NQ = NU;
+  static constexpr int NY = NW + M * NU;     // stage unknowns: dx, du, (du_mid,) du_next
+  static constexpr int NQ = M * NU;
+  static constexpr int QN = NW + (M - 1) * NU;   // column of du_next in y
   static constexpr int NC = 2 + NS;
   static constexpr int NY1 = NY + 1;
   // per-stage storage for the forward sweep: K (NQ x NW), kc (NQ x NC), Ge|ge (NS x NY1), stage gradient (NY)
@@ -35,11 +38,13 @@ struct OsDims {
 //        Ge      NS x NY1: dx_next = Ge [y; 1]
 //        Hs, gs  stage Hessian (NY x NY) and stage gradient (NY) in y (may be null = zero)
 //   out: P, pc   value function of this stage's state (own terms of this point NOT included), K, kc, Tnu updated
-template <class Sys>
+//        qdiag, qg1 (may be null): own bound terms of the controls that live only in this stage (the mid control of an RK4
+//                   step): added to the diagonal of the q block and to the mu column of its right-hand side
+template <class Sys, int M = 1>
 MYR_HD inline int os_riccati_stage(double* P, double* pc, double* Tnu, const double* Ge, const double* Hs, const double* gs,
-                                   double reg_floor, double* Kk, double* kc) {
-  using D = OsDims<Sys>;
-  constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = D::NY1;
+                                   double reg_floor, double* Kk, double* kc, const double* qdiag = nullptr, const double* qg1 = nullptr) {
+  using D = OsDims<Sys, M>;
+  constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = D::NY1, QN = D::QN;
   double T2[NW * NY1];
 #pragma unroll
   for (int r = 0; r < NW; ++r)
@@ -49,7 +54,7 @@ MYR_HD inline int os_riccati_stage(double* P, double* pc, double* Tnu, const dou
 #pragma unroll
       for (int t = 0; t < NS; ++t) s += P[r * NW + t] * Ge[t * NY1 + c];
 #pragma unroll
-      for (int a = 0; a < NU; ++a) if (c == NW + a) s += P[r * NW + NS + a];
+      for (int a = 0; a < NU; ++a) if (c == QN + a) s += P[r * NW + NS + a];
       T2[r * NY1 + c] = s;
     }
   double Q[NY * NY], qc[NY * NC];
@@ -61,7 +66,8 @@ MYR_HD inline int os_riccati_stage(double* P, double* pc, double* Tnu, const dou
 #pragma unroll
       for (int t = 0; t < NS; ++t) s += Ge[t * NY1 + r] * T2[t * NY1 + c];
 #pragma unroll
-      for (int a = 0; a < NU; ++a) if (r == NW + a) s += T2[(NS + a) * NY1 + c];
+      for (int a = 0; a < NU; ++a) if (r == QN + a) s += T2[(NS + a) * NY1 + c];
+      if (qdiag && r == c && r >= NW && r < QN) s += qdiag[r - NW];
       Q[r * NY + c] = s;
     }
 #pragma unroll
@@ -71,7 +77,8 @@ MYR_HD inline int os_riccati_stage(double* P, double* pc, double* Tnu, const dou
       for (int t = 0; t < NS; ++t) s += Ge[t * NY1 + r] * (pc[t * NC + cc] + (cc == 0 ? T2[t * NY1 + NY] : 0.0));
 #pragma unroll
       for (int a = 0; a < NU; ++a)
-        if (r == NW + a) s += pc[(NS + a) * NC + cc] + (cc == 0 ? T2[(NS + a) * NY1 + NY] : 0.0);
+        if (r == QN + a) s += pc[(NS + a) * NC + cc] + (cc == 0 ? T2[(NS + a) * NY1 + NY] : 0.0);
+      if (qg1 && cc == 1 && r >= NW && r < QN) s += qg1[r - NW];
       qc[r * NC + cc] = s;
     }
   }
@@ -458,19 +465,20 @@ struct TrapCore {
 // ====================================================================================================
 // Direct (multiple) shooting, Euler / Heun steps
 // ====================================================================================================
-template <class Sys>
+template <class Sys, int M = 1>
 struct ShootCore {
   using H = HsSolver<Sys>;
-  using D = OsDims<Sys>;
-  static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = D::NY1;
+  using D = OsDims<Sys, M>;
+  static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = D::NY1, QN = D::QN;
+  static constexpr int CM = M;                       // control rows per step: step i uses rows M i .. M i + M
   using SweepOut = typename H::SweepOut;
   using FwdOut = typename H::FwdOut;
 
   MYR_HD static inline int steps(const HsSolveOpts& o) { return o.N * o.cpi; }
-  MYR_HD static inline int nvars(const HsSolveOpts& o) { return (o.N + 1) * NS + (steps(o) + 1) * NU; }
+  MYR_HD static inline int nvars(const HsSolveOpts& o) { return (o.N + 1) * NS + (M * steps(o) + 1) * NU; }
   MYR_HD static inline long stage_doubles(int I, int cpi) { return (long)D::HEAD + (long)I * cpi * D::STAGE + (long)(I * cpi + 1) * NS; }
   MYR_HD static inline long xi(int k, int c) { return (long)k * NS + c; }                                   // node state
-  MYR_HD static inline long ui(const HsSolveOpts& o, int i, int a) { return (long)(o.N + 1) * NS + (long)i * NU + a; }
+  MYR_HD static inline long ui(const HsSolveOpts& o, int i, int a) { return (long)(o.N + 1) * NS + (long)i * NU + a; }   // control ROW i
   MYR_HD static inline double hstep(const HsSolveOpts& o) { return o.h / o.cpi; }                          // o.h = T / intervals
 
   MYR_HD static void init(const HsWork& w, int n) { H::init(w, n); }
@@ -658,6 +666,160 @@ struct ShootCore {
     fold();
   }
 
+  // ---- RK4 step (utils.py:31-38): y = (x, u1, u2, u3); stage points W_j = (X_j, U_j) with U = (u1, u2, u2, u3), X_1 = x,
+  // X_{j+1} = x + a_{j+1} h k_j, k_j = f(W_j); x_next = x + h sum b_j k_j, dc = h sum b_j g(W_j, t + a_j h) ------------------
+  MYR_HD static inline void rk4_val(double h, const double* x, const double* u1, const double* u2, const double* u3, const double* p,
+                                    double* xn, double& dc, double t0, bool last) {
+    const double* U[4] = {u1, u2, u2, u3};
+    const double aj[4] = {0.0, 0.5, 0.5, 1.0}, bj[4] = {1.0 / 6.0, 2.0 / 6.0, 2.0 / 6.0, 1.0 / 6.0};
+    double k[NS], X[NS], acc[NS], g = 0.0;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { acc[c] = 0.0; k[c] = 0.0; }
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int c = 0; c < NS; ++c) X[c] = x[c] + aj[j] * h * k[c];
+      Sys::f(X, U[j], p, k);
+      set_time<Sys>(p, t0 + aj[j] * h);
+      g += bj[j] * Sys::g(X, U[j], p);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) acc[c] += bj[j] * k[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) xn[c] = x[c] + h * acc[c];
+    dc = h * g;
+    if constexpr (Sys::HAS_TERMINAL) { if (last) dc += Sys::term(xn, u3, p); }
+  }
+
+  // Fy (NS x NY) = d x_next / dy, gy = d dc / dy, Hs = d2 (dc + pin^T x_next) / dy2 -- exact, by forward Jacobians J_j = dW_j/dy
+  // and a reverse pass for the stage weights: kappa_4 = h b_4 pin, xi_j = A_j^T kappa_j + h b_j dg/dx_j,
+  // kappa_{j-1} = h b_{j-1} pin + h a_j xi_j;  Hs = sum_j J_j^T [sum_i kappa_j,i d2 f_i + h b_j d2 g](W_j) J_j
+  MYR_HD static inline void rk4_lin(double h, const double* x, const double* u1, const double* u2, const double* u3, const double* p,
+                                    const double* pin_in, double* Fy, double* gy, double* Hs, double t0, bool last) {
+    static_assert(M == 2, "RK4 stages carry three control rows");
+    const double* U[4] = {u1, u2, u2, u3};
+    const int usel[4] = {0, 1, 1, 2};
+    const double aj[4] = {0.0, 0.5, 0.5, 1.0}, bj[4] = {1.0 / 6.0, 2.0 / 6.0, 2.0 / 6.0, 1.0 / 6.0};
+    double pin[NS], tg[NW];
+#pragma unroll
+    for (int c = 0; c < NW; ++c) tg[c] = 0.0;
+    if constexpr (Sys::HAS_TERMINAL) { if (last) Sys::term_grad(x, u3, p, tg); }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) pin[c] = pin_in[c] + tg[c];
+    HsPoint<Sys> P[4];
+    double J[4][NW * NY], dk[NS * NY], kprev[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) kprev[c] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS * NY; ++i) { dk[i] = 0.0; Fy[i] = 0.0; }
+#pragma unroll
+    for (int c = 0; c < NY; ++c) gy[c] = 0.0;
+    for (int j = 0; j < 4; ++j) {
+      // W_j and J_j
+#pragma unroll
+      for (int c = 0; c < NS; ++c) P[j].x[c] = x[c] + aj[j] * h * kprev[c];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) P[j].u[a] = U[j][a];
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+#pragma unroll
+        for (int c = 0; c < NY; ++c) J[j][r * NY + c] = ((r == c) ? 1.0 : 0.0) + aj[j] * h * dk[r * NY + c];
+#pragma unroll
+      for (int a = 0; a < NU; ++a)
+#pragma unroll
+        for (int c = 0; c < NY; ++c) J[j][(NS + a) * NY + c] = (c == NS + usel[j] * NU + a) ? 1.0 : 0.0;
+      set_time<Sys>(p, t0 + aj[j] * h);
+      Sys::lin_d2(P[j].x, P[j].u, p, P[j].f, P[j].A, P[j].B, &P[j].g, P[j].gw, P[j].D2);
+      // dk_j = [A_j B_j] J_j ; accumulate Fy, gy
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+#pragma unroll
+        for (int c = 0; c < NY; ++c) {
+          double v = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) v += P[j].A[r * NS + t] * J[j][t * NY + c];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) v += P[j].B[r * NU + a] * J[j][(NS + a) * NY + c];
+          dk[r * NY + c] = v;
+          Fy[r * NY + c] += h * bj[j] * v;
+        }
+#pragma unroll
+      for (int c = 0; c < NY; ++c) {
+        double v = 0.0;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) v += P[j].gw[t] * J[j][t * NY + c];
+        gy[c] += h * bj[j] * v;
+      }
+#pragma unroll
+      for (int c = 0; c < NS; ++c) kprev[c] = P[j].f[c];
+    }
+#pragma unroll
+    for (int r = 0; r < NS; ++r) Fy[r * NY + r] += 1.0;
+    // reverse pass: stage weights and Hessian
+#pragma unroll
+    for (int i = 0; i < NY * NY; ++i) Hs[i] = 0.0;
+    double kap[NS], W[NW * NW], T[NW * NY];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) kap[c] = h * bj[3] * pin[c];
+    for (int j = 3; j >= 0; --j) {
+      Sys::hessian(P[j].x, P[j].u, p, P[j].D2, kap, h * bj[j], W);
+#pragma unroll
+      for (int r = 0; r < NW; ++r)
+#pragma unroll
+        for (int c = 0; c < NY; ++c) {
+          double v = 0.0;
+#pragma unroll
+          for (int t = 0; t < NW; ++t) v += W[r * NW + t] * J[j][t * NY + c];
+          T[r * NY + c] = v;
+        }
+#pragma unroll
+      for (int r = 0; r < NY; ++r)
+#pragma unroll
+        for (int c = 0; c < NY; ++c) {
+          double v = 0.0;
+#pragma unroll
+          for (int t = 0; t < NW; ++t) v += J[j][t * NY + r] * T[t * NY + c];
+          Hs[r * NY + c] += v;
+        }
+      if (j > 0) {
+        double xiv[NS];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+          double v = h * bj[j] * P[j].gw[c];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) v += P[j].A[t * NS + c] * kap[t];
+          xiv[c] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) kap[c] = h * bj[j - 1] * pin[c] + h * aj[j] * xiv[c];
+      }
+    }
+    if constexpr (Sys::HAS_TERMINAL) {
+      if (last) {
+#pragma unroll
+        for (int c = 0; c < NY; ++c) {
+          double v = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) v += tg[t] * Fy[t * NY + c];
+          gy[c] += v;
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) gy[QN + a] += tg[NS + a];
+      }
+    }
+  }
+
+  // step on the (M+1) control rows uc = [u_{Mi} | .. | u_{Mi+M}] of step i
+  MYR_HD static inline void sval(int method, double h, const double* x, const double* uc, const double* p, double* xn, double& dc,
+                                 double t0, bool last) {
+    if constexpr (M == 2) rk4_val(h, x, uc, uc + NU, uc + 2 * NU, p, xn, dc, t0, last);
+    else step_val(method, h, x, uc, uc + NU, p, xn, dc, t0, last);
+  }
+  MYR_HD static inline void slin(int method, double h, const double* x, const double* uc, const double* p, const double* pin,
+                                 double* Fy, double* gy, double* Hs, double t0, bool last) {
+    if constexpr (M == 2) rk4_lin(h, x, uc, uc + NU, uc + 2 * NU, p, pin, Fy, gy, Hs, t0, last);
+    else step_lin(method, h, x, uc, uc + NU, p, pin, Fy, gy, Hs, t0, last);
+  }
+
   // own (bound) terms of one decision variable
   struct Own { double sigma, g1, zlu; bool pinned; };
   MYR_HD static inline Own own_of(const HsWork& w, long i, SweepOut& so) {
@@ -680,12 +842,12 @@ struct ShootCore {
 #pragma unroll
       for (int c = 0; c < NS; ++c) x[c] = w.z[xi(k, c)];
       for (int i = k * cpi; i < (k + 1) * cpi; ++i) {
-        double u[NU], un[NU], xn[NS], dc;
+        double uc[(M + 1) * NU], xn[NS], dc;
 #pragma unroll
         for (int c = 0; c < NS; ++c) w.st[xs0 + (long)i * NS + c] = x[c];
 #pragma unroll
-        for (int a = 0; a < NU; ++a) { u[a] = w.z[ui(o, i, a)]; un[a] = w.z[ui(o, i + 1, a)]; }
-        step_val(method, h, x, u, un, p, xn, dc, h * i, i == S - 1);
+        for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = w.z[ui(o, M * i, a)];     // rows M i .. M i + M are contiguous
+        sval(method, h, x, uc, p, xn, dc, h * i, i == S - 1);
         so.f += dc;
 #pragma unroll
         for (int c = 0; c < NS; ++c) x[c] = xn[c];
@@ -714,7 +876,7 @@ struct ShootCore {
     }
 #pragma unroll
     for (int a = 0; a < NU; ++a) {
-      Own ow = own_of(w, ui(o, S, a), so);
+      Own ow = own_of(w, ui(o, M * S, a), so);
       ru_c[a] = ow.zlu;
       P[(NS + a) * NW + NS + a] = ow.sigma + delta; pc[(NS + a) * NC + 1] = ow.g1;
     }
@@ -738,19 +900,34 @@ struct ShootCore {
         }
         so.n_mult += NS;
       }
-      double x[NS], u[NU], un[NU], Fy[NS * NY], gy[NY], Hs[NY * NY];
+      double x[NS], uc[(M + 1) * NU], Fy[NS * NY], gy[NY], Hs[NY * NY];
 #pragma unroll
       for (int c = 0; c < NS; ++c) x[c] = w.st[xs0 + (long)i * NS + c];
 #pragma unroll
-      for (int a = 0; a < NU; ++a) { u[a] = w.z[ui(o, i, a)]; un[a] = w.z[ui(o, i + 1, a)]; }
-      step_lin(method, h, x, u, un, p, pin, Fy, gy, Hs, h * i, i == S - 1);
-      // control-row stationarity of u_{i+1}
+      for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = w.z[ui(o, M * i, a)];
+      slin(method, h, x, uc, p, pin, Fy, gy, Hs, h * i, i == S - 1);
+      // control-row stationarity of the step's last control (row M i + M)
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
-        double r = ru_c[a] + gy[NW + a];
+        double r = ru_c[a] + gy[QN + a];
 #pragma unroll
-        for (int t = 0; t < NS; ++t) r += Fy[t * NY + NW + a] * pin[t];
+        for (int t = 0; t < NS; ++t) r += Fy[t * NY + QN + a] * pin[t];
         so.stat = dmax(so.stat, fabs(r));
+      }
+      // controls that live only in this stage (the mid control of an RK4 step): stationarity and own bound terms
+      double qdiag[NQ], qg1[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { qdiag[q] = 0.0; qg1[q] = 0.0; }
+      if constexpr (M > 1) {
+#pragma unroll
+        for (int q = 0; q < (M - 1) * NU; ++q) {
+          Own om = own_of(w, ui(o, M * i + 1, q), so);
+          double r = gy[NW + q] + om.zlu;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) r += Fy[t * NY + NW + q] * pin[t];
+          so.stat = dmax(so.stat, fabs(r));
+          qdiag[q] = om.sigma + delta; qg1[q] = om.g1;
+        }
       }
       double Ge[NS * NY1];
 #pragma unroll
@@ -760,7 +937,7 @@ struct ShootCore {
         Ge[r * NY1 + NY] = caff[r];
       }
       double Kk[NQ * NW], kc[NQ * NC];
-      so.nreg += os_riccati_stage<Sys>(P, pc, so.Tnu, Ge, Hs, gy, o.reg_floor, Kk, kc);
+      so.nreg += os_riccati_stage<Sys, M>(P, pc, so.Tnu, Ge, Hs, gy, o.reg_floor, Kk, kc, qdiag, qg1);
       if (so.nreg > 0 && so.abort_on_reg) return;
       const long base = (long)D::HEAD + (long)i * D::STAGE;
 #pragma unroll
@@ -785,7 +962,7 @@ struct ShootCore {
         double s = gy[NS + a];
 #pragma unroll
         for (int t = 0; t < NS; ++t) s += Fy[t * NY + NS + a] * pin[t];
-        Own ow = own_of(w, ui(o, i, a), so);
+        Own ow = own_of(w, ui(o, M * i, a), so);
         ru_c[a] = s + ow.zlu;
         if (i > 0) { P[(NS + a) * NW + NS + a] += ow.sigma + delta; pc[(NS + a) * NC + 1] += ow.g1; }
       }
@@ -872,8 +1049,12 @@ struct ShootCore {
 #pragma unroll
         for (int c = 0; c < NS; ++c) setvar(xi(k1, c), s[c]);
       }
+      if constexpr (M > 1) {
 #pragma unroll
-      for (int a = 0; a < NU; ++a) { s[NS + a] = y[NW + a]; setvar(ui(o, i + 1, a), y[NW + a]); }
+        for (int q = 0; q < (M - 1) * NU; ++q) setvar(ui(o, M * i + 1, q), y[NW + q]);
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { s[NS + a] = y[QN + a]; setvar(ui(o, M * i + M, a), y[QN + a]); }
     }
   }
 
@@ -893,9 +1074,9 @@ struct ShootCore {
       bar -= log(sl > 0.0 ? sl : 1.0) + log(su > 0.0 ? su : 1.0);
       return v;
     };
-    double un[NU];
+    double uc[(M + 1) * NU];
 #pragma unroll
-    for (int a = 0; a < NU; ++a) un[a] = val(ui(o, 0, a));
+    for (int a = 0; a < NU; ++a) uc[M * NU + a] = val(ui(o, 0, a));
     double xnode[NS];
 #pragma unroll
     for (int c = 0; c < NS; ++c) xnode[c] = val(xi(0, c));
@@ -904,10 +1085,12 @@ struct ShootCore {
 #pragma unroll
       for (int c = 0; c < NS; ++c) x[c] = xnode[c];
       for (int i = k * cpi; i < (k + 1) * cpi; ++i) {
-        double u[NU], xn[NS], dc;
+        double xn[NS], dc;
 #pragma unroll
-        for (int a = 0; a < NU; ++a) { u[a] = un[a]; un[a] = val(ui(o, i + 1, a)); }
-        step_val(method, h, x, u, un, p, xn, dc, h * i, i == I * cpi - 1);
+        for (int a = 0; a < NU; ++a) uc[a] = uc[M * NU + a];                       // the previous step's last control
+#pragma unroll
+        for (int a = 0; a < M * NU; ++a) uc[NU + a] = val(ui(o, M * i + 1, a));     // rows M i + 1 .. M i + M, each visited once
+        sval(method, h, x, uc, p, xn, dc, h * i, i == I * cpi - 1);
         f += dc;
 #pragma unroll
         for (int c = 0; c < NS; ++c) x[c] = xn[c];
@@ -923,7 +1106,7 @@ struct ShootCore {
   }
 
   MYR_HD static void solve(const HsWork& w, const HsSolveOpts& o, const double* p, HsSolveResult& res) {
-    IpLoop<ShootCore<Sys>>::run(w, o, p, res);
+    IpLoop<ShootCore<Sys, M>>::run(w, o, p, res);
   }
 };
 

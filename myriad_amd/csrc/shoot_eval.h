@@ -17,20 +17,22 @@ namespace myriad {
 
 // jblk layout per interval k: Jx = d c_k / d x_k (ns x ns, row-major), then Ju = d c_k / d u_{k*cpi .. (k+1)*cpi}
 // (ns x (cpi+1)*nu, row-major); d c_k / d x_{k+1} = -I is implied.
-template <class Sys>
+template <class Sys, int M = 1>
 __global__ __launch_bounds__(64)
 void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double* __restrict__ z,
                        const double* __restrict__ params, int params_stride, double* __restrict__ fout,
                        double* __restrict__ gout, double* __restrict__ cout, double* __restrict__ jout,
                        double* __restrict__ scratch, const double* __restrict__ lamin = nullptr, int with_cost = 1) {
+  // M control rows per step (1: Euler / Heun / midpoint, 2: RK4 with u[2i], u[2i+1], u[2i+2]).
   // lamin [B][I*NS] (optional): gout becomes (with_cost ? grad f : 0) + J^T lam -- the gradient of the Lagrangian in z
   // (nlp_solvers/extra_gradient.py:21-33) by the same reverse sweep, seeded with lam_k at the end of interval k
-  using SC = ShootCore<Sys>;
-  constexpr int NS = Sys::NS, NU = Sys::NU, NW = Sys::NW, NY = NW + NU;
+  using SC = ShootCore<Sys, M>;
+  constexpr int NS = Sys::NS, NU = Sys::NU, NW = Sys::NW, NY = SC::NY;
   const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int S = I * cpi;
-  const long n = (long)(I + 1) * NS + (long)(S + 1) * NU;
+  const int W = M * cpi + 1;                                   // control rows of one interval
+  const long n = (long)(I + 1) * NS + (long)(M * S + 1) * NU;
   const double h = T / S;
   const double* zb = z + b * n;
   const double* ub = zb + (long)(I + 1) * NS;
@@ -38,7 +40,7 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
   pp.load(params, b, params_stride);
   const double* p = pp.get();
   double* xs = scratch + b * (long)(cpi + 1) * NS;      // states of the current interval
-  const long jpi = (long)NS * NS + (long)NS * (cpi + 1) * NU;
+  const long jpi = (long)NS * NS + (long)NS * W * NU;
   double* gb = gout ? gout + b * n : nullptr;
   if (gb) for (long i = 0; i < n; ++i) gb[i] = 0.0;
   double ftot = 0.0;
@@ -51,7 +53,7 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
       double xn[NS], dc;
 #pragma unroll
       for (int c = 0; c < NS; ++c) xs[(long)j * NS + c] = x[c];
-      SC::step_val(method, h, x, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, xn, dc, h * i, i == S - 1);
+      SC::sval(method, h, x, ub + (long)M * i * NU, p, xn, dc, h * i, i == S - 1);
       ftot += dc;
 #pragma unroll
       for (int c = 0; c < NS; ++c) x[c] = xn[c];
@@ -63,8 +65,9 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
     if (!jout && !gb) continue;
     const double* lk = lamin ? lamin + b * (long)I * NS + (long)k * NS : nullptr;
     const double cw = with_cost ? 1.0 : 0.0;
-    // reverse sweep: Lam = d x_end / d x_{j+1} (ns x ns), a = d (cost of the rest of the interval) / d x_{j+1}
-    double Lam[NS * NS], a[NS], pendJ[NS * NU], pendg[NU];
+    // reverse sweep: Lam = d x_end / d x_{j+1} (ns x ns), a = d (cost of the rest of the interval [+ lam_k^T x_end]) / d x_{j+1};
+    // every step adds its direct contribution to each of its M+1 control rows (the rows shared by two steps get two)
+    double Lam[NS * NS], a[NS];
 #pragma unroll
     for (int r = 0; r < NS; ++r)
 #pragma unroll
@@ -74,55 +77,43 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
       a[c] = lk ? lk[c] : 0.0;                                   // d (lam_k^T c_k) / d x_end = lam_k
       if (lk && gb) gb[(long)(k + 1) * NS + c] -= lk[c];         // d (lam_k^T c_k) / d x_{k+1} = -lam_k
     }
-#pragma unroll
-    for (int q = 0; q < NS * NU; ++q) pendJ[q] = 0.0;
-#pragma unroll
-    for (int q = 0; q < NU; ++q) pendg[q] = 0.0;
     double* jb = jout ? jout + b * (long)I * jpi + (long)k * jpi : nullptr;
+    if (jb) for (long q = 0; q < (long)NS * W * NU; ++q) jb[NS * NS + q] = 0.0;
     const double zero[NS] = {0};
     for (int j = cpi - 1; j >= 0; --j) {
       const int i = k * cpi + j;
       double xi[NS], Fy[NS * NY], gy[NY], Hs[NY * NY];
 #pragma unroll
       for (int c = 0; c < NS; ++c) xi[c] = xs[(long)j * NS + c];
-      SC::step_lin(method, h, xi, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, zero, Fy, gy, Hs, h * i, i == S - 1);
-      // column block of u_{i+1}: this step's d/du_next + what step i+1 contributed as its own d/du
+      SC::slin(method, h, xi, ub + (long)M * i * NU, p, zero, Fy, gy, Hs, h * i, i == S - 1);
+      // direct contributions to the step's control rows M i + s, s = 0 .. M (local rows M j + s of the interval)
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        double gsum = pendg[u] + cw * gy[NW + u];
+      for (int sl = 0; sl <= M; ++sl)
 #pragma unroll
-        for (int t = 0; t < NS; ++t) gsum += a[t] * Fy[t * NY + NW + u];
-        if (gb) gb[(long)(I + 1) * NS + (long)(i + 1) * NU + u] += gsum;
+        for (int u = 0; u < NU; ++u) {
+          const int col = NS + sl * NU + u;
+          double gsum = cw * gy[col];
 #pragma unroll
-        for (int r = 0; r < NS; ++r) {
-          double s = pendJ[r * NU + u];
+          for (int t = 0; t < NS; ++t) gsum += a[t] * Fy[t * NY + col];
+          if (gb) gb[(long)(I + 1) * NS + (long)(M * i + sl) * NU + u] += gsum;
+          if (jb) {
 #pragma unroll
-          for (int t = 0; t < NS; ++t) s += Lam[r * NS + t] * Fy[t * NY + NW + u];
-          if (jb) jb[NS * NS + (long)r * (cpi + 1) * NU + (long)(j + 1) * NU + u] = s;
+            for (int r = 0; r < NS; ++r) {
+              double sj = 0.0;
+#pragma unroll
+              for (int t = 0; t < NS; ++t) sj += Lam[r * NS + t] * Fy[t * NY + col];
+              jb[NS * NS + (long)r * W * NU + (long)(M * j + sl) * NU + u] += sj;
+            }
+          }
         }
-      }
-      // pending contribution of this step to its own control u_i, then propagate the adjoints through the step
+      // propagate the adjoints through the step
       double nL[NS * NS], na[NS];
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        double g2 = cw * gy[NS + u];
-#pragma unroll
-        for (int t = 0; t < NS; ++t) g2 += a[t] * Fy[t * NY + NS + u];
-        pendg[u] = g2;
-#pragma unroll
-        for (int r = 0; r < NS; ++r) {
-          double s = 0.0;
-#pragma unroll
-          for (int t = 0; t < NS; ++t) s += Lam[r * NS + t] * Fy[t * NY + NS + u];
-          pendJ[r * NU + u] = s;
-        }
-      }
-#pragma unroll
       for (int c = 0; c < NS; ++c) {
-        double s = cw * gy[c];
+        double sg = cw * gy[c];
 #pragma unroll
-        for (int t = 0; t < NS; ++t) s += a[t] * Fy[t * NY + c];
-        na[c] = s;
+        for (int t = 0; t < NS; ++t) sg += a[t] * Fy[t * NY + c];
+        na[c] = sg;
 #pragma unroll
         for (int r = 0; r < NS; ++r) {
           double v = 0.0;
@@ -136,13 +127,7 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
 #pragma unroll
       for (int c = 0; c < NS; ++c) a[c] = na[c];
     }
-    // first control of the interval and the node state
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      if (gb) gb[(long)(I + 1) * NS + (long)(k * cpi) * NU + u] += pendg[u];
-#pragma unroll
-      for (int r = 0; r < NS; ++r) if (jb) jb[NS * NS + (long)r * (cpi + 1) * NU + u] = pendJ[r * NU + u];
-    }
+    // the node state
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
       if (gb) gb[(long)k * NS + c] += a[c];
@@ -155,16 +140,16 @@ void shoot_eval_kernel(int B, int I, int cpi, int method, double T, const double
 
 // out[b] = J(z_b) v_b for the shooting constraints c_k = x_end(x_k, u_{k cpi .. (k+1) cpi}) - x_{k+1}: forward tangent
 // propagation through the steps of each interval (one trajectory per lane)
-template <class Sys>
+template <class Sys, int M = 1>
 __global__ __launch_bounds__(64)
 void shoot_jvp_kernel(int B, int I, int cpi, int method, double T, const double* __restrict__ z, const double* __restrict__ v,
                       const double* __restrict__ params, int params_stride, double* __restrict__ out) {
-  using SC = ShootCore<Sys>;
-  constexpr int NS = Sys::NS, NU = Sys::NU, NW = Sys::NW, NY = NW + NU;
+  using SC = ShootCore<Sys, M>;
+  constexpr int NS = Sys::NS, NU = Sys::NU, NY = SC::NY;
   const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int S = I * cpi;
-  const long n = (long)(I + 1) * NS + (long)(S + 1) * NU;
+  const long n = (long)(I + 1) * NS + (long)(M * S + 1) * NU;
   const double h = T / S;
   const double* zb = z + b * n; const double* vb = v + b * n;
   const double* ub = zb + (long)(I + 1) * NS; const double* vu = vb + (long)(I + 1) * NS;
@@ -179,17 +164,17 @@ void shoot_jvp_kernel(int B, int I, int cpi, int method, double T, const double*
     for (int j = 0; j < cpi; ++j) {
       const int i = k * cpi + j;
       double xn[NS], dc, Fy[NS * NY], gy[NY], Hs[NY * NY], dn[NS];
-      SC::step_lin(method, h, x, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, zero, Fy, gy, Hs, h * i, false);
+      SC::slin(method, h, x, ub + (long)M * i * NU, p, zero, Fy, gy, Hs, h * i, false);
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < NS; ++c) s += Fy[r * NY + c] * dx[c];
 #pragma unroll
-        for (int a = 0; a < NU; ++a) s += Fy[r * NY + NS + a] * vu[(long)i * NU + a] + Fy[r * NY + NW + a] * vu[(long)(i + 1) * NU + a];
+        for (int a = 0; a < (M + 1) * NU; ++a) s += Fy[r * NY + NS + a] * vu[(long)M * i * NU + a];
         dn[r] = s;
       }
-      SC::step_val(method, h, x, ub + (long)i * NU, ub + (long)(i + 1) * NU, p, xn, dc, h * i, false);
+      SC::sval(method, h, x, ub + (long)M * i * NU, p, xn, dc, h * i, false);
 #pragma unroll
       for (int c = 0; c < NS; ++c) { x[c] = xn[c]; dx[c] = dn[c]; }
     }

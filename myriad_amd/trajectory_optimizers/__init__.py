@@ -130,7 +130,8 @@ class TrajectoryOptimizer(object):
       return hs_dense_from_blocks(blk, N, ns, nu)
     if self.transcription == "TRAPEZOIDAL":
       return trap_dense_from_blocks(blk, N, ns, nu)
-    return shoot_dense_from_blocks(blk, N, self.hp.controls_per_interval, ns, nu)
+    mc = 2 if self.hp.integration_method == IntegrationMethod.RK4 else 1     # RK4 control rows per step (shooting.py:31)
+    return shoot_dense_from_blocks(blk, N, mc * self.hp.controls_per_interval, ns, nu)
 
   # ---- Lagrangian products (collocation; experiments/e2e_sysid.py:113-141, nlp_solvers/extra_gradient.py:21-33) ----
   def lagrangian(self, variables, lmbdas, params=None):
@@ -358,8 +359,8 @@ def trap_dense_from_blocks(blk: np.ndarray, N: int, ns: int, nu: int) -> np.ndar
 
 
 def shoot_dense_from_blocks(blk: np.ndarray, I: int, cpi: int, ns: int, nu: int) -> np.ndarray:
-  """Dense (I ns) x ((I+1) ns + (I cpi + 1) nu) shooting Jacobian (Euler/Heun control layout) from the per-interval
-  blocks Jx (ns x ns), Ju (ns x (cpi+1) nu); d c_k / d x_{k+1} = -I is implied."""
+  """Dense (I ns) x ((I+1) ns + (I cpi + 1) nu) shooting Jacobian from the per-interval blocks Jx (ns x ns),
+  Ju (ns x (cpi+1) nu); d c_k / d x_{k+1} = -I is implied.  `cpi` = control rows per interval minus one (mc * cpi for RK4)."""
   n = (I + 1) * ns + (I * cpi + 1) * nu
   J = np.zeros((I * ns, n))
   for k in range(I):

@@ -167,7 +167,8 @@ extern "C" int hostsim_solve_shoot(int system_id, int I, int cpi, int method, do
   HsSolveOpts o{I, T / I, max_iter, 1e-8, 1e-6, 1e-7, 0.1};
   o.cpi = cpi; o.method = method;
   apply_env(o);
-#define SH(S) os_batch<ShootCore<S>, S>(o, (I + 1) * S::NS + (I * cpi + 1) * S::NU, I * S::NS, ShootCore<S>::stage_doubles(I, cpi), B, z, lb, ub, params, pstride, lam, cost, status, iters, kkt)
+#define SH(S) { if (method == 3) os_batch<ShootCore<S, 2>, S>(o, (I + 1) * S::NS + (2 * I * cpi + 1) * S::NU, I * S::NS, ShootCore<S, 2>::stage_doubles(I, cpi), B, z, lb, ub, params, pstride, lam, cost, status, iters, kkt); \
+                else os_batch<ShootCore<S>, S>(o, (I + 1) * S::NS + (I * cpi + 1) * S::NU, I * S::NS, ShootCore<S>::stage_doubles(I, cpi), B, z, lb, ub, params, pstride, lam, cost, status, iters, kkt); }
   switch (system_id) {
     case 0: SH(SysCARTPOLE); return 0;
     case 1: SH(SysVANDERPOL); return 0;

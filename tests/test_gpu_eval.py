@@ -73,8 +73,8 @@ def test_eval_edge_cases():
   trap = _lib.Engine("CARTPOLE", "TRAPEZOIDAL", 4, 2.0)
   assert (trap.n, trap.m, trap.jblk) == (25, 16, 4 * (2 * 16 + 2 * 4))
   rk = _lib.Engine("CARTPOLE", "SHOOTING", 2, 2.0, controls_per_interval=3, integration_method="RK4")
-  with pytest.raises(NotImplementedError):                     # RK4 shooting: rollout only
-    rk.eval(np.zeros((1, rk.n)))
+  assert (rk.n, rk.m, rk.jblk) == (3 * 4 + (2 * 6 + 1) * 1, 2 * 4, 2 * (16 + 4 * (2 * 3 + 1)))      # RK4: 2 control rows per step
+  assert rk.eval(np.zeros((1, rk.n)))["c"].shape == (1, 8)
 
 
 def test_eval_full_size_properties():

@@ -43,6 +43,9 @@ def test_trapezoidal_solve_matches_oracle_slsqp(sysname, N):
   ("CANCERTREATMENT", dict(intervals=1, controls_per_interval=100), "HEUN"),   # config 4 shape
   ("CARTPOLE", dict(intervals=10, controls_per_interval=5), "HEUN"),
   ("SIMPLECASE", dict(intervals=4, controls_per_interval=10), "EULER"),
+  ("VANDERPOL", dict(intervals=1, controls_per_interval=20), "RK4"),
+  ("CANCERTREATMENT", dict(intervals=1, controls_per_interval=30), "RK4"),
+  ("CARTPOLE", dict(intervals=5, controls_per_interval=4), "RK4"),
   ("VANDERPOL", dict(intervals=2, controls_per_interval=20), "MIDPOINT"),        # the reference's "midpoint" rule (quirk Q11)
   ("CANCERTREATMENT", dict(intervals=1, controls_per_interval=40), "MIDPOINT"),
 ])
@@ -64,12 +67,19 @@ def test_shooting_solve_matches_oracle_slsqp(sysname, kw, method):
   assert np.abs(rr[inact]).max() < 1e-5
 
 
-def test_shooting_rk4_solve_is_reported_unsupported():
+def test_shooting_rk4_reference_test_config():
+  """tests/tests.py:166-180 (test_RK4): SHOOTING with the RK4 rule -- three control rows per step (u[2i], u[2i+1], u[2i+2],
+  utils.py:91-96), solved by the same lifted Riccati with q = (du_mid, du_next)."""
   hp = HParams(system=SystemType.SIMPLECASE, optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.RK4,
                intervals=2, controls_per_interval=5, nlpsolver=NLPSolverType.SQP)
+  O, s, tr, cb = _oracle("SIMPLECASE", "SHOOTING", hp)
   opt = get_optimizer(hp, CFG, hp.system())
-  with pytest.raises(NotImplementedError):
-    opt.solve()
+  assert opt.guess.size == tr.guess.size == 3 * 1 + (2 * 10 + 1) * 1
+  sol = opt.solve()
+  z = sol['xs_and_us']
+  assert np.abs(cb.cons(z)).max() <= 1e-8 and cb.fun(z) == pytest.approx(sol['cost'], rel=1e-11)
+  r = O.solve(tr, "SLSQP", max_iter=500, extra_options={"ftol": 1e-13}, cb=cb)
+  assert sol['cost'] == pytest.approx(r['cost'], rel=1e-6)
 
 
 def test_vanderpol_shooting_batch_config3_shape():
@@ -121,6 +131,10 @@ def test_cancertreatment_parameter_sweep_config4_shape():
   ("SIMPLECASE", "SHOOTING", "TRAPEZOIDAL", "HEUN", dict(intervals=10, controls_per_interval=100)),
   ("VANDERPOL", "SHOOTING", "TRAPEZOIDAL", "EULER", dict(intervals=3, controls_per_interval=4)),
   ("VANDERPOL", "SHOOTING", "TRAPEZOIDAL", "MIDPOINT", dict(intervals=3, controls_per_interval=4)),
+  ("VANDERPOL", "SHOOTING", "TRAPEZOIDAL", "RK4", dict(intervals=3, controls_per_interval=4)),
+  ("CARTPOLE", "SHOOTING", "TRAPEZOIDAL", "RK4", dict(intervals=2, controls_per_interval=3)),
+  ("CANCERTREATMENT", "SHOOTING", "TRAPEZOIDAL", "RK4", dict(intervals=1, controls_per_interval=8)),
+  ("SIMPLECASE", "SHOOTING", "TRAPEZOIDAL", "RK4", dict(intervals=4, controls_per_interval=1)),
   ("CARTPOLE", "SHOOTING", "TRAPEZOIDAL", "MIDPOINT", dict(intervals=2, controls_per_interval=5)),
   ("CANCERTREATMENT", "SHOOTING", "TRAPEZOIDAL", "MIDPOINT", dict(intervals=1, controls_per_interval=12)),
 ])

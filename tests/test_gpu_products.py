@@ -134,7 +134,9 @@ def test_extragradient_solver_branch_runs_like_the_reference():
 
 @pytest.mark.parametrize("name,method,kw", [("VANDERPOL", "HEUN", dict(I=2, cpi=6)), ("CANCERTREATMENT", "HEUN", dict(I=1, cpi=12)),
                                             ("SIMPLECASE", "EULER", dict(I=3, cpi=4)), ("CARTPOLE", "MIDPOINT", dict(I=2, cpi=5)),
-                                            ("BACTERIA", "HEUN", dict(I=2, cpi=5)), ("HARVEST", "HEUN", dict(I=2, cpi=5))])
+                                            ("BACTERIA", "HEUN", dict(I=2, cpi=5)), ("HARVEST", "HEUN", dict(I=2, cpi=5)),
+                                            ("VANDERPOL", "RK4", dict(I=2, cpi=4)), ("HARVEST", "RK4", dict(I=1, cpi=5)),
+                                            ("TUMOUR", "RK4", dict(I=2, cpi=3))])
 def test_shooting_products_match_autodiff(name, method, kw):
   """J^T lam, grad L and J v of the SHOOTING transcription (reverse sweep seeded with lam / forward tangents) against the
   oracle's autodiff, incl. a terminal-cost and a time-dependent-cost system."""

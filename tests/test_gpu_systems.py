@@ -138,7 +138,7 @@ def test_discrete_system_is_refused_like_the_reference():
 
 def _shooting_checks(sysname, sys_host, sys_oracle):
   from oracle import myriad_oracle as O
-  for method in ("HEUN", "EULER", "MIDPOINT"):
+  for method in ("HEUN", "EULER", "MIDPOINT", "RK4"):
     hp = HParams(system=SystemType[sysname], optimizer=OptimizerType.SHOOTING, intervals=2, controls_per_interval=6,
                  integration_method=IntegrationMethod[method], nlpsolver=NLPSolverType.SQP, max_iter=500)
     tr = O.shooting(sys_oracle, 2, 6, method)
