@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional
 
 import numpy as np
@@ -61,6 +62,14 @@ def load() -> C.CDLL:
   if not os.path.exists(LIB_PATH):
     raise MyriadHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
                          "There is no CPU fallback.")
+  # PyTorch-ROCm ships its own HIP runtime.  If this library brought the system runtime in first, a later torch.cuda
+  # initialisation in the same process reports "No HIP GPUs are available"; loading torch's libraries first makes one
+  # runtime serve both (torch is optional: nothing else here uses it).
+  if "torch" not in sys.modules and os.environ.get("MYRIAD_NO_TORCH_PRELOAD") is None:
+    try:
+      import torch  # noqa: F401
+    except Exception:
+      pass
   lib = C.CDLL(LIB_PATH)
   vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p   # raw addresses (host numpy or device pointers)
   lib.myr_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]
