@@ -56,7 +56,11 @@ enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2,
           evaluates it at the reference's point / step times */
        MYR_SYS_HARVEST = 18, MYR_SYS_TIMBERHARVEST = 19,
        /* lenhart/predator_prey.py: terminal cost and ONE pinned terminal state (x_T = [None, None, B]) */
-       MYR_SYS_PREDATORPREY = 20 };
+       MYR_SYS_PREDATORPREY = 20,
+       /* lenhart/invasive_plant.py: DISCRETE-time (five foci, five controls).  Only myr_fbsm (its discrete recurrences)
+          accepts it; the direct-transcription entry points return MYR_E_UNSUPPORTED, as the reference's direct optimisers
+          raise NotImplementedError for it (trajectory_optimizers/base.py:66-67) */
+       MYR_SYS_INVASIVEPLANT = 21 };
 /* transcription: OptimizerType x QuadratureRule (config.py:12-57) */
 enum { MYR_TR_HERMITE_SIMPSON = 0, MYR_TR_TRAPEZOIDAL = 1, MYR_TR_SHOOTING = 2 };
 /* IntegrationMethod (config.py:46-50) */
@@ -189,11 +193,12 @@ int myr_exgd(myr_handle h, int32_t B, double* z, double* lam, const double* lb, 
 /*
  * Batched Forward-Backward Sweep, the reference's indirect solver (trajectory_optimizers/forward_backward_sweep.py:20-116;
  * RK4 sweeps utils.py:138-197; stopping rule trajectory_optimizers/base.py:128-141) for B instances of the handle's
- * system.  Built for the continuous-time IndirectFHCS systems without terminal STATE conditions: SIMPLECASE,
- * CANCERTREATMENT, BACTERIA, BEARPOPULATIONS, BIOREACTOR, EPIDEMICSEIRN, GLUCOSE, HARVEST, HIVTREATMENT, MOULDFUNGICIDE,
- * SIMPLECASEWITHBOUNDS, TIMBERHARVEST, PREDATORPREY (others return MYR_E_UNSUPPORTED).  The secant `sequencesolver` for a
- * terminal state condition (PREDATORPREY) is a host loop over this call with different adj_T; the discrete variant is
- * not built.  The handle's transcription is not used.
+ * system.  Built for all fourteen IndirectFHCS systems: SIMPLECASE, CANCERTREATMENT, BACTERIA, BEARPOPULATIONS, BIOREACTOR,
+ * EPIDEMICSEIRN, GLUCOSE, HARVEST, HIVTREATMENT, MOULDFUNGICIDE, SIMPLECASEWITHBOUNDS, TIMBERHARVEST, PREDATORPREY, and the
+ * discrete-time INVASIVEPLANT (others return MYR_E_UNSUPPORTED).  The secant `sequencesolver` for a terminal state
+ * condition (PREDATORPREY) is a host loop over this call with different adj_T.  The handle's transcription is not used.
+ * Discrete systems (forward_backward_sweep.py:33-41, utils.py:184-188): N = int(T) unit steps, direct recurrences instead
+ * of RK4, `us` is [B][N][nu] (one control row per step) and `params` is required.
  *   N = hp.fbsm_intervals; x0 [B][ns]; adj_T [ns] or NULL (= 0); params as in myr_eval;
  *   clip_lo / clip_hi [nu]: the bounds each control's optim_characterization is clipped with (+-inf = not clipped);
  *   bang: max|bounds[-1]| for the bang-bang characterisations; delta: stopping tolerance (0.001)

@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libmyriad_hip.so")
 SYS_IDS = {"CARTPOLE": 0, "VANDERPOL": 1, "CANCERTREATMENT": 2, "SIMPLECASE": 3, "NODE_CARTPOLE": 4, "BIOREACTOR": 5,
            "GLUCOSE": 6, "MOULDFUNGICIDE": 7, "SIMPLECASEWITHBOUNDS": 8, "HIVTREATMENT": 9, "EPIDEMICSEIRN": 10, "SEIR": 11,
            "BEARPOPULATIONS": 12, "PENDULUM": 13, "MOUNTAINCAR": 14, "ROCKETLANDING": 15,
-           "BACTERIA": 16, "TUMOUR": 17, "HARVEST": 18, "TIMBERHARVEST": 19, "PREDATORPREY": 20}
+           "BACTERIA": 16, "TUMOUR": 17, "HARVEST": 18, "TIMBERHARVEST": 19, "PREDATORPREY": 20,
+           "INVASIVEPLANT": 21}   # INVASIVEPLANT: discrete-time, myr_fbsm only
 TR_IDS = {"HERMITE_SIMPSON": 0, "TRAPEZOIDAL": 1, "SHOOTING": 2}
 INT_IDS = {"EULER": 0, "HEUN": 1, "MIDPOINT": 2, "RK4": 3}
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -298,8 +299,9 @@ class Engine:
     else:
       _chk(self.lib.myr_jvp(self._h, int(B), _addr(z), _addr(w), _addr(params), int(params_stride), _addr(out), MEM_DEVICE), "myr_jvp")
 
-  def fbsm(self, x0, N, clip_lo, clip_hi, params=None, adj_T=None, delta=0.001, max_sweeps=10000, bang=0.0):
-    """Batched Forward-Backward Sweep: returns {'x' [B,N+1,ns], 'u' [B,N+1,nu], 'adj' [B,N+1,ns], 'sweeps' [B]}."""
+  def fbsm(self, x0, N, clip_lo, clip_hi, params=None, adj_T=None, delta=0.001, max_sweeps=10000, bang=0.0, discrete=False):
+    """Batched Forward-Backward Sweep: returns {'x' [B,N+1,ns], 'u' [B,N+1,nu], 'adj' [B,N+1,ns], 'sweeps' [B]};
+    for a discrete system (`discrete=True`, INVASIVEPLANT) 'u' is [B,N,nu], one row per step."""
     x0 = _f64(x0)
     if x0.ndim == 1:
       x0 = x0[None]
@@ -307,7 +309,7 @@ class Engine:
     p, ps = self._params(params, B)
     aT = None if adj_T is None else _f64(adj_T)
     lo = np.ascontiguousarray(np.broadcast_to(_f64(clip_lo), (self.nu,))); hi = np.ascontiguousarray(np.broadcast_to(_f64(clip_hi), (self.nu,)))
-    xs = np.empty((B, N + 1, self.ns)); us = np.empty((B, N + 1, self.nu)); adjs = np.empty((B, N + 1, self.ns))
+    xs = np.empty((B, N + 1, self.ns)); us = np.empty((B, N + (0 if discrete else 1), self.nu)); adjs = np.empty((B, N + 1, self.ns))
     sw = np.empty(B, dtype=np.int32)
     _chk(self.lib.myr_fbsm(self._h, B, int(N), _addr(x0), _addr(aT), _addr(p), ps, _addr(lo), _addr(hi), float(bang), float(delta),
                            int(max_sweeps), _addr(xs), _addr(us), _addr(adjs), _addr(sw), MEM_HOST), "myr_fbsm")

@@ -210,4 +210,113 @@ void fbsm_kernel(int B, long Bp, int N, double T, const double* __restrict__ x0,
   if (sweeps) sweeps[b] = n;
 }
 
+// ---- discrete-time variant (system.discrete: forward_backward_sweep.py:33-41, utils.py:184-188,193-197) -----------------
+// The sweeps are direct recurrences with h = 1 and N = int(T) steps; u has N rows (one per step), x and adj N+1:
+//   x_{i+1}   = dynamics(x_i, u_i)                              i = 0..N-1            (utils.py:186)
+//   adj_{i-1} = adj_ODE(adj_i, x_i, u_{i-1})                    i = N..1              (utils.py:188: u[idx], v[idx-1])
+//   u_i       = (clip(optim_characterization(adj_{i+1}, x_i)) + u_i) / 2              (shifted rows, invasive_plant.py:86-90)
+// -- note the backward recurrence pairs x_i (not x_{i-1}) with u_{i-1}; that is the reference's indexing and is kept.
+// The stopping rule is the one of the continuous sweep, with u summed over its N rows.
+//
+// INVASIVEPLANT (lenhart/invasive_plant.py:37-94): five independent foci, p = (B, k, eps), adj_T = 1.
+struct DiscINVASIVEPLANT {
+  static constexpr int NS = 5, NU = 5, NP = 3;
+  __device__ static inline double growth(double x, const double* p) { return x + x * p[1] / (p[2] + x); }          // :70
+  __device__ static inline void step(const double* x, const double* u, const double* p, double* out) {             // :68-72
+#pragma unroll
+    for (int c = 0; c < NS; ++c) out[c] = growth(x[c], p) * (1.0 - u[c]);
+  }
+  __device__ static inline void adj_prev(const double* adj, const double* x, const double* u, const double* p, double* out) {   // :77-81
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { const double d = p[2] + x[c]; out[c] = adj[c] * (1.0 - u[c]) * (1.0 + p[2] * p[1] / (d * d)); }
+  }
+  __device__ static inline void characterize(const double* adj_next, const double* x, const double* p, double* u) {  // :83-90
+#pragma unroll
+    for (int c = 0; c < NU; ++c) u[c] = 0.5 * adj_next[c] / p[0] * growth(x[c], p);
+  }
+};
+
+template <class D>
+__global__ __launch_bounds__(64)
+void fbsm_discrete_kernel(int B, long Bp, int N, const double* __restrict__ x0, const double* __restrict__ adjT,
+                          const double* __restrict__ params, int params_stride, VarScale clip_lo, VarScale clip_hi, double delta,
+                          int max_sweeps, double* xs, double* us, double* adjs, int32_t* sweeps) {
+  constexpr int NS = D::NS, NU = D::NU, NP = D::NP;
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double p[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) p[i] = params[(long)b * params_stride + i];
+  double* X = xs + b; double* U = us + b; double* A = adjs + b;
+  auto at = [Bp](double* a, int i, int c, int nc) -> double& { return a[((long)i * nc + c) * Bp]; };
+  for (int i = 0; i <= N; ++i) {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { at(X, i, c, NS) = (i == 0) ? x0[b * NS + c] : 0.0; at(A, i, c, NS) = (i == N && adjT) ? adjT[c] : 0.0; }
+    if (i < N) {
+#pragma unroll
+      for (int c = 0; c < NU; ++c) at(U, i, c, NU) = 0.0;
+    }
+  }
+  int n = 0;
+  bool go = true;
+  while (go && n < max_sweeps) {
+    double sx[NS], dx[NS], sa[NS], da[NS], su[NU], du[NU];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { sx[c] = dx[c] = sa[c] = da[c] = 0.0; }
+#pragma unroll
+    for (int c = 0; c < NU; ++c) { su[c] = du[c] = 0.0; }
+    // forward recurrence with the old controls
+    double x[NS], u[NU], xn[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { x[c] = at(X, 0, c, NS); sx[c] += fabs(x[c]); }
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+      for (int c = 0; c < NU; ++c) u[c] = at(U, i, c, NU);
+      D::step(x, u, p, xn);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        const double old = at(X, i + 1, c, NS);
+        x[c] = xn[c];
+        sx[c] += fabs(x[c]); dx[c] += fabs(x[c] - old);
+        at(X, i + 1, c, NS) = x[c];
+      }
+    }
+    // backward recurrence (new x, old u), then the control of the step below from the new adj_i and x_{i-1}
+    double a[NS], ap[NS], xi[NS], xj[NS], ue[NU];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { a[c] = at(A, N, c, NS); sa[c] += fabs(a[c]); xi[c] = x[c]; }
+    for (int i = N; i >= 1; --i) {
+#pragma unroll
+      for (int c = 0; c < NU; ++c) u[c] = at(U, i - 1, c, NU);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) xj[c] = at(X, i - 1, c, NS);
+      D::adj_prev(a, xi, u, p, ap);
+      D::characterize(a, xj, p, ue);
+#pragma unroll
+      for (int c = 0; c < NU; ++c) {
+        const double est = fmin(clip_hi.s[c], fmax(clip_lo.s[c], ue[c]));
+        const double nu_ = 0.5 * (est + u[c]);
+        su[c] += fabs(nu_); du[c] += fabs(nu_ - u[c]);
+        at(U, i - 1, c, NU) = nu_;
+      }
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        const double old = at(A, i - 1, c, NS);
+        a[c] = ap[c];
+        sa[c] += fabs(a[c]); da[c] += fabs(a[c] - old);
+        at(A, i - 1, c, NS) = a[c];
+        xi[c] = xj[c];
+      }
+    }
+    ++n;
+    double mn = INFINITY;
+#pragma unroll
+    for (int c = 0; c < NU; ++c) mn = fmin(mn, su[c] * delta - du[c]);
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { mn = fmin(mn, sx[c] * delta - dx[c]); mn = fmin(mn, sa[c] * delta - da[c]); }
+    go = mn < 0.0;
+  }
+  if (sweeps) sweeps[b] = n;
+}
+
 }  // namespace myriad

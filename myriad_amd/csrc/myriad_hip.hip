@@ -54,6 +54,7 @@ static bool sys_info(int id, SysInfo* s) {
     MYR_CLOSED_FORM_SYSTEMS(X)
 #undef X
     case MYR_SYS_NODE_CARTPOLE: *s = {SysNODE_CARTPOLE::NS, SysNODE_CARTPOLE::NU, SysNODE_CARTPOLE::NP, SysNODE_CARTPOLE::COST_DEP_X}; return true;
+    case MYR_SYS_INVASIVEPLANT: *s = {DiscINVASIVEPLANT::NS, DiscINVASIVEPLANT::NU, DiscINVASIVEPLANT::NP, false}; return true;   // myr_fbsm only
   }
   return false;
 }
@@ -676,6 +677,14 @@ extern "C" int myr_kernel_time_reset(myr_handle h) {
   return MYR_OK;
 }
 
+// systems without a direct-transcription path: INVASIVEPLANT is discrete-time (the reference refuses it in its direct
+// optimisers too, trajectory_optimizers/base.py:66-67) and only has the discrete FBSM
+static int no_such_path(myr_handle h, const char* who) {
+  if (h->d.system_id == MYR_SYS_INVASIVEPLANT)
+    return fail(MYR_E_UNSUPPORTED, std::string(who) + ": INVASIVEPLANT is a discrete-time system; only myr_fbsm is available for it");
+  return fail(MYR_E_ARG, std::string(who) + ": unknown system");
+}
+
 static int dispatch_eval(myr_handle h, int B, const double* z, const double* params, int pstride,
                          double* f, double* g, double* c, double* j) {
   switch (h->d.system_id) {
@@ -684,12 +693,13 @@ static int dispatch_eval(myr_handle h, int B, const double* z, const double* par
 #undef X
     case MYR_SYS_NODE_CARTPOLE: return eval_for_system<SysNODE_CARTPOLE>(h, B, z, params, pstride, f, g, c, j);
   }
-  return fail(MYR_E_ARG, "eval: unknown system");
+  return no_such_path(h, "eval");
 }
 
 extern "C" int myr_eval(myr_handle h, int32_t B, const double* z, const double* params, int32_t params_stride,
                         double* f, double* gradf, double* c, double* jblk, int32_t mem) {
   if (!h || !z) return fail(MYR_E_ARG, "myr_eval: null handle or z");
+  if (h->d.system_id == MYR_SYS_INVASIVEPLANT) return no_such_path(h, "myr_eval");
   if (B < 0) return fail(MYR_E_ARG, "myr_eval: negative batch");
   if (B == 0) return MYR_OK;
   if (params && params_stride != 0 && params_stride != h->dims.np)
@@ -733,12 +743,13 @@ static int dispatch_products(myr_handle h, const ProdArgs& a) {
 #undef X
     case MYR_SYS_NODE_CARTPOLE: return products_for_system<SysNODE_CARTPOLE>(h, a);
   }
-  return fail(MYR_E_ARG, "products: unknown system");
+  return no_such_path(h, "products");
 }
 
 static int check_products_args(myr_handle h, const char* who, int32_t B, const void* p0, const void* p1, const void* p2,
                                const double* params, int32_t params_stride) {
   if (!h || !p0 || !p1 || !p2) return fail(MYR_E_ARG, std::string(who) + ": null handle or array");
+  if (h->d.system_id == MYR_SYS_INVASIVEPLANT) return no_such_path(h, who);
   if (B < 0) return fail(MYR_E_ARG, std::string(who) + ": negative batch");
   if (params && params_stride != 0 && params_stride != h->dims.np)
     return fail(MYR_E_ARG, std::string(who) + ": params_stride must be 0 (shared) or np");
@@ -827,7 +838,7 @@ static int dispatch_solve(myr_handle h, int B, double* z, const double* lb, cons
 #undef X
     case MYR_SYS_NODE_CARTPOLE: return solve_for_system<SysNODE_CARTPOLE>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
-  return fail(MYR_E_ARG, "solve: unknown system");
+  return no_such_path(h, "solve");
 }
 
 // ---- variable scaling of the solve path ----------------------------------------------------------------------
@@ -904,6 +915,7 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
                          const double* params, int32_t params_stride, const myr_solve_opts* opts,
                          double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt, int32_t mem) {
   if (!h || !z || !lb || !ub) return fail(MYR_E_ARG, "myr_solve: null handle, z, lb or ub");
+  if (h->d.system_id == MYR_SYS_INVASIVEPLANT) return no_such_path(h, "myr_solve");
   if (B < 0) return fail(MYR_E_ARG, "myr_solve: negative batch");
   if (B == 0) return MYR_OK;
   if (params && params_stride != 0 && params_stride != h->dims.np)
@@ -959,7 +971,7 @@ static int dispatch_rollout(myr_handle h, int B, int num_steps, int u_rows, cons
     MYR_CLOSED_FORM_SYSTEMS(X)
 #undef X
     case MYR_SYS_NODE_CARTPOLE: rc = rollout_for_system<SysNODE_CARTPOLE>(h, B, num_steps, u_rows, x0, us, params, pstride, xs, cost); break;
-    default: return fail(MYR_E_ARG, "rollout: unknown system");
+    default: return no_such_path(h, "rollout");
   }
   if (rc) return rc;
   HIPCHK(hipGetLastError());
@@ -974,6 +986,7 @@ static int dispatch_rollout(myr_handle h, int B, int num_steps, int u_rows, cons
 extern "C" int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u_rows, const double* x0, const double* us,
                            const double* params, int32_t params_stride, double* xs, double* cost, int32_t mem) {
   if (!h || !x0 || !us) return fail(MYR_E_ARG, "myr_rollout: null handle, x0 or us");
+  if (h->d.system_id == MYR_SYS_INVASIVEPLANT) return no_such_path(h, "myr_rollout");
   if (B < 0 || num_steps < 1 || u_rows < 1) return fail(MYR_E_ARG, "myr_rollout: bad sizes");
   if (B == 0) return MYR_OK;
   if (params && params_stride != 0 && params_stride != h->dims.np)
@@ -1021,7 +1034,9 @@ extern "C" int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, co
   const myr_dims& dm = h->dims;
   long Bp = ((long)B + 63) / 64 * 64;
   if (((Bp / 64) & 1) == 0) Bp += 64;                 // odd multiple of 64 lanes: rotate points over HBM channels
-  const size_t rows_x = (size_t)(N + 1) * dm.ns, rows_u = (size_t)(N + 1) * dm.nu;
+  const bool discrete = h->d.system_id == MYR_SYS_INVASIVEPLANT;      // u has one row per step, not per point
+  if (discrete && !params) return fail(MYR_E_ARG, "myr_fbsm: a discrete system needs `params`");
+  const size_t rows_x = (size_t)(N + 1) * dm.ns, rows_u = (size_t)(N + (discrete ? 0 : 1)) * dm.nu;
   const size_t nx0 = (size_t)B * dm.ns, npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
   auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
   // batch-minor working arrays + instance-major staging for the transposes + sweeps
@@ -1044,6 +1059,21 @@ extern "C" int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, co
 #define X(N) case MYR_SYS_##N: MYR_FBSM(Sys##N); break;
     MYR_CLOSED_FORM_SYSTEMS(X)
 #undef X
+    case MYR_SYS_INVASIVEPLANT: {
+      KTimer& kt = h->kt[MYR_K_FBSM];
+      HIPCHK(hipEventRecord(kt.a, h->stream));
+      hipLaunchKernelGGL(fbsm_discrete_kernel<DiscINVASIVEPLANT>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, Bp, N, dx0,
+                         adj_T ? dadj : nullptr, dp, params_stride, vlo, vhi, delta, max_sweeps, X, U, A, dsw);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(kt.b, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+      kt.sum_ms += ms;
+      kt.launches += 1;
+      rc = MYR_OK;
+      break;
+    }
     default: rc = fail(MYR_E_UNSUPPORTED, "myr_fbsm: this system has no adjoint dynamics");
   }
 #undef MYR_FBSM

@@ -482,15 +482,23 @@ class PredatorPrey(IndirectFHCS):
 
 
 class InvasivePlant(IndirectFHCS):
-  """systems/lenhart/invasive_plant.py: a DISCRETE-time system.  Kept as a SystemType member for the reference's error
-  behaviour: the direct optimisers refuse discrete systems with NotImplementedError (trajectory_optimizers/base.py:66-67);
-  its discrete FBSM variant is not on the device path."""
+  """systems/lenhart/invasive_plant.py:11-94: a DISCRETE-time system (five foci, one removal ratio each).  The direct
+  optimisers refuse discrete systems with NotImplementedError (trajectory_optimizers/base.py:66-67); its solver is the
+  discrete Forward-Backward Sweep (csrc/fbsm.h, fbsm_discrete_kernel)."""
   name = "INVASIVEPLANT"
   param_names = ("B", "k", "eps")
 
   def __init__(self, B=1., k=1., eps=.01, x_0=(.5, 1., 1.5, 2., 10.), T=10.):
     super().__init__(x_0=list(x_0), x_T=None, T=T, bounds=[[-np.inf, np.inf]] * 5 + [[0., 1.]] * 5, discrete=True)
+    self.adj_T = np.ones(5)                                      # :60
     self.B, self.k, self.eps = B, k, eps
+
+  def dynamics(self, x_t, u_t, v_t=None, t=None):               # :68-72: the NEXT state, not a derivative
+    x_t = np.asarray(x_t, dtype=np.float64)
+    return (x_t + x_t * self.k / (self.eps + x_t)) * (1 - np.asarray(u_t, dtype=np.float64))
+
+  def cost(self, x_t, u_t, t=None):                              # :74-75
+    return float(self.B * (np.asarray(u_t, dtype=np.float64) ** 2).sum())
 
 
 class SystemType(Enum):

@@ -3,8 +3,8 @@ IndirectMethodOptimizer (trajectory_optimizers/base.py:106-141): same constructo
 ({'x','u','adj'}), with the sweeps on the GPU (`myr_fbsm`, csrc/fbsm.h).  EXTENSION: `solve_batch` runs B instances
 (parameter / start-state sweeps) in one call.
 
-Out of scope here, as in csrc/fbsm.h: systems with terminal state conditions (the secant `sequencesolver`, :118-158)
-and discrete systems (:33-35)."""
+Terminal state conditions go through the secant `sequencesolver` (:118-158, a host loop over device sweeps); discrete
+systems (:33-41; INVASIVEPLANT) run the direct recurrences of utils.py:184-188 in `fbsm_discrete_kernel`."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -41,15 +41,17 @@ class FBSM(IndirectMethodOptimizer):
   def __init__(self, hp: HParams, cfg: Config, system: IndirectFHCS):
     if not isinstance(system, IndirectFHCS):
       raise NotImplementedError("FBSM needs adjoint dynamics: an IndirectFHCS system (tests/test_smoke.py:34-37)")
-    if getattr(system, "discrete", False):
-      raise NotImplementedError("discrete systems are not on the device path")
     self.system = system
+    self.discrete = bool(getattr(system, "discrete", False))
     self.N = hp.fbsm_intervals                                   # :31
     self.h = system.T / self.N
+    if self.discrete:                                            # :33-35
+      self.N = int(system.T)
+      self.h = 1
     state_shape = system.x_0.shape[0]
     control_shape = system.bounds.shape[0] - state_shape
     self.x_guess = np.vstack((system.x_0, np.zeros((self.N, state_shape))))        # :38
-    self.u_guess = np.zeros((self.N + 1, control_shape))                           # :42
+    self.u_guess = np.zeros((self.N if self.discrete else self.N + 1, control_shape))   # :39-42
     if system.adj_T is not None:
       self.adj_guess = np.vstack((np.zeros((self.N, state_shape)), system.adj_T))  # :44
     else:
@@ -99,6 +101,8 @@ class FBSM(IndirectMethodOptimizer):
       lo, hi = [b[0, 0]], [b[0, 1]]
     elif name == "GLUCOSE":
       lo, hi = [-np.inf], [np.inf]
+    elif name == "INVASIVEPLANT":                                # invasive_plant.py:90: bounds[-1] for every control
+      lo, hi = [b[-1, 0]] * nu, [b[-1, 1]] * nu
     else:
       lo, hi = [b[-nu + c, 0] for c in range(nu)], [b[-nu + c, 1] for c in range(nu)]
     return np.array(lo, dtype=np.float64), np.array(hi, dtype=np.float64), float(np.max(np.abs(b[-1])))
@@ -109,13 +113,14 @@ class FBSM(IndirectMethodOptimizer):
       x0s = np.tile(self.system.x_0, (B, 1))
     p = self.system.device_params() if params is None else np.asarray(params, dtype=np.float64)
     lo, hi, bang = self._clip_bounds()
-    r = self.engine.fbsm(np.asarray(x0s, dtype=np.float64), self.N, lo, hi, params=p, adj_T=self.system.adj_T, max_sweeps=max_sweeps, bang=bang)
+    r = self.engine.fbsm(np.asarray(x0s, dtype=np.float64), self.N, lo, hi, params=p, adj_T=self.system.adj_T, max_sweeps=max_sweeps, bang=bang,
+                         discrete=self.discrete)
     return {'x': r['x'], 'u': r['u'], 'adj': r['adj'], 'sweeps': r['sweeps']}
 
   def _solve_with_adj_T(self, adj_T, max_sweeps):
     lo, hi, bang = self._clip_bounds()
     r = self.engine.fbsm(self.system.x_0[None], self.N, lo, hi, params=self.system.device_params(), adj_T=adj_T,
-                         max_sweeps=max_sweeps, bang=bang)
+                         max_sweeps=max_sweeps, bang=bang, discrete=self.discrete)
     return r['x'][0], r['u'][0], r['adj'][0]
 
   def sequencesolver(self, max_sweeps: int = 10000, max_secant: int = 100) -> Dict[str, np.ndarray]:
@@ -147,7 +152,8 @@ class FBSM(IndirectMethodOptimizer):
     return {'x': self.x_guess, 'u': self.u_guess, 'adj': self.adj_guess}
 
   def solve(self) -> Dict[str, np.ndarray]:
-    """:88-116 -- {'x': [N+1,ns], 'u': [N+1,nu], 'adj': [N+1,ns]}; the guesses are updated like the reference's."""
+    """:88-116 -- {'x': [N+1,ns], 'u': [N+1,nu] ([N,nu] for a discrete system), 'adj': [N+1,ns]}; the guesses are
+    updated like the reference's."""
     if self.terminal_cdtion:
       return self.sequencesolver()
     r = self.solve_batch()

@@ -24,6 +24,17 @@ def _engine_for(hp, system, device=0):
 def get_state_trajectory_and_cost(hp, system, start_state, us, params=None, engine=None) -> Tuple[np.ndarray, float]:
   """utils.py:258-298: integrate [x; cost] of the TRUE dynamics under `us` with hp.integration_method over
   hp.intervals*hp.controls_per_interval steps.  Batched when start_state is [B,ns] / us is [B,rows,nu]."""
+  if getattr(system, "discrete", False):
+    # DEVIATION: the reference integrates the next-state map of a discrete system as if it were an ODE right-hand side
+    # (utils.py:262-298 has no discrete branch), which has no meaning; here the recurrence x_{i+1} = dynamics(x_i, u_i)
+    # is applied over the rows of `us` and the running cost summed (host loop: int(T) steps).
+    x = np.asarray(start_state, dtype=np.float64)
+    xs, c = [x], 0.0
+    for u_t in np.asarray(us, dtype=np.float64):
+      c += system.cost(x, u_t)
+      x = system.dynamics(x, u_t)
+      xs.append(x)
+    return np.stack(xs), float(c)
   eng = engine or _engine_for(hp, system)
   num_steps = hp.intervals * hp.controls_per_interval
   x0 = np.asarray(start_state, dtype=np.float64)

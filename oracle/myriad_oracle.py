@@ -629,6 +629,35 @@ class PredatorPrey(System):
     return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], char))
 
 
+class InvasivePlant:
+  """myriad/systems/lenhart/invasive_plant.py:11-94 -- DISCRETE-time: `dynamics` returns the next state and `adj_ODE` the
+  previous adjoint.  Only the discrete FBSM applies (the direct optimisers refuse it, trajectory_optimizers/base.py:66-67),
+  so it is not in SYSTEMS."""
+  name = "INVASIVEPLANT"
+  param_names = ("B", "k", "eps")
+  discrete = True
+
+  def __init__(self, B=1., k=1., eps=.01, x_0=(.5, 1., 1.5, 2., 10.), T=10.):
+    self.B, self.k, self.eps = B, k, eps
+    self.x_0 = np.array(x_0, dtype=np.float64); self.x_T = None; self.T = float(T)
+    self.bounds = np.array([[-np.inf, np.inf]] * 5 + [[0., 1.]] * 5)
+    self.adj_T = np.ones(5)                                    # :60
+
+  def params(self):
+    return np.array([self.B, self.k, self.eps])
+
+  def np_dynamics(self, x, u):                               # :68-72
+    return (x + x * self.k / (self.eps + x)) * (1 - u)
+
+  def adj_ODE(self, adj, x, u, t=None):                      # :77-81
+    return adj * (1 - u) * (1 + self.eps * self.k / (self.eps + x) ** 2)
+
+  def optim_characterization(self, adj, x, t=None):          # :83-90 (rows shifted: adj[1:], x[:-1])
+    sa, sx = adj[1:, :], x[:-1, :]
+    char = 0.5 * sa / self.B * (sx + sx * self.k / (self.eps + sx))
+    return np.minimum(self.bounds[-1, 1], np.maximum(self.bounds[-1, 0], char))
+
+
 class Tumour(System):
   """myriad/systems/miscellaneous/tumour.py:52-108 (zero running cost; the objective is the terminal tumour volume)."""
   name = "TUMOUR"
@@ -1020,13 +1049,24 @@ def _rk4_fbsm(dyn, x_t1, u, u_next, v, v_next, h, t):
   return x_t1 + (h / 6) * (k1 + 2 * k2 + 2 * k3 + k4)
 
 
-def integrate_fbsm(dyn, x_0, u, h, N, v=None, t=None):
-  """utils.py:138-197, continuous systems: forward (h > 0) from index 0, backward (h < 0) from index N."""
+def integrate_fbsm(dyn, x_0, u, h, N, v=None, t=None, discrete=False):
+  """utils.py:138-197: forward (h > 0) from index 0, backward (h < 0) from index N.  `discrete` (:184-188): the direct
+  recurrences dyn(x, u[idx], v[idx], t[idx]) forward and dyn(x, u[idx], v[idx-1], t[idx-1]) backward (idx = N..1)."""
   if v is None:
     v = np.zeros_like(u)
   if t is None:
     t = np.zeros(N + 1)
   out = np.zeros((N + 1,) + np.shape(x_0))
+  if discrete:
+    if h >= 0:
+      out[0] = x_0
+      for i in range(N):
+        out[i + 1] = dyn(out[i], u[i], v[i], t[i])
+    else:
+      out[N] = x_0
+      for i in range(N, 0, -1):
+        out[i - 1] = dyn(out[i], u[i], v[i - 1], t[i - 1])
+    return out
   if h >= 0:
     out[0] = x_0
     for i in range(N):
@@ -1045,9 +1085,12 @@ def fbsm(system, N: int = 1000, delta: float = 0.001, max_sweeps: int = 10000):
   ns = system.x_0.shape[0]
   nu = system.bounds.shape[0] - ns
   h = system.T / N
+  disc = bool(getattr(system, "discrete", False))
+  if disc:                                                     # :33-35 (the `N` argument is ignored, as hp.fbsm_intervals is)
+    N, h = int(system.T), 1
   t = np.linspace(0, system.T, N + 1)                          # :48
   x = np.vstack([system.x_0, np.zeros((N, ns))])               # :38
-  u = np.zeros((N + 1, nu))                                    # :42
+  u = np.zeros((N if disc else N + 1, nu))                     # :39-42
   adj_T = getattr(system, "adj_T", None)
   adj = np.zeros((N + 1, ns)) if adj_T is None else np.vstack([np.zeros((N, ns)), np.asarray(adj_T, dtype=np.float64)])   # :44-47
   f = lambda x_, u_, v_, t_: system.np_dynamics(x_, u_)
@@ -1055,8 +1098,8 @@ def fbsm(system, N: int = 1000, delta: float = 0.001, max_sweeps: int = 10000):
   n = 0
   while True:
     old_u, old_x, old_adj = u.copy(), x.copy(), adj.copy()
-    x = integrate_fbsm(f, x[0], u, h, N, t=t)                              # :95-96
-    adj = integrate_fbsm(a, adj[-1], x, -h, N, u, t=t)                     # :97-98
+    x = integrate_fbsm(f, x[0], u, h, N, t=t, discrete=disc)               # :95-96
+    adj = integrate_fbsm(a, adj[-1], x, -h, N, u, t=t, discrete=disc)      # :97-98
     u = 0.5 * (system.optim_characterization(adj, x, t[:, None]) + old_u)  # :100-102
     n += 1
     stop = np.hstack([np.abs(v).sum(0) * delta - np.abs(v - o).sum(0) for v, o in ((u, old_u), (x, old_x), (adj, old_adj))])

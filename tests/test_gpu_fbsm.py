@@ -87,7 +87,7 @@ def test_direct_sqp_solution_agrees_with_pontryagin_solution(st):
 
 
 def test_fbsm_rejects_systems_without_adjoint():
-  for st in (SystemType.CARTPOLE, SystemType.SEIR, SystemType.INVASIVEPLANT):     # no adjoint / no adjoint / discrete
+  for st in (SystemType.CARTPOLE, SystemType.SEIR):               # no adjoint dynamics
     hp = HParams(system=st, optimizer=OptimizerType.FBSM)
     with pytest.raises(NotImplementedError):
       get_optimizer(hp, CFG, hp.system())
@@ -105,3 +105,43 @@ def test_fbsm_secant_solver_for_a_terminal_state_condition():
   assert abs(sol['x'][-1, 2] - 5.0) <= 1e-10
   for k in ('x', 'u', 'adj'):
     np.testing.assert_allclose(sol[k], ref[k], rtol=1e-8, atol=1e-10, err_msg=k)
+
+
+def test_discrete_fbsm_invasive_plant_matches_oracle():
+  """The discrete variant (forward_backward_sweep.py:33-41, utils.py:184-188) on INVASIVEPLANT: N = int(T) unit steps,
+  u with one row per step, the reference's index pairing in the backward recurrence; default parameters (B = 1: the
+  fixed point removes everything in the last step) and weights with interior controls."""
+  from oracle import myriad_oracle as O
+  hp = HParams(system=SystemType.INVASIVEPLANT, optimizer=OptimizerType.FBSM, fbsm_intervals=1000)   # fbsm_intervals is ignored (:33-35)
+  opt = get_optimizer(hp, CFG, hp.system())
+  assert opt.N == 10 and opt.h == 1 and opt.u_guess.shape == (10, 5) and opt.x_guess.shape == (11, 5)
+  sol = opt.solve()
+  ref = O.fbsm(O.InvasivePlant())
+  assert sol['x'].shape == (11, 5) and sol['u'].shape == (10, 5) and sol['adj'].shape == (11, 5)
+  for k in ('x', 'u', 'adj'):
+    np.testing.assert_allclose(sol[k], ref[k], rtol=1e-12, atol=1e-13, err_msg=k)
+  np.testing.assert_allclose(sol['u'][-1], 1.0, rtol=0, atol=1e-6)   # eradication in the last step (u <- (1 + u) / 2)
+  # parameter and start-state sweep, more than one wavefront
+  rng = np.random.default_rng(5)
+  B = 130
+  P = np.stack([rng.uniform(2.0, 100.0, B), rng.uniform(0.5, 1.5, B), rng.uniform(0.005, 0.05, B)], 1)   # B, k, eps
+  x0 = rng.uniform(0.2, 10.0, (B, 5))
+  r = opt.solve_batch(x0s=x0, params=P)
+  assert r['u'].shape == (B, 10, 5)
+  assert np.all((r['u'] >= 0.0) & (r['u'] <= 1.0))
+  for b in (0, 31, 63, 64, 127, 128, 129):
+    ref = O.fbsm(O.InvasivePlant(B=P[b, 0], k=P[b, 1], eps=P[b, 2], x_0=x0[b]))
+    assert int(r['sweeps'][b]) == ref['sweeps']
+    for k in ('x', 'u', 'adj'):
+      np.testing.assert_allclose(r[k][b], ref[k], rtol=1e-11, atol=1e-12, err_msg=f"{k}[{b}]")
+
+
+def test_discrete_system_only_has_the_fbsm_entry_point():
+  from myriad_amd import _lib
+  e = _lib.Engine("INVASIVEPLANT", "HERMITE_SIMPSON", 4, 10.0, max_batch=1)
+  assert (e.ns, e.nu, e.np) == (5, 5, 3)
+  with pytest.raises(NotImplementedError, match="discrete-time"):   # MYR_E_UNSUPPORTED
+    e.eval(np.zeros((1, e.n)))
+  with pytest.raises(NotImplementedError, match="discrete-time"):
+    e.rollout(np.zeros((1, 5)), np.zeros((1, 5, 5)), 4)
+  e.close()

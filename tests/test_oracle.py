@@ -139,6 +139,32 @@ def test_fbsm_restatement_is_a_pontryagin_fixed_point():
     assert r["adj"][-1, 0] == 0.0                                # transversality: adj(T) = adj_T = 0
 
 
+def test_discrete_fbsm_restatement_first_sweep_by_hand():
+  """Discrete variant (forward_backward_sweep.py:33-41, utils.py:184-188) on INVASIVEPLANT with T = 2: the first sweep
+  written out focus by focus -- the forward recurrence with u = 0, the backward one pairing x_i with u_{i-1} (the
+  reference's indexing), the shifted characterisation (invasive_plant.py:86-88) and the halving update."""
+  B, k, eps = 7.0, 1.3, 0.02
+  s = O.InvasivePlant(B=B, k=k, eps=eps, x_0=(.5, 1., 1.5, 2., 10.), T=2.)
+  r = O.fbsm(s, max_sweeps=1)
+  assert r["sweeps"] == 1 and r["x"].shape == (3, 5) and r["u"].shape == (2, 5) and r["adj"].shape == (3, 5)
+  g = lambda x: x + x * k / (eps + x)
+  for j, rho in enumerate((.5, 1., 1.5, 2., 10.)):
+    x1 = g(rho); x2 = g(x1)
+    a2 = 1.0
+    a1 = a2 * (1 - 0.0) * (1 + eps * k / (eps + x2) ** 2)
+    a0 = a1 * (1 - 0.0) * (1 + eps * k / (eps + x1) ** 2)
+    u0 = 0.5 * min(1.0, max(0.0, 0.5 * a1 / B * g(rho)))
+    u1 = 0.5 * min(1.0, max(0.0, 0.5 * a2 / B * x2))           # g(x1) = x2
+    np.testing.assert_allclose(r["x"][:, j], [rho, x1, x2], rtol=1e-15)
+    np.testing.assert_allclose(r["adj"][:, j], [a0, a1, a2], rtol=1e-15)
+    np.testing.assert_allclose(r["u"][:, j], [u0, u1], rtol=1e-15)
+  # default weights: the fixed point removes every focus in the last step (u = 1, x_T = 0, cost = 5 B)
+  r = O.fbsm(O.InvasivePlant())
+  assert r["sweeps"] < 100
+  np.testing.assert_allclose(r["u"][-1], 1.0, rtol=0, atol=1e-6)  # u <- (1 + u) / 2: 1 - 2^-sweeps
+  np.testing.assert_allclose(r["x"][-1], 0.0, rtol=0, atol=1e-4)
+
+
 def test_golden_shooting_solutions_are_feasible_optima_of_the_oracle_problem(golden_dir):
   """tests/golden/solve_shoot_*.npz: recomputed feasibility / cost, bounds, and first-order optimality in the
   null space of the constraints at the stored optimum (projected gradient on the inactive variables)."""
