@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from myriad_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmyriad_hip_timing.so")
+_lib.LIB_PATH = os.environ.get("MYRIAD_VARIANT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmyriad_hip_timing.so")
 from bench import build_workload
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 x0, z0, lb, ub, T = build_workload(B, 100, 2019)
