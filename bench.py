@@ -127,6 +127,7 @@ def main():
   rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
   assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+  local %= torch.cuda.device_count()      # a launcher that narrows the visible devices per rank leaves one device, index 0
   torch.cuda.set_device(local)
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
