@@ -391,10 +391,11 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
                            int32_t* iters, double* kkt) {
   const int N = h->d.intervals;
   const myr_dims& dm = h->dims;
-  if (h->solve_mode == 1) {
+  // one trajectory per wavefront while its LDS working set fits a CU (N <= ~480 for CARTPOLE); beyond that the
+  // lane-per-trajectory form, which keeps everything in global scratch, takes over
+  if (h->solve_mode == 1 && HsWave<Sys>::lds_bytes(N) <= 160 * 1024) {
     using W = HsWave<Sys>;
     const size_t lds = W::lds_bytes(N);
-    if (lds > 160 * 1024) return fail(MYR_E_CAPACITY, "hs_solve(wave): intervals too large for the LDS working set");
     long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
     if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate trajectories over HBM channels
     const size_t need = (size_t)B * (size_t)stride * 8;

@@ -137,3 +137,18 @@ def test_wave_and_lane_kernels_agree(monkeypatch):
   assert (out["wave"]["iters"] == out["lane"]["iters"]).mean() >= 0.8
   assert np.abs(out["wave"]["z"] - out["lane"]["z"]).max() < 1e-6
   assert np.abs(out["wave"]["lam"] - out["lane"]["lam"]).max() < 1e-4 * max(1.0, np.abs(out["lane"]["lam"]).max())
+
+
+def test_long_horizon_falls_back_to_the_lane_solver():
+  """N = 600 intervals: the wavefront solver's LDS working set (~200 KB) exceeds a CU, so the lane-per-trajectory form
+  runs instead of an error; same optimum as a coarser grid to discretisation accuracy."""
+  from myriad_amd.config import Config, HParams, OptimizerType, QuadratureRule
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  cfg = Config(verbose=False, plot=False)
+  sols = {}
+  for N in (60, 600):
+    hp = HParams(system=SystemType.VANDERPOL, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON, intervals=N)
+    sols[N] = get_optimizer(hp, cfg, hp.system()).solve()
+  assert sols[600]['x'].shape == (1201, 2)
+  assert abs(sols[600]['cost'] - sols[60]['cost']) < 1e-4 * max(1.0, abs(sols[60]['cost']))
