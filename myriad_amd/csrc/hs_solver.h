@@ -57,6 +57,18 @@ struct HsSolveOpts {
   double rho_term = 1e4;   // quadratic weight on pinned terminal states inside the QP (does not change its solution)
 };
 
+// penalty relaxation of the l1 merit function (compile-time: the by-value options struct of the kernels is left alone,
+// see DESIGN.md on the compiler's sensitivity to its layout): the penalty only has to dominate the CURRENT multipliers;
+// steps blocked by bounds early on can push it orders of magnitude above that, after which every full step is rejected
+// for a marginal increase of the constraint violation (Maratos-type crawl: config 3's stragglers).  When it has
+// exceeded PEN_RELAX_RATIO x the value the descent condition asks for during PEN_RELAX consecutive iterations it is
+// reset to twice that value, at most PEN_RELAX_MAX times per solve (so the monotone argument applies from then on).
+#ifndef MYR_PEN_RELAX
+#define MYR_PEN_RELAX 5          // 0 = off
+#endif
+constexpr int PEN_RELAX = MYR_PEN_RELAX, PEN_RELAX_MAX = 8;
+constexpr double PEN_RELAX_RATIO = 10.0;
+
 struct HsSolveResult {
   int status, iters;
   int sweeps = 0;          // factorisation sweeps incl. inertia-correction retries
@@ -913,6 +925,7 @@ struct IpLoop {
     const int n = Core::nvars(o);
     Core::init(w, n);
     double mu = o.mu_init, pen = 1.0;
+    int pen_over = 0, pen_cuts = 0;
     double nuT[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) nuT[i] = 0.0;
@@ -975,6 +988,11 @@ struct IpLoop {
       if (so.c1 > 0.0) {
         const double need = fo.gphi / (0.9 * so.c1);
         if (pen < need) pen = need + 1.0;
+        if (PEN_RELAX > 0) {
+          const double want = 2.0 * dmax(need, 0.0) + 1.0;
+          pen_over = (pen > PEN_RELAX_RATIO * want) ? pen_over + 1 : 0;
+          if (pen_over >= PEN_RELAX && pen_cuts < PEN_RELAX_MAX) { pen = want; pen_over = 0; ++pen_cuts; }
+        }
       }
       const double Dphi = fo.gphi - pen * so.c1;
       double f0, bar0, c10;

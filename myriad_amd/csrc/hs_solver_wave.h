@@ -931,6 +931,7 @@ struct HsWave {
 #pragma unroll
     for (int q = 0; q < NS; ++q) { const long i = zi(c, c.K - 1, q); c.term_pinned[q] = !(c.lb[i] < c.ub[i]); }
     double mu = o.mu_init, pen = 1.0;
+    int pen_over = 0, pen_cuts = 0;
     double nuT[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) nuT[i] = 0.0;
@@ -1020,6 +1021,11 @@ struct HsWave {
       if (c1 > 0.0) {
         const double need = fo.gphi / (0.9 * c1);
         if (pen < need) pen = need + 1.0;
+        if (PEN_RELAX > 0) {         // penalty relaxation (see hs_solver.h)
+          const double want = 2.0 * dmax(need, 0.0) + 1.0;
+          pen_over = (pen > PEN_RELAX_RATIO * want) ? pen_over + 1 : 0;
+          if (pen_over >= PEN_RELAX && pen_cuts < PEN_RELAX_MAX) { pen = want; pen_over = 0; ++pen_cuts; }
+        }
       }
       const double Dphi = fo.gphi - pen * c1;
       double f0, bar0, c10;

@@ -91,9 +91,11 @@ def test_vanderpol_shooting_batch_config3_shape():
   B = 8192
   x0 = O.random_x0(O.VanDerPol(), B, seed=2019)
   res = opt.solve_batch(x0s=x0)
-  # single shooting over T=10 with tight control bounds: a few instances per thousand crawl (bound multipliers blow up in
-  # the first blocked steps) and hit max_iter; they are REPORTED (status 1), never silently wrong -- see DESIGN.md section 9
-  assert (res['status'] == 0).mean() >= 0.99, np.bincount(res['status'])
+  # single shooting over T=10 with tight control bounds: a few instances per thousand used to crawl to max_iter (the l1
+  # penalty blown up by the first blocked steps, then every full step rejected); the penalty relaxation of the merit
+  # function (hs_solver.h) brings all of them home
+  assert (res['status'] == 0).all(), np.bincount(res['status'])
+  assert res['iters'].max() < 1000
   ok = res['status'] == 0
   xs, cost = opt.engine.rollout(x0, res['u'], 50)
   assert np.abs(xs[ok, -1, :]).max() <= 1e-7            # x_T = 0
