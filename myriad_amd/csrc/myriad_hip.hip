@@ -371,6 +371,7 @@ static HsSolveOpts make_opts(myr_handle h, const myr_solve_opts& so) {
   if (const char* e = getenv("MYRIAD_NONMONO")) o.nonmono = atoi(e);      // developer knobs (globalisation ablations)
   if (const char* e = getenv("MYRIAD_RECENTER")) o.recenter = atoi(e);
   if (const char* e = getenv("MYRIAD_DELTA_WARM")) o.delta_warm = atoi(e);
+  if (const char* e = getenv("MYRIAD_DELTA_WARM_MIN")) o.delta_warm_min = atof(e);
   if (const char* e = getenv("MYRIAD_KAPPA_MU")) o.kappa_mu = atof(e);    // barrier schedule ablations
   if (const char* e = getenv("MYRIAD_THETA_MU")) o.theta_mu = atof(e);
   if (const char* e = getenv("MYRIAD_KAPPA_EPS")) o.kappa_eps = atof(e);
