@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmyriad_hip.so")
+LIB_PATH = os.environ.get("MYRIAD_HIP_LIB") or os.path.join(_HERE, "libmyriad_hip.so")   # override: development builds
 
 SYS_IDS = {"CARTPOLE": 0, "VANDERPOL": 1, "CANCERTREATMENT": 2, "SIMPLECASE": 3, "NODE_CARTPOLE": 4, "BIOREACTOR": 5,
            "GLUCOSE": 6, "MOULDFUNGICIDE": 7, "SIMPLECASEWITHBOUNDS": 8, "HIVTREATMENT": 9, "EPIDEMICSEIRN": 10, "SEIR": 11,

@@ -66,6 +66,14 @@ struct HsSolveOpts {
 #ifndef MYR_PEN_RELAX
 #define MYR_PEN_RELAX 5          // 0 = off
 #endif
+// warm-started inertia correction (delta_warm): the first attempt of an iteration uses delta_last / DELTA_WARM_DIV; a
+// failed attempt multiplies by 8, i.e. lands at 1.33 delta_last.  Measured on the headline workload (ms per 4096
+// solves / median / p99 iterations): div 3: 39.1 / 21 / 34, 4: 39.7 / 21 / 34, 5: 38.0 / 21 / 26, 6: 36.1 / 20 / 25,
+// 8: 38.9 / 20 / 25, 12: 38.7 / 21 / 27 -- with 3 the retry overshoots to 2.7 delta_last and the correction ratchets up.
+#ifndef MYR_DW_DIV
+#define MYR_DW_DIV 6.0
+#endif
+constexpr double DELTA_WARM_DIV = MYR_DW_DIV;
 constexpr int PEN_RELAX = MYR_PEN_RELAX, PEN_RELAX_MAX = 8;
 constexpr double PEN_RELAX_RATIO = 10.0;
 
@@ -940,7 +948,7 @@ struct IpLoop {
       // inertia correction (global, as in interior-point NLP codes): retry the factorisation with W + delta I
       // until every stage pivot is positive; the last resort keeps the stage-local convexification.
       double delta = lm;     // Levenberg-Marquardt floor adapted from the line-search history (see below)
-      if (o.delta_warm && delta_last > o.delta_warm_min) delta = dmax(delta, delta_last / 3.0);   // skip the doomed delta = 0 attempt
+      if (o.delta_warm && delta_last > o.delta_warm_min) delta = dmax(delta, delta_last / DELTA_WARM_DIV);   // skip the doomed delta = 0 attempt
       for (int tr_ = 0; tr_ < 12; ++tr_) {
         so.abort_on_reg = (tr_ < 11);
         Core::backward(w, o, p, nuT, delta, so);

@@ -961,7 +961,7 @@ struct HsWave {
       MYR_PH(4)
       // inertia correction with retries (only the delta-dependent phases are redone)
       double delta = lm;
-      if (o.delta_warm && delta_last > o.delta_warm_min) delta = dmax(delta, delta_last / 3.0);
+      if (o.delta_warm && delta_last > o.delta_warm_min) delta = dmax(delta, delta_last / DELTA_WARM_DIV);
       int nreg = 0;
       for (int tr_ = 0; tr_ < 12; ++tr_) {
         bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
