@@ -10,11 +10,13 @@ dp = C.c_void_p
 sim.hostsim_solve.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp]
 A = lambda a: a.ctypes.data
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-x0, z, lb, ub, T = build_workload(B, 100, 2019)
+x0, z, lb, ub, T = build_workload(B, int(os.environ.get("NINT", "100")), int(os.environ.get("SEED", "2019")))
 z = z.copy()
-lam = np.zeros((B, 800)); cost = np.zeros(B); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
+lam = np.zeros((B, 8 * int(os.environ.get("NINT", "100")))); cost = np.zeros(B); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
 t0 = time.time()
-sim.hostsim_solve(0, 100, T, B, A(z), A(lb), A(ub), None, 0, 1000, 1e-8, 1e-6, 1e-7, 0.1, A(lam), A(cost), A(st), A(it), A(kkt))
+sim.hostsim_solve(0, int(os.environ.get("NINT", "100")), T, B, A(z), A(lb), A(ub), None, 0, 1000, 1e-8, 1e-6, 1e-7, 0.1, A(lam), A(cost), A(st), A(it), A(kkt))
 print("time", time.time() - t0, "converged", (st == 0).mean(), "iters mean", it.mean(), "pct", np.percentile(it, [50, 90, 99, 100]), "cost mean", cost.mean())
 if os.environ.get("SAVE"):
   np.savez(os.environ["SAVE"], cost=cost, st=st, it=it)
+if os.environ.get("SWEEPS"):
+  print("sweeps mean", kkt[:, 2].mean(), "per iteration", kkt[:, 2].sum() / it.sum())
