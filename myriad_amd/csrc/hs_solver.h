@@ -75,7 +75,10 @@ struct HsSolveOpts {
 #endif
 constexpr double DELTA_WARM_DIV = MYR_DW_DIV;
 constexpr int PEN_RELAX = MYR_PEN_RELAX, PEN_RELAX_MAX = 8;
-constexpr double PEN_RELAX_RATIO = 10.0;
+#ifndef MYR_PEN_RELAX_LAM
+#define MYR_PEN_RELAX_LAM 1.1
+#endif
+constexpr double PEN_RELAX_RATIO = 10.0, PEN_RELAX_LAM = MYR_PEN_RELAX_LAM;
 
 struct HsSolveResult {
   int status, iters;
@@ -230,6 +233,7 @@ struct HsPoint {
 
 template <class Sys>
 struct HsSolver {
+  static constexpr bool PEN_LAM_FLOOR = false;   // penalty relaxation: floor at the multipliers (see IpLoop)
   using D = HsSol<Sys>;
   static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC;
 
@@ -997,7 +1001,12 @@ struct IpLoop {
         const double need = fo.gphi / (0.9 * so.c1);
         if (pen < need) pen = need + 1.0;
         if (PEN_RELAX > 0) {
-          const double want = 2.0 * dmax(need, 0.0) + 1.0;
+          // never below the multipliers where the core asks for it (exactness of the l1 penalty): single shooting, whose
+          // stragglers need it (config 3: slowest solve 257 -> 130 iterations).  The collocation cores keep the plain
+          // rule: with the floor the trapezoidal lane kernel lost 9 % of a CARTPOLE batch on the GPU -- in fixed lane
+          // positions, and not on the host build of the same code (compiler fragility).
+          const double floor_ = Core::PEN_LAM_FLOOR ? PEN_RELAX_LAM * so.lam_inf : 0.0;
+          const double want = dmax(2.0 * dmax(need, 0.0) + 1.0, floor_);
           pen_over = (pen > PEN_RELAX_RATIO * want) ? pen_over + 1 : 0;
           if (pen_over >= PEN_RELAX && pen_cuts < PEN_RELAX_MAX) { pen = want; pen_over = 0; ++pen_cuts; }
         }

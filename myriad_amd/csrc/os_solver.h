@@ -175,6 +175,7 @@ MYR_HD inline int os_first_point(const double* P, const double* pc, const double
 template <class Sys>
 struct TrapCore {
   using H = HsSolver<Sys>;
+  static constexpr bool PEN_LAM_FLOOR = false;
   using D = OsDims<Sys>;
   static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = D::NY1;
   using SweepOut = typename H::SweepOut;
@@ -468,6 +469,7 @@ struct TrapCore {
 template <class Sys, int M = 1>
 struct ShootCore {
   using H = HsSolver<Sys>;
+  static constexpr bool PEN_LAM_FLOOR = true;
   using D = OsDims<Sys, M>;
   static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = D::NY1, QN = D::QN;
   static constexpr int CM = M;                       // control rows per step: step i uses rows M i .. M i + M

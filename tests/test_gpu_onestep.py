@@ -187,3 +187,18 @@ def test_shooting_solve_matches_golden_fixtures(tag, name, golden_dir):
   assert np.abs(r["z"] - d["z"])[:, :nx].max() < 1e-4
   assert np.abs(r["z"] - d["z"]).max() < 1e-3
   eng.close()
+
+
+def test_trapezoid_cartpole_batch_all_converge():
+  """README.md:83's literal config (CARTPOLE, trapezoidal, N=100) as a batch of random start states: every lane of every
+  wavefront converges (a build in which the penalty floor reached this core lost fixed lane positions of a batch)."""
+  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, intervals=100, nlpsolver=NLPSolverType.SQP)
+  opt = get_optimizer(hp, CFG, hp.system())
+  rng = np.random.default_rng(5)
+  B = 1024
+  x0 = np.clip(0.1 * rng.standard_normal((B, 4)), -2, 2)
+  res = opt.solve_batch(x0s=x0)
+  assert (res['status'] == 0).all(), np.nonzero(res['status'])[0][:20]
+  assert res['iters'].max() < 100
+  xs, cost = opt.engine.rollout(x0, res['u'], 100)
+  assert np.isfinite(cost).all()

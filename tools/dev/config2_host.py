@@ -12,6 +12,8 @@ A = lambda a: a.ctypes.data
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 x0, z, lb, ub, T = build_workload(B, int(os.environ.get("NINT", "100")), int(os.environ.get("SEED", "2019")))
 z = z.copy()
+if os.environ.get('ONLY'):
+  i = int(os.environ['ONLY']); z, lb, ub = z[i:i+1].copy(), lb[i:i+1].copy(), ub[i:i+1].copy(); B = 1
 lam = np.zeros((B, 8 * int(os.environ.get("NINT", "100")))); cost = np.zeros(B); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
 t0 = time.time()
 sim.hostsim_solve(0, int(os.environ.get("NINT", "100")), T, B, A(z), A(lb), A(ub), None, 0, 1000, 1e-8, 1e-6, 1e-7, 0.1, A(lam), A(cost), A(st), A(it), A(kkt))
@@ -20,3 +22,5 @@ if os.environ.get("SAVE"):
   np.savez(os.environ["SAVE"], cost=cost, st=st, it=it)
 if os.environ.get("SWEEPS"):
   print("sweeps mean", kkt[:, 2].mean(), "per iteration", kkt[:, 2].sum() / it.sum())
+slow = np.argsort(-it)[:12]
+print("slowest", slow.tolist(), it[slow].tolist())
