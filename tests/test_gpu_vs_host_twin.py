@@ -70,3 +70,33 @@ def test_shooting_batch_matches_host_twin(sim):
   lam = np.zeros((B, 2)); cost = np.zeros(B); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
   sim.hostsim_solve_shoot(1, 1, 50, 1, opt.system.T, B, A(z), A(lb), A(ub), None, 0, hp.max_iter, A(lam), A(cost), A(st), A(it), A(kkt))
   _compare(res, st, it, cost, "shooting")
+
+
+def test_wavefront_hs_solver_matches_host_twin_of_the_lane_form():
+  """The wavefront-per-trajectory Hermite-Simpson kernel (hs_solver_wave.h) and the lane form (hs_solver.h, here its host
+  build) are two implementations of one algorithm: on the headline workload they must agree instance by instance."""
+  subprocess.run(["bash", os.path.join(HERE, "hostsim", "build.sh")], check=True)
+  lib = C.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+  dp = C.c_void_p
+  lib.hostsim_solve.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp]
+  import sys
+  sys.path.insert(0, os.path.dirname(HERE))
+  from bench import build_workload
+  from myriad_amd import _lib
+  B, N = 512, 100
+  x0, z0, lb, ub, T = build_workload(B, N, 2019)
+  eng = _lib.Engine("CARTPOLE", "HERMITE_SIMPSON", N, T, max_batch=B)
+  res = eng.solve(z0, lb, ub)
+  eng.close()
+  z = z0.copy()
+  lam = np.zeros((B, 2 * N * 4)); cost = np.zeros(B); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
+  os.environ["DWARM"] = "1"
+  try:
+    lib.hostsim_solve(0, N, T, B, A(z), A(lb), A(ub), None, 0, 1000, 1e-8, 1e-6, 1e-7, 0.1, A(lam), A(cost), A(st), A(it), A(kkt))
+  finally:
+    del os.environ["DWARM"]
+  assert (res['status'] == 0).all() and (st == 0).all()
+  d = np.abs(res['iters'].astype(int) - it.astype(int))
+  assert (d <= 2).mean() >= 0.97, np.bincount(d)
+  same = np.isclose(res['cost'], cost, rtol=1e-6)
+  assert same.mean() >= 0.99, (~same).sum()          # non-convex: a different basin for a handful at most
