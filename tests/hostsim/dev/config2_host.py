@@ -1,6 +1,6 @@
 # dev tool: the headline workload (CARTPOLE HS N=100) on the host twin of the solver (lane form): iteration statistics
 import ctypes as C, os, sys, subprocess, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from bench import build_workload

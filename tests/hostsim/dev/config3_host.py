@@ -1,6 +1,6 @@
 # dev tool: config 3 (VANDERPOL single shooting 1x50, Heun) on the host twin of the solver: find the stragglers
 import ctypes as C, os, sys, subprocess, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import myriad_oracle as O

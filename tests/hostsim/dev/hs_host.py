@@ -1,6 +1,6 @@
 # dev tool: one Hermite-Simpson solve on the host twin (lane form) with the reference's guess; env knobs of hostsim apply
 import ctypes as C, os, sys, subprocess
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import myriad_oracle as O

@@ -1,6 +1,6 @@
 # dev tool: README:83 literal config (CARTPOLE trapezoidal N=100) on the host twin: convergence / iteration statistics
 import ctypes as C, os, sys, subprocess, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import myriad_oracle as O
