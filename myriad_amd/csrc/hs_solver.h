@@ -847,6 +847,7 @@ struct HsSolver {
         const long i = zi(K, j, c);
         zv[c] = w.z[i]; dv[c] = w.dz[i]; lv[c] = w.lb[i]; uv[c] = w.ub[i];
       }
+      double slk = 1.0; int sexp = 0;
 #pragma unroll
       for (int c = 0; c < NW; ++c) {
         const double v = zv[c] + alpha * dv[c];
@@ -854,9 +855,11 @@ struct HsSolver {
         const bool hl = fr && (lv[c] > -INFINITY), hu = fr && (uv[c] < INFINITY);
         const double sl = hl ? v - lv[c] : 1.0, su = hu ? uv[c] - v : 1.0;
         bad += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
-        bar -= log(sl > 0.0 ? sl : 1.0) + log(su > 0.0 ? su : 1.0);
+        { int e_; slk *= frexp((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0), &e_); sexp += e_; }
         if (c < NS) x[c] = v; else u[c - NS] = v;
       }
+      // one log per point instead of 2 NW: slack pairs multiplied as mantissas, binary exponents summed (no under/overflow)
+      bar -= log(slk) + sexp * 0.6931471805599453;
       Sys::f(x, u, p, ff);
       set_time<Sys>(p, 0.5 * h * j);
       f += wsimp(K, j, h) * Sys::g(x, u, p);

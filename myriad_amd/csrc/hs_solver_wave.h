@@ -851,6 +851,9 @@ struct HsWave {
     double fa = 0, ba = 0; int bad = 0;
     for (int j = c.lane; j < K; j += 64) {
       double x[NS], u[NU], ff[NS];
+      // one log per point instead of 2 NW (fp64 log is a long software sequence and dominated the trial): the slack
+      // pairs (z-l)(u-z) are multiplied as mantissas, their binary exponents summed, so no product can under- or overflow
+      double slk = 1.0; int sexp = 0;
 #pragma unroll
       for (int q = 0; q < NW; ++q) {
         const long i = zi(c, j, q);
@@ -860,9 +863,10 @@ struct HsWave {
         const bool hl = fr && (l > -INFINITY), hu = fr && (ub < INFINITY);
         const double sl = hl ? v - l : 1.0, su = hu ? ub - v : 1.0;
         bad += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
-        ba -= log(sl > 0.0 ? sl : 1.0) + log(su > 0.0 ? su : 1.0);
+        { int e_; slk *= frexp((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0), &e_); sexp += e_; }
         if (q < NS) x[q] = v; else u[q - NS] = v;
       }
+      ba -= log(slk) + sexp * 0.6931471805599453;
       Sys::f(x, u, c.pp.get(), ff);
       set_time<Sys>(c.pp.get(), 0.5 * c.h * j);
       fa += S::wsimp(K, j, c.h) * Sys::g(x, u, c.pp.get());

@@ -426,6 +426,7 @@ struct TrapCore {
       double zv[NW], dv[NW], lv[NW], uv[NW];
 #pragma unroll
       for (int c = 0; c < NW; ++c) { const long i = zi(Kp, j, c); zv[c] = w.z[i]; dv[c] = w.dz[i]; lv[c] = w.lb[i]; uv[c] = w.ub[i]; }
+      double slk = 1.0; int sexp = 0;
 #pragma unroll
       for (int c = 0; c < NW; ++c) {
         const double v = zv[c] + alpha * dv[c];
@@ -433,9 +434,11 @@ struct TrapCore {
         const bool hl = fr && (lv[c] > -INFINITY), hu = fr && (uv[c] < INFINITY);
         const double sl = hl ? v - lv[c] : 1.0, su = hu ? uv[c] - v : 1.0;
         bad += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
-        bar -= log(sl > 0.0 ? sl : 1.0) + log(su > 0.0 ? su : 1.0);
+        { int e_; slk *= frexp((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0), &e_); sexp += e_; }
         if (c < NS) x[c] = v; else u[c - NS] = v;
       }
+      // one log per point instead of 2 NW: slack pairs multiplied as mantissas, binary exponents summed (no under/overflow)
+      bar -= log(slk) + sexp * 0.6931471805599453;
       Sys::f(x, u, p, ff);
       set_time<Sys>(p, h * j);
       double gj = Sys::g(x, u, p);
@@ -1073,7 +1076,7 @@ struct ShootCore {
       const bool hl = fr && (l > -INFINITY), hu = fr && (ub < INFINITY);
       const double sl = hl ? v - l : 1.0, su = hu ? ub - v : 1.0;
       bad += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
-      bar -= log(sl > 0.0 ? sl : 1.0) + log(su > 0.0 ? su : 1.0);
+      bar -= log((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0));     // one log per variable (sl + su = u - l: the pair cannot underflow)
       return v;
     };
     double uc[(M + 1) * NU];
