@@ -736,16 +736,19 @@ struct HsSolver {
     const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
     const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
     const double zlv = hl ? zl : 1.0, zuv = hu ? zu : 1.0;
+    // five fp64 divisions instead of eight (each is a ~35-instruction sequence): one reciprocal per slack, one for the
+    // step component (only the bound the step moves towards can limit it)
+    const double rsl = 1.0 / sl, rsu = 1.0 / su;
     double gb = wg_grad;
-    gb -= hl ? mu / sl : 0.0;
-    gb += hu ? mu / su : 0.0;
-    const double dzl = -zlv + (mu - zlv * d) / sl;
-    const double dzu = -zuv + (mu + zuv * d) / su;
-    const double ap_l = (hl && d < 0.0) ? -tau * sl / d : 1.0;
-    const double ap_u = (hu && d > 0.0) ? tau * su / d : 1.0;
+    gb -= hl ? mu * rsl : 0.0;
+    gb += hu ? mu * rsu : 0.0;
+    const double dzl = -zlv + (mu - zlv * d) * rsl;
+    const double dzu = -zuv + (mu + zuv * d) * rsu;
+    const bool tol_ = hl && d < 0.0, tou_ = hu && d > 0.0;
+    const double ap_ = (tol_ || tou_) ? tau * (tol_ ? sl : su) / fabs(d) : 1.0;
     const double ad_l = (hl && dzl < 0.0) ? -tau * zlv / dzl : 1.0;
     const double ad_u = (hu && dzu < 0.0) ? -tau * zuv / dzu : 1.0;
-    fo.alpha_p = detail::dmin(fo.alpha_p, detail::dmin(ap_l, ap_u));
+    fo.alpha_p = detail::dmin(fo.alpha_p, ap_);
     fo.alpha_d = detail::dmin(fo.alpha_d, detail::dmin(ad_l, ad_u));
     fo.gphi += fr ? gb * d : 0.0;
   }
@@ -884,6 +887,7 @@ struct HsSolver {
 
   // accept the step: z += a_p dz, zL += a_d dzL, zU += a_d dzU (with the usual safeguard on the bound multipliers)
   MYR_HD static void update(const HsWork& w, int n, double ap, double ad, double mu, double ksig = 1e10) {
+    const double iks = 1.0 / ksig;
     for (int i = 0; i < n; ++i) {
       const double l = w.lb[i], u = w.ub[i], zv = w.z[i], d = w.dz[i], zl = w.zL[i], zu = w.zU[i];
       const bool fr = l < u;
@@ -893,8 +897,9 @@ struct HsSolver {
       const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
       double vl = zl + ad * (-zl + (mu - zl * d) / sl);
       double vu = zu + ad * (-zu + (mu + zu * d) / su);
-      vl = detail::dmax(detail::dmin(vl, ksig * mu / snl), mu / (ksig * snl));
-      vu = detail::dmax(detail::dmin(vu, ksig * mu / snu), mu / (ksig * snu));
+      const double ml = mu / snl, mu_ = mu / snu;        // one division per new slack; the safeguard band is [m / ksig, m ksig]
+      vl = detail::dmax(detail::dmin(vl, ksig * ml), ml * iks);
+      vu = detail::dmax(detail::dmin(vu, ksig * mu_), mu_ * iks);
       w.z[i] = zn;
       w.zL[i] = hl ? vl : 0.0;
       w.zU[i] = hu ? vu : 0.0;

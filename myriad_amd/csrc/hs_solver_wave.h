@@ -894,6 +894,7 @@ struct HsWave {
   }
 
   __device__ static void update(Ctx& c, double ap, double ad, double mu, double ksig) {
+    const double iks = 1.0 / ksig;
     for (int i = c.lane; i < c.n; i += 64) {
       const double l = c.lb[i], u = c.ub[i], zv = c.z[i], d = c.dz[i], zl = c.zL[i], zu = c.zU[i];
       const bool fr = l < u;
@@ -903,8 +904,9 @@ struct HsWave {
       const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
       double vl = zl + ad * (-zl + (mu - zl * d) / sl);
       double vu = zu + ad * (-zu + (mu + zu * d) / su);
-      vl = detail::dmax(detail::dmin(vl, ksig * mu / snl), mu / (ksig * snl));
-      vu = detail::dmax(detail::dmin(vu, ksig * mu / snu), mu / (ksig * snu));
+      const double ml = mu / snl, mu_ = mu / snu;        // one division per new slack; the safeguard band is [m / ksig, m ksig]
+      vl = detail::dmax(detail::dmin(vl, ksig * ml), ml * iks);
+      vu = detail::dmax(detail::dmin(vu, ksig * mu_), mu_ * iks);
       c.z[i] = zn; c.zL[i] = hl ? vl : 0.0; c.zU[i] = hu ? vu : 0.0;
     }
   }
