@@ -142,11 +142,12 @@ struct HsWave {
   __device__ static inline long zi(const Ctx& c, int j, int comp) { return S::zi(c.K, j, comp); }
 
   // ---- phase 1: lanes over points -- linearisation, bound terms ----------------------------------------------
-  struct P1 { double f, cmax, cmin, sm; int nm; };
+  struct P1 { double f, cmax, cmin, sm, lg; int nm; };   // lg = -sum log(slack): barrier term of the merit function / mu
   __device__ static void points_lin(Ctx& c, P1& o) {
-    double f = 0, cmax = 0, cmin = INFINITY, sm = 0; int nm = 0;
+    double f = 0, cmax = 0, cmin = INFINITY, sm = 0, lg = 0; int nm = 0;
     for (int j = c.lane; j < c.K; j += 64) {
       typename S::VarBlk V;
+      double slk = 1.0; int sexp = 0;       // as in trial(): one log per point
 #pragma unroll
       for (int q = 0; q < NW; ++q) {
         const long i = zi(c, j, q);
@@ -175,10 +176,13 @@ struct HsWave {
         const bool hl = fr && (V.l[q] > -INFINITY), hu = fr && (V.u[q] < INFINITY);
         sm += (hl ? V.zl[q] : 0.0) + (hu ? V.zu[q] : 0.0);
         nm += (hl ? 1 : 0) + (hu ? 1 : 0);
+        const double sl = hl ? V.z[q] - V.l[q] : 1.0, su = hu ? V.u[q] - V.z[q] : 1.0;
+        { int e_; slk *= frexp((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0), &e_); sexp += e_; }
       }
+      lg -= log(slk) + sexp * 0.6931471805599453;
       f += S::wsimp(K, j, c.h) * P.g;
     }
-    o.f = wv_sum(f); o.cmax = wv_max(cmax); o.cmin = wv_min(cmin); o.sm = wv_sum(sm); o.nm = wv_isum(nm);
+    o.f = wv_sum(f); o.cmax = wv_max(cmax); o.cmin = wv_min(cmin); o.sm = wv_sum(sm); o.nm = wv_isum(nm); o.lg = wv_sum(lg);
   }
 
   __device__ static inline void read_pt(const Ctx& c, int j, double* x, double* f, double* A, double* B) {
@@ -1034,8 +1038,9 @@ struct HsWave {
         }
       }
       const double Dphi = fo.gphi - pen * c1;
-      double f0, bar0, c10;
-      trial(c, 0.0, mu, f0, bar0, c10);
+      // merit value at the current point: objective, barrier sum and l1 defect norm are by-products of the
+      // linearisation phases (same formulas as trial()), so no trial at alpha = 0 is spent on it
+      const double f0 = p1.f, bar0 = mu * p1.lg, c10 = c1;
       const double phi0 = f0 + bar0 + pen * c10;
       // non-monotone Armijo reference (see hs_solver.h)
       if (mu != hist_mu || pen != hist_pen) { nhist = 0; hpos = 0; hist_mu = mu; hist_pen = pen; }
