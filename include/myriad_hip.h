@@ -82,7 +82,8 @@ typedef struct {
   int32_t intervals;             /* hp.intervals                                      */
   int32_t controls_per_interval; /* hp.controls_per_interval (1 for collocation)      */
   int32_t device;                /* HIP device ordinal                                */
-  int32_t max_batch;             /* capacity B_max the handle sizes its scratch for   */
+  int32_t max_batch;             /* HINT: batch the handle pre-sizes its scratch for; larger batches are accepted
+                                    (scratch grows on demand, MYR_E_HIP if the device cannot hold it)          */
   int32_t reserved;
   double  T;                     /* horizon system.T                                  */
 } myr_problem_desc;

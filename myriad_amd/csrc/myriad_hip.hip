@@ -106,14 +106,15 @@ static int launch_hs_eval(myr_handle h, int B, const double* z, const double* pa
   const int N = h->d.intervals;
   const double hstep = h->d.T / N;
   const int wpt = h->eval_wpt;
-  const size_t lds = hs_eval_lds_bytes<Sys, SCHEME>(N, wpt);
-  if (lds > 160 * 1024) return fail(MYR_E_CAPACITY, "hs_eval: intervals too large for the 160 KiB LDS record");
+  // LDS is sized for the number of wavefronts ACTUALLY launched (the non-NT fallback always runs 4 per workgroup)
+  if (hs_eval_lds_bytes<Sys, SCHEME>(N, 8) > 160 * 1024) return fail(MYR_E_CAPACITY, "hs_eval: intervals too large for the 160 KiB LDS record");
   KTimer& kt = h->kt[MYR_K_EVAL];
   // the start event is recorded after the host-side attribute call, directly in front of the launch: the interval
   // between the two events is the kernel plus its dispatch, not host work
 #define MYR_EVAL_LAUNCH(W, NTV)                                                                                   \
   {                                                                                                               \
     auto kern = hs_eval_kernel<Sys, W, NTV, SCHEME>;                                                                   \
+    const size_t lds = hs_eval_lds_bytes<Sys, SCHEME>(N, W);                                                      \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     HIPCHK(hipEventRecord(kt.a, h->stream));                                                                      \
     hipLaunchKernelGGL(kern, dim3(B), dim3(64 * W), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);    \

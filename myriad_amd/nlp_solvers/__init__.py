@@ -32,10 +32,10 @@ def solve(hp: HParams, cfg: Config, opt_dict: Dict) -> Dict[str, np.ndarray]:
     from scipy.optimize import minimize
     if opt is None:
       raise ValueError("opt_dict['optimizer'] is required")
-    params_map = None
+    pm = opt_dict.get('params_map')     # solve_with_params: the derivatives see the same parameters as fun / constraints
     inputs = {'fun': opt_dict['objective'], 'x0': opt_dict['guess'],
-              'constraints': ({'type': 'eq', 'fun': opt_dict['constraints'], 'jac': lambda z: opt.constraints_jac(z)}),
-              'bounds': opt_dict['bounds'], 'jac': lambda z: opt.objective_grad(z), 'options': {'maxiter': hp.max_iter},
+              'constraints': ({'type': 'eq', 'fun': opt_dict['constraints'], 'jac': lambda z: opt.constraints_jac(z, params=pm)}),
+              'bounds': opt_dict['bounds'], 'jac': lambda z: opt.objective_grad(z, params=pm), 'options': {'maxiter': hp.max_iter},
               'method': 'SLSQP' if hp.nlpsolver == NLPSolverType.SLSQP else 'trust-constr'}
     solution = minimize(**inputs)
   elif hp.nlpsolver == NLPSolverType.EXTRAGRADIENT:

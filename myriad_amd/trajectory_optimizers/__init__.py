@@ -161,10 +161,18 @@ class TrajectoryOptimizer(object):
 
   # ---- solve ---------------------------------------------------------------------------------------
   def _opt_inputs(self, params=None, guess=None) -> Dict:
-    return {'objective': self.objective, 'guess': self.guess if guess is None else np.asarray(guess),
-            'constraints': self.constraints, 'bounds': self.bounds, 'unravel': self.unravel,
+    """base.py:69-93: `solve` passes the default-parameter callables, `solve_with_params` closures over
+    parametrized_objective / parametrized_constraints (base.py:81-93), so EVERY solver branch sees `params`."""
+    if params is None:
+      objective, constraints = self.objective, self.constraints
+    else:
+      objective = lambda variables: self.parametrized_objective(params, variables)
+      constraints = lambda variables: self.parametrized_constraints(params, variables)
+    return {'objective': objective, 'guess': self.guess if guess is None else np.asarray(guess),
+            'constraints': constraints, 'bounds': self.bounds, 'unravel': self.unravel,
             # descriptor for the device solver, which owns the transcription (SURVEY.md 8(b) inner boundary)
-            'optimizer': self, 'params': self.system.device_params() if params is None else self.system.params_from_mapping(params)}
+            'optimizer': self, 'params_map': params,
+            'params': self.system.device_params() if params is None else self.system.params_from_mapping(params)}
 
   def solve(self) -> Dict[str, np.ndarray]:
     from myriad_amd.nlp_solvers import solve
@@ -248,7 +256,7 @@ class HermiteSimpsonCollocationOptimizer(TrajectoryOptimizer):
 
 
 class TrapezoidalCollocationOptimizer(TrajectoryOptimizer):
-  """collocation/trapezoidal.py:16-77 (host part; device kernels for this transcription: next round)."""
+  """collocation/trapezoidal.py:16-77 (eval: hs_eval_kernel<.., EVAL_TRAP>, solve: TrapCore in csrc/os_solver.h)."""
 
   def __init__(self, hp: HParams, cfg: Config, system):
     N = hp.intervals
@@ -269,7 +277,7 @@ class TrapezoidalCollocationOptimizer(TrajectoryOptimizer):
 
 
 class MultipleShootingOptimizer(TrajectoryOptimizer):
-  """shooting.py:16-77,247-275 (host part; device kernels for this transcription: next round)."""
+  """shooting.py:16-77,247-275 (eval: hs_eval_kernel<.., EVAL_TRAP>, solve: TrapCore in csrc/os_solver.h)."""
 
   def __init__(self, hp: HParams, cfg: Config, system, key=None):
     I, cpi = hp.intervals, hp.controls_per_interval

@@ -8,8 +8,6 @@ import numpy as np
 
 from myriad_amd import _lib
 
-_METHOD = {"EULER": "EULER", "HEUN": "HEUN", "MIDPOINT": "MIDPOINT", "RK4": "RK4"}
-
 
 def _engine_for(hp, system, device=0):
   from myriad_amd.config import OptimizerType, QuadratureRule

@@ -128,3 +128,98 @@ def test_gather_solutions_gloo_world2():
   res = sorted(q.get(timeout=120) for _ in range(2))
   [p.join(60) for p in ps]
   assert res == [(0, True, 2.0), (1, True, 2.0)]
+
+
+class _StubEngine:
+  """CPU stand-in with the DeviceEngine interface of bench.py: 'solves' by leaving z at the guess and reporting status 0
+  for every instance except (global) instance 3, so that the multi-rank bookkeeping of bench.run() is checkable."""
+
+  def __init__(self, N, T, dev, B):
+    self.m, self.ngrad, self.jblk = 2 * N * 4, 2 * N + 1, N * 100
+    self.B = B
+
+  def solve(self, B, z, lb, ub, lam, cost, status, iters, kkt):
+    assert B == self.B == z.shape[0]
+    status.zero_(); iters.fill_(7); cost.fill_(1.0); lam.zero_()
+    status[(z[:, 0] == self.bad_x0)] = 1
+
+  def eval(self, B, z, fv, gv, cv, jv):
+    cv.zero_()
+
+  def timer_reset(self):
+    pass
+
+  def timers(self):
+    return (1.0, 1), (2.0, 1)
+
+
+def _bench_worker(rank, world, port, scaling, batch, q):
+  import argparse
+  import torch
+  import torch.distributed as dist
+  import bench
+  os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  a = argparse.Namespace(gpus=world, steps=2, warmup=1, batch=batch, scaling=scaling, intervals=4, cpu_budget=0.0)
+  # the instance to fail: global index 3 of the strong-scaling workload (rank 0's shard) -- its x0[0] identifies it
+  _StubEngine.bad_x0 = float(bench.build_workload(batch, 4, 2019)[1][3, 0])
+  out = bench.run(a, rank, world, torch.device("cpu"), lambda N, T, dev, B: _StubEngine(N, T, dev, B))
+  q.put((rank, out))
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scaling,batch", [("weak", 6), ("strong", 11)])
+def test_bench_run_world2_gloo_with_stub_engine(scaling, batch):
+  """bench.py's N>1 logic (sharding per --scaling, gather to rank 0, max-over-ranks time, summed convergence count, the
+  JSON line) on two gloo ranks with a stub engine -- what the driver's 8-GPU run exercises over RCCL."""
+  import torch.multiprocessing as mp
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = 31500 + (os.getpid() % 2000) + (7 if scaling == "weak" else 0)
+  ps = [ctx.Process(target=_bench_worker, args=(r, 2, port, scaling, batch, q)) for r in range(2)]
+  [p.start() for p in ps]
+  res = dict(q.get(timeout=180) for _ in range(2))
+  [p.join(60) for p in ps]
+  assert res[1] is None
+  out = res[0]
+  total = batch * 2 if scaling == "weak" else batch
+  assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["steps"] == 2 and out["warmup"] == 1
+  assert out["config"]["global_batch"] == total
+  assert out["config"]["per_gpu_batch"] == ([6, 6] if scaling == "weak" else [6, 5])
+  assert "gloo group of 2 ranks" in out["config"]["parallelism"]
+  # exactly one instance (global index 3, on rank 0 in both modes) is reported unconverged in every step
+  assert out["converged_fraction"] == pytest.approx((total - 1) / total)
+  assert out["value"] == pytest.approx(2 * (total - 1) / (out["ms_per_step"] * 2e-3), rel=1e-9)
+  assert out["unit"] == "solves/s" and out["higher_is_better"] is True and out["dtype"] == "f64"
+  assert "cpu_baseline" not in out          # rank 0 at N=1 only
+
+
+def test_gather_to_one_rank_gloo_world2():
+  import torch.multiprocessing as mp
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = 33500 + (os.getpid() % 2000)
+  ps = [ctx.Process(target=_gather_dst_worker, args=(r, 2, port, q)) for r in range(2)]
+  [p.start() for p in ps]
+  res = sorted(q.get(timeout=120) for _ in range(2))
+  [p.join(60) for p in ps]
+  assert res == [(0, True), (1, True)]
+
+
+def _gather_dst_worker(rank, world, port, q):
+  import torch
+  import torch.distributed as dist
+  from myriad_amd.batched import shard_range, gather_solutions
+  os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  total = 9
+  counts = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+  lo, hi = shard_range(total, rank, world)
+  idx = torch.arange(lo, hi, dtype=torch.float64)
+  out = gather_solutions({"z": idx[:, None].repeat(1, 3), "status": idx.to(torch.int32)}, counts, dst=0)
+  if rank == 0:
+    ok = torch.equal(out["z"][:, 2], torch.arange(total, dtype=torch.float64)) and torch.equal(out["status"], torch.arange(total, dtype=torch.int32))
+  else:
+    ok = out == {}
+  q.put((rank, bool(ok)))
+  dist.destroy_process_group()
