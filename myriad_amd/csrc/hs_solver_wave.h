@@ -532,6 +532,45 @@ struct HsWave {
     return __hiloint2double(hi, lo);
   }
 
+  // first point: dx_0 = 0; add its control terms, eliminate du_0 (every lane redundantly; tiny).  P, pc, Tnu come from
+  // the sweep through LDS (sP, sPc, sTnu).
+  __device__ static int riccati_first_point(Ctx& c, const HsSolveOpts& o, double delta, int nreg) {
+    using namespace detail;
+    const int lane = c.lane;
+    {
+      const double* hr = c.hr;   // point 0
+      double Puu[NU * NU], ku[NU * NC], pun[NU * NS];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+#pragma unroll
+        for (int b = 0; b < NU; ++b) Puu[a * NU + b] = c.sP[(NS + a) * NW + NS + b] + hr[HR_H + (NS + a) * NW + NS + b] + ((a == b) ? delta : 0.0);
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc)
+          ku[a * NC + cc] = c.sPc[(NS + a) * NC + cc] + (cc == 0 ? hr[HR_G0 + NS + a] : (cc == 1 ? hr[HR_G1 + NS + a] : 0.0));
+#pragma unroll
+        for (int i = 0; i < NS; ++i) pun[a * NS + i] = ku[a * NC + 2 + i];
+      }
+      nreg += chol_reg<NU>(Puu, o.reg_floor);
+      chol_solve<NU, NC>(Puu, ku);
+      __syncthreads();
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < NU; ++a) s += pun[a * NS + i] * ku[a * NC + cc];
+            c.sTnu[i * NC + cc] -= s;
+          }
+#pragma unroll
+        for (int i = 0; i < NU * NC; ++i) c.sKu[i] = ku[i];
+      }
+      __syncthreads();
+    }
+    return nreg;
+  }
+
   __device__ static int riccati(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
     using namespace detail;
     static_assert(NY + NC <= 64, "one column per lane");
@@ -687,39 +726,168 @@ struct HsWave {
     __syncthreads();
     if (isC && cc >= 2) c.sTnu[(cc - 2) * NC + 0] += tnuA;
     __syncthreads();
-    // first point: dx_0 = 0; add its control terms, eliminate du_0 (every lane redundantly; tiny)
-    {
-      const double* hr = c.hr;   // point 0
-      double Puu[NU * NU], ku[NU * NC], pun[NU * NS];
+    return riccati_first_point(c, o, delta, nreg);
+  }
+
+  // ---- phase 6, matrix-core form (NU == 1, NS <= 4): the SAME stage algebra as riccati() on v_mfma_f64_16x16x4_f64 -------
+  // The stage update is three small dense products,
+  //     R~      = P' [Ge^ | ge^] + [0 | pc']                          (NW x (NY+NC))
+  //     [Q|qc]  = [Qm | qcm] + Ge^^T R~                               (NY x (NY+NC))
+  //     [P|pc]  = [Qss | qc_s] - Qsq (Qqq^-1 [Qqs | qc_q])            (NW x (NW+NC))   (+ the dual bookkeeping rows)
+  // and one 16x16 matrix-core tile holds all of a stage: the SAME slot placement is used for rows and for columns,
+  //     0..3 dx_s | 4,5 du_s (twice) | 6 rhs "1" (where ge enters) | 7 rhs mu | 8,9 du_e (twice) | 10,11,14,15 rhs nu_1..4 |
+  //     12,13 du_m (twice),
+  // chosen for the register layout of the instruction (A[i][k] and B[k][j] one value per lane at lane 16k+i / 16k+j; C/D
+  // element (i,j) at lane 16 (i%4) + j, register i/4 -- probed on the hardware, tools/dev/mfma/probe_f64.hip):
+  //   * rows 0..3 of a result (register 0) ARE the B operand of the next product, and, P and Q being symmetric, also its A
+  //     operand: the three products chain without any data movement between lanes;
+  //   * the rows of the two eliminated controls du_m (12,13) and du_e (8,9) share lanes (registers 3 and 2 of lane groups
+  //     0 and 1), so every column's gain is a per-lane 2x2 solve; keeping du_s, du_m, du_e TWICE gives lane groups 0 and 1
+  //     each their own copy, which is exactly where the rank-2 update wants its two K-slots;
+  //   * the dual bookkeeping Tnu (the rows ge^T pc' and -qc_q^T kc of riccati()) falls out of the same instructions as
+  //     extra result rows (6 and 10,11,14,15) that are otherwise unused.
+  // Per stage: 3 MFMA + ~70 VALU + 6 v_readlane, no LDS, no barrier (riccati(): ~430 instructions, 2 barriers).
+#ifndef MYR_RICCATI_PF
+#define MYR_RICCATI_PF 4
+#endif
+#ifndef MYR_RICCATI_INLINE
+#define MYR_RICCATI_INLINE
+#endif
+  static constexpr bool MFMA_RICCATI = (NU == 1 && NS <= 4);
+  typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+  // lane l <- lane l-4 within its row of 16 lanes (0 where l%16 < 4).  Inline asm on purpose: the compiler sinks the
+  // DPP builtin into the divergent branch of the select that consumes it, and a DPP read of a lane that EXEC has
+  // switched off returns 0 -- the shifted value must be produced with every lane enabled.
+  __device__ static inline double dpp_row_shr4(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v), rlo, rhi;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_mov_b32_dpp %1, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi));
+    return __hiloint2double(rhi, rlo);
+  }
+  __device__ static MYR_RICCATI_INLINE int riccati_mfma(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
+    using namespace detail;
+    const int lane = c.lane, N = c.N;
+    const int g = lane >> 4, j = lane & 15;
+    // what column / row slot j stands for
+    const int scol = j < 4 ? (j < NS ? j : -1) : (j < 6 ? NS : -1);                       // index into s = (dx, du)
+    const int ycol = scol >= 0 ? scol : ((j == 12 || j == 13) ? NS + 1 : ((j == 8 || j == 9) ? NS + 2 : -1));   // into y
+    const int cc = j == 6 ? 0 : (j == 7 ? 1 : (j == 10 ? 2 : (j == 11 ? 3 : (j == 14 ? 4 : (j == 15 ? 5 : -1)))));
+    const int rcc = (cc >= 0 && cc < NC) ? cc : -1;                                        // right-hand-side column
+    const bool rowx = g < NS;                 // register-0 row g is a state row
+    // ---- per-lane addresses of the stage inputs (stage N-1), zero block for the slots that hold no input ----
+    const double* he = c.hr + (long)(2 * (N - 1) + 2) * HR_N;
+    const double* st = c.st + (long)(N - 1) * SG_N;
+    auto hsel = [&](int row, bool on) -> const double* {          // element (row, column slot j) of [H | g0 | g1]
+      if (!on) return c.zr;
+      if (scol >= 0) return he + HR_H + scol * NW + row;
+      if (rcc == 0) return he + HR_G0 + row;
+      if (rcc == 1) return he + HR_G1 + row;
+      return c.zr;
+    };
+    auto msel = [&](int yrow, bool on) -> const double* {         // element (yrow, column slot j) of [Qm | qcm]
+      if (!on) return c.zr;
+      if (ycol >= 0) return st + SG_QM + ycol * NY + yrow;
+      if (rcc == 0 || rcc == 1) return st + SG_QCM + yrow * 2 + rcc;
+      return c.zr;
+    };
+    const double* p_h0 = hsel(g, rowx);
+    const double* p_h1 = hsel(NS, g < 2);
+    const double* p_g = !rowx ? c.zr : (ycol >= 0 ? st + SG_GE + g * NY1 + ycol : (rcc == 0 ? st + SG_GE + g * NY1 + NY : c.zr));
+    const double* p_m0 = msel(g, rowx);
+    const double* p_m1 = msel(NS, g < 2);
+    const double* p_m2 = msel(NS + 2, g < 2);
+    const double* p_m3 = msel(NS + 1, g < 2);
+    const long s_h0 = (p_h0 == c.zr) ? 0 : 2 * HR_N, s_h1 = (p_h1 == c.zr) ? 0 : 2 * HR_N;
+    const long s_g = (p_g == c.zr) ? 0 : SG_N, s_m0 = (p_m0 == c.zr) ? 0 : SG_N, s_m1 = (p_m1 == c.zr) ? 0 : SG_N,
+               s_m2 = (p_m2 == c.zr) ? 0 : SG_N, s_m3 = (p_m3 == c.zr) ? 0 : SG_N;
+    // ---- state: X = [P | pc] in result layout (rows 0..3 register 0, row du twice in register 1 of groups 0, 1) ----
+    const bool pinr = rowx && c.term_pinned[rowx ? g : 0];
+    double X0 = (pinr && scol == g) ? o.rho_term - delta : ((pinr && rcc == 2 + g) ? 1.0 : 0.0), X1 = 0.0;
+    const double dv0 = (rowx && scol == g) ? delta : 0.0, dv1 = (g < 2 && scol == NS) ? delta : 0.0;
+    double T1 = 0.0, T2 = 0.0, T3 = 0.0;      // dual bookkeeping rows 6 | 10, 11 | 14, 15 (register 1 | 2 | 3 of groups 2, 3)
+    const bool a1_on = j < 6, c1_keep = rcc >= 0, c1_shift = (j == 8 || j == 9);
+    const bool a3_on = g < 2 && (j < 6 || j == 10 || j == 11 || j == 14 || j == 15);
+    // where this lane's gain goes in the per-stage record K | kc (group 0 only, one copy of the du_s column)
+    const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
+    const int k_str = (scol >= 0) ? NW : NC;
+    int nreg = 0;
+    // Stage inputs are prefetched PF stages ahead into registers (7 doubles per stage): a stage is ~600 cycles of
+    // dependent work, an HBM/L2 round trip under load ~2000.  The loop is unrolled by PF so that the ring of prefetch
+    // registers is addressed statically.  Stages below 0 are read too (valid scratch in front of the records) and never used.
+    constexpr int PF = MYR_RICCATI_PF;
+    double in[PF][7];
 #pragma unroll
-      for (int a = 0; a < NU; ++a) {
-#pragma unroll
-        for (int b = 0; b < NU; ++b) Puu[a * NU + b] = c.sP[(NS + a) * NW + NS + b] + hr[HR_H + (NS + a) * NW + NS + b] + ((a == b) ? delta : 0.0);
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc)
-          ku[a * NC + cc] = c.sPc[(NS + a) * NC + cc] + (cc == 0 ? hr[HR_G0 + NS + a] : (cc == 1 ? hr[HR_G1 + NS + a] : 0.0));
-#pragma unroll
-        for (int i = 0; i < NS; ++i) pun[a * NS + i] = ku[a * NC + 2 + i];
-      }
-      nreg += chol_reg<NU>(Puu, o.reg_floor);
-      chol_solve<NU, NC>(Puu, ku);
-      __syncthreads();
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-#pragma unroll
-          for (int cc = 0; cc < NC; ++cc) {
-            double s = 0.0;
-#pragma unroll
-            for (int a = 0; a < NU; ++a) s += pun[a * NS + i] * ku[a * NC + cc];
-            c.sTnu[i * NC + cc] -= s;
-          }
-#pragma unroll
-        for (int i = 0; i < NU * NC; ++i) c.sKu[i] = ku[i];
-      }
-      __syncthreads();
+    for (int u = 0; u < PF; ++u) {
+      in[u][0] = *p_h0; in[u][1] = *p_h1; in[u][2] = *p_g; in[u][3] = *p_m0; in[u][4] = *p_m1; in[u][5] = *p_m2; in[u][6] = *p_m3;
+      p_h0 -= s_h0; p_h1 -= s_h1; p_g -= s_g; p_m0 -= s_m0; p_m1 -= s_m1; p_m2 -= s_m2; p_m3 -= s_m3;
     }
-    return nreg;
+    for (int kb = N - 1; kb >= 0; kb -= PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int k = kb - u;
+        if (k < 0) break;
+        // (a) P' = P + H_e + delta I, pc' = pc + gbar_e
+        X0 += in[u][0] + dv0; X1 += in[u][1] + dv1;
+        const double G = in[u][2], M0 = in[u][3], M1 = in[u][4], M2 = in[u][5], M3 = in[u][6];
+        // refill this slot with stage k - PF
+        in[u][0] = *p_h0; in[u][1] = *p_h1; in[u][2] = *p_g; in[u][3] = *p_m0; in[u][4] = *p_m1; in[u][5] = *p_m2; in[u][6] = *p_m3;
+        p_h0 -= s_h0; p_h1 -= s_h1; p_g -= s_g; p_m0 -= s_m0; p_m1 -= s_m1; p_m2 -= s_m2; p_m3 -= s_m3;
+        // (b) R~ = P' [Ge^ | ge^] + [0 | pc']; the selector row of Ge^ (du_e) is the shifted column du of P'
+        const double sh0 = dpp_row_shr4(X0), sh1 = dpp_row_shr4(X1);
+        mfma_d4 C1;
+        C1[0] = c1_keep ? X0 : (c1_shift ? sh0 : 0.0);
+        C1[1] = c1_keep ? X1 : (c1_shift ? sh1 : 0.0);
+        C1[2] = 0.0; C1[3] = 0.0;
+        const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_on ? X0 : 0.0, G, C1, 0, 0, 0);
+        // (c) [Q | qc] = [Qm | qcm] + Ge^^T R~  (selector row: the du_e rows take R~'s row du); rows 6, 10.. carry Tnu
+        mfma_d4 C2;
+        C2[0] = M0; C2[1] = M1 + T1; C2[2] = M2 + T2 + D1[1]; C2[3] = M3 + T3;
+        const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
+        // (d) L D L^T of Qqq (same pivot rule as ldl_reg), this column's gains
+        const double q00 = rdlane(D2[3], 12), q10 = rdlane(D2[2], 12), q11 = rdlane(D2[2], 8);
+        double d0 = q00;
+        if (!(d0 > o.reg_floor)) { d0 = dmax(fabs(d0), o.reg_floor); ++nreg; }
+        const double i0 = fast_rcp(d0);
+        const double l10 = q10 * i0;
+        double d1 = q11 - l10 * l10 * d0;
+        if (!(d1 > o.reg_floor)) { d1 = dmax(fabs(d1), o.reg_floor); ++nreg; }
+        if (nreg > 0 && abort_on_reg) return nreg;
+        const double i1 = fast_rcp(d1);
+        double kk0 = D2[3], kk1 = D2[2];
+        kk1 -= l10 * kk0;
+        kk0 *= i0; kk1 *= i1;
+        kk0 -= l10 * kk1;
+        if (k_off >= 0) {
+          double* Kst = c.kg + (long)k * KST;
+          Kst[k_off] = kk0; Kst[k_off + k_str] = kk1;
+        }
+        // (e) [P | pc] = [Qss | qc_s] - Qsq [K | kc]; rows 10, 11, 14, 15: Tnu -= qc_q[:, nu]^T kc
+        const double A3 = a3_on ? -(g == 0 ? D2[3] : D2[2]) : 0.0;
+        const double B3 = g == 0 ? kk0 : (g == 1 ? kk1 : 0.0);
+        const mfma_d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, B3, D2, 0, 0, 0);
+        X0 = D3[0];
+        X1 = g < 2 ? D3[1] : 0.0;
+        T1 = g == 2 ? D3[1] : 0.0;
+        T2 = g >= 2 ? D3[2] : 0.0;
+        T3 = g >= 2 ? D3[3] : 0.0;
+      }
+    }
+    // hand P, pc, Tnu to the first-point step through LDS (layouts of riccati())
+    if (scol >= 0 && j != 5) {
+      if (rowx) c.sP[g * NW + scol] = X0;
+      if (g == 0) c.sP[NS * NW + scol] = X1;
+    }
+    if (rcc >= 0) {
+      if (rowx) c.sPc[g * NC + rcc] = X0;
+      if (g == 0) c.sPc[NS * NC + rcc] = X1;
+      if (g >= 2 && g - 2 < NS) c.sTnu[(g - 2) * NC + rcc] = T2;
+      if (g >= 2 && g < NS) c.sTnu[g * NC + rcc] = T3;
+    }
+    __syncthreads();
+    if (g == 2 && rcc >= 2) c.sTnu[(rcc - 2) * NC + 0] += T1;       // row 6: ge^T pc'[:, nu_i], summed over the stages
+    __syncthreads();
+    return riccati_first_point(c, o, delta, nreg);
   }
 
   // ---- phase 8a: lanes over intervals -- closed-loop stage maps  s_{k+1} = Phi_k s_k + phi_k, s = (dx, du) of a knot
@@ -978,7 +1146,45 @@ struct HsWave {
         intervals_qm(c, delta);
         __syncthreads();
         MYR_PH(5)
-        nreg = riccati(c, o, delta, abort_on_reg);
+#ifdef MYR_RICCATI_CHECK   // dev self-check: both forms on the same inputs, differences of every output printed
+        if constexpr (MFMA_RICCATI) {
+          const int nv = riccati(c, o, delta, abort_on_reg);
+          __syncthreads();
+          const int nk = c.N * KST, nl = NW * NW + NW * NC + NS * NY1 + NS * NC + NU * NC;
+          for (int i = c.lane; i < nk; i += 64) c.r0[i] = c.kg[i];
+          for (int i = c.lane; i < nl; i += 64) c.r0[nk + i] = c.sP[i];
+          __syncthreads();
+          for (int i = c.lane; i < nk; i += 64) c.kg[i] = -7.0;
+          __syncthreads();
+          const int nm = riccati_mfma(c, o, delta, false);
+          __syncthreads();
+          double dk = 0, dP = 0, dPc = 0, dT = 0, dKu = 0, mk = 0;
+          int worst = -1;
+          for (int i = c.lane; i < nk; i += 64) { const double d = fabs(c.r0[i] - c.kg[i]); if (d > dk) { dk = d; worst = i; } mk = dmax(mk, fabs(c.r0[i])); }
+          for (int i = c.lane; i < nl; i += 64) {
+            const double d = fabs(c.r0[nk + i] - c.sP[i]);
+            if (i < NW * NW) dP = dmax(dP, d);
+            else if (i < NW * NW + NW * NC) dPc = dmax(dPc, d);
+            else if (i < NW * NW + NW * NC + NS * NY1) ;
+            else if (i < NW * NW + NW * NC + NS * NY1 + NS * NC) dT = dmax(dT, d);
+            else dKu = dmax(dKu, d);
+          }
+          const double dkm = wv_max(dk);
+          const int wl = (dk == dkm) ? worst : -1;
+          const int wmax = -wv_isum(0) + (int)wv_max((double)wl);
+          dP = wv_max(dP); dPc = wv_max(dPc); dT = wv_max(dT); dKu = wv_max(dKu); mk = wv_max(mk);
+          if (c.lane == 0 && blockIdx.x == 0)
+            printf("ricc check it %d delta %.3g: nreg valu %d mfma %d | max|dK| %.3e (|K| %.3e, worst elem %d = stage %d field %d) dP %.3e dPc %.3e dTnu %.3e dKu %.3e\n",
+                   it, delta, nv, nm, dkm, mk, wmax, wmax / KST, wmax % KST, dP, dPc, dT, dKu);
+          nreg = nm;
+        } else nreg = riccati(c, o, delta, abort_on_reg);
+#else
+#ifndef MYR_RICCATI_VALU
+        if constexpr (MFMA_RICCATI) nreg = riccati_mfma(c, o, delta, abort_on_reg);
+        else
+#endif
+          nreg = riccati(c, o, delta, abort_on_reg);
+#endif
         __syncthreads();
         MYR_PH(6)
         if (nreg == 0) break;

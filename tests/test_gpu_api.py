@@ -70,15 +70,22 @@ def test_solve_with_params_reaches_the_scipy_branch():
   heavy = {'g': 9.81, 'm1': 1.0, 'm2': 0.6, 'length': 0.5}
   hp = _hp(5, nlpsolver=NLPSolverType.SLSQP)
   opt = get_optimizer(hp, CFG, hp.system())
-  sol_default = opt.solve()
-  sol_slsqp = opt.solve_with_params(heavy)
   hp2 = _hp(5, nlpsolver=NLPSolverType.SQP)
   opt2 = get_optimizer(hp2, CFG, hp2.system())
   sol_sqp = opt2.solve_with_params(heavy)
-  assert sol_slsqp['cost'] == pytest.approx(sol_sqp['cost'], rel=1e-4)
+  sol_default = opt2.solve()
+  # swing-up is non-convex (SLSQP from the straight-line guess may pick another basin), so start SLSQP at the optimum of
+  # the HEAVY model: it must stay there -- it would walk away if any of its four callbacks still saw the default model
+  sol_slsqp = opt.solve_with_params(heavy, guess=sol_sqp['xs_and_us'])
+  assert sol_slsqp['cost'] == pytest.approx(sol_sqp['cost'], rel=1e-5)
+  np.testing.assert_allclose(sol_slsqp['xs_and_us'], sol_sqp['xs_and_us'], atol=1e-3)
   assert abs(sol_slsqp['cost'] - sol_default['cost']) > 0.02 * sol_default['cost']
   assert np.abs(opt.parametrized_constraints(heavy, sol_slsqp['xs_and_us'])).max() <= 1e-6
   assert np.abs(opt.constraints(sol_slsqp['xs_and_us'])).max() > 1e-4      # NOT feasible for the default model
+  # and from the reference guess it returns a point that is feasible for the heavy model, not for the default one
+  sol_cold = opt.solve_with_params(heavy)
+  assert np.abs(opt.parametrized_constraints(heavy, sol_cold['xs_and_us'])).max() <= 1e-6
+  assert np.abs(opt.constraints(sol_cold['xs_and_us'])).max() > 1e-4
 
 
 def test_solve_batch_extension_parameter_sweep():
