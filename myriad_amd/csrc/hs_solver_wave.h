@@ -753,6 +753,7 @@ struct HsWave {
 #ifndef MYR_RICCATI_INLINE
 #define MYR_RICCATI_INLINE
 #endif
+  static_assert(MYR_RICCATI_PF >= 2, "the prefetch ring needs two slots");
   static constexpr bool MFMA_RICCATI = (NU == 1 && NS <= 4);
   typedef double mfma_d4 __attribute__((ext_vector_type(4)));
   // lane l <- lane l-4 within its row of 16 lanes (0 where l%16 < 4).  Inline asm on purpose: the compiler sinks the
@@ -762,6 +763,13 @@ struct HsWave {
     int lo = __double2loint(v), hi = __double2hiint(v), rlo, rhi;
     asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                  "v_mov_b32_dpp %1, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi));
+    return __hiloint2double(rhi, rlo);
+  }
+  __device__ static inline double dpp_row_shr8(double v) {      // lane l <- lane l-8 within its row of 16
+    int lo = __double2loint(v), hi = __double2hiint(v), rlo, rhi;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_mov_b32_dpp %1, %3 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
                  : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi));
     return __hiloint2double(rhi, rlo);
   }
@@ -776,52 +784,66 @@ struct HsWave {
     const int rcc = (cc >= 0 && cc < NC) ? cc : -1;                                        // right-hand-side column
     const bool rowx = g < NS;                 // register-0 row g is a state row
     // ---- per-lane addresses of the stage inputs (stage N-1), zero block for the slots that hold no input ----
-    const double* he = c.hr + (long)(2 * (N - 1) + 2) * HR_N;
+    const double* he = c.hr + (long)(2 * (N - 1) + 2) * HR_N;   // end point of the stage
+    const double* hm = he - HR_N;                                 // its midpoint
     const double* st = c.st + (long)(N - 1) * SG_N;
-    auto hsel = [&](int row, bool on) -> const double* {          // element (row, column slot j) of [H | g0 | g1]
+    auto hsel = [&](const double* rec, int row, bool on) -> const double* {   // element (row, column slot j) of [H | g0 | g1]
       if (!on) return c.zr;
-      if (scol >= 0) return he + HR_H + scol * NW + row;
-      if (rcc == 0) return he + HR_G0 + row;
-      if (rcc == 1) return he + HR_G1 + row;
+      if (scol >= 0) return rec + HR_H + scol * NW + row;
+      if (rcc == 0) return rec + HR_G0 + row;
+      if (rcc == 1) return rec + HR_G1 + row;
       return c.zr;
     };
-    auto msel = [&](int yrow, bool on) -> const double* {         // element (yrow, column slot j) of [Qm | qcm]
-      if (!on) return c.zr;
-      if (ycol >= 0) return st + SG_QM + ycol * NY + yrow;
-      if (rcc == 0 || rcc == 1) return st + SG_QCM + yrow * 2 + rcc;
+    auto gsel = [&](int off) -> const double* {                  // element (row g, column slot j) of [G | g], G = Ge or Gm
+      if (!rowx) return c.zr;
+      if (ycol >= 0) return st + off + g * NY1 + ycol;
+      if (rcc == 0) return st + off + g * NY1 + NY;
       return c.zr;
     };
-    const double* p_h0 = hsel(g, rowx);
-    const double* p_h1 = hsel(NS, g < 2);
-    const double* p_g = !rowx ? c.zr : (ycol >= 0 ? st + SG_GE + g * NY1 + ycol : (rcc == 0 ? st + SG_GE + g * NY1 + NY : c.zr));
-    const double* p_m0 = msel(g, rowx);
-    const double* p_m1 = msel(NS, g < 2);
-    const double* p_m2 = msel(NS + 2, g < 2);
-    const double* p_m3 = msel(NS + 1, g < 2);
-    const long s_h0 = (p_h0 == c.zr) ? 0 : 2 * HR_N, s_h1 = (p_h1 == c.zr) ? 0 : 2 * HR_N;
-    const long s_g = (p_g == c.zr) ? 0 : SG_N, s_m0 = (p_m0 == c.zr) ? 0 : SG_N, s_m1 = (p_m1 == c.zr) ? 0 : SG_N,
-               s_m2 = (p_m2 == c.zr) ? 0 : SG_N, s_m3 = (p_m3 == c.zr) ? 0 : SG_N;
+    // six input streams per stage: H_e rows 0..3 | H_e row du | Ge^ | H_m rows 0..3 | H_m row du | Gm^
+    const double* ptr[6] = {hsel(he, g, rowx), hsel(he, NS, g < 2), gsel(SG_GE), hsel(hm, g, rowx), hsel(hm, NS, g < 2), gsel(SG_GM)};
+    long stp[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) stp[q] = (ptr[q] == c.zr) ? 0 : ((q == 2 || q == 5) ? (long)SG_N : 2L * HR_N);
     // ---- state: X = [P | pc] in result layout (rows 0..3 register 0, row du twice in register 1 of groups 0, 1) ----
     const bool pinr = rowx && c.term_pinned[rowx ? g : 0];
     double X0 = (pinr && scol == g) ? o.rho_term - delta : ((pinr && rcc == 2 + g) ? 1.0 : 0.0), X1 = 0.0;
     const double dv0 = (rowx && scol == g) ? delta : 0.0, dv1 = (g < 2 && scol == NS) ? delta : 0.0;
     double T1 = 0.0, T2 = 0.0, T3 = 0.0;      // dual bookkeeping rows 6 | 10, 11 | 14, 15 (register 1 | 2 | 3 of groups 2, 3)
-    const bool a1_on = j < 6, c1_keep = rcc >= 0, c1_shift = (j == 8 || j == 9);
+    const bool a1_on = j < 6, c1_keep = rcc >= 0, c1_shift = (j == 8 || j == 9), c1_shift_m = (j == 12 || j == 13);
     const bool a3_on = g < 2 && (j < 6 || j == 10 || j == 11 || j == 14 || j == 15);
     // where this lane's gain goes in the per-stage record K | kc (group 0 only, one copy of the du_s column)
     const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
     const int k_str = (scol >= 0) ? NW : NC;
+    double reg_floor = o.reg_floor;
+    asm volatile("" : "+v"(reg_floor));       // own register: otherwise every use reloads the spilled 16-SGPR argument block
     int nreg = 0;
-    // Stage inputs are prefetched PF stages ahead into registers (7 doubles per stage): a stage is ~600 cycles of
-    // dependent work, an HBM/L2 round trip under load ~2000.  The loop is unrolled by PF so that the ring of prefetch
-    // registers is addressed statically.  Stages below 0 are read too (valid scratch in front of the records) and never used.
+    // Stage inputs are prefetched PF stages ahead into registers (6 doubles per stage).  The loop is unrolled by PF so that the
+    // ring of prefetch registers is addressed statically.  Stages below 0 are read too (valid scratch in front of the
+    // records) and never used.
     constexpr int PF = MYR_RICCATI_PF;
-    double in[PF][7];
+    double in[PF][6];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      in[u][0] = *p_h0; in[u][1] = *p_h1; in[u][2] = *p_g; in[u][3] = *p_m0; in[u][4] = *p_m1; in[u][5] = *p_m2; in[u][6] = *p_m3;
-      p_h0 -= s_h0; p_h1 -= s_h1; p_g -= s_g; p_m0 -= s_m0; p_m1 -= s_m1; p_m2 -= s_m2; p_m3 -= s_m3;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
     }
+    // midpoint part of a stage, Qm^ = Gm^^T (H_m + delta I) [Gm^ | gm^] + Gm^^T [g0 g1]: the same two products as the
+    // end-point part with H_m in the place of P'; it depends on loaded data only, so stage k-1's is issued while stage
+    // k waits for its pivots (this is what intervals_qm() computes, lanes over intervals, for riccati())
+    auto mid_part = [&](double n0, double n1, double Gm) -> mfma_d4 {
+      n0 += dv0; n1 += dv1;
+      const double s0 = dpp_row_shr8(n0), s1 = dpp_row_shr8(n1);
+      mfma_d4 C;
+      C[0] = c1_keep ? n0 : (c1_shift_m ? s0 : 0.0);
+      C[1] = c1_keep ? n1 : (c1_shift_m ? s1 : 0.0);
+      C[2] = 0.0; C[3] = 0.0;
+      const mfma_d4 R = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_on ? n0 : 0.0, Gm, C, 0, 0, 0);
+      mfma_d4 C2;
+      C2[0] = 0.0; C2[1] = 0.0; C2[2] = 0.0; C2[3] = R[1];          // selector row: the du_m rows take R's row du
+      return __builtin_amdgcn_mfma_f64_16x16x4f64(Gm, R[0], C2, 0, 0, 0);
+    };
+    mfma_d4 Qm = mid_part(in[0][3], in[0][4], in[0][5]);
     for (int kb = N - 1; kb >= 0; kb -= PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -829,10 +851,12 @@ struct HsWave {
         if (k < 0) break;
         // (a) P' = P + H_e + delta I, pc' = pc + gbar_e
         X0 += in[u][0] + dv0; X1 += in[u][1] + dv1;
-        const double G = in[u][2], M0 = in[u][3], M1 = in[u][4], M2 = in[u][5], M3 = in[u][6];
+        const double G = in[u][2];
+        // inputs of the next stage's midpoint part (slot u+1 of the ring, already loaded)
+        const double nn0 = in[(u + 1) % PF][3], nn1 = in[(u + 1) % PF][4], nGm = in[(u + 1) % PF][5];
         // refill this slot with stage k - PF
-        in[u][0] = *p_h0; in[u][1] = *p_h1; in[u][2] = *p_g; in[u][3] = *p_m0; in[u][4] = *p_m1; in[u][5] = *p_m2; in[u][6] = *p_m3;
-        p_h0 -= s_h0; p_h1 -= s_h1; p_g -= s_g; p_m0 -= s_m0; p_m1 -= s_m1; p_m2 -= s_m2; p_m3 -= s_m3;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
         // (b) R~ = P' [Ge^ | ge^] + [0 | pc']; the selector row of Ge^ (du_e) is the shifted column du of P'
         const double sh0 = dpp_row_shr4(X0), sh1 = dpp_row_shr4(X1);
         mfma_d4 C1;
@@ -840,18 +864,20 @@ struct HsWave {
         C1[1] = c1_keep ? X1 : (c1_shift ? sh1 : 0.0);
         C1[2] = 0.0; C1[3] = 0.0;
         const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_on ? X0 : 0.0, G, C1, 0, 0, 0);
-        // (c) [Q | qc] = [Qm | qcm] + Ge^^T R~  (selector row: the du_e rows take R~'s row du); rows 6, 10.. carry Tnu
+        // (c) [Q | qc] = Qm^ + Ge^^T R~  (selector row: the du_e rows take R~'s row du); rows 6, 10.. carry Tnu
         mfma_d4 C2;
-        C2[0] = M0; C2[1] = M1 + T1; C2[2] = M2 + T2 + D1[1]; C2[3] = M3 + T3;
+        C2[0] = Qm[0]; C2[1] = Qm[1] + T1; C2[2] = Qm[2] + T2 + D1[1]; C2[3] = Qm[3] + T3;
         const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
+        // midpoint part of stage k-1 (independent of the recursion)
+        Qm = mid_part(nn0, nn1, nGm);
         // (d) L D L^T of Qqq (same pivot rule as ldl_reg), this column's gains
         const double q00 = rdlane(D2[3], 12), q10 = rdlane(D2[2], 12), q11 = rdlane(D2[2], 8);
         double d0 = q00;
-        if (!(d0 > o.reg_floor)) { d0 = dmax(fabs(d0), o.reg_floor); ++nreg; }
+        if (!(d0 > reg_floor)) { d0 = dmax(fabs(d0), reg_floor); ++nreg; }
         const double i0 = fast_rcp(d0);
         const double l10 = q10 * i0;
         double d1 = q11 - l10 * l10 * d0;
-        if (!(d1 > o.reg_floor)) { d1 = dmax(fabs(d1), o.reg_floor); ++nreg; }
+        if (!(d1 > reg_floor)) { d1 = dmax(fabs(d1), reg_floor); ++nreg; }
         if (nreg > 0 && abort_on_reg) return nreg;
         const double i1 = fast_rcp(d1);
         double kk0 = D2[3], kk1 = D2[2];
@@ -1143,7 +1169,11 @@ struct HsWave {
       int nreg = 0;
       for (int tr_ = 0; tr_ < 12; ++tr_) {
         bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
+#if defined(MYR_RICCATI_VALU) || defined(MYR_RICCATI_CHECK)
         intervals_qm(c, delta);
+#else
+        if constexpr (!MFMA_RICCATI) intervals_qm(c, delta);   // the matrix-core sweep forms the midpoint terms itself
+#endif
         __syncthreads();
         MYR_PH(5)
 #ifdef MYR_RICCATI_CHECK   // dev self-check: both forms on the same inputs, differences of every output printed
