@@ -109,7 +109,7 @@ struct HsWave {
 
   __host__ __device__ static long scratch_doubles(int N) {
     const long K = 2 * N + 1, n = K * NW;
-    return 3 * n + (long)PF_N * K + (long)HR_N * K + (long)SG_N * N + (long)KST * N + ZR +
+    return 3 * n + (long)PF_N * K + (long)HR_N * K + (long)SG_N * N + (long)KST * N + ZR + 2 /* write-only slot */ +
            2L * N * NS /* lambda when the caller passes none */;
   }
   // LDS doubles: region R0 (adjoint M|v, later Phi|phi, later trial x|f), Pi, S, exchange
@@ -766,6 +766,16 @@ struct HsWave {
                  : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi));
     return __hiloint2double(rhi, rlo);
   }
+  // every lane <- lane N of its own row of 16 (DPP row_newbcast: stays in the vector pipe, ~10 cycles; v_readlane goes
+  // through the scalar file and costs ~55 cycles before a vector instruction can use the value)
+  template <int LANE>
+  __device__ static inline double dpp_row_bcast(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v), rlo, rhi;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %1, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi), "n"(LANE));
+    return __hiloint2double(rhi, rlo);
+  }
   __device__ static inline double dpp_row_shr8(double v) {      // lane l <- lane l-8 within its row of 16
     int lo = __double2loint(v), hi = __double2hiint(v), rlo, rhi;
     asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -809,12 +819,21 @@ struct HsWave {
     const bool pinr = rowx && c.term_pinned[rowx ? g : 0];
     double X0 = (pinr && scol == g) ? o.rho_term - delta : ((pinr && rcc == 2 + g) ? 1.0 : 0.0), X1 = 0.0;
     const double dv0 = (rowx && scol == g) ? delta : 0.0, dv1 = (g < 2 && scol == NS) ? delta : 0.0;
-    double T1 = 0.0, T2 = 0.0, T3 = 0.0;      // dual bookkeeping rows 6 | 10, 11 | 14, 15 (register 1 | 2 | 3 of groups 2, 3)
-    const bool a1_on = j < 6, c1_keep = rcc >= 0, c1_shift = (j == 8 || j == 9), c1_shift_m = (j == 12 || j == 13);
+    // Lane selections are per-lane 0/1 factors folded into multiply-adds (one fp64 instruction instead of two 32-bit
+    // selects plus an add).  A factor 0 meets only finite values: the unused rows / columns of the tile hold finite
+    // combinations of the inputs (if an input is not finite the solve is reported NAN anyway).
+    const double f_a1 = j < 6 ? 1.0 : 0.0;                                  // A operand of the R~ products: P' / H_m columns
+    const double f_keep = rcc >= 0 ? 1.0 : 0.0;                             // C operand: the right-hand-side columns pass
+    const double f_she = (j == 8 || j == 9) ? 1.0 : 0.0, f_shm = (j == 12 || j == 13) ? 1.0 : 0.0;   // selector columns
+    const double f_x1 = g < 2 ? 1.0 : 0.0, f_t1 = g == 2 ? 1.0 : 0.0, f_t23 = g >= 2 ? 1.0 : 0.0;    // rows of registers 1..3
     const bool a3_on = g < 2 && (j < 6 || j == 10 || j == 11 || j == 14 || j == 15);
-    // where this lane's gain goes in the per-stage record K | kc (group 0 only, one copy of the du_s column)
+    const double f_a3m = (a3_on && g == 0) ? -1.0 : 0.0, f_a3e = (a3_on && g == 1) ? -1.0 : 0.0;
+    // where this lane's gain goes in the per-stage record K | kc (group 0 only, one copy of the du_s column); the other
+    // lanes store unconditionally too, into the 2 spare doubles behind the block of zeros (never read)
     const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
-    const int k_str = (scol >= 0) ? NW : NC;
+    const int k_str = k_off < 0 ? 1 : ((scol >= 0) ? NW : NC);
+    double* k_ptr = k_off >= 0 ? c.kg + (long)(N - 1) * KST + k_off : c.zr + ZR;
+    const long k_step = k_off >= 0 ? KST : 0;
     double reg_floor = o.reg_floor;
     asm volatile("" : "+v"(reg_floor));       // own register: otherwise every use reloads the spilled 16-SGPR argument block
     int nreg = 0;
@@ -835,22 +854,29 @@ struct HsWave {
       n0 += dv0; n1 += dv1;
       const double s0 = dpp_row_shr8(n0), s1 = dpp_row_shr8(n1);
       mfma_d4 C;
-      C[0] = c1_keep ? n0 : (c1_shift_m ? s0 : 0.0);
-      C[1] = c1_keep ? n1 : (c1_shift_m ? s1 : 0.0);
+      C[0] = fma(s0, f_shm, n0 * f_keep);
+      C[1] = fma(s1, f_shm, n1 * f_keep);
       C[2] = 0.0; C[3] = 0.0;
-      const mfma_d4 R = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_on ? n0 : 0.0, Gm, C, 0, 0, 0);
+      const mfma_d4 R = __builtin_amdgcn_mfma_f64_16x16x4f64(n0 * f_a1, Gm, C, 0, 0, 0);
       mfma_d4 C2;
       C2[0] = 0.0; C2[1] = 0.0; C2[2] = 0.0; C2[3] = R[1];          // selector row: the du_m rows take R's row du
       return __builtin_amdgcn_mfma_f64_16x16x4f64(Gm, R[0], C2, 0, 0, 0);
     };
     mfma_d4 Qm = mid_part(in[0][3], in[0][4], in[0][5]);
+    mfma_d4 D3 = {X0, X1, 0.0, 0.0};          // previous stage's result: rows 0..5 [P | pc], rows 6, 10, 11, 14, 15 Tnu
     for (int kb = N - 1; kb >= 0; kb -= PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int k = kb - u;
         if (k < 0) break;
+#ifdef MYR_RICC_PROBE
+        unsigned long long tp[8]; tp[0] = __builtin_amdgcn_s_memtime();
+#define MYR_TP(i) tp[i] = __builtin_amdgcn_s_memtime();
+#else
+#define MYR_TP(i)
+#endif
         // (a) P' = P + H_e + delta I, pc' = pc + gbar_e
-        X0 += in[u][0] + dv0; X1 += in[u][1] + dv1;
+        X0 = D3[0] + (in[u][0] + dv0); X1 = fma(D3[1], f_x1, in[u][1] + dv1);
         const double G = in[u][2];
         // inputs of the next stage's midpoint part (slot u+1 of the ring, already loaded)
         const double nn0 = in[(u + 1) % PF][3], nn1 = in[(u + 1) % PF][4], nGm = in[(u + 1) % PF][5];
@@ -860,45 +886,81 @@ struct HsWave {
         // (b) R~ = P' [Ge^ | ge^] + [0 | pc']; the selector row of Ge^ (du_e) is the shifted column du of P'
         const double sh0 = dpp_row_shr4(X0), sh1 = dpp_row_shr4(X1);
         mfma_d4 C1;
-        C1[0] = c1_keep ? X0 : (c1_shift ? sh0 : 0.0);
-        C1[1] = c1_keep ? X1 : (c1_shift ? sh1 : 0.0);
+        C1[0] = fma(sh0, f_she, X0 * f_keep);
+        C1[1] = fma(sh1, f_she, X1 * f_keep);
         C1[2] = 0.0; C1[3] = 0.0;
-        const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1_on ? X0 : 0.0, G, C1, 0, 0, 0);
+        MYR_TP(1)
+        const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X0 * f_a1, G, C1, 0, 0, 0);
         // (c) [Q | qc] = Qm^ + Ge^^T R~  (selector row: the du_e rows take R~'s row du); rows 6, 10.. carry Tnu
         mfma_d4 C2;
-        C2[0] = Qm[0]; C2[1] = Qm[1] + T1; C2[2] = Qm[2] + T2 + D1[1]; C2[3] = Qm[3] + T3;
+        C2[0] = Qm[0]; C2[1] = fma(D3[1], f_t1, Qm[1]); C2[2] = fma(D3[2], f_t23, Qm[2]) + D1[1]; C2[3] = fma(D3[3], f_t23, Qm[3]);
+        MYR_TP(2)
         const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
-        // midpoint part of stage k-1 (independent of the recursion)
-        Qm = mid_part(nn0, nn1, nGm);
-        // (d) L D L^T of Qqq (same pivot rule as ldl_reg), this column's gains
+        // (d) this column's gains [K | kc] = Qqq^-1 [Qqs | qc_q].  Pivots of the L D L^T of Qqq as in ldl_reg: d0 = q00,
+        // d1 = q11 - q10^2 / q00 = det / q00, both required > reg_floor.  When they are (always, except inside the inertia
+        // correction's probing), the 2x2 solve is Cramer's rule with ONE reciprocal, 1 / det, whose dependent chain
+        // (product, fma, rcp + Newton, product) is a third of the factor-and-substitute one; the numerators do not depend
+        // on it.
         const double q00 = rdlane(D2[3], 12), q10 = rdlane(D2[2], 12), q11 = rdlane(D2[2], 8);
-        double d0 = q00;
-        if (!(d0 > reg_floor)) { d0 = dmax(fabs(d0), reg_floor); ++nreg; }
-        const double i0 = fast_rcp(d0);
-        const double l10 = q10 * i0;
-        double d1 = q11 - l10 * l10 * d0;
-        if (!(d1 > reg_floor)) { d1 = dmax(fabs(d1), reg_floor); ++nreg; }
-        if (nreg > 0 && abort_on_reg) return nreg;
-        const double i1 = fast_rcp(d1);
-        double kk0 = D2[3], kk1 = D2[2];
-        kk1 -= l10 * kk0;
-        kk0 *= i0; kk1 *= i1;
-        kk0 -= l10 * kk1;
-        if (k_off >= 0) {
-          double* Kst = c.kg + (long)k * KST;
-          Kst[k_off] = kk0; Kst[k_off + k_str] = kk1;
+        MYR_TP(3)
+#ifdef MYR_RICC_PROBE
+        { double t_ = q00 + q10 + q11; asm volatile("" : "+v"(t_)); tp[7] = __builtin_amdgcn_s_memtime(); }
+#endif
+        const double det = fma(q00, q11, -(q10 * q10));
+        const double rdet = fast_rcp(det);
+#ifdef MYR_RICC_PROBE
+        unsigned long long tq; { double t_ = rdet; asm volatile("" : "+v"(t_)); tq = __builtin_amdgcn_s_memtime(); }
+#endif
+        const double b0 = D2[3], b1 = D2[2];
+        double kk0 = fma(q11, b0, -(q10 * b1)) * rdet;
+        double kk1 = fma(q00, b1, -(q10 * b0)) * rdet;
+        if (!(q00 > reg_floor) || !(det > reg_floor * q00)) {          // wave-uniform, rare
+          const double u00 = q00, u10 = q10, u11 = q11;
+          double d0 = u00;
+          if (!(d0 > reg_floor)) { d0 = dmax(fabs(d0), reg_floor); ++nreg; }
+          const double i0 = fast_rcp(d0);
+          const double l10 = u10 * i0;
+          double d1 = u11 - l10 * l10 * d0;
+          if (!(d1 > reg_floor)) { d1 = dmax(fabs(d1), reg_floor); ++nreg; }
+          if (nreg > 0 && abort_on_reg) return nreg;
+          const double i1 = fast_rcp(d1);
+          kk0 = b0; kk1 = b1;
+          kk1 -= l10 * kk0;
+          kk0 *= i0; kk1 *= i1;
+          kk0 -= l10 * kk1;
         }
+        MYR_TP(4)
+        k_ptr[0] = kk0; k_ptr[k_str] = kk1;                            // (lanes without a gain write a scratch slot)
+        k_ptr -= k_step;
         // (e) [P | pc] = [Qss | qc_s] - Qsq [K | kc]; rows 10, 11, 14, 15: Tnu -= qc_q[:, nu]^T kc
-        const double A3 = a3_on ? -(g == 0 ? D2[3] : D2[2]) : 0.0;
-        const double B3 = g == 0 ? kk0 : (g == 1 ? kk1 : 0.0);
-        const mfma_d4 D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, B3, D2, 0, 0, 0);
-        X0 = D3[0];
-        X1 = g < 2 ? D3[1] : 0.0;
-        T1 = g == 2 ? D3[1] : 0.0;
-        T2 = g >= 2 ? D3[2] : 0.0;
-        T3 = g >= 2 ? D3[3] : 0.0;
+        const double A3 = fma(D2[3], f_a3m, D2[2] * f_a3e);
+        const double B3 = g == 0 ? kk0 : (g == 1 ? kk1 : 0.0);     // (a select: groups 2, 3 may hold non-finite junk)
+        MYR_TP(5)
+        D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, B3, D2, 0, 0, 0);
+        // midpoint part of stage k-1, first product: independent of the recursion, both products run behind D3
+        // while the next stage's operands are prepared
+        double m0 = nn0 + dv0, m1 = nn1 + dv1;
+        const double ms0 = dpp_row_shr8(m0), ms1 = dpp_row_shr8(m1);
+        mfma_d4 Cm;
+        Cm[0] = fma(ms0, f_shm, m0 * f_keep);
+        Cm[1] = fma(ms1, f_shm, m1 * f_keep);
+        Cm[2] = 0.0; Cm[3] = 0.0;
+        const mfma_d4 Rm = __builtin_amdgcn_mfma_f64_16x16x4f64(m0 * f_a1, nGm, Cm, 0, 0, 0);
+        // midpoint part of stage k-1, second product (selector row: the du_m rows take Rm's row du)
+        mfma_d4 Cq;
+        Cq[0] = 0.0; Cq[1] = 0.0; Cq[2] = 0.0; Cq[3] = Rm[1];
+        Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(nGm, Rm[0], Cq, 0, 0, 0);
+#ifdef MYR_RICC_PROBE
+        asm volatile("" : "+v"(D3));
+        tp[6] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 0 && lane == 0 && k >= N / 2 - 2 && k <= N / 2 + 1 && delta == 0.0)
+          printf("stage %d: top->D1 %llu  D1->D2 %llu  D2+mid->ldl %llu  [wait D2+readlane %llu  det+rcp %llu  gains %llu]  gains->D3 %llu  D3 issue %llu | total %llu\n", k,
+                 tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[7] - tp[3], tq - tp[7], tp[4] - tq, tp[5] - tp[4], tp[6] - tp[5], tp[6] - tp[0]);
+#endif
       }
     }
+    X0 = D3[0]; X1 = D3[1];                                          // (X1 is read below in group 0 only)
+    const double T1 = D3[1], T2 = D3[2], T3 = D3[3];                 // read in groups 2, 3 only
     // hand P, pc, Tnu to the first-point step through LDS (layouts of riccati())
     if (scol >= 0 && j != 5) {
       if (rowx) c.sP[g * NW + scol] = X0;
@@ -1340,7 +1402,7 @@ void hs_solve_wave_kernel(int B, HsSolveOpts o, VarScale vs, double* __restrict_
   c.hr = s; s += (long)W::HR_N * c.K;
   c.st = s; s += (long)W::SG_N * c.N;
   c.kg = s; s += (long)W::KST * c.N;
-  c.zr = s; s += W::ZR;
+  c.zr = s; s += W::ZR + 2;
   c.lam = lam ? lam + b * (long)(2 * c.N * W::NS) : s;
   c.pp.load(params, b, params_stride);
   c.pp.set_scale(vs.s);

@@ -7,7 +7,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 SRC=${1:-$ROOT/myriad_amd/csrc}; OUT=${2:-libvar.so}; shift 2 || true
 mkdir -p $ROOT/variants /tmp/variant_obj
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DMYR_TU_SYSTEM=SysCARTPOLE "$@" $SRC/myriad_hip.hip -o /tmp/variant_obj/$OUT.SysCARTPOLE.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -c -DMYR_TU_SYSTEM=SysCARTPOLE "$@" $SRC/myriad_hip.hip -o /tmp/variant_obj/$OUT.SysCARTPOLE.o
 OBJS=$(ls $ROOT/build/obj/*.o | grep -v SysCARTPOLE.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $OBJS /tmp/variant_obj/$OUT.SysCARTPOLE.o -o $ROOT/variants/$OUT
 echo built $ROOT/variants/$OUT
