@@ -102,7 +102,11 @@ struct HsWave {
   // per-stage record, AoS
   static constexpr int SG_GE = 0, SG_GM = SG_GE + NS * NY1, SG_LD = SG_GM + NS * NY1, SG_LD0 = SG_LD + NS * NS,
                        SG_LI = SG_LD0 + NS, SG_LI0 = SG_LI + NS * NS, SG_QM = SG_LI0 + NS, SG_QCM = SG_QM + NY * NY,
+#if defined(MYR_RICCATI_VALU) || defined(MYR_RICCATI_CHECK)
                        SG_N = SG_QCM + NY * 2;
+#else     // the matrix-core sweep forms Qm | qcm itself: the record ends before them (CARTPOLE: 167 -> 104 doubles per stage)
+                       SG_N = (NU == 1 && NS <= 4) ? SG_QM : SG_QCM + NY * 2;
+#endif
   static constexpr int KST = NQ * NW + NQ * NC;   // K | kc per stage (global scratch)
   static constexpr int ZR = 2 * NY + 2;           // block of zeros (masked stage inputs of the Riccati lanes read it)
   static constexpr int PHI = NW * (NW + 1);       // closed-loop stage map Phi | phi per stage (LDS)
@@ -1381,31 +1385,28 @@ struct HsWave {
 #ifndef MYR_WAVE_MIN_WAVES
 #define MYR_WAVE_MIN_WAVES 1   // waves per SIMD the register allocation must allow (occupancy)
 #endif
-// grid = B wavefronts (one 64-thread workgroup per trajectory); dynamic LDS = HsWave<Sys>::lds_bytes(N)
+// Persistent: grid = the wavefronts the device keeps resident (one 64-thread workgroup each, dynamic LDS =
+// HsWave<Sys>::lds_bytes(N)); every workgroup pulls trajectories from `ticket` until the batch is done and owns ONE
+// scratch block (slot blockIdx.x) that it re-uses for all of them.
 template <class Sys>
 __global__ __launch_bounds__(64, MYR_WAVE_MIN_WAVES)
-void hs_solve_wave_kernel(int B, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
+void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                           const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                           const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
                           int32_t* iters, double* kkt) {
   using W = HsWave<Sys>;
   extern __shared__ __attribute__((aligned(16))) char smem_wave[];
-  const long b = blockIdx.x;
-  if (b >= B) return;
   typename W::Ctx c;
   c.N = o.N; c.K = 2 * o.N + 1; c.n = c.K * W::NW; c.lane = threadIdx.x;
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
-  c.z = z + b * (long)c.n; c.lb = lb + b * (long)c.n; c.ub = ub + b * (long)c.n;
-  double* s = scratch + b * scratch_stride;
+  double* s = scratch + (long)blockIdx.x * scratch_stride;
   c.zL = s; s += c.n; c.zU = s; s += c.n; c.dz = s; s += c.n;
   c.pt = s; s += (long)W::PF_N * c.K;
   c.hr = s; s += (long)W::HR_N * c.K;
   c.st = s; s += (long)W::SG_N * c.N;
   c.kg = s; s += (long)W::KST * c.N;
   c.zr = s; s += W::ZR + 2;
-  c.lam = lam ? lam + b * (long)(2 * c.N * W::NS) : s;
-  c.pp.load(params, b, params_stride);
-  c.pp.set_scale(vs.s);
+  double* const lam_own = s;
   double* l = reinterpret_cast<double*>(smem_wave);
   c.r0 = l; l += W::r0_doubles(c.N);
   c.sPi = l; l += c.N * W::NS;
@@ -1415,24 +1416,35 @@ void hs_solve_wave_kernel(int B, HsSolveOpts o, VarScale vs, double* __restrict_
   c.sGe = l; l += W::NS * W::NY1;
   c.sTnu = l; l += W::NS * W::NC;
   c.sKu = l; l += W::NU * W::NC;
-  HsSolveResult r;
+  for (;;) {
+    int t = 0;
+    if (threadIdx.x == 0) t = atomicAdd(ticket, 1);
+    const long b = __builtin_amdgcn_readfirstlane(t);
+    if (b >= B) break;
+    c.z = z + b * (long)c.n; c.lb = lb + b * (long)c.n; c.ub = ub + b * (long)c.n;
+    c.lam = lam ? lam + b * (long)(2 * c.N * W::NS) : lam_own;
+    c.pp.load(params, b, params_stride);
+    c.pp.set_scale(vs.s);
+    HsSolveResult r;
 #ifdef MYR_PHASE_TIMING
-  for (int i = 0; i < 16; ++i) c.tph[i] = 0;
-  c.t0 = clock64();
+    for (int i = 0; i < 16; ++i) c.tph[i] = 0;
+    c.t0 = clock64();
 #endif
-  W::solve(c, o, r);
+    W::solve(c, o, r);
 #ifdef MYR_PHASE_TIMING
-  if (threadIdx.x == 0 && b < 4) {
-    printf("traj %ld it %d: lin %lld elim %lld adj %lld lam %lld hess %lld qm %lld ricc %lld nu %lld fwd %lld dz %lld lim %lld ls %lld upd %lld\n",
-           b, r.iters, c.tph[0], c.tph[1], c.tph[2], c.tph[3], c.tph[4], c.tph[5], c.tph[6], c.tph[7], c.tph[8], c.tph[9],
-           c.tph[10], c.tph[11], c.tph[12]);
-  }
+    if (threadIdx.x == 0 && b < 4) {
+      printf("traj %ld it %d: lin %lld elim %lld adj %lld lam %lld hess %lld qm %lld ricc %lld nu %lld fwd %lld dz %lld lim %lld ls %lld upd %lld\n",
+             b, r.iters, c.tph[0], c.tph[1], c.tph[2], c.tph[3], c.tph[4], c.tph[5], c.tph[6], c.tph[7], c.tph[8], c.tph[9],
+             c.tph[10], c.tph[11], c.tph[12]);
+    }
 #endif
-  if (threadIdx.x == 0) {
-    if (cost) cost[b] = r.cost;
-    if (status) status[b] = r.status;
-    if (iters) iters[b] = r.iters;
-    if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
+    if (threadIdx.x == 0) {
+      if (cost) cost[b] = r.cost;
+      if (status) status[b] = r.status;
+      if (iters) iters[b] = r.iters;
+      if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
+    }
+    __syncthreads();      // the slot's scratch and LDS are handed to the next trajectory
   }
 }
 

@@ -81,6 +81,8 @@ struct myr_handle_s {
   // solver scratch (batch-minor / SoA)
   void* sbuf = nullptr;
   size_t sbuf_bytes = 0;
+  int* ticket = nullptr;      // work counter of the persistent solve kernel (one int)
+  int solve_slots = 0;        // MYRIAD_SOLVE_SLOTS: resident wavefronts of the solve kernel (0 = what the device holds)
   // variable scaling of the solve path (myr_set_var_scale): the solver kernels see z/s, lb/s, ub/s
   VarScale vscale{{1, 1, 1, 1, 1, 1, 1, 1}};
   bool vscale_on = false;
@@ -400,21 +402,36 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   if (h->solve_mode == 1 && HsWave<Sys>::lds_bytes(N) <= 160 * 1024) {
     using W = HsWave<Sys>;
     const size_t lds = W::lds_bytes(N);
+    auto kern = hs_solve_wave_kernel<Sys>;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // Persistent form: as many workgroups as the device keeps resident (registers and LDS allow 4 wavefronts per CU), each
+    // pulling trajectories from a ticket counter.  Scratch belongs to the SLOT, not to the trajectory: the working set of
+    // a launch is slots x 273 KB (280 MB for CARTPOLE N=100) instead of B x 273 KB (1.1 GB at B = 4096) and is re-used
+    // trajectory after trajectory, i.e. it stays in the 256 MB Infinity Cache instead of streaming through HBM.
+    int slots = h->solve_slots;
+    if (slots <= 0) {
+      int per_cu = 0, dev = 0, cus = 0;
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64, lds));
+      HIPCHK(hipGetDevice(&dev));
+      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      slots = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256);
+    }
+    if (slots > B) slots = B;
     long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
-    if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate trajectories over HBM channels
-    const size_t need = (size_t)B * (size_t)stride * 8;
+    if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate slots over HBM channels
+    const size_t need = (size_t)slots * (size_t)stride * 8;
     if (need > h->sbuf_bytes) {
       if (h->sbuf) HIPCHK(hipFree(h->sbuf));
       h->sbuf = nullptr; h->sbuf_bytes = 0;
       HIPCHK(hipMalloc(&h->sbuf, need));
       h->sbuf_bytes = need;
     }
+    if (!h->ticket) HIPCHK(hipMalloc(&h->ticket, sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int), h->stream));
     HsSolveOpts o = make_opts(h, so);
-    auto kern = hs_solve_wave_kernel<Sys>;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KTimer& kt = h->kt[MYR_K_SOLVE];
     HIPCHK(hipEventRecord(kt.a, h->stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, h->stream, B, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
+    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
                        params, pstride, cost, status, iters, kkt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(kt.b, h->stream));
@@ -647,6 +664,7 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
   if (md) h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1;
   const char* l = getenv("MYRIAD_SOLVE_LPW");
   if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
+  if (const char* e = getenv("MYRIAD_SOLVE_SLOTS")) h->solve_slots = atoi(e);   // developer knob: resident wavefronts of the solve kernel
   *out = h;
   return MYR_OK;
 }
@@ -656,6 +674,7 @@ extern "C" int myr_destroy(myr_handle h) {
   (void)hipSetDevice(h->d.device);
   if (h->dbuf) (void)hipFree(h->dbuf);
   if (h->sbuf) (void)hipFree(h->sbuf);
+  if (h->ticket) (void)hipFree(h->ticket);
   if (h->vbuf) (void)hipFree(h->vbuf);
   for (int i = 0; i < MYR_K_COUNT; ++i) {
     if (h->kt[i].a) (void)hipEventDestroy(h->kt[i].a);
