@@ -83,6 +83,24 @@ __device__ inline void ldl_solve(const double* a, const double* dinv, double* b)
   }
 }
 
+// every lane <- lane LANE of its own row of 16 lanes (DPP row_newbcast: stays in the vector pipe, ~10 cycles; v_readlane
+// goes through the scalar register file and costs ~55 cycles before a vector instruction can use the value)
+template <int LANE>
+__device__ inline double wv_row_bcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v), rlo, rhi;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_mov_b32_dpp %1, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+               : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi), "n"(LANE));
+  return __hiloint2double(rhi, rlo);
+}
+template <int NQ_>
+struct RowBcast {       // q[i] = value of lane i (i < NQ_ <= 16) of the caller's row, for all i
+  template <int I = 0>
+  __device__ static inline void all(double v, double* q) {
+    if constexpr (I < NQ_) { q[I] = wv_row_bcast<I>(v); all<I + 1>(v, q); }
+  }
+};
+
 __device__ inline int wv_isum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -363,32 +381,33 @@ struct HsWave {
   // adjoint recurrence Pi_{k-1} = M_k Pi_k + v_k, k = N-1 .. 0: lane r < NS owns row r of M|v (LDS, prefetched one
   // stage ahead); Pi travels between lanes with v_readlane, so a stage is NS FMAs + NS readlanes and no barrier.
   __device__ static void adjoint_recur(Ctx& c, const double* nuT) {
-    const int lane = c.lane, r = lane < NS ? lane : 0;
-    constexpr int MV = NS * NS + NS;
+    // every row of 16 lanes repeats the computation of lanes 0..NS-1 (the broadcast below is per row); row 0 stores
+    const int lane = c.lane, l16 = lane & 15, r = l16 < NS ? l16 : 0;
+    constexpr int MV = NS * NS + NS, UB = 4;       // UB stages per batch of LDS reads: their latency is paid once per batch
     double piq[NS], own = 0.0;
 #pragma unroll
-    for (int q = 0; q < NS; ++q) { piq[q] = c.term_pinned[q] ? nuT[q] : 0.0; own = (q == lane) ? piq[q] : own; }
-    double pre[NS + 1];
-    {
-      const double* M = c.r0 + (long)(c.N - 1) * MV;
+    for (int q = 0; q < NS; ++q) { piq[q] = c.term_pinned[q] ? nuT[q] : 0.0; own = (q == l16) ? piq[q] : own; }
+    for (int kb = c.N - 1; kb >= 0; kb -= UB) {
+      double row[UB][NS + 1];
 #pragma unroll
-      for (int q = 0; q < NS; ++q) pre[q] = M[r * NS + q];
-      pre[NS] = M[NS * NS + r];
-    }
-    for (int k = c.N - 1; k >= 0; --k) {
-      if (lane < NS) c.sPi[k * NS + lane] = own;
-      double v = pre[NS];
+      for (int u = 0; u < UB; ++u) {
+        const int k = kb - u > 0 ? kb - u : 0;      // (stages below 0: a valid row, not used)
+        const double* M = c.r0 + (long)k * MV;
 #pragma unroll
-      for (int q = 0; q < NS; ++q) v += pre[q] * piq[q];
-      if (k > 0) {
-        const double* M = c.r0 + (long)(k - 1) * MV;
-#pragma unroll
-        for (int q = 0; q < NS; ++q) pre[q] = M[r * NS + q];
-        pre[NS] = M[NS * NS + r];
+        for (int q = 0; q < NS; ++q) row[u][q] = M[r * NS + q];
+        row[u][NS] = M[NS * NS + r];
       }
 #pragma unroll
-      for (int q = 0; q < NS; ++q) piq[q] = rdlane(v, q);
-      own = v;
+      for (int u = 0; u < UB; ++u) {
+        const int k = kb - u;
+        if (k < 0) break;
+        if (lane < NS) c.sPi[k * NS + lane] = own;
+        double v = row[u][NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) v += row[u][q] * piq[q];
+        RowBcast<NS>::all(v, piq);        // lanes 0..NS-1 hold the rows: broadcast within each row of 16 lanes
+        own = v;
+      }
     }
   }
 
@@ -1030,31 +1049,36 @@ struct HsWave {
   // ---- phase 8b: forward recursion (sequential): lane r < NW owns row r of Phi|phi (prefetched one stage ahead),
   // s travels between lanes with v_readlane; s_k -> LDS for phase 9.  No barrier inside the loop.
   __device__ static void forward_recur(Ctx& c, const double* th) {
-    const int lane = c.lane, N = c.N, r = lane < NW ? lane : 0;
+    // every row of 16 lanes repeats the computation of lanes 0..NW-1 (the broadcast below is per row); row 0 stores
+    const int lane = c.lane, N = c.N, l16 = lane & 15, r = l16 < NW ? l16 : 0;
+    constexpr int UB = 4;                          // stages per batch of LDS reads
     double v = 0.0;
-    if (lane >= NS && lane < NW) {
+    if (l16 >= NS && l16 < NW) {
 #pragma unroll
-      for (int cc = 0; cc < NC; ++cc) v -= c.sKu[(lane - NS) * NC + cc] * th[cc];
+      for (int cc = 0; cc < NC; ++cc) v -= c.sKu[(l16 - NS) * NC + cc] * th[cc];
     }
     double sq[NW];
-#pragma unroll
-    for (int q = 0; q < NW; ++q) sq[q] = rdlane(v, q);
+    RowBcast<NW>::all(v, sq);
     if (lane < NW) c.sS[lane] = v;
-    double pre[NW + 1];
+    for (int kb = 0; kb < N; kb += UB) {
+      double row[UB][NW + 1];
 #pragma unroll
-    for (int q = 0; q <= NW; ++q) pre[q] = c.r0[r * (NW + 1) + q];
-    for (int k = 0; k < N; ++k) {
-      v = pre[NW];
+      for (int u = 0; u < UB; ++u) {
+        const int k = kb + u < N ? kb + u : N - 1;
+        const double* P = c.r0 + (long)k * PHI + r * (NW + 1);
 #pragma unroll
-      for (int q = 0; q < NW; ++q) v += pre[q] * sq[q];
-      if (k + 1 < N) {
-        const double* P = c.r0 + (long)(k + 1) * PHI + r * (NW + 1);
-#pragma unroll
-        for (int q = 0; q <= NW; ++q) pre[q] = P[q];
+        for (int q = 0; q <= NW; ++q) row[u][q] = P[q];
       }
 #pragma unroll
-      for (int q = 0; q < NW; ++q) sq[q] = rdlane(v, q);
-      if (lane < NW) c.sS[(k + 1) * NW + lane] = v;
+      for (int u = 0; u < UB; ++u) {
+        const int k = kb + u;
+        if (k >= N) break;
+        v = row[u][NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) v += row[u][q] * sq[q];
+        RowBcast<NW>::all(v, sq);
+        if (lane < NW) c.sS[(k + 1) * NW + lane] = v;
+      }
     }
   }
 
