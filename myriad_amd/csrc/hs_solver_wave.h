@@ -17,8 +17,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "hs_solver.h"
+#include "node_mfma.h"
 
 namespace myriad {
+
+// network dynamics (node_system.h) are evaluated by the matrix-core passes of node_mfma.h inside the wavefront solver
+template <class True, int H1, int H2, int ID_> struct SysNODE;
+template <class Sys> struct NodeTraits { static constexpr bool mlp = false; static constexpr int lds_doubles = 0; };
+template <class True, int ID_> struct NodeTraits<SysNODE<True, 64, 64, ID_>> {
+  static constexpr bool mlp = (True::NS == 4 && True::NU == 1);
+  static constexpr int lds_doubles = mlp ? NodeMfma64::L_N : 0;
+};
 
 __device__ inline double wv_sum(double v) {
 #pragma unroll
@@ -112,9 +121,11 @@ struct HsWave {
   using S = HsSolver<Sys>;
   using D = HsSol<Sys>;
   static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = NY + 1;
+  static constexpr bool MLP = NodeTraits<Sys>::mlp;
+  static constexpr int ND2 = MLP ? NodeMfma64::NPAIR : Sys::NNZ2;   // stored second-derivative data per point
   // per-point record, SoA over points: field f of point j at pt[f*K + j]
   static constexpr int PF_F = 0, PF_A = PF_F + NS, PF_B = PF_A + NS * NS, PF_GW = PF_B + NS * NU, PF_D2 = PF_GW + NW,
-                       PF_SIG = PF_D2 + Sys::NNZ2, PF_G1 = PF_SIG + NW, PF_ZLU = PF_G1 + NW, PF_N = PF_ZLU + NW;
+                       PF_SIG = PF_D2 + ND2, PF_G1 = PF_SIG + NW, PF_ZLU = PF_G1 + NW, PF_N = PF_ZLU + NW;
   // per-point Hessian record, AoS: H (NW x NW), g0 (NW), g1 (NW)
   static constexpr int HR_H = 0, HR_G0 = NW * NW, HR_G1 = HR_G0 + NW, HR_N = HR_G1 + NW;
   // per-stage record, AoS
@@ -140,7 +151,8 @@ struct HsWave {
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
   }
   static constexpr int EXCH = NW * NW + NW * NC + NS * NY1 + NS * NC + NU * NC + 8;
-  __host__ __device__ static size_t lds_bytes(int N) { return (size_t)(r0_doubles(N) + N * NS + (N + 1) * NW + EXCH) * 8 + 64; }
+  __host__ __device__ static int lds_solver_doubles(int N) { return r0_doubles(N) + N * NS + (N + 1) * NW + EXCH + 8; }
+  __host__ __device__ static size_t lds_bytes(int N) { return (size_t)(lds_solver_doubles(N) + NodeTraits<Sys>::lds_doubles) * 8; }
 
   struct Ctx {
     int N, K, n, lane;
@@ -151,6 +163,7 @@ struct HsWave {
     bool term_pinned[NS];
     // LDS
     double *r0, *sPi, *sS, *sP, *sPc, *sGe, *sTnu, *sKu;
+    double* wl;           // network weights in LDS (node_mfma.h), network systems only
 #ifdef MYR_PHASE_TIMING
     long long tph[16], t0;
 #endif
@@ -163,9 +176,23 @@ struct HsWave {
 
   __device__ static inline long zi(const Ctx& c, int j, int comp) { return S::zi(c.K, j, comp); }
 
+  // ---- network systems: matrix-core passes over all points (node_mfma.h) ---------------------------------------------
+  template <int MODE>
+  __device__ static inline void node_pass(Ctx& c, double alpha) {
+    if constexpr (MLP) {
+      NodeMfma64::Args a;
+      a.z = (const nd_glb*)c.z; a.dz = (const nd_glb*)c.dz; a.lam = (const nd_glb*)c.lam; a.pt = (nd_glb*)c.pt;
+      a.sF = (nd_lds*)(c.r0 + (long)c.K * NS);
+      a.alpha = alpha; a.h6 = c.h6; a.h8 = c.h8; a.K = c.K; a.N = c.N;
+      a.pf_f = PF_F; a.pf_a = PF_A; a.pf_b = PF_B; a.pf_d2 = PF_D2;
+      NodeMfma64::pass<MODE>((const nd_lds*)c.wl, a, c.lane);
+    } else { (void)c; (void)alpha; }
+  }
+
   // ---- phase 1: lanes over points -- linearisation, bound terms ----------------------------------------------
   struct P1 { double f, cmax, cmin, sm, lg; int nm; };   // lg = -sum log(slack): barrier term of the merit function / mu
   __device__ static void points_lin(Ctx& c, P1& o) {
+    node_pass<1>(c, 0.0);
     double f = 0, cmax = 0, cmin = INFINITY, sm = 0, lg = 0; int nm = 0;
     for (int j = c.lane; j < c.K; j += 64) {
       typename S::VarBlk V;
@@ -177,19 +204,27 @@ struct HsWave {
       }
       HsPoint<Sys> P;
       set_time<Sys>(c.pp.get(), 0.5 * c.h * j);
-      S::lin_point(V, c.pp.get(), P);
       double* pt = c.pt + j;
       const int K = c.K;
+      if constexpr (MLP) {            // f, A, B come from the matrix-core pass; only the (closed-form) cost is per lane
 #pragma unroll
-      for (int q = 0; q < NS; ++q) pt[(PF_F + q) * K] = P.f[q];
+        for (int q = 0; q < NS; ++q) P.x[q] = V.z[q];
 #pragma unroll
-      for (int q = 0; q < NS * NS; ++q) pt[(PF_A + q) * K] = P.A[q];
+        for (int q = 0; q < NU; ++q) P.u[q] = V.z[NS + q];
+        Sys::cost_grad(P.x, P.u, c.pp.get(), &P.g, P.gw);
+      } else {
+        S::lin_point(V, c.pp.get(), P);
 #pragma unroll
-      for (int q = 0; q < NS * NU; ++q) pt[(PF_B + q) * K] = P.B[q];
+        for (int q = 0; q < NS; ++q) pt[(PF_F + q) * K] = P.f[q];
+#pragma unroll
+        for (int q = 0; q < NS * NS; ++q) pt[(PF_A + q) * K] = P.A[q];
+#pragma unroll
+        for (int q = 0; q < NS * NU; ++q) pt[(PF_B + q) * K] = P.B[q];
+#pragma unroll
+        for (int q = 0; q < Sys::NNZ2; ++q) pt[(PF_D2 + q) * K] = P.D2[q];
+      }
 #pragma unroll
       for (int q = 0; q < NW; ++q) pt[(PF_GW + q) * K] = P.gw[q];
-#pragma unroll
-      for (int q = 0; q < Sys::NNZ2; ++q) pt[(PF_D2 + q) * K] = P.D2[q];
 #pragma unroll
       for (int q = 0; q < NW; ++q) {
         typename S::BV b = S::bound_terms(V.z[q], V.l[q], V.u[q], V.zl[q], V.zu[q], cmax, cmin);
@@ -435,6 +470,7 @@ struct HsWave {
 
   // ---- phase 4: lanes over points -- Lagrangian Hessian, gradient columns, control-row stationarity ------------
   __device__ static void points_hess(Ctx& c, double& stat) {
+    node_pass<2>(c, 0.0);
     const int N = c.N, K = c.K;
     const double h6 = c.h6, h8 = c.h8;
     double st_ = 0;
@@ -456,11 +492,11 @@ struct HsWave {
         }
       }
       const double wj = S::wsimp(K, j, c.h);
-      double gw[NW], D2[Sys::NNZ2], W[NW * NW];
+      double gw[NW], D2[ND2], W[NW * NW];
 #pragma unroll
       for (int q = 0; q < NW; ++q) gw[q] = pt[(PF_GW + q) * K];
 #pragma unroll
-      for (int q = 0; q < Sys::NNZ2; ++q) D2[q] = pt[(PF_D2 + q) * K];
+      for (int q = 0; q < ND2; ++q) D2[q] = pt[(PF_D2 + q) * K];
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         double r = wj * gw[NS + u] + pt[(PF_ZLU + NS + u) * K];
@@ -474,7 +510,8 @@ struct HsWave {
         for (int q = 0; q < NS; ++q) xj[q] = c.z[zi(c, j, q)];
 #pragma unroll
         for (int q = 0; q < NU; ++q) uj[q] = c.z[zi(c, j, NS + q)];
-        Sys::hessian(xj, uj, c.pp.get(), D2, a, wj, W);
+        if constexpr (MLP) Sys::hessian_packed(xj, uj, D2, wj, W);   // D2: the network's contraction, from the matrix-core pass
+        else Sys::hessian(xj, uj, c.pp.get(), D2, a, wj, W);
       }
       double* hr = c.hr + (long)j * HR_N;
       const bool last = (j == K - 1);
@@ -1136,6 +1173,7 @@ struct HsWave {
   __device__ static bool trial(Ctx& c, double alpha, double mu, double& f, double& bar, double& c1) {
     const int N = c.N, K = c.K;
     double* sX = c.r0; double* sF = c.r0 + (long)K * NS;
+    node_pass<0>(c, alpha);                 // network systems: f of every trial point by the matrix-core pass -> sF
     double fa = 0, ba = 0; int bad = 0;
     for (int j = c.lane; j < K; j += 64) {
       double x[NS], u[NU], ff[NS];
@@ -1155,11 +1193,11 @@ struct HsWave {
         if (q < NS) x[q] = v; else u[q - NS] = v;
       }
       ba -= log(slk) + sexp * 0.6931471805599453;
-      Sys::f(x, u, c.pp.get(), ff);
+      if constexpr (!MLP) Sys::f(x, u, c.pp.get(), ff);
       set_time<Sys>(c.pp.get(), 0.5 * c.h * j);
       fa += S::wsimp(K, j, c.h) * Sys::g(x, u, c.pp.get());
 #pragma unroll
-      for (int q = 0; q < NS; ++q) { sX[j * NS + q] = x[q]; sF[j * NS + q] = ff[q]; }
+      for (int q = 0; q < NS; ++q) { sX[j * NS + q] = x[q]; if constexpr (!MLP) sF[j * NS + q] = ff[q]; }
     }
     __syncthreads();
     double ca = 0;
@@ -1440,6 +1478,8 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
   c.sGe = l; l += W::NS * W::NY1;
   c.sTnu = l; l += W::NS * W::NC;
   c.sKu = l; l += W::NU * W::NC;
+  c.wl = reinterpret_cast<double*>(smem_wave) + W::lds_solver_doubles(c.N);
+  bool weights_loaded = false;
   for (;;) {
     int t = 0;
     if (threadIdx.x == 0) t = atomicAdd(ticket, 1);
@@ -1449,6 +1489,13 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
     c.lam = lam ? lam + b * (long)(2 * c.N * W::NS) : lam_own;
     c.pp.load(params, b, params_stride);
     c.pp.set_scale(vs.s);
+    if constexpr (W::MLP) {      // network weights -> LDS: once per workgroup when the batch shares them, else per trajectory
+      if (!weights_loaded || params_stride != 0) {
+        NodeMfma64::load_weights(c.pp.get(), c.wl, c.lane);
+        weights_loaded = true;
+        __syncthreads();
+      }
+    }
     HsSolveResult r;
 #ifdef MYR_PHASE_TIMING
     for (int i = 0; i < 16; ++i) c.tph[i] = 0;

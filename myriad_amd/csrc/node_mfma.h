@@ -1,0 +1,219 @@
+// node_mfma.h -- the neural-ODE dynamics of BASELINE config 5 (x' = MLP([x; u]), 2 x 64 sigmoid layers) on fp64 matrix cores.
+//
+// What the reference does per collocation point through jax autodiff (/root/reference/myriad/systems/neural_ode/
+// node_system.py:35-38, network of /root/reference/myriad/neural_ode/create_node.py:110-117) -- value, input Jacobian and the
+// multiplier-contracted second derivative of the network -- is evaluated here for SIXTEEN points at a time by one
+// wavefront with v_mfma_f64_16x16x4_f64, in the transposed ("features along rows") form
+//     A1 = W1^T X + b1,  H1 = s(A1);   A2 = W2^T H1 + b2,  H2 = s(A2);   F = W3^T H2 + b3          (columns = points)
+// because of the register layout of that instruction (probed: tools/dev/mfma/probe_f64.hip): a 16 x 16 result tile keeps
+// element (row n, column i) in lane 16 (n % 4) + i, register n / 4, and the B operand of the next product wants element
+// (k, i) in lane 16 (k % 4) + i for k-step k / 4 -- register s of a result tile IS k-step s of the next layer's B operand.
+// A whole layer chains into the next one without moving a single value between lanes; the elementwise work (sigmoid, its
+// derivatives, the tangent seeds) runs on all 64 lanes on 16 values each.  The weights are the A operands: they sit in LDS
+// (40 KB, loaded once per workgroup, re-used for every trajectory of the persistent kernel) in layouts whose 64-lane
+// reads are conflict-free, one ds_read_b64 per 1024-FMA instruction.  (The per-lane form this replaces pulled 4 804
+// weights through scalar loads for every point and ran at <1 % of the fp64 rate.)
+//
+//   MODE 0  F                                   (merit-function trials)               88 MFMA per 16 points
+//   MODE 1  F, dF/dx, dF/du  (forward tangents) (linearisation)                       488
+//   MODE 2  sum_r a_r d2 F_r / d(x,u)2          (Lagrangian Hessian, 15 entries)      476
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace myriad {
+
+typedef __attribute__((address_space(3))) double nd_lds;
+typedef __attribute__((address_space(1))) double nd_glb;
+typedef double nd4 __attribute__((ext_vector_type(4)));
+
+struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
+  static constexpr int NS = 4, NU = 1, NW = 5, H = 64, LD2 = 65;
+  // LDS block (doubles): W1 [8][64] (rows 5..7 zero) | W2 [64][65] (padded rows: column reads are conflict-free too) |
+  // W3 [64][4] | b1 | b2 | b3
+  static constexpr int L_W1 = 0, L_W2 = L_W1 + 8 * H, L_W3 = L_W2 + H * LD2, L_B1 = L_W3 + H * NS, L_B2 = L_B1 + H, L_B3 = L_B2 + H,
+                       L_N = (L_B3 + NS + 7) / 8 * 8;
+  // parameter vector in global memory (node_system.h): w1 [5][64] | b1 | w2 [64][64] | b2 | w3 [64][4] | b3
+  static constexpr int O_W1 = 0, O_B1 = O_W1 + NW * H, O_W2 = O_B1 + H, O_B2 = O_W2 + H * H, O_W3 = O_B2 + H, O_B3 = O_W3 + H * NS;
+  static constexpr int NPAIR = NW * (NW + 1) / 2;       // entries of the symmetric 5 x 5 contraction
+
+  __device__ static inline void load_weights(const double* p, double* wl, int lane) {
+    for (int e = lane; e < 8 * H; e += 64) wl[L_W1 + e] = e < NW * H ? p[O_W1 + e] : 0.0;
+    for (int e = lane; e < H * H; e += 64) wl[L_W2 + (e >> 6) * LD2 + (e & 63)] = p[O_W2 + e];
+    for (int e = lane; e < H * NS; e += 64) wl[L_W3 + e] = p[O_W3 + e];
+    wl[L_B1 + lane] = p[O_B1 + lane];
+    wl[L_B2 + lane] = p[O_B2 + lane];
+    if (lane < NS) wl[L_B3 + lane] = p[O_B3 + lane];
+  }
+
+  __device__ static inline nd4 mm(double a, double b, nd4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  __device__ static inline double sigm(double a) { return 1.0 / (1.0 + exp(-a)); }
+
+  // out = W2^T in (+ b2): row m = 16 mt + i of the A operand, k = n = 16 t + 4 s + g
+  template <bool BIAS>
+  __device__ static inline void gemm_t(const nd_lds* wl, int g, int i, const nd4* in, nd4* out) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      nd4 acc;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[s] = BIAS ? wl[L_B2 + 16 * mt + 4 * s + g] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mm(wl[L_W2 + (16 * t + 4 * s + g) * LD2 + 16 * mt + i], in[t][s], acc);
+      out[mt] = acc;
+    }
+  }
+  // out = W2 in: row n = 16 nt + i, k = m = 16 t + 4 s + g
+  __device__ static inline void gemm_n(const nd_lds* wl, int g, int i, const nd4* in, nd4* out) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      nd4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mm(wl[L_W2 + (16 * nt + i) * LD2 + 16 * t + 4 * s + g], in[t][s], acc);
+      out[nt] = acc;
+    }
+  }
+  // rows 0..3 of W3^T in (+ b3): result for output r of point i in lane 16 r + i
+  template <bool BIAS>
+  __device__ static inline double layer3(const nd_lds* wl, int g, int i, const nd4* in) {
+    nd4 acc = {BIAS ? wl[L_B3 + g] : 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double a = wl[L_W3 + (16 * t + 4 * s + g) * NS + (i & 3)];
+        acc = mm(i < NS ? a : 0.0, in[t][s], acc);
+      }
+    return acc[0];
+  }
+
+  struct Args {
+    const nd_glb* z; const nd_glb* dz; const nd_glb* lam;   // decision vector, step (MODE 0), multipliers (MODE 2)
+    nd_glb* pt;                                             // per-point records, field f of point j at pt[f * K + j]
+    nd_lds* sF;                                             // MODE 0: f of point j at sF[j * NS + r]
+    double alpha, h6, h8;
+    int K, N, pf_f, pf_a, pf_b, pf_d2;
+  };
+
+  template <int MODE>
+  __device__ __attribute__((noinline)) static void pass(const nd_lds* wl, Args a, int lane) {
+    const int g = lane >> 4, i = lane & 15, K = a.K;
+    for (int j0 = 0; j0 < K; j0 += 16) {
+      const bool valid = j0 + i < K;
+      const int j = valid ? j0 + i : K - 1;
+      // inputs in B-operand layout: state component g of point i, and the control in lane group 0 of the second k-step
+      double xg = a.z[(long)j * NS + g], ug = g == 0 ? a.z[(long)K * NS + j] : 0.0;
+      if (MODE == 0) {
+        xg += a.alpha * a.dz[(long)j * NS + g];
+        if (g == 0) ug += a.alpha * a.dz[(long)K * NS + j];
+      }
+      nd4 h1[4], sp1[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        nd4 acc;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] = wl[L_B1 + 16 * mt + 4 * s + g];
+        acc = mm(wl[L_W1 + g * H + 16 * mt + i], xg, acc);
+        acc = mm(wl[L_W1 + (4 + g) * H + 16 * mt + i], ug, acc);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { const double hv = sigm(acc[s]); h1[mt][s] = hv; sp1[mt][s] = hv * (1.0 - hv); }
+      }
+      nd4 h2[4], sp2[4];
+      gemm_t<true>(wl, g, i, h1, h2);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { const double hv = sigm(h2[mt][s]); h2[mt][s] = hv; sp2[mt][s] = hv * (1.0 - hv); }
+      if (MODE == 0 || MODE == 1) {
+        const double F = layer3<true>(wl, g, i, h2);
+        if (MODE == 0) { if (valid) a.sF[j * NS + g] = F; }
+        else if (valid) a.pt[(long)(a.pf_f + g) * K + j] = F;
+      }
+      if (MODE == 1) {
+        // forward tangents: d A1 / d w_c = W1[c, :] (constant), so d H1 = s'(A1) * W1[c, :], then the two upper layers
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+          nd4 d1[4], d2[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) d1[mt][s] = sp1[mt][s] * wl[L_W1 + c * H + 16 * mt + 4 * s + g];
+          gemm_t<false>(wl, g, i, d1, d2);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) d2[mt][s] *= sp2[mt][s];
+          const double dF = layer3<false>(wl, g, i, d2);      // d F_g / d w_c at point i
+          if (valid) a.pt[(long)(c < NS ? a.pf_a + g * NS + c : a.pf_b + g * NU) * K + j] = dF;
+        }
+      }
+      if (MODE == 2) {
+        // multiplier combination of this point (what points_hess() forms per lane): component g in lane group g
+        double ar;
+        if (j & 1) ar = -4.0 * a.h6 * a.lam[(long)((j - 1) >> 1) * NS + g];
+        else {
+          const int kL = (j >> 1) - 1, kR = j >> 1;
+          ar = 0.0;
+          if (kL >= 0) ar += -a.h6 * a.lam[(long)kL * NS + g] + a.h8 * a.lam[(long)a.N * NS + (long)kL * NS + g];
+          if (kR < a.N) ar += -a.h6 * a.lam[(long)kR * NS + g] - a.h8 * a.lam[(long)a.N * NS + (long)kR * NS + g];
+        }
+        // g2 = W3 a (one k-step: k = output r = lane group), e2 = g2 s'(A2), c2 = g2 s''(A2)
+        nd4 e2[4], c2[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          nd4 acc = {0.0, 0.0, 0.0, 0.0};
+          acc = mm(wl[L_W3 + (16 * nt + i) * NS + g], ar, acc);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { const double e = acc[s] * sp2[nt][s]; e2[nt][s] = e; c2[nt][s] = e * (1.0 - 2.0 * h2[nt][s]); }
+        }
+        // g1 = W2 e2, c1 = g1 s''(A1)
+        nd4 c1[4];
+        gemm_n(wl, g, i, e2, c1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) c1[mt][s] *= sp1[mt][s] * (1.0 - 2.0 * h1[mt][s]);
+        // m_c = W2^T (s'(A1) * W1[c, :]): the five tangents of A2
+        nd4 m[NW][4];
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+          nd4 d1[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) d1[mt][s] = sp1[mt][s] * wl[L_W1 + c * H + 16 * mt + 4 * s + g];
+          gemm_t<false>(wl, g, i, d1, m[c]);
+        }
+        // W[a][b] = sum_n c1_n W1[a][n] W1[b][n] + sum_n c2_n m_a[n] m_b[n]: 16 hidden units per lane, then over the 4 groups
+        double acc[NPAIR];
+#pragma unroll
+        for (int e = 0; e < NPAIR; ++e) acc[e] = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            double w1v[NW];
+#pragma unroll
+            for (int c = 0; c < NW; ++c) w1v[c] = wl[L_W1 + c * H + 16 * mt + 4 * s + g];
+            int e = 0;
+#pragma unroll
+            for (int p = 0; p < NW; ++p)
+#pragma unroll
+              for (int q = p; q < NW; ++q, ++e)
+                acc[e] += c1[mt][s] * w1v[p] * w1v[q] + c2[mt][s] * m[p][mt][s] * m[q][mt][s];
+          }
+#pragma unroll
+        for (int e = 0; e < NPAIR; ++e) {
+          double v = acc[e];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (valid && (e & 3) == g) a.pt[(long)(a.pf_d2 + e) * K + j] = v;
+        }
+      }
+    }
+  }
+};
+
+}  // namespace myriad

@@ -176,6 +176,21 @@ struct SysNODE {
 #pragma unroll
       for (int b = a; b < NW; ++b) { const double v = Wacc[a * NW + b] + Wg[a * NW + b]; W[a * NW + b] = v; W[b * NW + a] = v; }
   }
+  // the same with the network part already contracted (node_mfma.h, MODE 2): Wm = upper triangle of
+  // sum_r mu_r d2 MLP_r / dw2, row by row; adds the true cost's second derivative
+  MYR_HD static inline void hessian_packed(const double* x, const double* u, const double* Wm, double wg, double* W) {
+    double tp[True::NPX], tf[NS], tA[NS * NS], tB[NS * NU], tg, tgw[NW], tD2[True::NNZ2], Wg[NW * NW], zero[NS];
+    True::default_params(tp);
+#pragma unroll
+    for (int r = 0; r < NS; ++r) zero[r] = 0.0;
+    True::lin_d2(x, u, tp, tf, tA, tB, &tg, tgw, tD2);
+    True::contract(tD2, zero, wg, Wg);
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < NW; ++a)
+#pragma unroll
+      for (int b = a; b < NW; ++b, ++e) { const double v = Wm[e] + Wg[a * NW + b]; W[a * NW + b] = v; W[b * NW + a] = v; }
+  }
   MYR_HD static inline void default_params(double* p) { (void)p; }
 };
 
