@@ -16,6 +16,10 @@
 #pragma once
 #include "hs_solver.h"
 
+#ifndef MYR_TRAP_LAM_FLOOR
+#define MYR_TRAP_LAM_FLOOR false   // penalty-relaxation floor at 1.1 |lambda|_inf for the trapezoidal core
+#endif
+
 namespace myriad {
 
 // M = control rows a stage adds after its own: 1 for trapezoid / Euler / Heun / midpoint steps (du_next), 2 for an RK4
@@ -175,7 +179,7 @@ MYR_HD inline int os_first_point(const double* P, const double* pc, const double
 template <class Sys>
 struct TrapCore {
   using H = HsSolver<Sys>;
-  static constexpr bool PEN_LAM_FLOOR = false;
+  static constexpr bool PEN_LAM_FLOOR = MYR_TRAP_LAM_FLOOR;
   using D = OsDims<Sys>;
   static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = D::NY1;
   using SweepOut = typename H::SweepOut;

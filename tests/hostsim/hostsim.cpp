@@ -44,6 +44,10 @@ static void solve_batch(int N, double T, int B, double* z, const double* lb, con
   for (int b = 0; b < B; ++b) {
     std::vector<double> zL(n), zU(n), dz(n), lbv(lb + (size_t)b * n, lb + (size_t)(b + 1) * n),
         ubv(ub + (size_t)b * n, ub + (size_t)(b + 1) * n), st(HsSol<Sys>::stage_doubles(N));
+    if (getenv("POISON")) {   // the device scratch is not zero-initialised: NaN here exposes a read-before-write
+      for (auto* v : {&zL, &zU, &dz, &st}) for (auto& x : *v) x = NAN;
+      for (int i = 0; i < m; ++i) lam[(size_t)b * m + i] = NAN;
+    }
     SysParams<Sys> pp;
     pp.load(params, b, pstride);
     const double* p = pp.get();
