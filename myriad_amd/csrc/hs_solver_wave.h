@@ -124,8 +124,13 @@ struct HsWave {
   static constexpr bool MLP = NodeTraits<Sys>::mlp;
   static constexpr int ND2 = MLP ? NodeMfma64::NPAIR : Sys::NNZ2;   // stored second-derivative data per point
   // per-point record, SoA over points: field f of point j at pt[f*K + j]
-  static constexpr int PF_F = 0, PF_A = PF_F + NS, PF_B = PF_A + NS * NS, PF_GW = PF_B + NS * NU, PF_D2 = PF_GW + NW,
-                       PF_SIG = PF_D2 + ND2, PF_G1 = PF_SIG + NW, PF_ZLU = PF_G1 + NW, PF_N = PF_ZLU + NW;
+  // f and A, which only the elimination phase reads, come LAST: the Hessian records (written after that phase, dead before
+  // the next linearisation) are overlaid on them -- and the gains K | kc on the adjoint maps Ld..li0 of the stage record,
+  // read for the last time before the sweep writes gains.  273 -> 223 KB of scratch per resident wavefront: the
+  // working set of a launch (1024 slots) drops below the 256 MB Infinity Cache.
+  static constexpr int PF_B = 0, PF_GW = PF_B + NS * NU, PF_D2 = PF_GW + NW,
+                       PF_SIG = PF_D2 + ND2, PF_G1 = PF_SIG + NW, PF_ZLU = PF_G1 + NW, PF_F = PF_ZLU + NW, PF_A = PF_F + NS,
+                       PF_N = PF_A + NS * NS;
   // per-point Hessian record, AoS: H (NW x NW), g0 (NW), g1 (NW)
   static constexpr int HR_H = 0, HR_G0 = NW * NW, HR_G1 = HR_G0 + NW, HR_N = HR_G1 + NW;
   // per-stage record, AoS
@@ -137,12 +142,19 @@ struct HsWave {
                        SG_N = (NU == 1 && NS <= 4) ? SG_QM : SG_QCM + NY * 2;
 #endif
   static constexpr int KST = NQ * NW + NQ * NC;   // K | kc per stage (global scratch)
+#ifdef MYR_RICCATI_CHECK
+  static constexpr bool OVERLAY_K = false;        // (the self-check addresses the gains as one flat array)
+#else
+  static constexpr bool OVERLAY_K = KST <= 2 * (NS * NS + NS);
+#endif
+  static constexpr int KSTR = OVERLAY_K ? SG_N : KST;   // stride of the gain records
   static constexpr int ZR = 2 * NY + 2;           // block of zeros (masked stage inputs of the Riccati lanes read it)
   static constexpr int PHI = NW * (NW + 1);       // closed-loop stage map Phi | phi per stage (LDS)
 
   __host__ __device__ static long scratch_doubles(int N) {
     const long K = 2 * N + 1, n = K * NW;
-    return 3 * n + (long)PF_N * K + (long)HR_N * K + (long)SG_N * N + (long)KST * N + ZR + 2 /* write-only slot */ +
+    const long fa = (long)(NS + NS * NS) * K, hrn = (long)HR_N * K;        // hr overlays the f | A fields at the end of pt
+    return 3 * n + (long)PF_N * K + (hrn > fa ? hrn - fa : 0) + (long)SG_N * N + (OVERLAY_K ? 0 : (long)KST * N) + ZR + 2 /* write-only slot */ +
            2L * N * NS /* lambda when the caller passes none */;
   }
   // LDS doubles: region R0 (adjoint M|v, later Phi|phi, later trial x|f), Pi, S, exchange
@@ -745,7 +757,7 @@ struct HsWave {
       for (int r = 0; r < NQ; ++r) kk[r] = col[NW + r];
       ldl_solve<NQ>(Lq, dinv, kk);
       {
-        double* Kst = c.kg + (long)k * KST;
+        double* Kst = c.kg + (long)k * KSTR;
         if (isP) {
 #pragma unroll
           for (int r = 0; r < NQ; ++r) Kst[r * NW + lane] = kk[r];
@@ -892,8 +904,8 @@ struct HsWave {
     // lanes store unconditionally too, into the 2 spare doubles behind the block of zeros (never read)
     const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
     const int k_str = k_off < 0 ? 1 : ((scol >= 0) ? NW : NC);
-    double* k_ptr = k_off >= 0 ? c.kg + (long)(N - 1) * KST + k_off : c.zr + ZR;
-    const long k_step = k_off >= 0 ? KST : 0;
+    double* k_ptr = k_off >= 0 ? c.kg + (long)(N - 1) * KSTR + k_off : c.zr + ZR;
+    const long k_step = k_off >= 0 ? KSTR : 0;
     double reg_floor = o.reg_floor;
     asm volatile("" : "+v"(reg_floor));       // own register: otherwise every use reloads the spilled 16-SGPR argument block
     int nreg = 0;
@@ -1043,7 +1055,7 @@ struct HsWave {
   __device__ static void intervals_phi(Ctx& c, const double* th) {
     const int N = c.N;
     for (int k = c.lane; k < N; k += 64) {
-      const double* Kst = c.kg + (long)k * KST;
+      const double* Kst = c.kg + (long)k * KSTR;
       const double* st = c.st + (long)k * SG_N;
       double Kk[NQ * NW], kq[NQ];
 #pragma unroll
@@ -1125,7 +1137,7 @@ struct HsWave {
     if (c.lane < NW) c.dz[zi(c, 0, c.lane)] = c.lane < NS ? 0.0 : c.sS[c.lane];
     for (int k = c.lane; k < N; k += 64) {
       const double* st = c.st + (long)k * SG_N;
-      const double* Kst = c.kg + (long)k * KST;
+      const double* Kst = c.kg + (long)k * KSTR;
       double y[NY];
 #pragma unroll
       for (int q = 0; q < NW; ++q) y[q] = c.sS[(long)k * NW + q];
@@ -1464,9 +1476,11 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
   double* s = scratch + (long)blockIdx.x * scratch_stride;
   c.zL = s; s += c.n; c.zU = s; s += c.n; c.dz = s; s += c.n;
   c.pt = s; s += (long)W::PF_N * c.K;
-  c.hr = s; s += (long)W::HR_N * c.K;
+  c.hr = c.pt + (long)W::PF_F * c.K;                            // overlaid on the f | A fields (see PF_*)
+  if (W::HR_N > W::NS + W::NS * W::NS) s += (long)(W::HR_N - W::NS - W::NS * W::NS) * c.K;
   c.st = s; s += (long)W::SG_N * c.N;
-  c.kg = s; s += (long)W::KST * c.N;
+  if (W::OVERLAY_K) c.kg = c.st + W::SG_LD;                     // overlaid on the adjoint maps of the stage records
+  else { c.kg = s; s += (long)W::KST * c.N; }
   c.zr = s; s += W::ZR + 2;
   double* const lam_own = s;
   double* l = reinterpret_cast<double*>(smem_wave);
