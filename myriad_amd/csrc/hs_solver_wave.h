@@ -203,16 +203,44 @@ struct HsWave {
 
   // ---- phase 1: lanes over points -- linearisation, bound terms ----------------------------------------------
   struct P1 { double f, cmax, cmin, sm, lg; int nm; };   // lg = -sum log(slack): barrier term of the merit function / mu
-  __device__ static void points_lin(Ctx& c, P1& o) {
+  // The accepted step of the previous iteration is applied HERE, on the values this phase loads anyway (update() as a
+  // phase of its own re-read six arrays and paid their latency sixteen rounds in a row): z += a_p dz, zL/zU += a_d d..,
+  // same formulas, same order of operations as update().
+  struct Step { bool on; double ap, ad, mu, ksig; };
+  __device__ static void points_lin(Ctx& c, P1& o, const Step& st) {
+    if constexpr (MLP) {       // the network pass reads z from memory: apply the step first
+      if (st.on) { update(c, st.ap, st.ad, st.mu, st.ksig); __syncthreads(); }
+    }
     node_pass<1>(c, 0.0);
     double f = 0, cmax = 0, cmin = INFINITY, sm = 0, lg = 0; int nm = 0;
+    const double iks = 1.0 / st.ksig;
     for (int j = c.lane; j < c.K; j += 64) {
       typename S::VarBlk V;
       double slk = 1.0; int sexp = 0;       // as in trial(): one log per point
+      if (!MLP && st.on) {
 #pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        const long i = zi(c, j, q);
-        V.z[q] = c.z[i]; V.l[q] = c.lb[i]; V.u[q] = c.ub[i]; V.zl[q] = c.zL[i]; V.zu[q] = c.zU[i];
+        for (int q = 0; q < NW; ++q) {
+          const long i = zi(c, j, q);
+          const double l = c.lb[i], u = c.ub[i], zv = c.z[i], d = c.dz[i], zl = c.zL[i], zu = c.zU[i];
+          const bool fr = l < u;
+          const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+          const double zn = fr ? zv + st.ap * d : zv;
+          const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
+          const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
+          double vl = zl + st.ad * (-zl + (st.mu - zl * d) / sl);
+          double vu = zu + st.ad * (-zu + (st.mu + zu * d) / su);
+          const double ml = st.mu / snl, mu_ = st.mu / snu;
+          vl = detail::dmax(detail::dmin(vl, st.ksig * ml), ml * iks);
+          vu = detail::dmax(detail::dmin(vu, st.ksig * mu_), mu_ * iks);
+          V.z[q] = zn; V.l[q] = l; V.u[q] = u; V.zl[q] = hl ? vl : 0.0; V.zu[q] = hu ? vu : 0.0;
+          c.z[i] = V.z[q]; c.zL[i] = V.zl[q]; c.zU[i] = V.zu[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+          const long i = zi(c, j, q);
+          V.z[q] = c.z[i]; V.l[q] = c.lb[i]; V.u[q] = c.ub[i]; V.zl[q] = c.zL[i]; V.zu[q] = c.zU[i];
+        }
       }
       HsPoint<Sys> P;
       set_time<Sys>(c.pp.get(), 0.5 * c.h * j);
@@ -1285,9 +1313,11 @@ struct HsWave {
     double delta_last = 0.0, lm = 0.0;
     constexpr int NMMAX = 8;
     double hist[NMMAX]; int nhist = 0, hpos = 0; double hist_mu = -1.0, hist_pen = -1.0;
+    Step pending{false, 0.0, 0.0, 0.0, o.kappa_sigma};
     for (int it = 0; it <= o.max_iter; ++it) {
       P1 p1;
-      points_lin(c, p1);
+      points_lin(c, p1, pending);
+      pending.on = false;
       __syncthreads();
       MYR_PH(0)
       double c1, cinf, lam_inf, sum_mult, stat_raw;
@@ -1437,7 +1467,7 @@ struct HsWave {
         if (++stall > 5) { res.status = 3; res.iters = it; return; }
       } else stall = 0;
       MYR_PH(11)
-      update(c, a, o.dual_follow ? fo.alpha_d * (a / fo.alpha_p) : fo.alpha_d, mu, o.kappa_sigma);
+      pending.on = true; pending.ap = a; pending.ad = o.dual_follow ? fo.alpha_d * (a / fo.alpha_p) : fo.alpha_d; pending.mu = mu;
       MYR_PH(12)
 #pragma unroll
       for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
