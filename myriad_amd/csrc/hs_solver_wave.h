@@ -227,9 +227,9 @@ struct HsWave {
           const double zn = fr ? zv + st.ap * d : zv;
           const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
           const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
-          double vl = zl + st.ad * (-zl + (st.mu - zl * d) / sl);
-          double vu = zu + st.ad * (-zu + (st.mu + zu * d) / su);
-          const double ml = st.mu / snl, mu_ = st.mu / snu;
+          double vl = zl + st.ad * (-zl + (st.mu - zl * d) * detail::rcp_(sl));
+          double vu = zu + st.ad * (-zu + (st.mu + zu * d) * detail::rcp_(su));
+          const double ml = st.mu * detail::rcp_(snl), mu_ = st.mu * detail::rcp_(snu);
           vl = detail::dmax(detail::dmin(vl, st.ksig * ml), ml * iks);
           vu = detail::dmax(detail::dmin(vu, st.ksig * mu_), mu_ * iks);
           V.z[q] = zn; V.l[q] = l; V.u[q] = u; V.zl[q] = hl ? vl : 0.0; V.zu[q] = hu ? vu : 0.0;
@@ -1268,9 +1268,9 @@ struct HsWave {
       const double zn = fr ? zv + ap * d : zv;
       const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
       const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
-      double vl = zl + ad * (-zl + (mu - zl * d) / sl);
-      double vu = zu + ad * (-zu + (mu + zu * d) / su);
-      const double ml = mu / snl, mu_ = mu / snu;        // one division per new slack; the safeguard band is [m / ksig, m ksig]
+      double vl = zl + ad * (-zl + (mu - zl * d) * detail::rcp_(sl));
+      double vu = zu + ad * (-zu + (mu + zu * d) * detail::rcp_(su));
+      const double ml = mu * detail::rcp_(snl), mu_ = mu * detail::rcp_(snu);  // the safeguard band is [m / ksig, m ksig]
       vl = detail::dmax(detail::dmin(vl, ksig * ml), ml * iks);
       vu = detail::dmax(detail::dmin(vu, ksig * mu_), mu_ * iks);
       c.z[i] = zn; c.zL[i] = hl ? vl : 0.0; c.zU[i] = hu ? vu : 0.0;
