@@ -218,10 +218,16 @@ struct HsWave {
       typename S::VarBlk V;
       double slk = 1.0; int sexp = 0;       // as in trial(): one log per point
       if (!MLP && st.on) {
+        double dv[NW];                        // all loads of the point before its first store (see points_hess)
 #pragma unroll
         for (int q = 0; q < NW; ++q) {
           const long i = zi(c, j, q);
-          const double l = c.lb[i], u = c.ub[i], zv = c.z[i], d = c.dz[i], zl = c.zL[i], zu = c.zU[i];
+          V.z[q] = c.z[i]; V.l[q] = c.lb[i]; V.u[q] = c.ub[i]; V.zl[q] = c.zL[i]; V.zu[q] = c.zU[i]; dv[q] = c.dz[i];
+        }
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+          const long i = zi(c, j, q);
+          const double l = V.l[q], u = V.u[q], zv = V.z[q], d = dv[q], zl = V.zl[q], zu = V.zu[q];
           const bool fr = l < u;
           const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
           const double zn = fr ? zv + st.ap * d : zv;
@@ -331,6 +337,15 @@ struct HsWave {
           E[r * NS + q] = s;
         }
       lu_factor<NS>(E);
+      // (loads of the point records before the first store to the stage record: see points_hess)
+      const double* pm = c.pt + jm; const double* pe = c.pt + je;
+      const double wm = S::wsimp(K, jm, c.h), we = S::wsimp(K, je, c.h);
+      double rm[NS], owne[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        rm[q] = wm * pm[(PF_GW + q) * K] + pm[(PF_ZLU + q) * K];
+        owne[q] = (k == N - 1 && c.term_pinned[q]) ? 0.0 : (we * pe[(PF_GW + q) * K] + pe[(PF_ZLU + q) * K]);
+      }
       double* st = c.st + (long)k * SG_N;
       // Ge | ge
       double Ge[NS * NY1];
@@ -380,14 +395,6 @@ struct HsWave {
         for (int q = 0; q <= NY; ++q) st[SG_GM + r * NY1 + q] = row[q];
       }
       // adjoint maps: lam_d = Ld Pi + ld0, lam_i = Li Pi + li0, Pi_prev = M Pi + v
-      const double* pm = c.pt + jm; const double* pe = c.pt + je;
-      const double wm = S::wsimp(K, jm, c.h), we = S::wsimp(K, je, c.h);
-      double rm[NS], owne[NS];
-#pragma unroll
-      for (int q = 0; q < NS; ++q) {
-        rm[q] = wm * pm[(PF_GW + q) * K] + pm[(PF_ZLU + q) * K];
-        owne[q] = (k == N - 1 && c.term_pinned[q]) ? 0.0 : (we * pe[(PF_GW + q) * K] + pe[(PF_ZLU + q) * K]);
-      }
       double Ld[NS * NS], ld0[NS], Li[NS * NS], li0[NS];
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
@@ -490,7 +497,12 @@ struct HsWave {
   __device__ static void intervals_lambda(Ctx& c, double& lam_inf, double& sum_mult) {
     double li = 0, sm = 0;
     for (int k = c.lane; k < c.N; k += 64) {
-      const double* st = c.st + (long)k * SG_N;
+      double st[SG_QM];                        // the adjoint maps of this interval, loaded before the first store (see points_hess)
+      {
+        const double* sg = c.st + (long)k * SG_N;
+#pragma unroll
+        for (int q = SG_LD; q < SG_QM; ++q) st[q] = sg[q];
+      }
       double pi[NS];
 #pragma unroll
       for (int q = 0; q < NS; ++q) pi[q] = c.sPi[k * NS + q];
@@ -532,9 +544,11 @@ struct HsWave {
         }
       }
       const double wj = S::wsimp(K, j, c.h);
-      double gw[NW], D2[ND2], W[NW * NW];
+      // every load of this point BEFORE the first store: the stores below may alias what is loaded as far as the compiler
+      // can tell (they do alias the f | A fields of pt), so a load placed between them waits for a full memory round trip
+      double gw[NW], D2[ND2], W[NW * NW], sig[NW], g1v[NW];
 #pragma unroll
-      for (int q = 0; q < NW; ++q) gw[q] = pt[(PF_GW + q) * K];
+      for (int q = 0; q < NW; ++q) { gw[q] = pt[(PF_GW + q) * K]; sig[q] = pt[(PF_SIG + q) * K]; g1v[q] = pt[(PF_G1 + q) * K]; }
 #pragma unroll
       for (int q = 0; q < ND2; ++q) D2[q] = pt[(PF_D2 + q) * K];
 #pragma unroll
@@ -561,10 +575,10 @@ struct HsWave {
 #pragma unroll
         for (int q = 0; q < NW; ++q) {
           const bool zq = last && q < NS && c.term_pinned[q];
-          hr[HR_H + r * NW + q] = (zr || zq) ? 0.0 : (W[r * NW + q] + ((r == q) ? pt[(PF_SIG + r) * K] : 0.0));
+          hr[HR_H + r * NW + q] = (zr || zq) ? 0.0 : (W[r * NW + q] + ((r == q) ? sig[r] : 0.0));
         }
         hr[HR_G0 + r] = zr ? 0.0 : wj * gw[r];
-        hr[HR_G1 + r] = zr ? 0.0 : pt[(PF_G1 + r) * K];
+        hr[HR_G1 + r] = zr ? 0.0 : g1v[r];
       }
     }
     stat = wv_max(st_);
@@ -1178,12 +1192,17 @@ struct HsWave {
         for (int cc = 0; cc < NC; ++cc) v -= Kst[NQ * NW + t * NC + cc] * th[cc];
         y[NW + t] = v;
       }
+      double vmr[NS];                          // (all loads before the first store, see points_hess)
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         double vm = st[SG_GM + r * NY1 + NY];
 #pragma unroll
         for (int q = 0; q < NY; ++q) vm += st[SG_GM + r * NY1 + q] * y[q];
-        c.dz[zi(c, 2 * k + 1, r)] = vm;
+        vmr[r] = vm;
+      }
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        c.dz[zi(c, 2 * k + 1, r)] = vmr[r];
         c.dz[zi(c, 2 * k + 2, r)] = c.sS[(long)(k + 1) * NW + r];     // = Ge y + ge (0 on a pinned terminal state)
       }
 #pragma unroll
