@@ -116,13 +116,28 @@ __device__ inline int wv_isum(int v) {
   return v;
 }
 
-template <class Sys>
+// SCHEME 0: Hermite-Simpson (K = 2N+1 points, stage unknowns y = (dx_s, du_s, du_m, du_e), two eliminated controls);
+// SCHEME 1: trapezoidal collocation (/root/reference/myriad/trajectory_optimizers/collocation/trapezoidal.py:80-163; K = N+1
+// points, y = (dx_s, du_s, du_e), one eliminated control, no midpoint terms) -- the same phases, the same sweep, the
+// algorithm of TrapCore (os_solver.h), against whose host build it is tested.
+template <class Sys, int SCHEME = 0>
 struct HsWave {
   using S = HsSolver<Sys>;
   using D = HsSol<Sys>;
-  static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = NY + 1;
+  static constexpr bool TRAP = SCHEME == 1;
+  static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = TRAP ? NS + 2 * NU : D::NY, NQ = TRAP ? NU : D::NQ, NC = D::NC, NY1 = NY + 1;
+  static constexpr int QE = NQ - NU;               // position of du_e among the eliminated controls q
+  static constexpr int MLAM = TRAP ? 1 : 2;        // multiplier blocks (NS each) per interval
   static constexpr bool MLP = NodeTraits<Sys>::mlp;
+  static_assert(!(MLP && TRAP), "network dynamics are built for the Hermite-Simpson transcription");
   static constexpr int ND2 = MLP ? NodeMfma64::NPAIR : Sys::NNZ2;   // stored second-derivative data per point
+  __host__ __device__ static constexpr int npoints(int N) { return TRAP ? N + 1 : 2 * N + 1; }
+  // quadrature weight and time of point j (hermite_simpson.py:212-214 / trapezoidal.py:80-94)
+  __host__ __device__ static inline double wq(int K, int j, double h) {
+    if (TRAP) return (j == 0 || j == K - 1) ? 0.5 * h : h;
+    return S::wsimp(K, j, h);
+  }
+  __host__ __device__ static inline double tq(int j, double h) { return TRAP ? h * j : 0.5 * h * j; }
   // per-point record, SoA over points: field f of point j at pt[f*K + j]
   // f and A, which only the elimination phase reads, come LAST: the Hessian records (written after that phase, dead before
   // the next linearisation) are overlaid on them -- and the gains K | kc on the adjoint maps Ld..li0 of the stage record,
@@ -133,33 +148,34 @@ struct HsWave {
                        PF_N = PF_A + NS * NS;
   // per-point Hessian record, AoS: H (NW x NW), g0 (NW), g1 (NW)
   static constexpr int HR_H = 0, HR_G0 = NW * NW, HR_G1 = HR_G0 + NW, HR_N = HR_G1 + NW;
-  // per-stage record, AoS
-  static constexpr int SG_GE = 0, SG_GM = SG_GE + NS * NY1, SG_LD = SG_GM + NS * NY1, SG_LD0 = SG_LD + NS * NS,
-                       SG_LI = SG_LD0 + NS, SG_LI0 = SG_LI + NS * NS, SG_QM = SG_LI0 + NS, SG_QCM = SG_QM + NY * NY,
+  // per-stage record, AoS (the trapezoidal scheme has no midpoint map Gm and one multiplier block per interval)
+  static constexpr int SG_GE = 0, SG_GM = SG_GE + NS * NY1, SG_LD = SG_GM + (TRAP ? 0 : NS * NY1), SG_LD0 = SG_LD + NS * NS,
+                       SG_LI = SG_LD0 + NS, SG_LI0 = SG_LI + (TRAP ? 0 : NS * NS), SG_QM = SG_LI0 + (TRAP ? 0 : NS),
+                       SG_QCM = SG_QM + (TRAP ? 0 : NY * NY),
 #if defined(MYR_RICCATI_VALU) || defined(MYR_RICCATI_CHECK)
-                       SG_N = SG_QCM + NY * 2;
+                       SG_N = SG_QCM + (TRAP ? 0 : NY * 2);
 #else     // the matrix-core sweep forms Qm | qcm itself: the record ends before them (CARTPOLE: 167 -> 104 doubles per stage)
-                       SG_N = (NU == 1 && NS <= 4) ? SG_QM : SG_QCM + NY * 2;
+                       SG_N = (NU == 1 && NS <= 4) ? SG_QM : SG_QCM + (TRAP ? 0 : NY * 2);
 #endif
   static constexpr int KST = NQ * NW + NQ * NC;   // K | kc per stage (global scratch)
 #ifdef MYR_RICCATI_CHECK
   static constexpr bool OVERLAY_K = false;        // (the self-check addresses the gains as one flat array)
 #else
-  static constexpr bool OVERLAY_K = KST <= 2 * (NS * NS + NS);
+  static constexpr bool OVERLAY_K = KST <= SG_QM - SG_LD;
 #endif
   static constexpr int KSTR = OVERLAY_K ? SG_N : KST;   // stride of the gain records
   static constexpr int ZR = 2 * NY + 2;           // block of zeros (masked stage inputs of the Riccati lanes read it)
   static constexpr int PHI = NW * (NW + 1);       // closed-loop stage map Phi | phi per stage (LDS)
 
   __host__ __device__ static long scratch_doubles(int N) {
-    const long K = 2 * N + 1, n = K * NW;
+    const long K = npoints(N), n = K * NW;
     const long fa = (long)(NS + NS * NS) * K, hrn = (long)HR_N * K;        // hr overlays the f | A fields at the end of pt
     return 3 * n + (long)PF_N * K + (hrn > fa ? hrn - fa : 0) + (long)SG_N * N + (OVERLAY_K ? 0 : (long)KST * N) + ZR + 2 /* write-only slot */ +
-           2L * N * NS /* lambda when the caller passes none */;
+           (long)MLAM * N * NS /* lambda when the caller passes none */;
   }
   // LDS doubles: region R0 (adjoint M|v, later Phi|phi, later trial x|f), Pi, S, exchange
   __host__ __device__ static int r0_doubles(int N) {
-    const int a = N * (NS * NS + NS), b = N * PHI, c = 2 * (2 * N + 1) * NS;
+    const int a = N * (NS * NS + NS), b = N * PHI, c = 2 * npoints(N) * NS;
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
   }
   static constexpr int EXCH = NW * NW + NW * NC + NS * NY1 + NS * NC + NU * NC + 8;
@@ -249,7 +265,7 @@ struct HsWave {
         }
       }
       HsPoint<Sys> P;
-      set_time<Sys>(c.pp.get(), 0.5 * c.h * j);
+      set_time<Sys>(c.pp.get(), tq(j, c.h));
       double* pt = c.pt + j;
       const int K = c.K;
       if constexpr (MLP) {            // f, A, B come from the matrix-core pass; only the (closed-form) cost is per lane
@@ -260,6 +276,7 @@ struct HsWave {
         Sys::cost_grad(P.x, P.u, c.pp.get(), &P.g, P.gw);
       } else {
         S::lin_point(V, c.pp.get(), P);
+        if (TRAP && j == K - 1) fold_terminal<Sys>(P.x, P.u, c.pp.get(), wq(K, j, c.h), P.g, P.gw);   // trapezoidal.py:126-127
 #pragma unroll
         for (int q = 0; q < NS; ++q) pt[(PF_F + q) * K] = P.f[q];
 #pragma unroll
@@ -283,7 +300,7 @@ struct HsWave {
         { int e_; slk *= frexp((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0), &e_); sexp += e_; }
       }
       lg -= log(slk) + sexp * 0.6931471805599453;
-      f += S::wsimp(K, j, c.h) * P.g;
+      f += wq(K, j, c.h) * P.g;
     }
     o.f = wv_sum(f); o.cmax = wv_max(cmax); o.cmin = wv_min(cmin); o.sm = wv_sum(sm); o.nm = wv_isum(nm); o.lg = wv_sum(lg);
   }
@@ -300,7 +317,81 @@ struct HsWave {
   }
 
   // ---- phase 2: lanes over intervals -- constraints, eliminations, adjoint maps -------------------------------
+  // trapezoidal scheme (TrapCore::backward, os_solver.h): c_k = h/2 (f_k + f_{k+1}) - (x_{k+1} - x_k);
+  // E = I - h/2 A_e, E dx_e = (I + h/2 A_s) dx_s + h/2 B_s du_s + h/2 B_e du_e + c_k; adjoint E^T lam_k = own_e + Pi_k,
+  // Pi_{k-1} = (I + h/2 A_s)^T lam_k
+  __device__ static void intervals_elim_trap(Ctx& c, double& c1o, double& cinfo) {
+    using namespace detail;
+    const int N = c.N, K = c.K;
+    const double hh = 0.5 * c.h;
+    double c1 = 0, cinf = 0;
+    for (int k = c.lane; k < N; k += 64) {
+      double xs[NS], fs[NS], As[NS * NS], Bs[NS * NU], xe[NS], fe[NS], Ae[NS * NS], Be[NS * NU];
+      read_pt(c, k, xs, fs, As, Bs); read_pt(c, k + 1, xe, fe, Ae, Be);
+      const double* pe = c.pt + (k + 1);
+      const double we = wq(K, k + 1, c.h);
+      double owne[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        owne[q] = (k == N - 1 && c.term_pinned[q]) ? 0.0 : (we * pe[(PF_GW + q) * K] + pe[(PF_ZLU + q) * K]);
+      double E[NS * NS], Ge[NS * NY1];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        const double cj = hh * (fs[r] + fe[r]) - (xe[r] - xs[r]);
+        c1 += fabs(cj); cinf = dmax(cinf, fabs(cj));
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          E[r * NS + q] = ((r == q) ? 1.0 : 0.0) - hh * Ae[r * NS + q];
+          Ge[r * NY1 + q] = ((r == q) ? 1.0 : 0.0) + hh * As[r * NS + q];
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { Ge[r * NY1 + NS + a] = hh * Bs[r * NU + a]; Ge[r * NY1 + NW + a] = hh * Be[r * NU + a]; }
+        Ge[r * NY1 + NY] = cj;
+      }
+      lu_factor<NS>(E);
+      lu_solve<NS, NY1>(E, Ge);
+      double* st = c.st + (long)k * SG_N;
+#pragma unroll
+      for (int q = 0; q < NS * NY1; ++q) st[SG_GE + q] = Ge[q];
+      // lam_k = Ld Pi_k + ld0 with Ld = E^-T, ld0 = E^-T own_e
+      double Ld[NS * NS], ld0[NS];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        double y[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) y[q] = (q == i) ? 1.0 : 0.0;
+        lu_solve_t<NS>(E, y);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) Ld[q * NS + i] = y[q];
+      }
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) v += Ld[r * NS + q] * owne[q];
+        ld0[r] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < NS * NS; ++q) st[SG_LD + q] = Ld[q];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) st[SG_LD0 + q] = ld0[q];
+      double* M = c.r0 + (long)k * (NS * NS + NS);
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+#pragma unroll
+        for (int q = 0; q <= NS; ++q) {
+          double v = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) v += (((r == t) ? 1.0 : 0.0) + hh * As[t * NS + r]) * (q < NS ? Ld[t * NS + q] : ld0[t]);
+          if (q < NS) M[r * NS + q] = v; else M[NS * NS + r] = v;
+        }
+      }
+    }
+    c1o = wv_sum(c1); cinfo = wv_max(cinf);
+  }
+
   __device__ static void intervals_elim(Ctx& c, double& c1o, double& cinfo) {
+    if constexpr (TRAP) { intervals_elim_trap(c, c1o, cinfo); return; }
     using namespace detail;
     const int N = c.N, K = c.K;
     const double h6 = c.h6, h8 = c.h8;
@@ -339,7 +430,7 @@ struct HsWave {
       lu_factor<NS>(E);
       // (loads of the point records before the first store to the stage record: see points_hess)
       const double* pm = c.pt + jm; const double* pe = c.pt + je;
-      const double wm = S::wsimp(K, jm, c.h), we = S::wsimp(K, je, c.h);
+      const double wm = wq(K, jm, c.h), we = wq(K, je, c.h);
       double rm[NS], owne[NS];
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
@@ -508,11 +599,11 @@ struct HsWave {
       for (int q = 0; q < NS; ++q) pi[q] = c.sPi[k * NS + q];
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
-        double d = st[SG_LD0 + r], i2 = st[SG_LI0 + r];
+        double d = st[SG_LD0 + r], i2 = TRAP ? 0.0 : st[SG_LI0 + r];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) { d += st[SG_LD + r * NS + q] * pi[q]; i2 += st[SG_LI + r * NS + q] * pi[q]; }
+        for (int q = 0; q < NS; ++q) { d += st[SG_LD + r * NS + q] * pi[q]; if (!TRAP) i2 += st[SG_LI + r * NS + q] * pi[q]; }
         c.lam[(long)k * NS + r] = d;
-        c.lam[(long)c.N * NS + (long)k * NS + r] = i2;
+        if (!TRAP) c.lam[(long)c.N * NS + (long)k * NS + r] = i2;
         li = detail::dmax(li, detail::dmax(fabs(d), fabs(i2)));
         sm += fabs(d) + fabs(i2);
       }
@@ -529,7 +620,15 @@ struct HsWave {
     for (int j = c.lane; j < K; j += 64) {
       const double* pt = c.pt + j;
       double a[NS];
-      if (j & 1) {
+      if (TRAP) {           // a_j = h/2 (lam_{j-1} + lam_j): TrapCore's mue = mu_c + h/2 lam
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = 0.0;
+          if (j >= 1) s += 0.5 * c.h * c.lam[(long)(j - 1) * NS + q];
+          if (j < N) s += 0.5 * c.h * c.lam[(long)j * NS + q];
+          a[q] = s;
+        }
+      } else if (j & 1) {
         const int k = (j - 1) >> 1;
 #pragma unroll
         for (int q = 0; q < NS; ++q) a[q] = -4.0 * h6 * c.lam[(long)k * NS + q];
@@ -543,7 +642,7 @@ struct HsWave {
           a[q] = s;
         }
       }
-      const double wj = S::wsimp(K, j, c.h);
+      const double wj = wq(K, j, c.h);
       // every load of this point BEFORE the first store: the stores below may alias what is loaded as far as the compiler
       // can tell (they do alias the f | A fields of pt), so a load placed between them waits for a full memory round trip
       double gw[NW], D2[ND2], W[NW * NW], sig[NW], g1v[NW];
@@ -586,6 +685,7 @@ struct HsWave {
 
   // ---- phase 5: lanes over intervals -- midpoint Schur terms Qm = Gm^^T (H_m + delta I) Gm^, qcm ----------------
   __device__ static void intervals_qm(Ctx& c, double delta) {
+    if constexpr (TRAP) { (void)c; (void)delta; return; } else {
     for (int k = c.lane; k < c.N; k += 64) {
       double* st = c.st + (long)k * SG_N;
       const double* hr = c.hr + (long)(2 * k + 1) * HR_N;
@@ -628,6 +728,7 @@ struct HsWave {
         for (int a = 0; a < NU; ++a) if (r == NS + NU + a) { s0 += T1[(NS + a) * NY1 + NY] + hr[HR_G0 + NS + a]; s1 += hr[HR_G1 + NS + a]; }
         st[SG_QCM + r * 2 + 0] = s0; st[SG_QCM + r * 2 + 1] = s1;
       }
+    }
     }
   }
 
@@ -696,7 +797,7 @@ struct HsWave {
     const bool isVal = isP || isC;
     // per-lane addressing of the stage inputs: base pointer + stride per stage; lanes without an input (the nu
     // columns have no qcm, lanes past the columns have nothing) read a block of zeros, so every load is unconditional
-    const bool m_on = isY || (isC && cc < 2);   // Qm column (unit stride; Qm is symmetric) | qcm column (stride 2)
+    const bool m_on = !TRAP && (isY || (isC && cc < 2));   // Qm column (unit stride; Qm is symmetric) | qcm column (stride 2); none for the trapezoidal scheme
     const double* m_ptr = m_on ? c.st + (isY ? SG_QM + lane * NY : SG_QCM + (cc == 1 ? 1 : 0)) : c.zr;
     const int m_str = isY ? 1 : 2;
     const long m_step = m_on ? SG_N : 0;
@@ -761,7 +862,7 @@ struct HsWave {
 #pragma unroll
       for (int t = 0; t < NS; ++t) v[t] = v_on * c.sGe[t * NY1 + v_col];
 #pragma unroll
-      for (int a = 0; a < NU; ++a) v[NS + a] = (lane == NS + 2 * NU + a) ? 1.0 : 0.0;
+      for (int a = 0; a < NU; ++a) v[NS + a] = (lane == NY - NU + a) ? 1.0 : 0.0;     // selector of du_e, the last NU entries of y
 #pragma unroll
       for (int r = 0; r < NW; ++r) {
         double s = c_on * val[r];
@@ -776,7 +877,7 @@ struct HsWave {
         double s = m[r];
 #pragma unroll
         for (int t = 0; t < NS; ++t) s += c.sGe[t * NY1 + r] * tv[t];
-        if (r >= NS + 2 * NU) s += tv[NS + (r - NS - 2 * NU)];
+        if (r >= NY - NU) s += tv[NS + (r - (NY - NU))];
         col[r] = s;
       }
       // terminal-multiplier bookkeeping, part 1 (lanes NY+2+i): Tnu[i][0] += ge^T pc'[:, nu_i]
@@ -898,6 +999,7 @@ struct HsWave {
     return __hiloint2double(rhi, rlo);
   }
   __device__ static MYR_RICCATI_INLINE int riccati_mfma(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
+    static_assert(!TRAP, "Hermite-Simpson form");
     using namespace detail;
     const int lane = c.lane, N = c.N;
     const int g = lane >> 4, j = lane & 15;
@@ -1092,6 +1194,102 @@ struct HsWave {
     return riccati_first_point(c, o, delta, nreg);
   }
 
+  // The same sweep for the trapezoidal scheme: y = (dx_s, du_s, du_e), ONE eliminated control per stage, no midpoint part --
+  // three MFMA per stage (R~, [Q|qc], the rank-1 update), the single pivot Q[du_e][du_e] read from lane 8 of register 2.
+  // Slots as above (12, 13 unused); the end point of stage k is point k+1.
+  __device__ static MYR_RICCATI_INLINE int riccati_mfma_trap(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
+    using namespace detail;
+    static_assert(NQ == 1, "one control");
+    const int lane = c.lane, N = c.N;
+    const int g = lane >> 4, j = lane & 15;
+    const int scol = j < 4 ? (j < NS ? j : -1) : (j < 6 ? NS : -1);
+    const int ycol = scol >= 0 ? scol : ((j == 8 || j == 9) ? NW : -1);
+    const int cc = j == 6 ? 0 : (j == 7 ? 1 : (j == 10 ? 2 : (j == 11 ? 3 : (j == 14 ? 4 : (j == 15 ? 5 : -1)))));
+    const int rcc = (cc >= 0 && cc < NC) ? cc : -1;
+    const bool rowx = g < NS;
+    const double* he = c.hr + (long)N * HR_N;
+    const double* st = c.st + (long)(N - 1) * SG_N;
+    auto hsel = [&](int row, bool on) -> const double* {
+      if (!on) return c.zr;
+      if (scol >= 0) return he + HR_H + scol * NW + row;
+      if (rcc == 0) return he + HR_G0 + row;
+      if (rcc == 1) return he + HR_G1 + row;
+      return c.zr;
+    };
+    const double* ptr[3] = {hsel(g, rowx), hsel(NS, g < 2),
+                            !rowx ? c.zr : (ycol >= 0 ? st + SG_GE + g * NY1 + ycol : (rcc == 0 ? st + SG_GE + g * NY1 + NY : c.zr))};
+    long stp[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) stp[q] = (ptr[q] == c.zr) ? 0 : (q == 2 ? (long)SG_N : (long)HR_N);
+    const bool pinr = rowx && c.term_pinned[rowx ? g : 0];
+    const double X0i = (pinr && scol == g) ? o.rho_term - delta : ((pinr && rcc == 2 + g) ? 1.0 : 0.0);
+    const double dv0 = (rowx && scol == g) ? delta : 0.0, dv1 = (g < 2 && scol == NS) ? delta : 0.0;
+    const double f_a1 = j < 6 ? 1.0 : 0.0, f_keep = rcc >= 0 ? 1.0 : 0.0, f_she = (j == 8 || j == 9) ? 1.0 : 0.0;
+    const double f_x1 = g < 2 ? 1.0 : 0.0, f_t1 = g == 2 ? 1.0 : 0.0, f_t23 = g >= 2 ? 1.0 : 0.0;
+    const double f_a3 = (g == 0 && (j < 6 || j == 10 || j == 11 || j == 14 || j == 15)) ? -1.0 : 0.0;
+    const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
+    double* k_ptr = k_off >= 0 ? c.kg + (long)(N - 1) * KSTR + k_off : c.zr + ZR;
+    const long k_step = k_off >= 0 ? KSTR : 0;
+    double reg_floor = o.reg_floor;
+    asm volatile("" : "+v"(reg_floor));
+    int nreg = 0;
+    constexpr int PF = MYR_RICCATI_PF;
+    double in[PF][3];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
+    }
+    mfma_d4 D3 = {X0i, 0.0, 0.0, 0.0};
+    for (int kb = N - 1; kb >= 0; kb -= PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int k = kb - u;
+        if (k < 0) break;
+        const double X0 = D3[0] + (in[u][0] + dv0), X1 = fma(D3[1], f_x1, in[u][1] + dv1);
+        const double G = in[u][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
+        const double sh0 = dpp_row_shr4(X0), sh1 = dpp_row_shr4(X1);
+        mfma_d4 C1;
+        C1[0] = fma(sh0, f_she, X0 * f_keep);
+        C1[1] = fma(sh1, f_she, X1 * f_keep);
+        C1[2] = 0.0; C1[3] = 0.0;
+        const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X0 * f_a1, G, C1, 0, 0, 0);
+        mfma_d4 C2;
+        C2[0] = 0.0; C2[1] = D3[1] * f_t1; C2[2] = fma(D3[2], f_t23, D1[1]); C2[3] = D3[3] * f_t23;
+        const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
+        const double q11 = rdlane(D2[2], 8);
+        double d = q11;
+        if (!(d > reg_floor)) {                                        // wave-uniform, rare (same pivot rule as chol_reg)
+          d = dmax(fabs(d), reg_floor); ++nreg;
+          if (abort_on_reg) return nreg;
+        }
+        const double kk = D2[2] * fast_rcp(d);
+        k_ptr[0] = kk;
+        k_ptr -= k_step;
+        const double A3 = D2[2] * f_a3;
+        const double B3 = g == 0 ? kk : 0.0;
+        D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, B3, D2, 0, 0, 0);
+      }
+    }
+    const double X0 = D3[0], X1 = D3[1], T1 = D3[1], T2 = D3[2], T3 = D3[3];
+    if (scol >= 0 && j != 5) {
+      if (rowx) c.sP[g * NW + scol] = X0;
+      if (g == 0) c.sP[NS * NW + scol] = X1;
+    }
+    if (rcc >= 0) {
+      if (rowx) c.sPc[g * NC + rcc] = X0;
+      if (g == 0) c.sPc[NS * NC + rcc] = X1;
+      if (g >= 2 && g - 2 < NS) c.sTnu[(g - 2) * NC + rcc] = T2;
+      if (g >= 2 && g < NS) c.sTnu[g * NC + rcc] = T3;
+    }
+    __syncthreads();
+    if (g == 2 && rcc >= 2) c.sTnu[(rcc - 2) * NC + 0] += T1;
+    __syncthreads();
+    return riccati_first_point(c, o, delta, nreg);
+  }
+
   // ---- phase 8a: lanes over intervals -- closed-loop stage maps  s_{k+1} = Phi_k s_k + phi_k, s = (dx, du) of a knot
   // (the gains applied to the elimination rows, for the multipliers theta = (1, mu, nu)); rows -> LDS region R0
   __device__ static void intervals_phi(Ctx& c, const double* th) {
@@ -1131,8 +1329,8 @@ struct HsWave {
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
 #pragma unroll
-        for (int q = 0; q < NW; ++q) P[(NS + a) * (NW + 1) + q] = -Kk[(NU + a) * NW + q];
-        P[(NS + a) * (NW + 1) + NW] = -kq[NU + a];
+        for (int q = 0; q < NW; ++q) P[(NS + a) * (NW + 1) + q] = -Kk[(QE + a) * NW + q];
+        P[(NS + a) * (NW + 1) + NW] = -kq[QE + a];
       }
     }
   }
@@ -1176,6 +1374,14 @@ struct HsWave {
   // ---- phase 9: lanes over intervals -- step for midpoint / end point variables ---------------------------------
   __device__ static void intervals_dz(Ctx& c, const double* th) {
     const int N = c.N;
+    if constexpr (TRAP) {       // every point is a knot: dz of point j is the recursion's s_j = (dx_j, du_j)
+      (void)th;
+      for (int e = c.lane; e < (N + 1) * NW; e += 64) {
+        const int j = e / NW, q = e - j * NW;
+        c.dz[zi(c, j, q)] = (j == 0 && q < NS) ? 0.0 : c.sS[e];
+      }
+      return;
+    }
     if (c.lane < NW) c.dz[zi(c, 0, c.lane)] = c.lane < NS ? 0.0 : c.sS[c.lane];
     for (int k = c.lane; k < N; k += 64) {
       const double* st = c.st + (long)k * SG_N;
@@ -1218,7 +1424,7 @@ struct HsWave {
     const double tau = detail::dmax(o.tau_min, 1.0 - mu);
     typename S::FwdOut l; l.alpha_p = 1.0; l.alpha_d = 1.0; l.gphi = 0.0;
     for (int j = c.lane; j < c.K; j += 64) {
-      const double wj = S::wsimp(c.K, j, c.h);
+      const double wj = wq(c.K, j, c.h);
 #pragma unroll
       for (int q = 0; q < NW; ++q) {
         const long i = zi(c, j, q);
@@ -1253,14 +1459,22 @@ struct HsWave {
       }
       ba -= log(slk) + sexp * 0.6931471805599453;
       if constexpr (!MLP) Sys::f(x, u, c.pp.get(), ff);
-      set_time<Sys>(c.pp.get(), 0.5 * c.h * j);
-      fa += S::wsimp(K, j, c.h) * Sys::g(x, u, c.pp.get());
+      set_time<Sys>(c.pp.get(), tq(j, c.h));
+      double gj = Sys::g(x, u, c.pp.get());
+      if (TRAP && j == K - 1) fold_terminal<Sys>(x, u, c.pp.get(), wq(K, j, c.h), gj, nullptr);
+      fa += wq(K, j, c.h) * gj;
 #pragma unroll
       for (int q = 0; q < NS; ++q) { sX[j * NS + q] = x[q]; if constexpr (!MLP) sF[j * NS + q] = ff[q]; }
     }
     __syncthreads();
     double ca = 0;
     for (int k = c.lane; k < N; k += 64) {
+      if constexpr (TRAP) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+          ca += fabs(0.5 * c.h * (sF[k * NS + q] + sF[(k + 1) * NS + q]) - (sX[(k + 1) * NS + q] - sX[k * NS + q]));
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         const double xs = sX[(2 * k) * NS + q], xm = sX[(2 * k + 1) * NS + q], xe = sX[(2 * k + 2) * NS + q];
@@ -1361,7 +1575,7 @@ struct HsWave {
 #if defined(MYR_RICCATI_VALU) || defined(MYR_RICCATI_CHECK)
         intervals_qm(c, delta);
 #else
-        if constexpr (!MFMA_RICCATI) intervals_qm(c, delta);   // the matrix-core sweep forms the midpoint terms itself
+        if constexpr (!MFMA_RICCATI && !TRAP) intervals_qm(c, delta);   // the matrix-core sweep forms the midpoint terms itself
 #endif
         __syncthreads();
         MYR_PH(5)
@@ -1399,7 +1613,8 @@ struct HsWave {
         } else nreg = riccati(c, o, delta, abort_on_reg);
 #else
 #ifndef MYR_RICCATI_VALU
-        if constexpr (MFMA_RICCATI) nreg = riccati_mfma(c, o, delta, abort_on_reg);
+        if constexpr (MFMA_RICCATI && TRAP) nreg = riccati_mfma_trap(c, o, delta, abort_on_reg);
+        else if constexpr (MFMA_RICCATI) nreg = riccati_mfma(c, o, delta, abort_on_reg);
         else
 #endif
           nreg = riccati(c, o, delta, abort_on_reg);
@@ -1412,7 +1627,7 @@ struct HsWave {
         else delta *= (delta_last > 0.0) ? 8.0 : 100.0;
       }
       delta_last = (delta > lm) ? delta : 0.0;
-      const int nm = 2 * c.N * NS + p1.nm;
+      const int nm = MLAM * c.N * NS + p1.nm;
       const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
       const double stat = stat_raw / sd, comp = p1.cmax / sd;
       res.cost = p1.f; res.feas = cinf; res.stat = stat; res.compl_ = comp;
@@ -1511,16 +1726,16 @@ struct HsWave {
 // Persistent: grid = the wavefronts the device keeps resident (one 64-thread workgroup each, dynamic LDS =
 // HsWave<Sys>::lds_bytes(N)); every workgroup pulls trajectories from `ticket` until the batch is done and owns ONE
 // scratch block (slot blockIdx.x) that it re-uses for all of them.
-template <class Sys>
+template <class Sys, int SCHEME = 0>
 __global__ __launch_bounds__(64, MYR_WAVE_MIN_WAVES)
 void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                           const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                           const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
                           int32_t* iters, double* kkt) {
-  using W = HsWave<Sys>;
+  using W = HsWave<Sys, SCHEME>;
   extern __shared__ __attribute__((aligned(16))) char smem_wave[];
   typename W::Ctx c;
-  c.N = o.N; c.K = 2 * o.N + 1; c.n = c.K * W::NW; c.lane = threadIdx.x;
+  c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x;
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
   double* s = scratch + (long)blockIdx.x * scratch_stride;
   c.zL = s; s += c.n; c.zU = s; s += c.n; c.dz = s; s += c.n;
@@ -1549,7 +1764,7 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
     const long b = __builtin_amdgcn_readfirstlane(t);
     if (b >= B) break;
     c.z = z + b * (long)c.n; c.lb = lb + b * (long)c.n; c.ub = ub + b * (long)c.n;
-    c.lam = lam ? lam + b * (long)(2 * c.N * W::NS) : lam_own;
+    c.lam = lam ? lam + b * (long)(W::MLAM * c.N * W::NS) : lam_own;
     c.pp.load(params, b, params_stride);
     c.pp.set_scale(vs.s);
     if constexpr (W::MLP) {      // network weights -> LDS: once per workgroup when the batch shares them, else per trajectory

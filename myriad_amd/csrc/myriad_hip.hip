@@ -391,7 +391,7 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
                              int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                              int32_t* iters, double* kkt);
 
-template <class Sys>
+template <class Sys, int SCHEME = 0>
 static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                            int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                            int32_t* iters, double* kkt) {
@@ -399,10 +399,10 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   const myr_dims& dm = h->dims;
   // one trajectory per wavefront while its LDS working set fits a CU (N <= ~480 for CARTPOLE); beyond that the
   // lane-per-trajectory form, which keeps everything in global scratch, takes over
-  if (h->solve_mode == 1 && HsWave<Sys>::lds_bytes(N) <= 160 * 1024) {
-    using W = HsWave<Sys>;
+  if (h->solve_mode == 1 && HsWave<Sys, SCHEME>::lds_bytes(N) <= 160 * 1024) {
+    using W = HsWave<Sys, SCHEME>;
     const size_t lds = W::lds_bytes(N);
-    auto kern = hs_solve_wave_kernel<Sys>;
+    auto kern = hs_solve_wave_kernel<Sys, SCHEME>;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // Persistent form: as many workgroups as the device keeps resident (registers and LDS allow 4 wavefronts per CU), each
     // pulling trajectories from a ticket counter.  Scratch belongs to the SLOT, not to the trajectory: the working set of
@@ -442,7 +442,10 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     kt.launches += 1;
     return MYR_OK;
   }
-  return launch_lane_solve<HsSolver<Sys>, Sys>(h, B, HsSol<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  if constexpr (SCHEME == 1)
+    return launch_lane_solve<TrapCore<Sys>, Sys>(h, B, TrapCore<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  else
+    return launch_lane_solve<HsSolver<Sys>, Sys>(h, B, HsSol<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
 }
 
 // lane-per-trajectory path, any sweep core (Hermite-Simpson, trapezoidal, shooting)
@@ -512,8 +515,8 @@ int solve_for_system(myr_handle h, int B, double* z, const double* lb, const dou
   switch (h->d.transcription) {
     case MYR_TR_HERMITE_SIMPSON:
       return launch_hs_solve<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-    case MYR_TR_TRAPEZOIDAL:
-      return launch_lane_solve<TrapCore<Sys>, Sys>(h, B, TrapCore<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_TR_TRAPEZOIDAL:     // wavefront form (falls back to the lane form for MYRIAD_SOLVE_MODE=lane / very large N)
+      return launch_hs_solve<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     case MYR_TR_SHOOTING:
       if (h->d.integration_method == MYR_INT_RK4)
         return launch_lane_solve<ShootCore<Sys, 2>, Sys>(h, B, ShootCore<Sys, 2>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
