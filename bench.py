@@ -298,10 +298,10 @@ def run(a, rank, world, dev, make_engine):
                  "achieved": alg / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": alg / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from_profile": traffic_src,
                  "alg_bytes_per_launch": alg, "avg_ms": ev_ms, "launches": ev_n},
-    "solver_kernel": {"kernel": ("hs_solve_wave_kernel<CARTPOLE> (one trajectory per wavefront, whole SQP in one launch)"
+    "solver_kernel": {"kernel": ("hs_solve_wave_kernel<CARTPOLE> (persistent, one trajectory per wavefront, Riccati sweep on fp64 MFMA, whole SQP in one launch)"
                                  if os.environ.get("MYRIAD_SOLVE_MODE", "wave") != "lane" else
                                  "hs_solve_kernel<CARTPOLE> (one trajectory per lane, whole SQP in one launch)"),
-                      "avg_ms": sv_ms, "launches": sv_n, "bound": "latency/occupancy (see DESIGN.md)",
+                      "avg_ms": sv_ms, "launches": sv_n, "bound": "memory latency + HBM-side record traffic at 1 wave/SIMD (see DESIGN.md section 4)",
                       "alg_io_bytes_per_launch": B * 8 * (3 * (2 * N + 1) * 5 + (2 * N + 1) * 5 + 2 * N * 4),
                       "hbm_bytes_per_launch_from_profile": sol_bytes, "hbm_profile": sol_src,
                       "hbm_GBps": (sol_bytes / (sv_ms * 1e-3) / 1e9) if (sol_bytes and sv_ms) else None,
