@@ -12,6 +12,7 @@
 #include "colloc_products.h"
 #include "hs_solver.h"
 #include "hs_solver_wave.h"
+#include "shoot_solver_wave.h"
 #include "os_solver.h"
 #include "shoot_eval.h"
 #include "rollout.h"
@@ -502,6 +503,43 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
   return MYR_OK;
 }
 
+// shooting, one trajectory per wavefront (shoot_solver_wave.h) while the iterate fits 64 KB of LDS; else the lane form
+template <class Sys, int M>
+static int launch_shoot_solve(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
+                              int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
+                              int32_t* iters, double* kkt) {
+  const int N = h->d.intervals, cpi = h->d.controls_per_interval;
+  using W = ShootWave<Sys, M>;
+  const size_t lds = W::lds_bytes(N, cpi);
+  if (h->solve_mode != 1 || lds > 64 * 1024)
+    return launch_lane_solve<ShootCore<Sys, M>, Sys>(h, B, ShootCore<Sys, M>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  auto kern = shoot_solve_wave_kernel<Sys, M>;
+  int slots = h->solve_slots;
+  if (slots <= 0) {
+    int per_cu = 0, dev = 0, cus = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64, lds));
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    slots = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256);
+  }
+  if (slots > B) slots = B;
+  if (!h->ticket) HIPCHK(hipMalloc(&h->ticket, sizeof(int)));
+  HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int), h->stream));
+  HsSolveOpts o = make_opts(h, so);
+  KTimer& kt = h->kt[MYR_K_SOLVE];
+  HIPCHK(hipEventRecord(kt.a, h->stream));
+  hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, params, pstride,
+                     cost, status, iters, kkt);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(kt.b, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+  kt.sum_ms += ms;
+  kt.launches += 1;
+  return MYR_OK;
+}
+
 template <class Sys>
 int solve_for_system(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                             int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
@@ -519,8 +557,8 @@ int solve_for_system(myr_handle h, int B, double* z, const double* lb, const dou
       return launch_hs_solve<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     case MYR_TR_SHOOTING:
       if (h->d.integration_method == MYR_INT_RK4)
-        return launch_lane_solve<ShootCore<Sys, 2>, Sys>(h, B, ShootCore<Sys, 2>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-      return launch_lane_solve<ShootCore<Sys>, Sys>(h, B, ShootCore<Sys>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+        return launch_shoot_solve<Sys, 2>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+      return launch_shoot_solve<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   return fail(MYR_E_ARG, "solve: unknown transcription");
 }

@@ -1,0 +1,678 @@
+// shoot_solver_wave.h -- the shooting solver (ShootCore, os_solver.h) mapped ONE TRAJECTORY PER WAVEFRONT.
+//
+// The lane-per-trajectory kernel runs a whole shooting solve in one lane: at the batch sizes of the reference's
+// workloads (config 3: 8192 trajectories per GPU) that is 8192 busy lanes on a machine that retires 16 k fp64 lanes per
+// cycle, and the launch lasts as long as its slowest trajectory (119 iterations x 0.7 ms).  Here a 64-lane workgroup owns
+// one trajectory, the whole iterate lives in LDS (variables, bounds, bound multipliers, rollout states, stage
+// records, gains -- 21 KB for VANDERPOL 1 x 50), and the workgroups are persistent (ticket counter, as hs_solver_wave.h):
+//   * lanes over VARIABLES: starting point, bound terms, step limits, trial point + barrier, update;
+//   * lanes over STEPS: the step linearisations (first order, then -- with the costates known -- the step Hessians);
+//   * lanes over INTERVALS: rollouts (states, continuity defects, objective) of the sweep and of every trial point;
+//   * one lane, out of LDS: the costate recursion, the Riccati recursion (os_riccati_stage, the code of the lane kernel)
+//     and the forward recursion.  An inertia-correction retry (W + delta I) repeats only the Riccati recursion: the
+//     rollout, both linearisation passes and the costates do not depend on delta.
+// The algorithm, its constants and its control flow are ShootCore's: the outer loop IS IpLoop<> (hs_solver.h), executed
+// redundantly by all 64 lanes on wave-uniform scalars, with this struct as its `Core`.  Only the association of the sums
+// (objective, defect norms, barrier, directional derivative: wave reductions instead of one running sum) differs from
+// the lane kernel, against which -- and against the same oracle / golden solutions -- it is tested.
+//
+// Replaces, per trajectory, IPOPT on /root/reference/myriad/trajectory_optimizers/shooting.py:169-241 (objective :169-210,
+// constraints :230-241) as called from nlp_solvers/__init__.py:32-96.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "os_solver.h"
+#include "hs_solver_wave.h"
+
+namespace myriad {
+
+template <class Sys, int M = 1>
+struct ShootWave {
+  using SC = ShootCore<Sys, M>;
+  using H = HsSolver<Sys>;
+  using D = OsDims<Sys, M>;
+  static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = D::NY1, QN = D::QN;
+  static constexpr bool PEN_LAM_FLOOR = SC::PEN_LAM_FLOOR;
+  using SweepOut = typename H::SweepOut;
+  using FwdOut = typename H::FwdOut;
+
+  // stage record: Fy | c_k (NS x NY1, the step map dx_next = Fy y + c), gy (NY), Hs (NY x NY)
+  static constexpr int R_GE = 0, R_GY = R_GE + NS * NY1, R_HS = R_GY + NY, REC = R_HS + NY * NY;
+  static constexpr int KG = NQ * NW + NQ * NC;        // gains K | kc of a stage
+  // exchange block (first in LDS): results of the one-lane phases and of the last linearisation, for all lanes
+  static constexpr int X_VALID = 0, X_F = 1, X_C1 = 2, X_CINF = 3, X_STAT = 4, X_CMAX = 5, X_CMIN = 6, X_LAMINF = 7, X_SUMMULT = 8,
+                       X_NMULT = 9, X_NREG = 10, X_GPHI = 11, X_TNU = 12, X_TP = X_TNU + NS * NC, X_T = X_TP + NS /* 8 phase timers (developer knob MYR_SW_TIMING) */,
+                       X_Z = X_T + 8 /* a zero and a write-only slot */, X_P = X_Z + 2, X_PC = X_P + NW * NW, X_N = (X_PC + NW * NC + 7) / 8 * 8;
+
+  __host__ __device__ static inline int steps(const HsSolveOpts& o) { return o.N * o.cpi; }
+  __host__ __device__ static inline int nvars(const HsSolveOpts& o) { return (o.N + 1) * NS + (M * steps(o) + 1) * NU; }
+  __host__ __device__ static inline long xi(int k, int c) { return SC::xi(k, c); }
+  __host__ __device__ static inline long ui(const HsSolveOpts& o, int i, int a) { return SC::ui(o, i, a); }
+  __host__ __device__ static long lds_doubles(int I, int cpi) {
+    const long S = (long)I * cpi, n = (long)(I + 1) * NS + (M * S + 1) * NU;
+    return X_N + 10 * n + 2 * (S + 1) * NS + S * (REC + KG) + NU * NC + (long)I * NS;
+  }
+  __host__ __device__ static size_t lds_bytes(int I, int cpi) { return (size_t)lds_doubles(I, cpi) * 8; }
+
+  struct Lds {
+    double *ex, *z, *lb, *ub, *zL, *zU, *dz, *zt, *sig, *g1, *zlu, *xs, *pi, *rec, *kg, *ku, *lam;
+  };
+  __device__ static inline Lds lds(const HsSolveOpts& o) {
+    extern __shared__ __attribute__((aligned(16))) char smem_wave[];
+    const long S = steps(o), n = nvars(o);
+    Lds l;
+    double* s = reinterpret_cast<double*>(smem_wave);
+    l.ex = s; s += X_N;
+    l.z = s; s += n; l.lb = s; s += n; l.ub = s; s += n; l.zL = s; s += n; l.zU = s; s += n; l.dz = s; s += n; l.zt = s; s += n;
+    l.sig = s; s += n; l.g1 = s; s += n; l.zlu = s; s += n;
+    l.xs = s; s += (S + 1) * NS; l.pi = s; s += (S + 1) * NS;
+    l.rec = s; s += S * REC; l.kg = s; s += S * KG; l.ku = s; s += NU * NC; l.lam = s;
+    return l;
+  }
+#ifdef MYR_SW_TIMING
+#define MYR_SWT(k) { const long long t1_ = wall_clock64(); if (threadIdx.x == 0) exch()[X_T + k] += (double)(t1_ - t0_); t0_ = t1_; }
+#define MYR_SWT0 long long t0_ = wall_clock64();
+#else
+#define MYR_SWT(k)
+#define MYR_SWT0
+#endif
+  __device__ static inline double* exch() {
+    extern __shared__ __attribute__((aligned(16))) char smem_wave[];
+    return reinterpret_cast<double*>(smem_wave);
+  }
+
+  // ---- lanes over variables: starting point and accepted step (HsSolver::init / update, one variable per lane) ----
+  __device__ static void init(const HsWork& w, int n) {
+    const double k1 = 1e-2, k2 = 1e-2;
+    for (int i = threadIdx.x; i < n; i += 64) {
+      const double l = w.lb[i], u = w.ub[i], v0 = w.z[i];
+      const bool fr = l < u;
+      const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+      const double width = (hl && hu) ? (u - l) : INFINITY;
+      const double pl = detail::dmin(k1 * detail::dmax(1.0, fabs(l)), k2 * width);
+      const double pu = detail::dmin(k1 * detail::dmax(1.0, fabs(u)), k2 * width);
+      double v = v0;
+      v = hl ? detail::dmax(v, l + pl) : v;
+      v = hu ? detail::dmin(v, u - pu) : v;
+      v = fr ? v : l;
+      w.z[i] = v;
+      w.zL[i] = hl ? 1.0 : 0.0;
+      w.zU[i] = hu ? 1.0 : 0.0;
+    }
+    if (threadIdx.x == 0) exch()[X_VALID] = 0.0;
+    __syncthreads();
+  }
+  __device__ static void update(const HsWork& w, int n, double ap, double ad, double mu, double ksig) {
+    const double iks = 1.0 / ksig;
+    for (int i = threadIdx.x; i < n; i += 64) {
+      const double l = w.lb[i], u = w.ub[i], zv = w.z[i], d = w.dz[i], zl = w.zL[i], zu = w.zU[i];
+      const bool fr = l < u;
+      const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+      const double zn = fr ? zv + ap * d : zv;
+      const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
+      const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
+      double vl = zl + ad * (-zl + (mu - zl * d) / sl);
+      double vu = zu + ad * (-zu + (mu + zu * d) / su);
+      const double ml = mu / snl, mu_ = mu / snu;
+      vl = detail::dmax(detail::dmin(vl, ksig * ml), ml * iks);
+      vu = detail::dmax(detail::dmin(vu, ksig * mu_), mu_ * iks);
+      w.z[i] = zn;
+      w.zL[i] = hl ? vl : 0.0;
+      w.zU[i] = hu ? vu : 0.0;
+    }
+    if (threadIdx.x == 0) exch()[X_VALID] = 0.0;
+    __syncthreads();
+  }
+  __device__ static void solve_nu(const SweepOut& so, double mu, double* nu) { H::solve_nu(so, mu, nu); }
+
+  // one interval's rollout from x (values of the variables in `v`): states -> xs (if given), end state -> x
+  __device__ static inline void roll_interval(const HsSolveOpts& o, const double* p, const double* v, int k, double* x, double* xs, double& f) {
+    const int cpi = o.cpi, S = steps(o);
+    const double h = SC::hstep(o);
+    for (int i = k * cpi; i < (k + 1) * cpi; ++i) {
+      double uc[(M + 1) * NU], xn[NS], dc;
+#pragma unroll
+      for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = v[ui(o, M * i, a)];
+      if (xs) {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) xs[(long)i * NS + c] = x[c];
+      }
+      SC::sval(o.method, h, x, uc, p, xn, dc, h * i, i == S - 1);
+      f += dc;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) x[c] = xn[c];
+    }
+  }
+
+  // ---- Riccati recursion on the matrix cores (one control, NS <= 4, one control row per step) --------------------------
+  // The stage algebra of os_riccati_stage as three v_mfma_f64_16x16x4_f64 per step -- the sweep of the trapezoidal wavefront
+  // solver (HsWave<Sys, 1>::riccati_mfma_trap: same tile slots, same chaining of the products through the result
+  // registers, same pivot and gain rule) with the step map Fy | c in the place of the eliminated collocation rows and
+  // the FULL step Hessian Hs | gy as the C operand of the second product (where Hermite-Simpson feeds its midpoint terms).
+  // Own (bound) terms are diagonal here: sigma + delta of the control row of every point, of the state rows at nodes only.
+  static constexpr bool MFMA_RICCATI = (M == 1 && NU == 1 && NS <= 4);
+  using HW = HsWave<Sys, 1>;
+  typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+#ifndef MYR_SHOOT_RICCATI_PF
+#define MYR_SHOOT_RICCATI_PF 2
+#endif
+  __device__ static int riccati_mfma(const Lds& l, const HsSolveOpts& o, double delta, bool abort_on_reg, bool& aborted) {
+    using namespace detail;
+    const int lane = threadIdx.x, S = steps(o), cpi = o.cpi;
+    const int g = lane >> 4, j = lane & 15;
+    const int scol = j < 4 ? (j < NS ? j : -1) : (j < 6 ? NS : -1);
+    const int ycol = scol >= 0 ? scol : ((j == 8 || j == 9) ? NW : -1);
+    const int cc = j == 6 ? 0 : (j == 7 ? 1 : (j == 10 ? 2 : (j == 11 ? 3 : (j == 14 ? 4 : (j == 15 ? 5 : -1)))));
+    const int rcc = (cc >= 0 && cc < NC) ? cc : -1;
+    const bool rowx = g < NS;
+    const double* zr = l.ex + X_Z;
+    // per-lane input streams of step i (whose end point is point i+1):
+    //   0 own terms of the control row of point i+1 (row du, lane groups 0, 1)   1 Fy | c   2..4 Hs | gy rows dx, du, du_next
+    // and, at nodes only, the own terms of the node's state rows
+    const double* ptr[5]; long stp[5];
+    ptr[0] = (g < 2 && scol == NS) ? l.sig + ui(o, S, 0) : ((g < 2 && rcc == 1) ? l.g1 + ui(o, S, 0) : zr);
+    stp[0] = (ptr[0] == zr) ? 0 : NU;
+    const double* rec = l.rec + (long)(S - 1) * REC;
+    ptr[1] = !rowx ? zr : (ycol >= 0 ? rec + R_GE + g * NY1 + ycol : (rcc == 0 ? rec + R_GE + g * NY1 + NY : zr));
+    auto hsel = [&](int row, bool on) -> const double* {
+      if (!on) return zr;
+      if (ycol >= 0) return rec + R_HS + row * NY + ycol;
+      if (rcc == 0) return rec + R_GY + row;
+      return zr;
+    };
+    ptr[2] = hsel(g, rowx); ptr[3] = hsel(NS, g < 2); ptr[4] = hsel(NW, g < 2);
+#pragma unroll
+    for (int q = 1; q < 5; ++q) stp[q] = (ptr[q] == zr) ? 0 : REC;
+    const double* nptr = (rowx && scol == g) ? l.sig + g : ((rowx && rcc == 1) ? l.g1 + g : zr);   // + NS * node index
+    const long nstr = (nptr == zr) ? 0 : NS;
+    const bool pinr = rowx && (l.ex[X_TP + (rowx ? g : 0)] != 0.0);
+    const double X0i = (pinr && scol == g) ? o.rho_term - delta : ((pinr && rcc == 2 + g) ? 1.0 : 0.0);
+    const double dv0 = (rowx && scol == g) ? delta : 0.0, dv1 = (g < 2 && scol == NS) ? delta : 0.0;
+    const double f_a1 = j < 6 ? 1.0 : 0.0, f_keep = rcc >= 0 ? 1.0 : 0.0, f_she = (j == 8 || j == 9) ? 1.0 : 0.0;
+    const double f_x1 = g < 2 ? 1.0 : 0.0, f_t1 = g == 2 ? 1.0 : 0.0, f_t23 = g >= 2 ? 1.0 : 0.0;
+    const double f_a3 = (g == 0 && (j < 6 || j == 10 || j == 11 || j == 14 || j == 15)) ? -1.0 : 0.0;
+    const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
+    double* k_ptr = k_off >= 0 ? l.kg + (long)(S - 1) * KG + k_off : l.ex + X_Z + 1;
+    const long k_step = k_off >= 0 ? KG : 0;
+    double reg_floor = o.reg_floor;
+    asm volatile("" : "+v"(reg_floor));
+    int nreg = 0;
+    aborted = false;
+    constexpr int PF = MYR_SHOOT_RICCATI_PF;
+    double in[PF][5];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {         // (steps below 0 are read too -- valid LDS in front of the records -- and never used)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
+    }
+    mfma_d4 D3 = {X0i, 0.0, 0.0, 0.0};
+    for (int ib = S - 1; ib >= 0; ib -= PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int i = ib - u;
+        if (i < 0) break;
+        double own0 = 0.0;
+        if (((i + 1) % cpi) == 0) own0 = nptr[(long)((i + 1) / cpi) * nstr] + dv0;       // wave-uniform: the end point is a node
+        const double X0 = D3[0] + own0, X1 = fma(D3[1], f_x1, in[u][0] + dv1);
+        const double G = in[u][1], H0 = in[u][2], H1 = in[u][3], H2 = in[u][4];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
+        const double sh0 = HW::dpp_row_shr4(X0), sh1 = HW::dpp_row_shr4(X1);
+        mfma_d4 C1;
+        C1[0] = fma(sh0, f_she, X0 * f_keep);
+        C1[1] = fma(sh1, f_she, X1 * f_keep);
+        C1[2] = 0.0; C1[3] = 0.0;
+        const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X0 * f_a1, G, C1, 0, 0, 0);
+        mfma_d4 C2;
+        C2[0] = H0; C2[1] = fma(D3[1], f_t1, H1); C2[2] = fma(D3[2], f_t23, D1[1]) + H2; C2[3] = D3[3] * f_t23;
+        const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
+        const double q11 = HW::rdlane(D2[2], 8);
+        double d = q11;
+        if (!(d > reg_floor)) {                                        // wave-uniform, rare (same pivot rule as chol_reg)
+          d = dmax(fabs(d), reg_floor); ++nreg;
+          if (abort_on_reg) { aborted = true; return nreg; }
+        }
+        const double kk = D2[2] * fast_rcp(d);
+        k_ptr[0] = kk;
+        k_ptr -= k_step;
+        const double A3 = D2[2] * f_a3;
+        const double B3 = g == 0 ? kk : 0.0;
+        D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, B3, D2, 0, 0, 0);
+      }
+    }
+    const double X0 = D3[0], X1 = D3[1], T1 = D3[1], T2 = D3[2], T3 = D3[3];
+    double* sP = l.ex + X_P; double* sPc = l.ex + X_PC; double* sTnu = l.ex + X_TNU;
+    if (scol >= 0 && j != 5) {
+      if (rowx) sP[g * NW + scol] = X0;
+      if (g == 0) sP[NS * NW + scol] = X1;
+    }
+    if (rcc >= 0) {
+      if (rowx) sPc[g * NC + rcc] = X0;
+      if (g == 0) sPc[NS * NC + rcc] = X1;
+      if (g >= 2 && g - 2 < NS) sTnu[(g - 2) * NC + rcc] = T2;
+      if (g >= 2 && g < NS) sTnu[g * NC + rcc] = T3;
+    }
+    __syncthreads();
+    if (g == 2 && rcc >= 2) sTnu[(rcc - 2) * NC + 0] += T1;          // row 6: c^T pc'[:, nu_i], summed over the steps
+    __syncthreads();
+    return nreg;
+  }
+
+  // ---- backward sweep (ShootCore::backward): linearisation at the current iterate (once per iterate), Riccati recursion ----
+  __device__ static void backward(const HsWork& w, const HsSolveOpts& o, const double* p, const double* nuT, double delta, SweepOut& so) {
+    using namespace detail;
+    (void)w;
+    const Lds l = lds(o);
+    const int lane = threadIdx.x, I = o.N, cpi = o.cpi, S = I * cpi, n = nvars(o);
+    const double h = SC::hstep(o);
+    MYR_SWT0
+    if (l.ex[X_VALID] == 0.0) {
+      // own (bound) terms of every variable
+      double cmax = 0, cmin = INFINITY;
+      for (int v = lane; v < n; v += 64) {
+        typename H::BV b = H::bound_terms(l.z[v], l.lb[v], l.ub[v], l.zL[v], l.zU[v], cmax, cmin);
+        l.sig[v] = b.sigma; l.g1[v] = b.g1; l.zlu[v] = b.zlu;
+      }
+      // rollouts: states at every step, continuity defects (parked in lam), objective
+      double f = 0, c1 = 0, cinf = 0;
+      for (int k = lane; k < I; k += 64) {
+        double x[NS];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) x[c] = l.z[xi(k, c)];
+        roll_interval(o, p, l.z, k, x, l.xs, f);
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+          const double ck = x[c] - l.z[xi(k + 1, c)];                      // shooting.py:239-241
+          l.lam[(long)k * NS + c] = ck;
+          c1 += fabs(ck);
+          cinf = dmax(cinf, fabs(ck));
+        }
+      }
+      f = wv_sum(f); c1 = wv_sum(c1); cinf = wv_max(cinf); cmax = wv_max(cmax); cmin = wv_min(cmin);
+      __syncthreads();
+      MYR_SWT(0)
+      // first-order step linearisations
+      const double zero[NS] = {0};
+      for (int i = lane; i < S; i += 64) {
+        double x[NS], uc[(M + 1) * NU], Fy[NS * NY], gy[NY], Hs[NY * NY];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) x[c] = l.xs[(long)i * NS + c];
+#pragma unroll
+        for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = l.z[ui(o, M * i, a)];
+        SC::slin(o.method, h, x, uc, p, zero, Fy, gy, Hs, h * i, i == S - 1);
+        double* r = l.rec + (long)i * REC;
+        const bool node_next = ((i + 1) % cpi) == 0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+#pragma unroll
+          for (int c = 0; c < NY; ++c) r[R_GE + t * NY1 + c] = Fy[t * NY + c];
+          r[R_GE + t * NY1 + NY] = node_next ? l.lam[(long)(i / cpi) * NS + t] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < NY; ++c) r[R_GY + c] = gy[c];
+      }
+      __syncthreads();
+      MYR_SWT(1)
+      // costates (one lane): pi_{i+1} = costate of the state after step i; multipliers of the node defects; stationarity
+      if (lane == 0) {
+        double pi_c[NS], ru_c[NU], stat = 0, lam_inf = 0, sum_mult = 0; int n_mult = 0;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+          const bool pinned = !(l.lb[xi(I, c)] < l.ub[xi(I, c)]);
+          l.ex[X_TP + c] = pinned ? 1.0 : 0.0;
+          pi_c[c] = pinned ? nuT[c] : l.zlu[xi(I, c)];
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ru_c[a] = l.zlu[ui(o, M * S, a)];
+        for (int i = S - 1; i >= 0; --i) {
+          const int k = i / cpi;
+          const bool node_next = ((i + 1) % cpi) == 0, node_here = (i % cpi) == 0;
+          double pin[NS];
+#pragma unroll
+          for (int c = 0; c < NS; ++c) { pin[c] = pi_c[c]; l.pi[(long)(i + 1) * NS + c] = pin[c]; }
+          if (node_next) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+              l.lam[(long)k * NS + c] = pin[c];            // lam_k = costate of the node
+              lam_inf = dmax(lam_inf, fabs(pin[c]));
+              sum_mult += fabs(pin[c]);
+            }
+            n_mult += NS;
+          }
+          const double* r = l.rec + (long)i * REC;
+          double Fy[NS * NY], gy[NY];
+#pragma unroll
+          for (int t = 0; t < NS; ++t)
+#pragma unroll
+            for (int c = 0; c < NY; ++c) Fy[t * NY + c] = r[R_GE + t * NY1 + c];
+#pragma unroll
+          for (int c = 0; c < NY; ++c) gy[c] = r[R_GY + c];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) {
+            double rr = ru_c[a] + gy[QN + a];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) rr += Fy[t * NY + QN + a] * pin[t];
+            stat = dmax(stat, fabs(rr));
+          }
+          if constexpr (M > 1) {
+#pragma unroll
+            for (int q = 0; q < (M - 1) * NU; ++q) {
+              double rr = gy[NW + q] + l.zlu[ui(o, M * i + 1, q)];
+#pragma unroll
+              for (int t = 0; t < NS; ++t) rr += Fy[t * NY + NW + q] * pin[t];
+              stat = dmax(stat, fabs(rr));
+            }
+          }
+          double npi[NS];
+#pragma unroll
+          for (int c = 0; c < NS; ++c) {
+            double s = gy[c];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) s += Fy[t * NY + c] * pin[t];
+            npi[c] = s;
+          }
+#pragma unroll
+          for (int a = 0; a < NU; ++a) {
+            double s = gy[NS + a];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) s += Fy[t * NY + NS + a] * pin[t];
+            ru_c[a] = s + l.zlu[ui(o, M * i, a)];
+          }
+          if (node_here && i > 0) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) npi[c] += l.zlu[xi(k, c)];
+          }
+#pragma unroll
+          for (int c = 0; c < NS; ++c) pi_c[c] = npi[c];
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) stat = dmax(stat, fabs(ru_c[a]));
+        l.ex[X_F] = f; l.ex[X_C1] = c1; l.ex[X_CINF] = cinf; l.ex[X_STAT] = stat; l.ex[X_CMAX] = cmax; l.ex[X_CMIN] = cmin;
+        l.ex[X_LAMINF] = lam_inf; l.ex[X_SUMMULT] = sum_mult; l.ex[X_NMULT] = (double)n_mult;
+        l.ex[X_VALID] = 1.0;
+      }
+      __syncthreads();
+      MYR_SWT(2)
+      // step Hessians of the Lagrangian (costate of the step's end state)
+      for (int i = lane; i < S; i += 64) {
+        double x[NS], uc[(M + 1) * NU], pin[NS], Fy[NS * NY], gy[NY], Hs[NY * NY];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) { x[c] = l.xs[(long)i * NS + c]; pin[c] = l.pi[(long)(i + 1) * NS + c]; }
+#pragma unroll
+        for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = l.z[ui(o, M * i, a)];
+        SC::slin(o.method, h, x, uc, p, pin, Fy, gy, Hs, h * i, i == S - 1);
+        double* r = l.rec + (long)i * REC;
+#pragma unroll
+        for (int q = 0; q < NY * NY; ++q) r[R_HS + q] = Hs[q];
+      }
+      __syncthreads();
+      MYR_SWT(3)
+    }
+    // ---- Riccati recursion: matrix cores where the stage fits a tile, else one lane out of LDS ----
+    if constexpr (MFMA_RICCATI) {
+      bool aborted;
+      int nreg = riccati_mfma(l, o, delta, so.abort_on_reg, aborted);
+      if (lane == 0) {
+        if (!aborted) {     // first point: x_0 pinned, eliminate du_0
+          double P[NW * NW], pc[NW * NC], Tnu[NS * NC], Huu[NU * NU], g0u[NU], g1u[NU], ku[NU * NC];
+#pragma unroll
+          for (int q = 0; q < NW * NW; ++q) P[q] = l.ex[X_P + q];
+#pragma unroll
+          for (int q = 0; q < NW * NC; ++q) pc[q] = l.ex[X_PC + q];
+#pragma unroll
+          for (int q = 0; q < NS * NC; ++q) Tnu[q] = l.ex[X_TNU + q];
+          const long v = ui(o, 0, 0);
+          Huu[0] = l.sig[v] + delta; g0u[0] = 0.0; g1u[0] = l.g1[v];
+          nreg += os_first_point<Sys>(P, pc, Huu, g0u, g1u, o.reg_floor, Tnu, ku);
+#pragma unroll
+          for (int q = 0; q < NU * NC; ++q) l.ku[q] = ku[q];
+#pragma unroll
+          for (int q = 0; q < NS * NC; ++q) l.ex[X_TNU + q] = Tnu[q];
+        }
+        l.ex[X_NREG] = (double)nreg;
+      }
+    } else
+    if (lane == 0) {
+      double P[NW * NW], pc[NW * NC], Tnu[NS * NC];
+      int nreg = 0;
+#pragma unroll
+      for (int i = 0; i < NW * NW; ++i) P[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NW * NC; ++i) pc[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NS * NC; ++i) Tnu[i] = 0.0;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        const long v = xi(I, c);
+        if (l.ex[X_TP + c] != 0.0) { pc[c * NC + 2 + c] = 1.0; P[c * NW + c] = o.rho_term; }
+        else { P[c * NW + c] = l.sig[v] + delta; pc[c * NC + 1] = l.g1[v]; }
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        const long v = ui(o, M * S, a);
+        P[(NS + a) * NW + NS + a] = l.sig[v] + delta; pc[(NS + a) * NC + 1] = l.g1[v];
+      }
+      bool aborted = false;
+      for (int i = S - 1; i >= 0; --i) {
+        const int k = i / cpi;
+        const bool node_here = (i % cpi) == 0;
+        const double* r = l.rec + (long)i * REC;
+        double Ge[NS * NY1], gy[NY], Hs[NY * NY], qdiag[NQ], qg1[NQ], Kk[NQ * NW], kc[NQ * NC];
+#pragma unroll
+        for (int q = 0; q < NS * NY1; ++q) Ge[q] = r[R_GE + q];
+#pragma unroll
+        for (int q = 0; q < NY; ++q) gy[q] = r[R_GY + q];
+#pragma unroll
+        for (int q = 0; q < NY * NY; ++q) Hs[q] = r[R_HS + q];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { qdiag[q] = 0.0; qg1[q] = 0.0; }
+        if constexpr (M > 1) {
+#pragma unroll
+          for (int q = 0; q < (M - 1) * NU; ++q) {
+            const long v = ui(o, M * i + 1, q);
+            qdiag[q] = l.sig[v] + delta; qg1[q] = l.g1[v];
+          }
+        }
+        nreg += os_riccati_stage<Sys, M>(P, pc, Tnu, Ge, Hs, gy, o.reg_floor, Kk, kc, qdiag, qg1);
+        if (nreg > 0 && so.abort_on_reg) { aborted = true; break; }
+        double* g = l.kg + (long)i * KG;
+#pragma unroll
+        for (int q = 0; q < NQ * NW; ++q) g[q] = Kk[q];
+#pragma unroll
+        for (int q = 0; q < NQ * NC; ++q) g[NQ * NW + q] = kc[q];
+        if (i > 0) {
+#pragma unroll
+          for (int a = 0; a < NU; ++a) {
+            const long v = ui(o, M * i, a);
+            P[(NS + a) * NW + NS + a] += l.sig[v] + delta; pc[(NS + a) * NC + 1] += l.g1[v];
+          }
+          if (node_here) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+              const long v = xi(k, c);
+              P[c * NW + c] += l.sig[v] + delta; pc[c * NC + 1] += l.g1[v];
+            }
+          }
+        }
+      }
+      if (!aborted) {       // first point: x_0 pinned, eliminate du_0
+        double Huu[NU * NU], g0u[NU], g1u[NU], ku[NU * NC];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          const long v = ui(o, 0, a);
+#pragma unroll
+          for (int b2 = 0; b2 < NU; ++b2) Huu[a * NU + b2] = (a == b2) ? l.sig[v] + delta : 0.0;
+          g0u[a] = 0.0; g1u[a] = l.g1[v];
+        }
+        nreg += os_first_point<Sys>(P, pc, Huu, g0u, g1u, o.reg_floor, Tnu, ku);
+#pragma unroll
+        for (int q = 0; q < NU * NC; ++q) l.ku[q] = ku[q];
+      }
+      l.ex[X_NREG] = (double)nreg;
+#pragma unroll
+      for (int q = 0; q < NS * NC; ++q) l.ex[X_TNU + q] = Tnu[q];
+    }
+    __syncthreads();
+    so.f = l.ex[X_F]; so.c1 = l.ex[X_C1]; so.cinf = l.ex[X_CINF]; so.stat = l.ex[X_STAT]; so.compl_max = l.ex[X_CMAX];
+    so.compl_min = l.ex[X_CMIN]; so.lam_inf = l.ex[X_LAMINF]; so.sum_mult = l.ex[X_SUMMULT]; so.n_mult = (int)l.ex[X_NMULT];
+    so.nreg = (int)l.ex[X_NREG];
+#pragma unroll
+    for (int q = 0; q < NS * NC; ++q) so.Tnu[q] = l.ex[X_TNU + q];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) so.term_pinned[c] = l.ex[X_TP + c] != 0.0;
+    __syncthreads();
+  }
+
+  // ---- forward recursion (one lane) and step limits (lanes over variables) ----
+  __device__ static void forward(const HsWork& w, const HsSolveOpts& o, const double* p, double mu, const double* nu,
+                                 const bool* term_pinned, FwdOut& fo) {
+    (void)w; (void)p;
+    const Lds l = lds(o);
+    const int lane = threadIdx.x, I = o.N, cpi = o.cpi, S = I * cpi, n = nvars(o);
+    const double tau = detail::dmax(o.tau_min, 1.0 - mu);
+    MYR_SWT0
+    if (lane == 0) {
+      double th[NC], s[NW], gphi = 0.0;
+      th[0] = 1.0; th[1] = mu;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) { s[c] = 0.0; l.dz[xi(0, c)] = 0.0; }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        double v = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) v -= l.ku[a * NC + cc] * th[cc];
+        s[NS + a] = v;
+        l.dz[ui(o, 0, a)] = v;
+      }
+      for (int i = 0; i < S; ++i) {
+        const double* r = l.rec + (long)i * REC;
+        const double* g = l.kg + (long)i * KG;
+        const bool node_next = ((i + 1) % cpi) == 0;
+        double y[NY];
+#pragma unroll
+        for (int c = 0; c < NW; ++c) y[c] = s[c];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          double v = 0.0;
+#pragma unroll
+          for (int c = 0; c < NW; ++c) v -= g[q * NW + c] * s[c];
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) v -= g[NQ * NW + q * NC + cc] * th[cc];
+          y[NW + q] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < NY; ++c) gphi += r[R_GY + c] * y[c];      // d(objective) along the lifted step
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+          double v = r[R_GE + t * NY1 + NY];
+#pragma unroll
+          for (int c = 0; c < NY; ++c) v += r[R_GE + t * NY1 + c] * y[c];
+          s[t] = (i == S - 1 && term_pinned[t]) ? 0.0 : v;
+        }
+        if (node_next) {
+#pragma unroll
+          for (int c = 0; c < NS; ++c) l.dz[xi((i + 1) / cpi, c)] = s[c];
+        }
+        if constexpr (M > 1) {
+#pragma unroll
+          for (int q = 0; q < (M - 1) * NU; ++q) l.dz[ui(o, M * i + 1, q)] = y[NW + q];
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { s[NS + a] = y[QN + a]; l.dz[ui(o, M * i + M, a)] = y[QN + a]; }
+      }
+      l.ex[X_GPHI] = gphi;
+    }
+    __syncthreads();
+    FwdOut fl; fl.alpha_p = 1.0; fl.alpha_d = 1.0; fl.gphi = 0.0;
+    for (int v = NS + lane; v < n; v += 64)       // every variable but x_0 (ShootCore::forward sets dz = 0 there, no limits)
+      H::step_limits(l.z[v], l.lb[v], l.ub[v], l.zL[v], l.zU[v], l.dz[v], mu, 0.0, tau, fl);
+    fo.alpha_p = wv_min(fl.alpha_p); fo.alpha_d = wv_min(fl.alpha_d); fo.gphi = l.ex[X_GPHI] + wv_sum(fl.gphi);
+    __syncthreads();
+    MYR_SWT(5)
+  }
+
+  // ---- merit function at z + alpha dz: trial point and barrier (lanes over variables), rollouts (lanes over intervals) ----
+  __device__ static bool trial(const HsWork& w, const HsSolveOpts& o, const double* p, double alpha, double mu,
+                               double& f, double& bar, double& c1) {
+    (void)w;
+    const Lds l = lds(o);
+    const int lane = threadIdx.x, I = o.N, n = nvars(o);
+    double fl = 0, bl = 0, cl = 0; int bad = 0;
+    MYR_SWT0
+    for (int i = lane; i < n; i += 64) {
+      const double v = l.z[i] + alpha * l.dz[i];
+      const double lo = l.lb[i], ub = l.ub[i];
+      const bool fr = lo < ub;
+      const bool hl = fr && (lo > -INFINITY), hu = fr && (ub < INFINITY);
+      const double sl = hl ? v - lo : 1.0, su = hu ? ub - v : 1.0;
+      bad += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
+      bl -= log((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0));
+      l.zt[i] = v;
+    }
+    __syncthreads();
+    for (int k = lane; k < I; k += 64) {
+      double x[NS];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) x[c] = l.zt[xi(k, c)];
+      roll_interval(o, p, l.zt, k, x, nullptr, fl);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) cl += fabs(x[c] - l.zt[xi(k + 1, c)]);
+    }
+    f = wv_sum(fl); c1 = wv_sum(cl); bar = mu * wv_sum(bl); bad = wv_isum(bad);
+    __syncthreads();
+    MYR_SWT(6)
+    if (bad != 0) return false;
+    if (!detail::finite_(f)) return false;
+    if (!detail::finite_(c1)) return false;
+    return detail::finite_(bar);
+  }
+};
+
+// Persistent: grid = resident workgroups (one wavefront each); each pulls trajectories from `ticket`.  z / lb / ub / lam are
+// the caller's instance-major rows ([B][n], [B][I*NS]); the iterate is copied into LDS, solved there and copied back.
+template <class Sys, int M = 1>
+__global__ __launch_bounds__(64)
+void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
+                             const double* __restrict__ ub, double* __restrict__ lam, const double* __restrict__ params, int params_stride,
+                             double* cost, int32_t* status, int32_t* iters, double* kkt) {
+  using W = ShootWave<Sys, M>;
+  const typename W::Lds l = W::lds(o);
+  const int n = W::nvars(o), m = o.N * W::NS;
+  for (;;) {
+    int t = 0;
+    if (threadIdx.x == 0) t = atomicAdd(ticket, 1);
+    const long b = __builtin_amdgcn_readfirstlane(t);
+    if (b >= B) break;
+    for (int i = threadIdx.x; i < n; i += 64) { l.z[i] = z[b * n + i]; l.lb[i] = lb[b * n + i]; l.ub[i] = ub[b * n + i]; }
+    if (threadIdx.x == 0) l.ex[W::X_Z] = 0.0;
+    SysParams<Sys> pp;
+    pp.load(params, b, params_stride);
+    pp.set_scale(vs.s);
+    __syncthreads();
+    HsWork w{{l.z, 1}, {l.lb, 1}, {l.ub, 1}, {l.zL, 1}, {l.zU, 1}, {l.lam, 1}, {l.dz, 1}, {l.rec, 1}};
+    HsSolveResult r;
+#ifdef MYR_SW_TIMING
+    if (threadIdx.x < 8) l.ex[W::X_T + threadIdx.x] = 0.0;
+    const long long tall_ = wall_clock64();
+#endif
+    IpLoop<W>::run(w, o, pp.get(), r);
+    __syncthreads();
+#ifdef MYR_SW_TIMING
+    if (threadIdx.x == 0 && b < 3)
+      printf("traj %ld it %d sweeps %d, x10ns: total %lld | own+rollout %.0f lin1 %.0f costate %.0f hess %.0f riccati %.0f forward %.0f trial %.0f\n", b, r.iters,
+             r.sweeps, wall_clock64() - tall_, l.ex[W::X_T], l.ex[W::X_T + 1], l.ex[W::X_T + 2], l.ex[W::X_T + 3], l.ex[W::X_T + 4], l.ex[W::X_T + 5], l.ex[W::X_T + 6]);
+#endif
+    for (int i = threadIdx.x; i < n; i += 64) z[b * n + i] = l.z[i];
+    if (lam) for (int i = threadIdx.x; i < m; i += 64) lam[b * m + i] = l.lam[i];
+    if (threadIdx.x == 0) {
+      if (cost) cost[b] = r.cost;
+      if (status) status[b] = r.status;
+      if (iters) iters[b] = r.iters;
+      if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
+    }
+    __syncthreads();      // LDS is handed to the next trajectory
+  }
+}
+
+}  // namespace myriad
