@@ -4,17 +4,22 @@
 // workloads (config 3: 8192 trajectories per GPU) that is 8192 busy lanes on a machine that retires 16 k fp64 lanes per
 // cycle, and the launch lasts as long as its slowest trajectory (119 iterations x 0.7 ms).  Here a 64-lane workgroup owns
 // one trajectory, the whole iterate lives in LDS (variables, bounds, bound multipliers, rollout states, stage
-// records, gains -- 21 KB for VANDERPOL 1 x 50), and the workgroups are persistent (ticket counter, as hs_solver_wave.h):
+// records, gains -- 18 KB for VANDERPOL 1 x 50, eight workgroups per CU), and the workgroups are persistent (ticket
+// counter, as hs_solver_wave.h):
 //   * lanes over VARIABLES: starting point, bound terms, step limits, trial point + barrier, update;
-//   * lanes over STEPS: the step linearisations (first order, then -- with the costates known -- the step Hessians);
+//   * lanes over STEPS: the step linearisations (first order, then -- with the costates known -- the step Hessians),
+//     the closed-loop step maps and the step itself once the state recursion has run;
 //   * lanes over INTERVALS: rollouts (states, continuity defects, objective) of the sweep and of every trial point;
-//   * one lane, out of LDS: the costate recursion, the Riccati recursion (os_riccati_stage, the code of the lane kernel)
-//     and the forward recursion.  An inertia-correction retry (W + delta I) repeats only the Riccati recursion: the
+//   * sequential over the steps: the costate recursion and the closed-loop state recursion (one lane, small affine
+//     maps out of LDS, operands fetched one step ahead) and the Riccati recursion -- on the matrix cores (three
+//     v_mfma_f64_16x16x4_f64 per step, riccati_mfma below) for one-control systems with NS <= 4, else os_riccati_stage (the code of
+//     the lane kernel) in one lane.  An inertia-correction retry (W + delta I) repeats only the Riccati recursion: the
 //     rollout, both linearisation passes and the costates do not depend on delta.
 // The algorithm, its constants and its control flow are ShootCore's: the outer loop IS IpLoop<> (hs_solver.h), executed
 // redundantly by all 64 lanes on wave-uniform scalars, with this struct as its `Core`.  Only the association of the sums
-// (objective, defect norms, barrier, directional derivative: wave reductions instead of one running sum) differs from
-// the lane kernel, against which -- and against the same oracle / golden solutions -- it is tested.
+// (objective, defect norms, barrier, directional derivative: wave reductions instead of one running sum) and of the
+// forward recursion (closed-loop map applied in one product) differ from the lane kernel, against which -- and against
+// the same oracle / golden solutions -- it is tested.
 //
 // Replaces, per trajectory, IPOPT on /root/reference/myriad/trajectory_optimizers/shooting.py:169-241 (objective :169-210,
 // constraints :230-241) as called from nlp_solvers/__init__.py:32-96.
@@ -24,6 +29,15 @@
 #include "hs_solver_wave.h"
 
 namespace myriad {
+
+typedef __attribute__((address_space(3))) double sw_lds;     // LDS-typed pointers: ds_read / ds_write instead of flat accesses
+
+#ifndef MYR_SHOOT_RESTARTS
+#define MYR_SHOOT_RESTARTS 2       // second / third start of a failed solve (see the kernel)
+#endif
+#ifndef MYR_SHOOT_MIN_WAVES
+#define MYR_SHOOT_MIN_WAVES 2     // waves per SIMD the register allocation must allow (LDS allows 8 workgroups per CU)
+#endif
 
 template <class Sys, int M = 1>
 struct ShootWave {
@@ -35,56 +49,77 @@ struct ShootWave {
   using SweepOut = typename H::SweepOut;
   using FwdOut = typename H::FwdOut;
 
-  // stage record: Fy | c_k (NS x NY1, the step map dx_next = Fy y + c), gy (NY), Hs (NY x NY)
-  static constexpr int R_GE = 0, R_GY = R_GE + NS * NY1, R_HS = R_GY + NY, REC = R_HS + NY * NY;
+  // stage record: gy (NY), Fy | c (NS x NY1, the step map dx_next = Fy y + c), Hs (NY x NY, lower triangle packed).
+  // The forward sweep overlays its closed-loop map Phi | phi (NW x NW + NW) on Fy | c and Hs, both dead by then.
+  static constexpr int HSP = NY * (NY + 1) / 2;
+  static constexpr int R_GY = 0, R_GE = R_GY + NY, R_HS = R_GE + NS * NY1, REC = R_HS + HSP, R_PHI = R_GE;
+  static_assert(NW * NW + NW <= NS * NY1 + HSP, "closed-loop map fits the dead part of the stage record");
+  __host__ __device__ static constexpr int hsp(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
   static constexpr int KG = NQ * NW + NQ * NC;        // gains K | kc of a stage
   // exchange block (first in LDS): results of the one-lane phases and of the last linearisation, for all lanes
   static constexpr int X_VALID = 0, X_F = 1, X_C1 = 2, X_CINF = 3, X_STAT = 4, X_CMAX = 5, X_CMIN = 6, X_LAMINF = 7, X_SUMMULT = 8,
-                       X_NMULT = 9, X_NREG = 10, X_GPHI = 11, X_TNU = 12, X_TP = X_TNU + NS * NC, X_T = X_TP + NS /* 8 phase timers (developer knob MYR_SW_TIMING) */,
-                       X_Z = X_T + 8 /* a zero and a write-only slot */, X_P = X_Z + 2, X_PC = X_P + NW * NW, X_N = (X_PC + NW * NC + 7) / 8 * 8;
+                       X_NMULT = 9, X_NREG = 10, X_GPHI = 11, X_TNU = 12, X_TP = X_TNU + NS * NC,
+                       X_T = X_TP + NS /* 8 phase timers (developer knob MYR_SW_TIMING) */,
+                       X_Z = X_T + 8 /* a zero and a write-only slot */, X_P = X_Z + 2, X_PC = X_P + NW * NW,
+                       X_N = (X_PC + NW * NC + 7) / 8 * 8;
 
   __host__ __device__ static inline int steps(const HsSolveOpts& o) { return o.N * o.cpi; }
   __host__ __device__ static inline int nvars(const HsSolveOpts& o) { return (o.N + 1) * NS + (M * steps(o) + 1) * NU; }
   __host__ __device__ static inline long xi(int k, int c) { return SC::xi(k, c); }
   __host__ __device__ static inline long ui(const HsSolveOpts& o, int i, int a) { return SC::ui(o, i, a); }
+  // shared scratch region: rollout states | costates (linearisation), closed-loop states (forward), trial point (merit)
+  __host__ __device__ static long tmp_doubles(long S, long n) {
+    const long a = 2 * (S + 1) * NS, b = (S + 1) * NW;
+    return a > b ? (a > n ? a : n) : (b > n ? b : n);
+  }
   __host__ __device__ static long lds_doubles(int I, int cpi) {
     const long S = (long)I * cpi, n = (long)(I + 1) * NS + (M * S + 1) * NU;
-    return X_N + 10 * n + 2 * (S + 1) * NS + S * (REC + KG) + NU * NC + (long)I * NS;
+    return X_N + 9 * n + tmp_doubles(S, n) + S * (REC + KG) + NU * NC + (long)I * NS;
   }
   __host__ __device__ static size_t lds_bytes(int I, int cpi) { return (size_t)lds_doubles(I, cpi) * 8; }
 
   struct Lds {
-    double *ex, *z, *lb, *ub, *zL, *zU, *dz, *zt, *sig, *g1, *zlu, *xs, *pi, *rec, *kg, *ku, *lam;
+    sw_lds *ex, *z, *lb, *ub, *zL, *zU, *dz, *sig, *g1, *rec, *kg, *ku, *lam;
+    sw_lds *z0;              // the caller's starting point (restart after a failed solve, see the kernel)
+    sw_lds *zlu;             // = dz  (bound-multiplier difference, dead before the step is written)
+    // one region, three lives: rollout states | costates (linearisation), states of the closed-loop recursion (forward),
+    // trial point (merit function)
+    sw_lds *xs, *pi, *sS, *zt;
   };
-  __device__ static inline Lds lds(const HsSolveOpts& o) {
+  __device__ static inline sw_lds* lds_base() {
     extern __shared__ __attribute__((aligned(16))) char smem_wave[];
+    return (sw_lds*)reinterpret_cast<double*>(smem_wave);
+  }
+  __device__ static inline Lds lds(const HsSolveOpts& o) {
     const long S = steps(o), n = nvars(o);
     Lds l;
-    double* s = reinterpret_cast<double*>(smem_wave);
+    sw_lds* s = lds_base();
     l.ex = s; s += X_N;
-    l.z = s; s += n; l.lb = s; s += n; l.ub = s; s += n; l.zL = s; s += n; l.zU = s; s += n; l.dz = s; s += n; l.zt = s; s += n;
-    l.sig = s; s += n; l.g1 = s; s += n; l.zlu = s; s += n;
-    l.xs = s; s += (S + 1) * NS; l.pi = s; s += (S + 1) * NS;
+    l.z = s; s += n; l.lb = s; s += n; l.ub = s; s += n; l.zL = s; s += n; l.zU = s; s += n; l.dz = s; s += n;
+    l.sig = s; s += n; l.g1 = s; s += n; l.z0 = s; s += n;
+    l.zlu = l.dz;
+    l.xs = s; l.pi = s + (S + 1) * NS; l.sS = s; l.zt = s; s += tmp_doubles(S, n);
     l.rec = s; s += S * REC; l.kg = s; s += S * KG; l.ku = s; s += NU * NC; l.lam = s;
     return l;
   }
 #ifdef MYR_SW_TIMING
-#define MYR_SWT(k) { const long long t1_ = wall_clock64(); if (threadIdx.x == 0) exch()[X_T + k] += (double)(t1_ - t0_); t0_ = t1_; }
+#define MYR_SWT(k) { const long long t1_ = wall_clock64(); if (threadIdx.x == 0) lds_base()[X_T + k] += (double)(t1_ - t0_); t0_ = t1_; }
 #define MYR_SWT0 long long t0_ = wall_clock64();
+#define MYR_SWT0F MYR_SWT0
+#define MYR_SWTF(k) MYR_SWT(k)
 #else
+#define MYR_SWT0F
+#define MYR_SWTF(k)
 #define MYR_SWT(k)
 #define MYR_SWT0
 #endif
-  __device__ static inline double* exch() {
-    extern __shared__ __attribute__((aligned(16))) char smem_wave[];
-    return reinterpret_cast<double*>(smem_wave);
-  }
 
   // ---- lanes over variables: starting point and accepted step (HsSolver::init / update, one variable per lane) ----
   __device__ static void init(const HsWork& w, int n) {
     const double k1 = 1e-2, k2 = 1e-2;
+    sw_lds* z = (sw_lds*)w.z.p; sw_lds* lb = (sw_lds*)w.lb.p; sw_lds* ub = (sw_lds*)w.ub.p; sw_lds* zL = (sw_lds*)w.zL.p; sw_lds* zU = (sw_lds*)w.zU.p;
     for (int i = threadIdx.x; i < n; i += 64) {
-      const double l = w.lb[i], u = w.ub[i], v0 = w.z[i];
+      const double l = lb[i], u = ub[i], v0 = z[i];
       const bool fr = l < u;
       const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
       const double width = (hl && hu) ? (u - l) : INFINITY;
@@ -94,17 +129,19 @@ struct ShootWave {
       v = hl ? detail::dmax(v, l + pl) : v;
       v = hu ? detail::dmin(v, u - pu) : v;
       v = fr ? v : l;
-      w.z[i] = v;
-      w.zL[i] = hl ? 1.0 : 0.0;
-      w.zU[i] = hu ? 1.0 : 0.0;
+      z[i] = v;
+      zL[i] = hl ? 1.0 : 0.0;
+      zU[i] = hu ? 1.0 : 0.0;
     }
-    if (threadIdx.x == 0) exch()[X_VALID] = 0.0;
+    if (threadIdx.x == 0) lds_base()[X_VALID] = 0.0;
     __syncthreads();
   }
   __device__ static void update(const HsWork& w, int n, double ap, double ad, double mu, double ksig) {
     const double iks = 1.0 / ksig;
+    sw_lds* z = (sw_lds*)w.z.p; sw_lds* lb = (sw_lds*)w.lb.p; sw_lds* ub = (sw_lds*)w.ub.p; sw_lds* zL = (sw_lds*)w.zL.p; sw_lds* zU = (sw_lds*)w.zU.p;
+    sw_lds* dz = (sw_lds*)w.dz.p;
     for (int i = threadIdx.x; i < n; i += 64) {
-      const double l = w.lb[i], u = w.ub[i], zv = w.z[i], d = w.dz[i], zl = w.zL[i], zu = w.zU[i];
+      const double l = lb[i], u = ub[i], zv = z[i], d = dz[i], zl = zL[i], zu = zU[i];
       const bool fr = l < u;
       const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
       const double zn = fr ? zv + ap * d : zv;
@@ -115,23 +152,36 @@ struct ShootWave {
       const double ml = mu / snl, mu_ = mu / snu;
       vl = detail::dmax(detail::dmin(vl, ksig * ml), ml * iks);
       vu = detail::dmax(detail::dmin(vu, ksig * mu_), mu_ * iks);
-      w.z[i] = zn;
-      w.zL[i] = hl ? vl : 0.0;
-      w.zU[i] = hu ? vu : 0.0;
+      z[i] = zn;
+      zL[i] = hl ? vl : 0.0;
+      zU[i] = hu ? vu : 0.0;
     }
-    if (threadIdx.x == 0) exch()[X_VALID] = 0.0;
+    if (threadIdx.x == 0) lds_base()[X_VALID] = 0.0;
     __syncthreads();
   }
   __device__ static void solve_nu(const SweepOut& so, double mu, double* nu) { H::solve_nu(so, mu, nu); }
 
-  // one interval's rollout from x (values of the variables in `v`): states -> xs (if given), end state -> x
-  __device__ static inline void roll_interval(const HsSolveOpts& o, const double* p, const double* v, int k, double* x, double* xs, double& f) {
+  // one interval's rollout from x (values of the variables in `v`): states -> xs (if given), end state -> x.
+  // The control rows of step i+1 are fetched before step i is integrated (the chain of dependent steps never waits for LDS).
+  __device__ static inline void roll_interval(const HsSolveOpts& o, const double* p, const sw_lds* v, int k, double* x, sw_lds* xs, double& f) {
     const int cpi = o.cpi, S = steps(o);
     const double h = SC::hstep(o);
-    for (int i = k * cpi; i < (k + 1) * cpi; ++i) {
-      double uc[(M + 1) * NU], xn[NS], dc;
+    const int i0 = k * cpi, i1 = (k + 1) * cpi;
+    double uc[(M + 1) * NU], un[M * NU];
 #pragma unroll
-      for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = v[ui(o, M * i, a)];
+    for (int a = 0; a < NU; ++a) uc[M * NU + a] = v[ui(o, M * i0, a)];
+#pragma unroll
+    for (int a = 0; a < M * NU; ++a) un[a] = v[ui(o, M * i0 + 1, a)];
+    for (int i = i0; i < i1; ++i) {
+      double xn[NS], dc;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) uc[a] = uc[M * NU + a];                 // the previous step's last row
+#pragma unroll
+      for (int a = 0; a < M * NU; ++a) uc[NU + a] = un[a];
+      if (i + 1 < i1) {
+#pragma unroll
+        for (int a = 0; a < M * NU; ++a) un[a] = v[ui(o, M * (i + 1) + 1, a)];
+      }
       if (xs) {
 #pragma unroll
         for (int c = 0; c < NS; ++c) xs[(long)i * NS + c] = x[c];
@@ -164,26 +214,26 @@ struct ShootWave {
     const int cc = j == 6 ? 0 : (j == 7 ? 1 : (j == 10 ? 2 : (j == 11 ? 3 : (j == 14 ? 4 : (j == 15 ? 5 : -1)))));
     const int rcc = (cc >= 0 && cc < NC) ? cc : -1;
     const bool rowx = g < NS;
-    const double* zr = l.ex + X_Z;
+    const sw_lds* zr = l.ex + X_Z;
     // per-lane input streams of step i (whose end point is point i+1):
     //   0 own terms of the control row of point i+1 (row du, lane groups 0, 1)   1 Fy | c   2..4 Hs | gy rows dx, du, du_next
     // and, at nodes only, the own terms of the node's state rows
-    const double* ptr[5]; long stp[5];
+    const sw_lds* ptr[5]; int stp[5];
     ptr[0] = (g < 2 && scol == NS) ? l.sig + ui(o, S, 0) : ((g < 2 && rcc == 1) ? l.g1 + ui(o, S, 0) : zr);
     stp[0] = (ptr[0] == zr) ? 0 : NU;
-    const double* rec = l.rec + (long)(S - 1) * REC;
+    const sw_lds* rec = l.rec + (long)(S - 1) * REC;
     ptr[1] = !rowx ? zr : (ycol >= 0 ? rec + R_GE + g * NY1 + ycol : (rcc == 0 ? rec + R_GE + g * NY1 + NY : zr));
-    auto hsel = [&](int row, bool on) -> const double* {
+    auto hsel = [&](int row, bool on) -> const sw_lds* {
       if (!on) return zr;
-      if (ycol >= 0) return rec + R_HS + row * NY + ycol;
+      if (ycol >= 0) return rec + R_HS + hsp(row, ycol);
       if (rcc == 0) return rec + R_GY + row;
       return zr;
     };
     ptr[2] = hsel(g, rowx); ptr[3] = hsel(NS, g < 2); ptr[4] = hsel(NW, g < 2);
 #pragma unroll
     for (int q = 1; q < 5; ++q) stp[q] = (ptr[q] == zr) ? 0 : REC;
-    const double* nptr = (rowx && scol == g) ? l.sig + g : ((rowx && rcc == 1) ? l.g1 + g : zr);   // + NS * node index
-    const long nstr = (nptr == zr) ? 0 : NS;
+    const sw_lds* nptr = (rowx && scol == g) ? l.sig + g : ((rowx && rcc == 1) ? l.g1 + g : zr);   // + NS * node index
+    const int nstr = (nptr == zr) ? 0 : NS;
     const bool pinr = rowx && (l.ex[X_TP + (rowx ? g : 0)] != 0.0);
     const double X0i = (pinr && scol == g) ? o.rho_term - delta : ((pinr && rcc == 2 + g) ? 1.0 : 0.0);
     const double dv0 = (rowx && scol == g) ? delta : 0.0, dv1 = (g < 2 && scol == NS) ? delta : 0.0;
@@ -191,8 +241,8 @@ struct ShootWave {
     const double f_x1 = g < 2 ? 1.0 : 0.0, f_t1 = g == 2 ? 1.0 : 0.0, f_t23 = g >= 2 ? 1.0 : 0.0;
     const double f_a3 = (g == 0 && (j < 6 || j == 10 || j == 11 || j == 14 || j == 15)) ? -1.0 : 0.0;
     const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
-    double* k_ptr = k_off >= 0 ? l.kg + (long)(S - 1) * KG + k_off : l.ex + X_Z + 1;
-    const long k_step = k_off >= 0 ? KG : 0;
+    sw_lds* k_ptr = k_off >= 0 ? l.kg + (long)(S - 1) * KG + k_off : l.ex + X_Z + 1;
+    const int k_step = k_off >= 0 ? KG : 0;
     double reg_floor = o.reg_floor;
     asm volatile("" : "+v"(reg_floor));
     int nreg = 0;
@@ -205,13 +255,15 @@ struct ShootWave {
       for (int q = 0; q < 5; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
     }
     mfma_d4 D3 = {X0i, 0.0, 0.0, 0.0};
+    int to_node = 0, node = o.N;               // steps until the end point is a node again (no integer division in the loop)
     for (int ib = S - 1; ib >= 0; ib -= PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int i = ib - u;
         if (i < 0) break;
         double own0 = 0.0;
-        if (((i + 1) % cpi) == 0) own0 = nptr[(long)((i + 1) / cpi) * nstr] + dv0;       // wave-uniform: the end point is a node
+        if (to_node == 0) { own0 = nptr[node * nstr] + dv0; to_node = cpi; --node; }      // wave-uniform: the end point is a node
+        --to_node;
         const double X0 = D3[0] + own0, X1 = fma(D3[1], f_x1, in[u][0] + dv1);
         const double G = in[u][1], H0 = in[u][2], H1 = in[u][3], H2 = in[u][4];
 #pragma unroll
@@ -240,7 +292,7 @@ struct ShootWave {
       }
     }
     const double X0 = D3[0], X1 = D3[1], T1 = D3[1], T2 = D3[2], T3 = D3[3];
-    double* sP = l.ex + X_P; double* sPc = l.ex + X_PC; double* sTnu = l.ex + X_TNU;
+    sw_lds* sP = l.ex + X_P; sw_lds* sPc = l.ex + X_PC; sw_lds* sTnu = l.ex + X_TNU;
     if (scol >= 0 && j != 5) {
       if (rowx) sP[g * NW + scol] = X0;
       if (g == 0) sP[NS * NW + scol] = X1;
@@ -271,17 +323,21 @@ struct ShootWave {
       for (int v = lane; v < n; v += 64) {
         typename H::BV b = H::bound_terms(l.z[v], l.lb[v], l.ub[v], l.zL[v], l.zU[v], cmax, cmin);
         l.sig[v] = b.sigma; l.g1[v] = b.g1; l.zlu[v] = b.zlu;
+        // terminal state pinned?  Decided HERE, lane-divergently: as a wave-uniform select in the one-lane phase below,
+        // ROCm 7.2's hipcc lowered `pinned ? 1.0 : 0.0` to v_cmp_nlt_f64 vcc ; s_cselect_b32 -- a select on SCC, which the
+        // compare does not write (tools/dev/scan_scc.py finds the pattern in a listing)
+        if (v >= xi(I, 0) && v < xi(I, 0) + NS) l.ex[X_TP + (v - xi(I, 0))] = b.pinned ? 1.0 : 0.0;
       }
       // rollouts: states at every step, continuity defects (parked in lam), objective
       double f = 0, c1 = 0, cinf = 0;
       for (int k = lane; k < I; k += 64) {
-        double x[NS];
+        double x[NS], xe[NS];
 #pragma unroll
-        for (int c = 0; c < NS; ++c) x[c] = l.z[xi(k, c)];
+        for (int c = 0; c < NS; ++c) { x[c] = l.z[xi(k, c)]; xe[c] = l.z[xi(k + 1, c)]; }
         roll_interval(o, p, l.z, k, x, l.xs, f);
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
-          const double ck = x[c] - l.z[xi(k + 1, c)];                      // shooting.py:239-241
+          const double ck = x[c] - xe[c];                                  // shooting.py:239-241
           l.lam[(long)k * NS + c] = ck;
           c1 += fabs(ck);
           cinf = dmax(cinf, fabs(ck));
@@ -298,14 +354,17 @@ struct ShootWave {
         for (int c = 0; c < NS; ++c) x[c] = l.xs[(long)i * NS + c];
 #pragma unroll
         for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = l.z[ui(o, M * i, a)];
-        SC::slin(o.method, h, x, uc, p, zero, Fy, gy, Hs, h * i, i == S - 1);
-        double* r = l.rec + (long)i * REC;
         const bool node_next = ((i + 1) % cpi) == 0;
+        double caff[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) caff[t] = node_next ? l.lam[(long)(i / cpi) * NS + t] : 0.0;
+        SC::slin(o.method, h, x, uc, p, zero, Fy, gy, Hs, h * i, i == S - 1);
+        sw_lds* r = l.rec + (long)i * REC;
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
 #pragma unroll
           for (int c = 0; c < NY; ++c) r[R_GE + t * NY1 + c] = Fy[t * NY + c];
-          r[R_GE + t * NY1 + NY] = node_next ? l.lam[(long)(i / cpi) * NS + t] : 0.0;
+          r[R_GE + t * NY1 + NY] = caff[t];
         }
 #pragma unroll
         for (int c = 0; c < NY; ++c) r[R_GY + c] = gy[c];
@@ -317,35 +376,45 @@ struct ShootWave {
         double pi_c[NS], ru_c[NU], stat = 0, lam_inf = 0, sum_mult = 0; int n_mult = 0;
 #pragma unroll
         for (int c = 0; c < NS; ++c) {
-          const bool pinned = !(l.lb[xi(I, c)] < l.ub[xi(I, c)]);
-          l.ex[X_TP + c] = pinned ? 1.0 : 0.0;
-          pi_c[c] = pinned ? nuT[c] : l.zlu[xi(I, c)];
+          pi_c[c] = (l.ex[X_TP + c] != 0.0) ? nuT[c] : l.zlu[xi(I, c)];
         }
 #pragma unroll
         for (int a = 0; a < NU; ++a) ru_c[a] = l.zlu[ui(o, M * S, a)];
+        int k = I - 1, pos = cpi - 1;               // i = k cpi + pos (no integer division in the loop)
         for (int i = S - 1; i >= 0; --i) {
-          const int k = i / cpi;
-          const bool node_next = ((i + 1) % cpi) == 0, node_here = (i % cpi) == 0;
-          double pin[NS];
-#pragma unroll
-          for (int c = 0; c < NS; ++c) { pin[c] = pi_c[c]; l.pi[(long)(i + 1) * NS + c] = pin[c]; }
-          if (node_next) {
-#pragma unroll
-            for (int c = 0; c < NS; ++c) {
-              l.lam[(long)k * NS + c] = pin[c];            // lam_k = costate of the node
-              lam_inf = dmax(lam_inf, fabs(pin[c]));
-              sum_mult += fabs(pin[c]);
-            }
-            n_mult += NS;
-          }
-          const double* r = l.rec + (long)i * REC;
-          double Fy[NS * NY], gy[NY];
+          const bool node_next = pos == cpi - 1, node_here = pos == 0;
+          const int kk_ = k;
+          if (pos == 0) { pos = cpi - 1; --k; } else --pos;
+          const sw_lds* r = l.rec + (long)i * REC;
+          double Fy[NS * NY], gy[NY], zu[NU], zm[(M - 1) * NU + 1] = {0}, zx[NS] = {0};
 #pragma unroll
           for (int t = 0; t < NS; ++t)
 #pragma unroll
             for (int c = 0; c < NY; ++c) Fy[t * NY + c] = r[R_GE + t * NY1 + c];
 #pragma unroll
           for (int c = 0; c < NY; ++c) gy[c] = r[R_GY + c];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) zu[a] = l.zlu[ui(o, M * i, a)];
+          if constexpr (M > 1) {
+#pragma unroll
+            for (int q = 0; q < (M - 1) * NU; ++q) zm[q] = l.zlu[ui(o, M * i + 1, q)];
+          }
+          if (node_here && i > 0) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) zx[c] = l.zlu[xi(kk_, c)];
+          }
+          double pin[NS];
+#pragma unroll
+          for (int c = 0; c < NS; ++c) { pin[c] = pi_c[c]; l.pi[(long)(i + 1) * NS + c] = pin[c]; }
+          if (node_next) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+              l.lam[(long)kk_ * NS + c] = pin[c];            // lam_k = costate of the node
+              lam_inf = dmax(lam_inf, fabs(pin[c]));
+              sum_mult += fabs(pin[c]);
+            }
+            n_mult += NS;
+          }
 #pragma unroll
           for (int a = 0; a < NU; ++a) {
             double rr = ru_c[a] + gy[QN + a];
@@ -356,7 +425,7 @@ struct ShootWave {
           if constexpr (M > 1) {
 #pragma unroll
             for (int q = 0; q < (M - 1) * NU; ++q) {
-              double rr = gy[NW + q] + l.zlu[ui(o, M * i + 1, q)];
+              double rr = gy[NW + q] + zm[q];
 #pragma unroll
               for (int t = 0; t < NS; ++t) rr += Fy[t * NY + NW + q] * pin[t];
               stat = dmax(stat, fabs(rr));
@@ -375,11 +444,11 @@ struct ShootWave {
             double s = gy[NS + a];
 #pragma unroll
             for (int t = 0; t < NS; ++t) s += Fy[t * NY + NS + a] * pin[t];
-            ru_c[a] = s + l.zlu[ui(o, M * i, a)];
+            ru_c[a] = s + zu[a];
           }
           if (node_here && i > 0) {
 #pragma unroll
-            for (int c = 0; c < NS; ++c) npi[c] += l.zlu[xi(k, c)];
+            for (int c = 0; c < NS; ++c) npi[c] += zx[c];
           }
 #pragma unroll
           for (int c = 0; c < NS; ++c) pi_c[c] = npi[c];
@@ -400,9 +469,11 @@ struct ShootWave {
 #pragma unroll
         for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = l.z[ui(o, M * i, a)];
         SC::slin(o.method, h, x, uc, p, pin, Fy, gy, Hs, h * i, i == S - 1);
-        double* r = l.rec + (long)i * REC;
+        sw_lds* r = l.rec + (long)i * REC;
 #pragma unroll
-        for (int q = 0; q < NY * NY; ++q) r[R_HS + q] = Hs[q];
+        for (int a = 0; a < NY; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) r[R_HS + hsp(a, b)] = Hs[a * NY + b];
       }
       __syncthreads();
       MYR_SWT(3)
@@ -455,14 +526,16 @@ struct ShootWave {
       for (int i = S - 1; i >= 0; --i) {
         const int k = i / cpi;
         const bool node_here = (i % cpi) == 0;
-        const double* r = l.rec + (long)i * REC;
+        const sw_lds* r = l.rec + (long)i * REC;
         double Ge[NS * NY1], gy[NY], Hs[NY * NY], qdiag[NQ], qg1[NQ], Kk[NQ * NW], kc[NQ * NC];
 #pragma unroll
         for (int q = 0; q < NS * NY1; ++q) Ge[q] = r[R_GE + q];
 #pragma unroll
         for (int q = 0; q < NY; ++q) gy[q] = r[R_GY + q];
 #pragma unroll
-        for (int q = 0; q < NY * NY; ++q) Hs[q] = r[R_HS + q];
+        for (int a = 0; a < NY; ++a)
+#pragma unroll
+          for (int b = 0; b < NY; ++b) Hs[a * NY + b] = r[R_HS + hsp(a, b)];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { qdiag[q] = 0.0; qg1[q] = 0.0; }
         if constexpr (M > 1) {
@@ -474,7 +547,7 @@ struct ShootWave {
         }
         nreg += os_riccati_stage<Sys, M>(P, pc, Tnu, Ge, Hs, gy, o.reg_floor, Kk, kc, qdiag, qg1);
         if (nreg > 0 && so.abort_on_reg) { aborted = true; break; }
-        double* g = l.kg + (long)i * KG;
+        sw_lds* g = l.kg + (long)i * KG;
 #pragma unroll
         for (int q = 0; q < NQ * NW; ++q) g[q] = Kk[q];
 #pragma unroll
@@ -520,21 +593,70 @@ struct ShootWave {
 #pragma unroll
     for (int c = 0; c < NS; ++c) so.term_pinned[c] = l.ex[X_TP + c] != 0.0;
     __syncthreads();
+    MYR_SWT(4)
   }
 
-  // ---- forward recursion (one lane) and step limits (lanes over variables) ----
+  // ---- forward sweep (ShootCore::forward).  s_{i+1} = Phi_i s_i + phi_i, s = (dx, du) of a point: the closed-loop maps
+  // (gains applied to the step map, for the multipliers theta = (1, mu, nu)) are formed lanes-over-steps, the recursion is
+  // one small affine map per step in one lane, and the step y_i = (s_i, -K_i s_i - kc_i theta) with its directional
+  // derivative is again lanes-over-steps; step limits lanes-over-variables.
   __device__ static void forward(const HsWork& w, const HsSolveOpts& o, const double* p, double mu, const double* nu,
                                  const bool* term_pinned, FwdOut& fo) {
     (void)w; (void)p;
     const Lds l = lds(o);
-    const int lane = threadIdx.x, I = o.N, cpi = o.cpi, S = I * cpi, n = nvars(o);
+    const int lane = threadIdx.x, cpi = o.cpi, S = steps(o), n = nvars(o);
     const double tau = detail::dmax(o.tau_min, 1.0 - mu);
-    MYR_SWT0
-    if (lane == 0) {
-      double th[NC], s[NW], gphi = 0.0;
-      th[0] = 1.0; th[1] = mu;
+    MYR_SWT0F
+    double th[NC];
+    th[0] = 1.0; th[1] = mu;
 #pragma unroll
-      for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
+    for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
+    for (int i = lane; i < S; i += 64) {
+      sw_lds* r = l.rec + (long)i * REC;
+      const sw_lds* g = l.kg + (long)i * KG;
+      double Ge[NS * NY1], K[NQ * NW], kt[NQ];
+#pragma unroll
+      for (int q = 0; q < NS * NY1; ++q) Ge[q] = r[R_GE + q];
+#pragma unroll
+      for (int q = 0; q < NQ * NW; ++q) K[q] = g[q];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        double v = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) v += g[NQ * NW + q * NC + cc] * th[cc];
+        kt[q] = v;
+      }
+      double Phi[NW * NW], phi[NW];
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        const bool zero_ = (i == S - 1) && term_pinned[t];
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+          double v = Ge[t * NY1 + c];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) v -= Ge[t * NY1 + NW + q] * K[q * NW + c];
+          Phi[t * NW + c] = zero_ ? 0.0 : v;
+        }
+        double v = Ge[t * NY1 + NY];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v -= Ge[t * NY1 + NW + q] * kt[q];
+        phi[t] = zero_ ? 0.0 : v;
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        const int q = (M - 1) * NU + a;                   // the step's last control row is the next point's control
+#pragma unroll
+        for (int c = 0; c < NW; ++c) Phi[(NS + a) * NW + c] = -K[q * NW + c];
+        phi[NS + a] = -kt[q];
+      }
+#pragma unroll
+      for (int q = 0; q < NW * NW; ++q) r[R_PHI + q] = Phi[q];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) r[R_PHI + NW * NW + q] = phi[q];
+    }
+    __syncthreads();
+    if (lane == 0) {
+      double s[NW];
 #pragma unroll
       for (int c = 0; c < NS; ++c) { s[c] = 0.0; l.dz[xi(0, c)] = 0.0; }
 #pragma unroll
@@ -545,54 +667,71 @@ struct ShootWave {
         s[NS + a] = v;
         l.dz[ui(o, 0, a)] = v;
       }
+      double Pn[NW * NW + NW];
+#pragma unroll
+      for (int q = 0; q < NW * NW + NW; ++q) Pn[q] = l.rec[R_PHI + q];
       for (int i = 0; i < S; ++i) {
-        const double* r = l.rec + (long)i * REC;
-        const double* g = l.kg + (long)i * KG;
-        const bool node_next = ((i + 1) % cpi) == 0;
-        double y[NY];
+        double Pc[NW * NW + NW];
 #pragma unroll
-        for (int c = 0; c < NW; ++c) y[c] = s[c];
+        for (int q = 0; q < NW * NW + NW; ++q) Pc[q] = Pn[q];
+        if (i + 1 < S) {
+          const sw_lds* r = l.rec + (long)(i + 1) * REC + R_PHI;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          double v = 0.0;
-#pragma unroll
-          for (int c = 0; c < NW; ++c) v -= g[q * NW + c] * s[c];
-#pragma unroll
-          for (int cc = 0; cc < NC; ++cc) v -= g[NQ * NW + q * NC + cc] * th[cc];
-          y[NW + q] = v;
+          for (int q = 0; q < NW * NW + NW; ++q) Pn[q] = r[q];
         }
 #pragma unroll
-        for (int c = 0; c < NY; ++c) gphi += r[R_GY + c] * y[c];      // d(objective) along the lifted step
+        for (int c = 0; c < NW; ++c) l.sS[(long)i * NW + c] = s[c];
+        double sn[NW];
 #pragma unroll
-        for (int t = 0; t < NS; ++t) {
-          double v = r[R_GE + t * NY1 + NY];
+        for (int t = 0; t < NW; ++t) {
+          double v = Pc[NW * NW + t];
 #pragma unroll
-          for (int c = 0; c < NY; ++c) v += r[R_GE + t * NY1 + c] * y[c];
-          s[t] = (i == S - 1 && term_pinned[t]) ? 0.0 : v;
-        }
-        if (node_next) {
-#pragma unroll
-          for (int c = 0; c < NS; ++c) l.dz[xi((i + 1) / cpi, c)] = s[c];
-        }
-        if constexpr (M > 1) {
-#pragma unroll
-          for (int q = 0; q < (M - 1) * NU; ++q) l.dz[ui(o, M * i + 1, q)] = y[NW + q];
+          for (int c = 0; c < NW; ++c) v += Pc[t * NW + c] * s[c];
+          sn[t] = v;
         }
 #pragma unroll
-        for (int a = 0; a < NU; ++a) { s[NS + a] = y[QN + a]; l.dz[ui(o, M * i + M, a)] = y[QN + a]; }
+        for (int c = 0; c < NW; ++c) s[c] = sn[c];
       }
-      l.ex[X_GPHI] = gphi;
+#pragma unroll
+      for (int c = 0; c < NW; ++c) l.sS[(long)S * NW + c] = s[c];
+    }
+    __syncthreads();
+    double gphi = 0.0;
+    for (int i = lane; i < S; i += 64) {
+      const sw_lds* r = l.rec + (long)i * REC;
+      const sw_lds* g = l.kg + (long)i * KG;
+      double y[NY];
+#pragma unroll
+      for (int c = 0; c < NW; ++c) y[c] = l.sS[(long)i * NW + c];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        double v = 0.0;
+#pragma unroll
+        for (int c = 0; c < NW; ++c) v -= g[q * NW + c] * y[c];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) v -= g[NQ * NW + q * NC + cc] * th[cc];
+        y[NW + q] = v;
+      }
+#pragma unroll
+      for (int c = 0; c < NY; ++c) gphi += r[R_GY + c] * y[c];          // d(objective) along the lifted step
+      if (((i + 1) % cpi) == 0) {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) l.dz[xi((i + 1) / cpi, c)] = l.sS[(long)(i + 1) * NW + c];
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) l.dz[ui(o, M * i + 1, q)] = y[NW + q];     // rows M i + 1 .. M i + M: (mid,) next control
     }
     __syncthreads();
     FwdOut fl; fl.alpha_p = 1.0; fl.alpha_d = 1.0; fl.gphi = 0.0;
     for (int v = NS + lane; v < n; v += 64)       // every variable but x_0 (ShootCore::forward sets dz = 0 there, no limits)
       H::step_limits(l.z[v], l.lb[v], l.ub[v], l.zL[v], l.zU[v], l.dz[v], mu, 0.0, tau, fl);
-    fo.alpha_p = wv_min(fl.alpha_p); fo.alpha_d = wv_min(fl.alpha_d); fo.gphi = l.ex[X_GPHI] + wv_sum(fl.gphi);
+    fo.alpha_p = wv_min(fl.alpha_p); fo.alpha_d = wv_min(fl.alpha_d); fo.gphi = wv_sum(gphi + fl.gphi);
     __syncthreads();
-    MYR_SWT(5)
+    MYR_SWTF(5)
   }
 
-  // ---- merit function at z + alpha dz: trial point and barrier (lanes over variables), rollouts (lanes over intervals) ----
+  // ---- merit function at z + alpha dz: trial point and barrier (lanes over variables), rollouts (lanes over intervals).
+  // At alpha = 0 (the reference value of every line search) objective and defects are those of the sweep just done.
   __device__ static bool trial(const HsWork& w, const HsSolveOpts& o, const double* p, double alpha, double mu,
                                double& f, double& bar, double& c1) {
     (void)w;
@@ -600,6 +739,7 @@ struct ShootWave {
     const int lane = threadIdx.x, I = o.N, n = nvars(o);
     double fl = 0, bl = 0, cl = 0; int bad = 0;
     MYR_SWT0
+    const bool at_z = (alpha == 0.0) && (l.ex[X_VALID] != 0.0);
     for (int i = lane; i < n; i += 64) {
       const double v = l.z[i] + alpha * l.dz[i];
       const double lo = l.lb[i], ub = l.ub[i];
@@ -608,18 +748,23 @@ struct ShootWave {
       const double sl = hl ? v - lo : 1.0, su = hu ? ub - v : 1.0;
       bad += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
       bl -= log((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0));
-      l.zt[i] = v;
+      if (!at_z) l.zt[i] = v;
     }
-    __syncthreads();
-    for (int k = lane; k < I; k += 64) {
-      double x[NS];
+    if (at_z) {
+      f = l.ex[X_F]; c1 = l.ex[X_C1];
+    } else {
+      __syncthreads();
+      for (int k = lane; k < I; k += 64) {
+        double x[NS], xe[NS];
 #pragma unroll
-      for (int c = 0; c < NS; ++c) x[c] = l.zt[xi(k, c)];
-      roll_interval(o, p, l.zt, k, x, nullptr, fl);
+        for (int c = 0; c < NS; ++c) { x[c] = l.zt[xi(k, c)]; xe[c] = l.zt[xi(k + 1, c)]; }
+        roll_interval(o, p, l.zt, k, x, nullptr, fl);
 #pragma unroll
-      for (int c = 0; c < NS; ++c) cl += fabs(x[c] - l.zt[xi(k + 1, c)]);
+        for (int c = 0; c < NS; ++c) cl += fabs(x[c] - xe[c]);
+      }
+      f = wv_sum(fl); c1 = wv_sum(cl);
     }
-    f = wv_sum(fl); c1 = wv_sum(cl); bar = mu * wv_sum(bl); bad = wv_isum(bad);
+    bar = mu * wv_sum(bl); bad = wv_isum(bad);
     __syncthreads();
     MYR_SWT(6)
     if (bad != 0) return false;
@@ -632,7 +777,7 @@ struct ShootWave {
 // Persistent: grid = resident workgroups (one wavefront each); each pulls trajectories from `ticket`.  z / lb / ub / lam are
 // the caller's instance-major rows ([B][n], [B][I*NS]); the iterate is copied into LDS, solved there and copied back.
 template <class Sys, int M = 1>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, MYR_SHOOT_MIN_WAVES)
 void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                              const double* __restrict__ ub, double* __restrict__ lam, const double* __restrict__ params, int params_stride,
                              double* cost, int32_t* status, int32_t* iters, double* kkt) {
@@ -644,13 +789,14 @@ void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, dou
     if (threadIdx.x == 0) t = atomicAdd(ticket, 1);
     const long b = __builtin_amdgcn_readfirstlane(t);
     if (b >= B) break;
-    for (int i = threadIdx.x; i < n; i += 64) { l.z[i] = z[b * n + i]; l.lb[i] = lb[b * n + i]; l.ub[i] = ub[b * n + i]; }
+    for (int i = threadIdx.x; i < n; i += 64) { const double v = z[b * n + i]; l.z[i] = v; l.z0[i] = v; l.lb[i] = lb[b * n + i]; l.ub[i] = ub[b * n + i]; }
     if (threadIdx.x == 0) l.ex[W::X_Z] = 0.0;
     SysParams<Sys> pp;
     pp.load(params, b, params_stride);
     pp.set_scale(vs.s);
     __syncthreads();
-    HsWork w{{l.z, 1}, {l.lb, 1}, {l.ub, 1}, {l.zL, 1}, {l.zU, 1}, {l.lam, 1}, {l.dz, 1}, {l.rec, 1}};
+    HsWork w{{(double*)l.z, 1}, {(double*)l.lb, 1}, {(double*)l.ub, 1}, {(double*)l.zL, 1}, {(double*)l.zU, 1}, {(double*)l.lam, 1}, {(double*)l.dz, 1},
+             {(double*)l.rec, 1}};
     HsSolveResult r;
 #ifdef MYR_SW_TIMING
     if (threadIdx.x < 8) l.ex[W::X_T + threadIdx.x] = 0.0;
@@ -658,6 +804,23 @@ void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, dou
 #endif
     IpLoop<W>::run(w, o, pp.get(), r);
     __syncthreads();
+    // A solve that ends without a KKT point (line search stalled on a non-descent direction, iteration limit, non-finite
+    // values) is restarted from the caller's point with another initial barrier parameter (x3, then /3): the iterates of
+    // single shooting over a long horizon are sensitive enough that the slowest 0.01 % of a batch depend on rounding --
+    // config 3's trajectory 3985 stalls after 58 iterations from mu = 0.1 with this kernel's summation order and needs
+    // 31 .. 49 iterations from any of 0.01, 0.03, 0.3, 0.5, 1.  There is no restoration phase to fall back on;
+    // a second start is the cheap substitute.  Iterations and sweeps of all attempts are reported.
+    for (int attempt = 0; attempt < MYR_SHOOT_RESTARTS && r.status != 0; ++attempt) {
+      for (int i = threadIdx.x; i < n; i += 64) l.z[i] = l.z0[i];
+      __syncthreads();
+      HsSolveOpts o2 = o;
+      o2.mu_init = o.mu_init * (attempt == 0 ? 3.0 : 1.0 / 3.0);
+      HsSolveResult r2;
+      IpLoop<W>::run(w, o2, pp.get(), r2);
+      __syncthreads();
+      r2.iters += r.iters; r2.sweeps += r.sweeps;
+      r = r2;
+    }
 #ifdef MYR_SW_TIMING
     if (threadIdx.x == 0 && b < 3)
       printf("traj %ld it %d sweeps %d, x10ns: total %lld | own+rollout %.0f lin1 %.0f costate %.0f hess %.0f riccati %.0f forward %.0f trial %.0f\n", b, r.iters,
