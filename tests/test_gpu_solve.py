@@ -158,3 +158,64 @@ def test_long_horizon_falls_back_to_the_lane_solver():
     sols[N] = get_optimizer(hp, cfg, hp.system()).solve()
   assert sols[600]['x'].shape == (1201, 2)
   assert abs(sols[600]['cost'] - sols[60]['cost']) < 1e-4 * max(1.0, abs(sols[60]['cost']))
+
+
+def _shoot_opt(system, intervals, cpi, method):
+  from myriad_amd.config import Config, HParams, IntegrationMethod, NLPSolverType, OptimizerType
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = HParams(system=getattr(SystemType, system), optimizer=OptimizerType.SHOOTING, intervals=intervals, controls_per_interval=cpi,
+               integration_method=getattr(IntegrationMethod, method), nlpsolver=NLPSolverType.SQP)
+  return get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+
+
+@pytest.mark.parametrize("system,intervals,cpi,method", [
+    ("VANDERPOL", 1, 50, "HEUN"),        # config 3: single shooting, Riccati recursion on the matrix cores
+    ("VANDERPOL", 5, 10, "HEUN"),        # multiple shooting: node states with own terms inside the sweep
+    ("VANDERPOL", 1, 40, "EULER"),
+    ("VANDERPOL", 2, 20, "MIDPOINT"),
+    ("VANDERPOL", 1, 20, "RK4"),         # two control rows per step: the one-lane recursion (os_riccati_stage)
+    ("CARTPOLE", 4, 10, "HEUN"),         # NS = 4
+    ("CANCERTREATMENT", 1, 100, "HEUN"),
+])
+def test_shooting_wave_and_lane_kernels_agree(monkeypatch, system, intervals, cpi, method):
+  """shoot_solver_wave.h (one trajectory per wavefront, iterate in LDS) and ShootCore in the lane kernel are two mappings
+  of one algorithm: same status, same optimum, and the same iteration count on almost every instance (sums are associated
+  differently, so a few instances may take another number of iterations)."""
+  rng = np.random.default_rng(7)
+  B = 96
+  x_0 = np.array(_shoot_opt(system, intervals, cpi, method).system.x_0, float)
+  if system == "VANDERPOL":
+    x0 = np.clip(np.array([0., 1.]) + 0.1 * rng.standard_normal((B, 2)), -4, 4)
+  else:
+    x0 = x_0 * (1 + 0.05 * rng.standard_normal((B, len(x_0)))) + (0.02 * rng.standard_normal((B, len(x_0))) if system == "CARTPOLE" else 0.0)
+  out = {}
+  for mode in ("wave", "lane"):
+    monkeypatch.setenv("MYRIAD_SOLVE_MODE", mode)
+    out[mode] = _shoot_opt(system, intervals, cpi, method).solve_batch(x0s=x0)
+  w, l = out["wave"], out["lane"]
+  # same outcome, except where the wavefront kernel's second start (another initial barrier parameter) rescued a solve
+  # that runs into the iteration limit in both kernels (VANDERPOL, 40 Euler steps: 4 of 96)
+  assert ((w["status"] == l["status"]) | (w["status"] == 0)).all() and (w["status"] == 0).mean() >= 0.95
+  ok = (w["status"] == 0) & (l["status"] == 0)
+  np.testing.assert_allclose(w["cost"][ok], l["cost"][ok], rtol=1e-7)
+  assert (w["iters"][ok] == l["iters"][ok]).mean() >= 0.8, np.bincount(np.abs(w["iters"][ok] - l["iters"][ok]))
+  assert np.abs(w["xs_and_us"][ok] - l["xs_and_us"][ok]).max() < 1e-5
+  assert np.abs(w["lambda"][ok] - l["lambda"][ok]).max() < 1e-4 * max(1.0, np.abs(l["lambda"][ok]).max())
+
+
+def test_shooting_wave_kernel_restarts_a_stalled_solve(monkeypatch):
+  """Instance 3985 of the config-3 batch stalls in the line search after 58 iterations from mu = 0.1 with the wavefront
+  kernel's summation order (a non-descent direction at a point with 38 regularised pivots); the kernel starts it again from
+  the caller's point with mu x 3 and reports the iterations of both attempts."""
+  rng = np.random.default_rng(2019)
+  x0 = np.clip(np.array([0., 1.]) + 0.1 * rng.standard_normal((8192, 2)), -4, 4)[3985:3986]
+  monkeypatch.setenv("MYRIAD_SOLVE_MODE", "wave")
+  w = _shoot_opt("VANDERPOL", 1, 50, "HEUN").solve_batch(x0s=x0)
+  monkeypatch.setenv("MYRIAD_SOLVE_MODE", "lane")
+  l = _shoot_opt("VANDERPOL", 1, 50, "HEUN").solve_batch(x0s=x0)
+  assert w["status"][0] == 0 and l["status"][0] == 0
+  assert w["cost"][0] <= l["cost"][0] * (1 + 1e-6)
+  monkeypatch.setenv("MYRIAD_SOLVE_MODE", "wave")
+  opt = _shoot_opt("VANDERPOL", 1, 50, "HEUN")
+  assert np.abs(opt.constraints(w["xs_and_us"][0])).max() <= 1e-8
