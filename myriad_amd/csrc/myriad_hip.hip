@@ -503,7 +503,7 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
   return MYR_OK;
 }
 
-// shooting, one trajectory per wavefront (shoot_solver_wave.h) while the iterate fits 64 KB of LDS; else the lane form
+// shooting, one trajectory per wavefront (shoot_solver_wave.h) while the iterate fits the LDS of a CU; else the lane form
 template <class Sys, int M>
 static int launch_shoot_solve(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                               int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
@@ -511,9 +511,10 @@ static int launch_shoot_solve(myr_handle h, int B, double* z, const double* lb, 
   const int N = h->d.intervals, cpi = h->d.controls_per_interval;
   using W = ShootWave<Sys, M>;
   const size_t lds = W::lds_bytes(N, cpi);
-  if (h->solve_mode != 1 || lds > 64 * 1024)
+  if (h->solve_mode != 1 || lds > 160 * 1024)
     return launch_lane_solve<ShootCore<Sys, M>, Sys>(h, B, ShootCore<Sys, M>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   auto kern = shoot_solve_wave_kernel<Sys, M>;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int slots = h->solve_slots;
   if (slots <= 0) {
     int per_cu = 0, dev = 0, cus = 0;

@@ -176,6 +176,7 @@ def _shoot_opt(system, intervals, cpi, method):
     ("VANDERPOL", 2, 20, "MIDPOINT"),
     ("VANDERPOL", 1, 20, "RK4"),         # two control rows per step: the one-lane recursion (os_riccati_stage)
     ("CARTPOLE", 4, 10, "HEUN"),         # NS = 4
+    ("CARTPOLE", 20, 10, "HEUN"),        # 200 steps: 105 KB of LDS per trajectory, one workgroup per CU
     ("CANCERTREATMENT", 1, 100, "HEUN"),
 ])
 def test_shooting_wave_and_lane_kernels_agree(monkeypatch, system, intervals, cpi, method):
