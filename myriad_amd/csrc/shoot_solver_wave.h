@@ -309,6 +309,47 @@ struct ShootWave {
     return nreg;
   }
 
+  // Affine maps x -> A x + b (n x n) in registers, one per lane: composition and the two wave scans built on it.
+  // `wv_down(v, d)` = value of lane + d (own value beyond the wave), `wv_up` = lane - d.
+  __device__ static inline double wv_down(double v, int d) { return __shfl_down(v, d, 64); }
+  __device__ static inline double wv_up(double v, int d) { return __shfl_up(v, d, 64); }
+  template <int n>
+  __device__ static inline void affine_after(double* A, double* b, const double* A2, const double* b2) {   // (A,b) <- (A,b) o (A2,b2)
+    double R[n * n], r[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      double v = b[i];
+#pragma unroll
+      for (int k = 0; k < n; ++k) v += A[i * n + k] * b2[k];
+      r[i] = v;
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        double w = 0.0;
+#pragma unroll
+        for (int k = 0; k < n; ++k) w += A[i * n + k] * A2[k * n + j];
+        R[i * n + j] = w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) A[i] = R[i];
+#pragma unroll
+    for (int i = 0; i < n; ++i) b[i] = r[i];
+  }
+  // suffix scan: lane l <- T_l o T_{l+1} o .. o T_63        prefix scan: lane l <- T_l o T_{l-1} o .. o T_0
+  template <int n, bool SUFFIX>
+  __device__ static inline void affine_scan(double* A, double* b) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      double A2[n * n], b2[n];
+#pragma unroll
+      for (int i = 0; i < n * n; ++i) A2[i] = SUFFIX ? wv_down(A[i], d) : wv_up(A[i], d);
+#pragma unroll
+      for (int i = 0; i < n; ++i) b2[i] = SUFFIX ? wv_down(b[i], d) : wv_up(b[i], d);
+      if (SUFFIX ? (lane + d < 64) : (lane >= d)) affine_after<n>(A, b, A2, b2);
+    }
+  }
+
   // ---- backward sweep (ShootCore::backward): linearisation at the current iterate (once per iterate), Riccati recursion ----
   __device__ static void backward(const HsWork& w, const HsSolveOpts& o, const double* p, const double* nuT, double delta, SweepOut& so) {
     using namespace detail;
@@ -346,134 +387,128 @@ struct ShootWave {
       f = wv_sum(f); c1 = wv_sum(c1); cinf = wv_max(cinf); cmax = wv_max(cmax); cmin = wv_min(cmin);
       __syncthreads();
       MYR_SWT(0)
-      // first-order step linearisations
-      const double zero[NS] = {0};
-      for (int i = lane; i < S; i += 64) {
-        double x[NS], uc[(M + 1) * NU], Fy[NS * NY], gy[NY], Hs[NY * NY];
+      // Step linearisations, costates, step Hessians in ONE pass, lanes over steps (64 steps at a time, from the end).
+      // The costate recursion pi_i = Fx_i^T pi_{i+1} + gx_i (+ own terms of a node state) is affine: a suffix scan of map
+      // compositions over the wave (6 rounds) gives every lane the costate behind its step, with which it evaluates its
+      // step Hessian right away; multipliers of the node defects and the stationarity residuals follow lane-wise.
+      {
+        double piS[NS], ruS[NU];          // costate / control-row residual of the point behind the current block (uniform)
 #pragma unroll
-        for (int c = 0; c < NS; ++c) x[c] = l.xs[(long)i * NS + c];
+        for (int c = 0; c < NS; ++c) piS[c] = (l.ex[X_TP + c] != 0.0) ? nuT[c] : l.zlu[xi(I, c)];
 #pragma unroll
-        for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = l.z[ui(o, M * i, a)];
-        const bool node_next = ((i + 1) % cpi) == 0;
-        double caff[NS];
+        for (int a = 0; a < NU; ++a) ruS[a] = l.zlu[ui(o, M * S, a)];
+        double stat = 0, lam_inf = 0, sum_mult = 0;
+        const double zero[NS] = {0};
+        for (int base = ((S - 1) / 64) * 64; base >= 0; base -= 64) {
+          const int i = base + lane;
+          const bool on = i < S;
+          const int k = on ? i / cpi : 0;
+          const bool node_next = on && (i + 1 == (k + 1) * cpi), node_here = on && (i == k * cpi);
+          double x[NS], uc[(M + 1) * NU], Fy[NS * NY], gy[NY], Hs[NY * NY], A[NS * NS], bb[NS];
 #pragma unroll
-        for (int t = 0; t < NS; ++t) caff[t] = node_next ? l.lam[(long)(i / cpi) * NS + t] : 0.0;
-        SC::slin(o.method, h, x, uc, p, zero, Fy, gy, Hs, h * i, i == S - 1);
-        sw_lds* r = l.rec + (long)i * REC;
+          for (int q = 0; q < NS * NS; ++q) A[q] = ((q / NS) == (q % NS)) ? 1.0 : 0.0;     // identity beyond the last step
 #pragma unroll
-        for (int t = 0; t < NS; ++t) {
+          for (int q = 0; q < NS; ++q) bb[q] = 0.0;
 #pragma unroll
-          for (int c = 0; c < NY; ++c) r[R_GE + t * NY1 + c] = Fy[t * NY + c];
-          r[R_GE + t * NY1 + NY] = caff[t];
-        }
+          for (int q = 0; q < NS * NY; ++q) Fy[q] = 0.0;
 #pragma unroll
-        for (int c = 0; c < NY; ++c) r[R_GY + c] = gy[c];
-      }
-      __syncthreads();
-      MYR_SWT(1)
-      // costates (one lane): pi_{i+1} = costate of the state after step i; multipliers of the node defects; stationarity
-      if (lane == 0) {
-        double pi_c[NS], ru_c[NU], stat = 0, lam_inf = 0, sum_mult = 0; int n_mult = 0;
+          for (int q = 0; q < NY; ++q) gy[q] = 0.0;
+          if (on) {
 #pragma unroll
-        for (int c = 0; c < NS; ++c) {
-          pi_c[c] = (l.ex[X_TP + c] != 0.0) ? nuT[c] : l.zlu[xi(I, c)];
-        }
+            for (int c = 0; c < NS; ++c) x[c] = l.xs[(long)i * NS + c];
 #pragma unroll
-        for (int a = 0; a < NU; ++a) ru_c[a] = l.zlu[ui(o, M * S, a)];
-        int k = I - 1, pos = cpi - 1;               // i = k cpi + pos (no integer division in the loop)
-        for (int i = S - 1; i >= 0; --i) {
-          const bool node_next = pos == cpi - 1, node_here = pos == 0;
-          const int kk_ = k;
-          if (pos == 0) { pos = cpi - 1; --k; } else --pos;
-          const sw_lds* r = l.rec + (long)i * REC;
-          double Fy[NS * NY], gy[NY], zu[NU], zm[(M - 1) * NU + 1] = {0}, zx[NS] = {0};
+            for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = l.z[ui(o, M * i, a)];
+            double caff[NS];
 #pragma unroll
-          for (int t = 0; t < NS; ++t)
+            for (int t = 0; t < NS; ++t) caff[t] = node_next ? l.lam[(long)k * NS + t] : 0.0;
+            SC::slin(o.method, h, x, uc, p, zero, Fy, gy, Hs, h * i, i == S - 1);
+            sw_lds* r = l.rec + (long)i * REC;
 #pragma unroll
-            for (int c = 0; c < NY; ++c) Fy[t * NY + c] = r[R_GE + t * NY1 + c];
+            for (int t = 0; t < NS; ++t) {
 #pragma unroll
-          for (int c = 0; c < NY; ++c) gy[c] = r[R_GY + c];
+              for (int c = 0; c < NY; ++c) r[R_GE + t * NY1 + c] = Fy[t * NY + c];
+              r[R_GE + t * NY1 + NY] = caff[t];
+            }
 #pragma unroll
-          for (int a = 0; a < NU; ++a) zu[a] = l.zlu[ui(o, M * i, a)];
-          if constexpr (M > 1) {
-#pragma unroll
-            for (int q = 0; q < (M - 1) * NU; ++q) zm[q] = l.zlu[ui(o, M * i + 1, q)];
-          }
-          if (node_here && i > 0) {
-#pragma unroll
-            for (int c = 0; c < NS; ++c) zx[c] = l.zlu[xi(kk_, c)];
-          }
-          double pin[NS];
-#pragma unroll
-          for (int c = 0; c < NS; ++c) { pin[c] = pi_c[c]; l.pi[(long)(i + 1) * NS + c] = pin[c]; }
-          if (node_next) {
+            for (int c = 0; c < NY; ++c) r[R_GY + c] = gy[c];
 #pragma unroll
             for (int c = 0; c < NS; ++c) {
-              l.lam[(long)kk_ * NS + c] = pin[c];            // lam_k = costate of the node
-              lam_inf = dmax(lam_inf, fabs(pin[c]));
-              sum_mult += fabs(pin[c]);
-            }
-            n_mult += NS;
-          }
 #pragma unroll
-          for (int a = 0; a < NU; ++a) {
-            double rr = ru_c[a] + gy[QN + a];
-#pragma unroll
-            for (int t = 0; t < NS; ++t) rr += Fy[t * NY + QN + a] * pin[t];
-            stat = dmax(stat, fabs(rr));
-          }
-          if constexpr (M > 1) {
-#pragma unroll
-            for (int q = 0; q < (M - 1) * NU; ++q) {
-              double rr = gy[NW + q] + zm[q];
-#pragma unroll
-              for (int t = 0; t < NS; ++t) rr += Fy[t * NY + NW + q] * pin[t];
-              stat = dmax(stat, fabs(rr));
+              for (int t = 0; t < NS; ++t) A[c * NS + t] = Fy[t * NY + c];
+              bb[c] = gy[c] + ((node_here && i > 0) ? l.zlu[xi(k, c)] : 0.0);
             }
           }
-          double npi[NS];
+          affine_scan<NS, true>(A, bb);
+          double pi_i[NS], pin[NS];
 #pragma unroll
           for (int c = 0; c < NS; ++c) {
-            double s = gy[c];
+            double v = bb[c];
 #pragma unroll
-            for (int t = 0; t < NS; ++t) s += Fy[t * NY + c] * pin[t];
-            npi[c] = s;
+            for (int t = 0; t < NS; ++t) v += A[c * NS + t] * piS[t];
+            pi_i[c] = v;
           }
+#pragma unroll
+          for (int c = 0; c < NS; ++c) { const double t = wv_down(pi_i[c], 1); pin[c] = (lane == 63) ? piS[c] : t; }
+          // residual of the step's first control row (own part), then the stationarity of its last row
+          double ru[NU], run[NU];
 #pragma unroll
           for (int a = 0; a < NU; ++a) {
-            double s = gy[NS + a];
+            double v = ruS[a];
+            if (on) {
+              v = gy[NS + a] + l.zlu[ui(o, M * i, a)];
 #pragma unroll
-            for (int t = 0; t < NS; ++t) s += Fy[t * NY + NS + a] * pin[t];
-            ru_c[a] = s + zu[a];
+              for (int t = 0; t < NS; ++t) v += Fy[t * NY + NS + a] * pin[t];
+            }
+            ru[a] = v;
           }
-          if (node_here && i > 0) {
 #pragma unroll
-            for (int c = 0; c < NS; ++c) npi[c] += zx[c];
+          for (int a = 0; a < NU; ++a) { const double t = wv_down(ru[a], 1); run[a] = (lane == 63) ? ruS[a] : t; }
+          if (on) {
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+              double rr = run[a] + gy[QN + a];
+#pragma unroll
+              for (int t = 0; t < NS; ++t) rr += Fy[t * NY + QN + a] * pin[t];
+              stat = dmax(stat, fabs(rr));
+            }
+            if constexpr (M > 1) {
+#pragma unroll
+              for (int q = 0; q < (M - 1) * NU; ++q) {
+                double rr = gy[NW + q] + l.zlu[ui(o, M * i + 1, q)];
+#pragma unroll
+                for (int t = 0; t < NS; ++t) rr += Fy[t * NY + NW + q] * pin[t];
+                stat = dmax(stat, fabs(rr));
+              }
+            }
+            if (node_next) {
+#pragma unroll
+              for (int c = 0; c < NS; ++c) {
+                l.lam[(long)k * NS + c] = pin[c];            // lam_k = costate of the node
+                lam_inf = dmax(lam_inf, fabs(pin[c]));
+                sum_mult += fabs(pin[c]);
+              }
+            }
+            // step Hessian of the Lagrangian with the costate of the step's end state
+            SC::slin(o.method, h, x, uc, p, pin, Fy, gy, Hs, h * i, i == S - 1);
+            sw_lds* r = l.rec + (long)i * REC;
+#pragma unroll
+            for (int a = 0; a < NY; ++a)
+#pragma unroll
+              for (int b2 = 0; b2 <= a; ++b2) r[R_HS + hsp(a, b2)] = Hs[a * NY + b2];
           }
 #pragma unroll
-          for (int c = 0; c < NS; ++c) pi_c[c] = npi[c];
+          for (int c = 0; c < NS; ++c) piS[c] = __shfl(pi_i[c], 0, 64);
+#pragma unroll
+          for (int a = 0; a < NU; ++a) ruS[a] = __shfl(ru[a], 0, 64);
         }
 #pragma unroll
-        for (int a = 0; a < NU; ++a) stat = dmax(stat, fabs(ru_c[a]));
-        l.ex[X_F] = f; l.ex[X_C1] = c1; l.ex[X_CINF] = cinf; l.ex[X_STAT] = stat; l.ex[X_CMAX] = cmax; l.ex[X_CMIN] = cmin;
-        l.ex[X_LAMINF] = lam_inf; l.ex[X_SUMMULT] = sum_mult; l.ex[X_NMULT] = (double)n_mult;
-        l.ex[X_VALID] = 1.0;
-      }
-      __syncthreads();
-      MYR_SWT(2)
-      // step Hessians of the Lagrangian (costate of the step's end state)
-      for (int i = lane; i < S; i += 64) {
-        double x[NS], uc[(M + 1) * NU], pin[NS], Fy[NS * NY], gy[NY], Hs[NY * NY];
-#pragma unroll
-        for (int c = 0; c < NS; ++c) { x[c] = l.xs[(long)i * NS + c]; pin[c] = l.pi[(long)(i + 1) * NS + c]; }
-#pragma unroll
-        for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = l.z[ui(o, M * i, a)];
-        SC::slin(o.method, h, x, uc, p, pin, Fy, gy, Hs, h * i, i == S - 1);
-        sw_lds* r = l.rec + (long)i * REC;
-#pragma unroll
-        for (int a = 0; a < NY; ++a)
-#pragma unroll
-          for (int b = 0; b <= a; ++b) r[R_HS + hsp(a, b)] = Hs[a * NY + b];
+        for (int a = 0; a < NU; ++a) stat = dmax(stat, fabs(ruS[a]));          // first point
+        stat = wv_max(stat); lam_inf = wv_max(lam_inf); sum_mult = wv_sum(sum_mult);
+        if (lane == 0) {
+          l.ex[X_F] = f; l.ex[X_C1] = c1; l.ex[X_CINF] = cinf; l.ex[X_STAT] = stat; l.ex[X_CMAX] = cmax; l.ex[X_CMIN] = cmin;
+          l.ex[X_LAMINF] = lam_inf; l.ex[X_SUMMULT] = sum_mult; l.ex[X_NMULT] = (double)(I * NS);
+          l.ex[X_VALID] = 1.0;
+        }
       }
       __syncthreads();
       MYR_SWT(3)
@@ -596,10 +631,10 @@ struct ShootWave {
     MYR_SWT(4)
   }
 
-  // ---- forward sweep (ShootCore::forward).  s_{i+1} = Phi_i s_i + phi_i, s = (dx, du) of a point: the closed-loop maps
-  // (gains applied to the step map, for the multipliers theta = (1, mu, nu)) are formed lanes-over-steps, the recursion is
-  // one small affine map per step in one lane, and the step y_i = (s_i, -K_i s_i - kc_i theta) with its directional
-  // derivative is again lanes-over-steps; step limits lanes-over-variables.
+  // ---- forward sweep (ShootCore::forward).  s_{i+1} = Phi_i s_i + phi_i, s = (dx, du) of a point: every lane forms the
+  // closed-loop map of its step (gains applied to the step map, for the multipliers theta = (1, mu, nu)), a prefix scan
+  // of map compositions over the wave gives it the state in front of its step, from which it takes its step
+  // y_i = (s_i, -K_i s_i - kc_i theta) and its share of the directional derivative; step limits lanes-over-variables.
   __device__ static void forward(const HsWork& w, const HsSolveOpts& o, const double* p, double mu, const double* nu,
                                  const bool* term_pinned, FwdOut& fo) {
     (void)w; (void)p;
@@ -611,115 +646,104 @@ struct ShootWave {
     th[0] = 1.0; th[1] = mu;
 #pragma unroll
     for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
-    for (int i = lane; i < S; i += 64) {
-      sw_lds* r = l.rec + (long)i * REC;
-      const sw_lds* g = l.kg + (long)i * KG;
-      double Ge[NS * NY1], K[NQ * NW], kt[NQ];
+    // 64 steps at a time: closed-loop maps in registers, prefix scan of their compositions, then every lane's own step
+    double s0[NW], gphi = 0.0;          // state (dx, du) of the first point of the block (uniform)
 #pragma unroll
-      for (int q = 0; q < NS * NY1; ++q) Ge[q] = r[R_GE + q];
+    for (int c = 0; c < NS; ++c) s0[c] = 0.0;
 #pragma unroll
-      for (int q = 0; q < NQ * NW; ++q) K[q] = g[q];
+    for (int a = 0; a < NU; ++a) {
+      double v = 0.0;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        double v = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) v += g[NQ * NW + q * NC + cc] * th[cc];
-        kt[q] = v;
-      }
-      double Phi[NW * NW], phi[NW];
-#pragma unroll
-      for (int t = 0; t < NS; ++t) {
-        const bool zero_ = (i == S - 1) && term_pinned[t];
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-          double v = Ge[t * NY1 + c];
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) v -= Ge[t * NY1 + NW + q] * K[q * NW + c];
-          Phi[t * NW + c] = zero_ ? 0.0 : v;
-        }
-        double v = Ge[t * NY1 + NY];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) v -= Ge[t * NY1 + NW + q] * kt[q];
-        phi[t] = zero_ ? 0.0 : v;
-      }
-#pragma unroll
-      for (int a = 0; a < NU; ++a) {
-        const int q = (M - 1) * NU + a;                   // the step's last control row is the next point's control
-#pragma unroll
-        for (int c = 0; c < NW; ++c) Phi[(NS + a) * NW + c] = -K[q * NW + c];
-        phi[NS + a] = -kt[q];
-      }
-#pragma unroll
-      for (int q = 0; q < NW * NW; ++q) r[R_PHI + q] = Phi[q];
-#pragma unroll
-      for (int q = 0; q < NW; ++q) r[R_PHI + NW * NW + q] = phi[q];
+      for (int cc = 0; cc < NC; ++cc) v -= l.ku[a * NC + cc] * th[cc];
+      s0[NS + a] = v;
     }
-    __syncthreads();
     if (lane == 0) {
-      double s[NW];
 #pragma unroll
-      for (int c = 0; c < NS; ++c) { s[c] = 0.0; l.dz[xi(0, c)] = 0.0; }
+      for (int c = 0; c < NS; ++c) l.dz[xi(0, c)] = 0.0;
 #pragma unroll
-      for (int a = 0; a < NU; ++a) {
-        double v = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) v -= l.ku[a * NC + cc] * th[cc];
-        s[NS + a] = v;
-        l.dz[ui(o, 0, a)] = v;
-      }
-      double Pn[NW * NW + NW];
-#pragma unroll
-      for (int q = 0; q < NW * NW + NW; ++q) Pn[q] = l.rec[R_PHI + q];
-      for (int i = 0; i < S; ++i) {
-        double Pc[NW * NW + NW];
-#pragma unroll
-        for (int q = 0; q < NW * NW + NW; ++q) Pc[q] = Pn[q];
-        if (i + 1 < S) {
-          const sw_lds* r = l.rec + (long)(i + 1) * REC + R_PHI;
-#pragma unroll
-          for (int q = 0; q < NW * NW + NW; ++q) Pn[q] = r[q];
-        }
-#pragma unroll
-        for (int c = 0; c < NW; ++c) l.sS[(long)i * NW + c] = s[c];
-        double sn[NW];
-#pragma unroll
-        for (int t = 0; t < NW; ++t) {
-          double v = Pc[NW * NW + t];
-#pragma unroll
-          for (int c = 0; c < NW; ++c) v += Pc[t * NW + c] * s[c];
-          sn[t] = v;
-        }
-#pragma unroll
-        for (int c = 0; c < NW; ++c) s[c] = sn[c];
-      }
-#pragma unroll
-      for (int c = 0; c < NW; ++c) l.sS[(long)S * NW + c] = s[c];
+      for (int a = 0; a < NU; ++a) l.dz[ui(o, 0, a)] = s0[NS + a];
     }
-    __syncthreads();
-    double gphi = 0.0;
-    for (int i = lane; i < S; i += 64) {
-      const sw_lds* r = l.rec + (long)i * REC;
-      const sw_lds* g = l.kg + (long)i * KG;
-      double y[NY];
+    for (int base = 0; base < S; base += 64) {
+      const int i = base + lane;
+      const bool on = i < S;
+      double Phi[NW * NW], phi[NW], K[NQ * NW], kt[NQ], gy[NY];
 #pragma unroll
-      for (int c = 0; c < NW; ++c) y[c] = l.sS[(long)i * NW + c];
+      for (int q = 0; q < NW * NW; ++q) Phi[q] = ((q / NW) == (q % NW)) ? 1.0 : 0.0;       // identity beyond the last step
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        double v = 0.0;
+      for (int q = 0; q < NW; ++q) phi[q] = 0.0;
+      if (on) {
+        const sw_lds* r = l.rec + (long)i * REC;
+        const sw_lds* g = l.kg + (long)i * KG;
+        double Ge[NS * NY1];
 #pragma unroll
-        for (int c = 0; c < NW; ++c) v -= g[q * NW + c] * y[c];
+        for (int q = 0; q < NS * NY1; ++q) Ge[q] = r[R_GE + q];
 #pragma unroll
-        for (int cc = 0; cc < NC; ++cc) v -= g[NQ * NW + q * NC + cc] * th[cc];
-        y[NW + q] = v;
+        for (int q = 0; q < NY; ++q) gy[q] = r[R_GY + q];
+#pragma unroll
+        for (int q = 0; q < NQ * NW; ++q) K[q] = g[q];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          double v = 0.0;
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc) v += g[NQ * NW + q * NC + cc] * th[cc];
+          kt[q] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+          const bool zero_ = (i == S - 1) && term_pinned[t];
+#pragma unroll
+          for (int c = 0; c < NW; ++c) {
+            double v = Ge[t * NY1 + c];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) v -= Ge[t * NY1 + NW + q] * K[q * NW + c];
+            Phi[t * NW + c] = zero_ ? 0.0 : v;
+          }
+          double v = Ge[t * NY1 + NY];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) v -= Ge[t * NY1 + NW + q] * kt[q];
+          phi[t] = zero_ ? 0.0 : v;
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          const int q = (M - 1) * NU + a;                   // the step's last control row is the next point's control
+#pragma unroll
+          for (int c = 0; c < NW; ++c) Phi[(NS + a) * NW + c] = -K[q * NW + c];
+          phi[NS + a] = -kt[q];
+        }
+      }
+      affine_scan<NW, false>(Phi, phi);
+      double sn[NW], sc[NW];                // state behind / in front of this lane's step
+#pragma unroll
+      for (int t = 0; t < NW; ++t) {
+        double v = phi[t];
+#pragma unroll
+        for (int c = 0; c < NW; ++c) v += Phi[t * NW + c] * s0[c];
+        sn[t] = v;
       }
 #pragma unroll
-      for (int c = 0; c < NY; ++c) gphi += r[R_GY + c] * y[c];          // d(objective) along the lifted step
-      if (((i + 1) % cpi) == 0) {
+      for (int c = 0; c < NW; ++c) { const double t = wv_up(sn[c], 1); sc[c] = (lane == 0) ? s0[c] : t; }
+      if (on) {
+        double y[NY];
 #pragma unroll
-        for (int c = 0; c < NS; ++c) l.dz[xi((i + 1) / cpi, c)] = l.sS[(long)(i + 1) * NW + c];
+        for (int c = 0; c < NW; ++c) y[c] = sc[c];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          double v = -kt[q];
+#pragma unroll
+          for (int c = 0; c < NW; ++c) v -= K[q * NW + c] * y[c];
+          y[NW + q] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < NY; ++c) gphi += gy[c] * y[c];          // d(objective) along the lifted step
+        if (((i + 1) % cpi) == 0) {
+#pragma unroll
+          for (int c = 0; c < NS; ++c) l.dz[xi((i + 1) / cpi, c)] = sn[c];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) l.dz[ui(o, M * i + 1, q)] = y[NW + q];     // rows M i + 1 .. M i + M: (mid,) next control
       }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) l.dz[ui(o, M * i + 1, q)] = y[NW + q];     // rows M i + 1 .. M i + M: (mid,) next control
+      for (int c = 0; c < NW; ++c) s0[c] = __shfl(sn[c], 63, 64);
     }
     __syncthreads();
     FwdOut fl; fl.alpha_p = 1.0; fl.alpha_d = 1.0; fl.gphi = 0.0;
