@@ -49,11 +49,9 @@ struct ShootWave {
   using SweepOut = typename H::SweepOut;
   using FwdOut = typename H::FwdOut;
 
-  // stage record: gy (NY), Fy | c (NS x NY1, the step map dx_next = Fy y + c), Hs (NY x NY, lower triangle packed).
-  // The forward sweep overlays its closed-loop map Phi | phi (NW x NW + NW) on Fy | c and Hs, both dead by then.
+  // stage record: gy (NY), Fy | c (NS x NY1, the step map dx_next = Fy y + c), Hs (NY x NY, lower triangle packed)
   static constexpr int HSP = NY * (NY + 1) / 2;
-  static constexpr int R_GY = 0, R_GE = R_GY + NY, R_HS = R_GE + NS * NY1, REC = R_HS + HSP, R_PHI = R_GE;
-  static_assert(NW * NW + NW <= NS * NY1 + HSP, "closed-loop map fits the dead part of the stage record");
+  static constexpr int R_GY = 0, R_GE = R_GY + NY, R_HS = R_GE + NS * NY1, REC = R_HS + HSP;
   __host__ __device__ static constexpr int hsp(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
   static constexpr int KG = NQ * NW + NQ * NC;        // gains K | kc of a stage
   // exchange block (first in LDS): results of the one-lane phases and of the last linearisation, for all lanes
@@ -61,20 +59,20 @@ struct ShootWave {
                        X_NMULT = 9, X_NREG = 10, X_GPHI = 11, X_TNU = 12, X_TP = X_TNU + NS * NC,
                        X_T = X_TP + NS /* 8 phase timers (developer knob MYR_SW_TIMING) */,
                        X_Z = X_T + 8 /* a zero and a write-only slot */, X_P = X_Z + 2, X_PC = X_P + NW * NW,
-                       X_N = (X_PC + NW * NC + 7) / 8 * 8;
+                       // the last trial point: step length, objective, defect norms; 1 if its rollout is the current iterate's;
+                       // problem dimensions for the phases that are not handed the options (update)
+                       X_TA = X_PC + NW * NC, X_TF = X_TA + 1, X_TC1 = X_TF + 1, X_TCINF = X_TC1 + 1, X_ROLL = X_TCINF + 1,
+                       X_DN = X_ROLL + 1, X_DCPI = X_DN + 1, X_N = (X_DCPI + 1 + 7) / 8 * 8;
 
   __host__ __device__ static inline int steps(const HsSolveOpts& o) { return o.N * o.cpi; }
   __host__ __device__ static inline int nvars(const HsSolveOpts& o) { return (o.N + 1) * NS + (M * steps(o) + 1) * NU; }
   __host__ __device__ static inline long xi(int k, int c) { return SC::xi(k, c); }
   __host__ __device__ static inline long ui(const HsSolveOpts& o, int i, int a) { return SC::ui(o, i, a); }
-  // shared scratch region: rollout states | costates (linearisation), closed-loop states (forward), trial point (merit)
-  __host__ __device__ static long tmp_doubles(long S, long n) {
-    const long a = 2 * (S + 1) * NS, b = (S + 1) * NW;
-    return a > b ? (a > n ? a : n) : (b > n ? b : n);
-  }
+  // rollout states of the iterate, rollout states of the last trial point, the trial point
+  __host__ __device__ static long tmp_doubles(long S, long n) { return 2 * (S + 1) * NS + n; }
   __host__ __device__ static long lds_doubles(int I, int cpi) {
     const long S = (long)I * cpi, n = (long)(I + 1) * NS + (M * S + 1) * NU;
-    return X_N + 9 * n + tmp_doubles(S, n) + S * (REC + KG) + NU * NC + (long)I * NS;
+    return X_N + 9 * n + tmp_doubles(S, n) + S * (REC + KG) + NU * NC + 2 * (long)I * NS;
   }
   __host__ __device__ static size_t lds_bytes(int I, int cpi) { return (size_t)lds_doubles(I, cpi) * 8; }
 
@@ -82,9 +80,8 @@ struct ShootWave {
     sw_lds *ex, *z, *lb, *ub, *zL, *zU, *dz, *sig, *g1, *rec, *kg, *ku, *lam;
     sw_lds *z0;              // the caller's starting point (restart after a failed solve, see the kernel)
     sw_lds *zlu;             // = dz  (bound-multiplier difference, dead before the step is written)
-    // one region, three lives: rollout states | costates (linearisation), states of the closed-loop recursion (forward),
-    // trial point (merit function)
-    sw_lds *xs, *pi, *sS, *zt;
+    sw_lds *xs, *xt, *zt;    // rollout states of the iterate / of the last trial point, the trial point
+    sw_lds *ct;              // continuity defects of the last trial point
   };
   __device__ static inline sw_lds* lds_base() {
     extern __shared__ __attribute__((aligned(16))) char smem_wave[];
@@ -98,8 +95,8 @@ struct ShootWave {
     l.z = s; s += n; l.lb = s; s += n; l.ub = s; s += n; l.zL = s; s += n; l.zU = s; s += n; l.dz = s; s += n;
     l.sig = s; s += n; l.g1 = s; s += n; l.z0 = s; s += n;
     l.zlu = l.dz;
-    l.xs = s; l.pi = s + (S + 1) * NS; l.sS = s; l.zt = s; s += tmp_doubles(S, n);
-    l.rec = s; s += S * REC; l.kg = s; s += S * KG; l.ku = s; s += NU * NC; l.lam = s;
+    l.xs = s; l.xt = s + (S + 1) * NS; l.zt = s + 2 * (S + 1) * NS; s += tmp_doubles(S, n);
+    l.rec = s; s += S * REC; l.kg = s; s += S * KG; l.ku = s; s += NU * NC; l.lam = s; s += steps(o) / o.cpi * NS; l.ct = s;
     return l;
   }
 #ifdef MYR_SW_TIMING
@@ -133,30 +130,39 @@ struct ShootWave {
       zL[i] = hl ? 1.0 : 0.0;
       zU[i] = hu ? 1.0 : 0.0;
     }
-    if (threadIdx.x == 0) lds_base()[X_VALID] = 0.0;
+    if (threadIdx.x == 0) { lds_base()[X_VALID] = 0.0; lds_base()[X_ROLL] = 0.0; }
     __syncthreads();
   }
+  // The accepted step is the last trial point of the line search: its values ARE the new iterate (bit for bit), and its
+  // rollout -- states, defects, objective -- is kept for the next sweep instead of being integrated again.
   __device__ static void update(const HsWork& w, int n, double ap, double ad, double mu, double ksig) {
     const double iks = 1.0 / ksig;
-    sw_lds* z = (sw_lds*)w.z.p; sw_lds* lb = (sw_lds*)w.lb.p; sw_lds* ub = (sw_lds*)w.ub.p; sw_lds* zL = (sw_lds*)w.zL.p; sw_lds* zU = (sw_lds*)w.zU.p;
-    sw_lds* dz = (sw_lds*)w.dz.p;
+    sw_lds* ex = lds_base();
+    HsSolveOpts od; od.N = (int)ex[X_DN]; od.cpi = (int)ex[X_DCPI];
+    const Lds l = lds(od);
+    const bool reuse = ex[X_TA] == ap && ap > 0.0;
     for (int i = threadIdx.x; i < n; i += 64) {
-      const double l = lb[i], u = ub[i], zv = z[i], d = dz[i], zl = zL[i], zu = zU[i];
-      const bool fr = l < u;
-      const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
-      const double zn = fr ? zv + ap * d : zv;
-      const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
-      const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
+      const double lo = l.lb[i], u = l.ub[i], zv = l.z[i], d = l.dz[i], zl = l.zL[i], zu = l.zU[i];
+      const bool fr = lo < u;
+      const bool hl = fr && (lo > -INFINITY), hu = fr && (u < INFINITY);
+      const double zn = fr ? (reuse ? l.zt[i] : zv + ap * d) : zv;
+      const double sl = hl ? zv - lo : 1.0, su = hu ? u - zv : 1.0;
+      const double snl = hl ? zn - lo : 1.0, snu = hu ? u - zn : 1.0;
       double vl = zl + ad * (-zl + (mu - zl * d) / sl);
       double vu = zu + ad * (-zu + (mu + zu * d) / su);
       const double ml = mu / snl, mu_ = mu / snu;
       vl = detail::dmax(detail::dmin(vl, ksig * ml), ml * iks);
       vu = detail::dmax(detail::dmin(vu, ksig * mu_), mu_ * iks);
-      z[i] = zn;
-      zL[i] = hl ? vl : 0.0;
-      zU[i] = hu ? vu : 0.0;
+      l.z[i] = zn;
+      l.zL[i] = hl ? vl : 0.0;
+      l.zU[i] = hu ? vu : 0.0;
     }
-    if (threadIdx.x == 0) lds_base()[X_VALID] = 0.0;
+    if (reuse) {
+      const int S = steps(od);
+      for (int i = threadIdx.x; i < S * NS; i += 64) l.xs[i] = l.xt[i];
+      for (int i = threadIdx.x; i < od.N * NS; i += 64) l.lam[i] = l.ct[i];
+    }
+    if (threadIdx.x == 0) { ex[X_VALID] = 0.0; ex[X_ROLL] = reuse ? 1.0 : 0.0; }
     __syncthreads();
   }
   __device__ static void solve_nu(const SweepOut& so, double mu, double* nu) { H::solve_nu(so, mu, nu); }
@@ -369,22 +375,27 @@ struct ShootWave {
         // compare does not write (tools/dev/scan_scc.py finds the pattern in a listing)
         if (v >= xi(I, 0) && v < xi(I, 0) + NS) l.ex[X_TP + (v - xi(I, 0))] = b.pinned ? 1.0 : 0.0;
       }
-      // rollouts: states at every step, continuity defects (parked in lam), objective
+      // rollouts: states at every step, continuity defects (parked in lam), objective -- unless the accepted trial point's
+      // rollout is this iterate's (update())
       double f = 0, c1 = 0, cinf = 0;
-      for (int k = lane; k < I; k += 64) {
-        double x[NS], xe[NS];
+      const bool have_roll = l.ex[X_ROLL] != 0.0;
+      if (!have_roll) {
+        for (int k = lane; k < I; k += 64) {
+          double x[NS], xe[NS];
 #pragma unroll
-        for (int c = 0; c < NS; ++c) { x[c] = l.z[xi(k, c)]; xe[c] = l.z[xi(k + 1, c)]; }
-        roll_interval(o, p, l.z, k, x, l.xs, f);
+          for (int c = 0; c < NS; ++c) { x[c] = l.z[xi(k, c)]; xe[c] = l.z[xi(k + 1, c)]; }
+          roll_interval(o, p, l.z, k, x, l.xs, f);
 #pragma unroll
-        for (int c = 0; c < NS; ++c) {
-          const double ck = x[c] - xe[c];                                  // shooting.py:239-241
-          l.lam[(long)k * NS + c] = ck;
-          c1 += fabs(ck);
-          cinf = dmax(cinf, fabs(ck));
+          for (int c = 0; c < NS; ++c) {
+            const double ck = x[c] - xe[c];                                  // shooting.py:239-241
+            l.lam[(long)k * NS + c] = ck;
+            c1 += fabs(ck);
+            cinf = dmax(cinf, fabs(ck));
+          }
         }
       }
       f = wv_sum(f); c1 = wv_sum(c1); cinf = wv_max(cinf); cmax = wv_max(cmax); cmin = wv_min(cmin);
+      if (have_roll) { f = l.ex[X_TF]; c1 = l.ex[X_TC1]; cinf = l.ex[X_TCINF]; }
       __syncthreads();
       MYR_SWT(0)
       // Step linearisations, costates, step Hessians in ONE pass, lanes over steps (64 steps at a time, from the end).
@@ -778,15 +789,22 @@ struct ShootWave {
       f = l.ex[X_F]; c1 = l.ex[X_C1];
     } else {
       __syncthreads();
+      double cm = 0;
       for (int k = lane; k < I; k += 64) {
         double x[NS], xe[NS];
 #pragma unroll
         for (int c = 0; c < NS; ++c) { x[c] = l.zt[xi(k, c)]; xe[c] = l.zt[xi(k + 1, c)]; }
-        roll_interval(o, p, l.zt, k, x, nullptr, fl);
+        roll_interval(o, p, l.zt, k, x, l.xt, fl);
 #pragma unroll
-        for (int c = 0; c < NS; ++c) cl += fabs(x[c] - xe[c]);
+        for (int c = 0; c < NS; ++c) {
+          const double ck = x[c] - xe[c];
+          l.ct[(long)k * NS + c] = ck;
+          cl += fabs(ck);
+          cm = detail::dmax(cm, fabs(ck));
+        }
       }
-      f = wv_sum(fl); c1 = wv_sum(cl);
+      f = wv_sum(fl); c1 = wv_sum(cl); cm = wv_max(cm);
+      if (lane == 0) { l.ex[X_TA] = alpha; l.ex[X_TF] = f; l.ex[X_TC1] = c1; l.ex[X_TCINF] = cm; }
     }
     bar = mu * wv_sum(bl); bad = wv_isum(bad);
     __syncthreads();
@@ -814,7 +832,7 @@ void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, dou
     const long b = __builtin_amdgcn_readfirstlane(t);
     if (b >= B) break;
     for (int i = threadIdx.x; i < n; i += 64) { const double v = z[b * n + i]; l.z[i] = v; l.z0[i] = v; l.lb[i] = lb[b * n + i]; l.ub[i] = ub[b * n + i]; }
-    if (threadIdx.x == 0) l.ex[W::X_Z] = 0.0;
+    if (threadIdx.x == 0) { l.ex[W::X_Z] = 0.0; l.ex[W::X_DN] = (double)o.N; l.ex[W::X_DCPI] = (double)o.cpi; l.ex[W::X_TA] = -1.0; }
     SysParams<Sys> pp;
     pp.load(params, b, params_stride);
     pp.set_scale(vs.s);
