@@ -116,6 +116,84 @@ __device__ inline int wv_isum(int v) {
   return v;
 }
 
+// Affine maps x -> A x + b (n x n) in registers, one per lane: composition and the two wave scans built on it.
+// `wv_down(v, d)` = value of lane + d (own value beyond the wave), `wv_up` = lane - d.
+__device__ inline double wv_down(double v, int d) { return __shfl_down(v, d, 64); }
+__device__ inline double wv_up(double v, int d) { return __shfl_up(v, d, 64); }
+template <int n>
+__device__ inline void affine_after(double* A, double* b, const double* A2, const double* b2) {   // (A,b) <- (A,b) o (A2,b2)
+  double R[n * n], r[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    double v = b[i];
+#pragma unroll
+    for (int k = 0; k < n; ++k) v += A[i * n + k] * b2[k];
+    r[i] = v;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      double w = 0.0;
+#pragma unroll
+      for (int k = 0; k < n; ++k) w += A[i * n + k] * A2[k * n + j];
+      R[i * n + j] = w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < n * n; ++i) A[i] = R[i];
+#pragma unroll
+  for (int i = 0; i < n; ++i) b[i] = r[i];
+}
+// suffix scan: lane l <- T_l o T_{l+1} o .. o T_63        prefix scan: lane l <- T_l o T_{l-1} o .. o T_0
+template <int n, bool SUFFIX>
+__device__ inline void affine_scan(double* A, double* b) {
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    double A2[n * n], b2[n];
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) A2[i] = SUFFIX ? wv_down(A[i], d) : wv_up(A[i], d);
+#pragma unroll
+    for (int i = 0; i < n; ++i) b2[i] = SUFFIX ? wv_down(b[i], d) : wv_up(b[i], d);
+    if (SUFFIX ? (lane + d < 64) : (lane >= d)) affine_after<n>(A, b, A2, b2);
+  }
+}
+// The prefix scan with DPP moves instead of ds_bpermute (one VALU move per dword and round): four shifts inside the rows
+// of 16 lanes, then row_bcast:15 (rows 1, 3 take lane 15 / 47) and row_bcast:31 (lanes 32..63 take lane 31) -- the
+// wave-scan idiom of GFX9.  Inline asm, executed by all lanes: a DPP builtin sunk into the divergent branch that consumes
+// it would read 0 from the lanes EXEC has switched off (see dpp_row_shr4 below).
+template <int STEP>
+__device__ inline double dpp_scan_src(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v), rlo, rhi;
+  if constexpr (STEP == 0)
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %1, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi));
+  else if constexpr (STEP == 1)
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %1, %3 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi));
+  else if constexpr (STEP == 2)
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %1, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi));
+  else if constexpr (STEP == 3)
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %1, %3 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi));
+  else if constexpr (STEP == 4)
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_mov_b32_dpp %1, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi));
+  else
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_mov_b32_dpp %1, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" : "=&v"(rlo), "=&v"(rhi) : "v"(lo), "v"(hi));
+  return __hiloint2double(rhi, rlo);
+}
+template <int n, int STEP>
+__device__ inline void affine_prefix_round(double* A, double* b) {
+  const int lane = threadIdx.x, l16 = lane & 15;
+  double A2[n * n], b2[n];
+#pragma unroll
+  for (int i = 0; i < n * n; ++i) A2[i] = dpp_scan_src<STEP>(A[i]);
+#pragma unroll
+  for (int i = 0; i < n; ++i) b2[i] = dpp_scan_src<STEP>(b[i]);
+  const bool take = STEP < 4 ? (l16 >= (1 << STEP)) : (STEP == 4 ? ((lane >> 4) & 1) != 0 : lane >= 32);
+  if (take) affine_after<n>(A, b, A2, b2);
+}
+template <int n>
+__device__ inline void affine_prefix_scan_dpp(double* A, double* b) {       // lane l <- T_l o T_{l-1} o .. o T_0
+  affine_prefix_round<n, 0>(A, b); affine_prefix_round<n, 1>(A, b); affine_prefix_round<n, 2>(A, b);
+  affine_prefix_round<n, 3>(A, b); affine_prefix_round<n, 4>(A, b); affine_prefix_round<n, 5>(A, b);
+}
+
 // SCHEME 0: Hermite-Simpson (K = 2N+1 points, stage unknowns y = (dx_s, du_s, du_m, du_e), two eliminated controls);
 // SCHEME 1: trapezoidal collocation (/root/reference/myriad/trajectory_optimizers/collocation/trapezoidal.py:80-163; K = N+1
 // points, y = (dx_s, du_s, du_e), one eliminated control, no midpoint terms) -- the same phases, the same sweep, the
@@ -553,6 +631,45 @@ struct HsWave {
 
   // adjoint recurrence Pi_{k-1} = M_k Pi_k + v_k, k = N-1 .. 0: lane r < NS owns row r of M|v (LDS, prefetched one
   // stage ahead); Pi travels between lanes with v_readlane, so a stage is NS FMAs + NS readlanes and no barrier.
+#ifndef MYR_RECUR_SEQ
+  // Wave-scan form: the recurrence is affine, so the N dependent stages become a scan of map compositions, 64 stages at a
+  // time (6 DPP rounds of an NS x NS product per block).  Lane j takes stage base + 63 - j, which turns the suffix scan
+  // over the stages into the prefix scan over the lanes that the DPP idiom provides; lane j ends with Pi of its stage.
+  __device__ static void adjoint_recur(Ctx& c, const double* nuT) {
+    constexpr int MV = NS * NS + NS;
+    const int lane = c.lane, N = c.N;
+    double piS[NS];                          // Pi of the stage above the block (uniform)
+#pragma unroll
+    for (int q = 0; q < NS; ++q) piS[q] = c.term_pinned[q] ? nuT[q] : 0.0;
+    for (int base = ((N - 1) / 64) * 64; base >= 0; base -= 64) {
+      const int k = base + 63 - lane;
+      const bool on = k < N;
+      double A[NS * NS], b[NS];
+      const double* M = c.r0 + (long)(on ? k : 0) * MV;
+#pragma unroll
+      for (int q = 0; q < NS * NS; ++q) A[q] = on ? M[q] : (((q / NS) == (q % NS)) ? 1.0 : 0.0);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) b[q] = on ? M[NS * NS + q] : 0.0;
+      affine_prefix_scan_dpp<NS>(A, b);
+      double lo[NS];                         // Pi_{k-1}
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double v = b[r];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) v += A[r * NS + q] * piS[q];
+        lo[r] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const double t = wv_up(lo[q], 1);       // Pi_k = (Pi_{k'-1} of the lane below, whose stage is k' = k + 1)
+        const double own = (lane == 0) ? piS[q] : t;
+        if (on) c.sPi[k * NS + q] = own;
+      }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) piS[q] = __shfl(lo[q], 63, 64);
+    }
+  }
+#else
   __device__ static void adjoint_recur(Ctx& c, const double* nuT) {
     // every row of 16 lanes repeats the computation of lanes 0..NS-1 (the broadcast below is per row); row 0 stores
     const int lane = c.lane, l16 = lane & 15, r = l16 < NS ? l16 : 0;
@@ -583,6 +700,8 @@ struct HsWave {
       }
     }
   }
+
+#endif
 
   // ---- phase 3: lanes over intervals -- multipliers ------------------------------------------------------------
   __device__ static void intervals_lambda(Ctx& c, double& lam_inf, double& sum_mult) {
@@ -1337,6 +1456,55 @@ struct HsWave {
 
   // ---- phase 8b: forward recursion (sequential): lane r < NW owns row r of Phi|phi (prefetched one stage ahead),
   // s travels between lanes with v_readlane; s_k -> LDS for phase 9.  No barrier inside the loop.
+#if !defined(MYR_RECUR_SEQ) && !defined(MYR_RECUR_SEQ_FWD)
+  // Wave-scan form (see adjoint_recur): prefix scan of the closed-loop maps, lane k ends with s_{k+1}.
+  __device__ static void forward_recur(Ctx& c, const double* th) {
+    const int lane = c.lane, N = c.N;
+    double s0[NW];                           // state in front of the block (uniform)
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s0[q] = 0.0;
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+      double v = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) v -= c.sKu[a * NC + cc] * th[cc];
+      s0[NS + a] = v;
+    }
+    if (lane < NW) {
+      double v = 0.0;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) v = (q == lane) ? s0[q] : v;
+      c.sS[lane] = v;
+    }
+    for (int base = 0; base < N; base += 64) {
+      const int k = base + lane;
+      const bool on = k < N;
+      double A[NW * NW], b[NW];
+      const double* P = c.r0 + (long)(on ? k : 0) * PHI;
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) A[r * NW + q] = on ? P[r * (NW + 1) + q] : ((r == q) ? 1.0 : 0.0);
+        b[r] = on ? P[r * (NW + 1) + NW] : 0.0;
+      }
+      affine_prefix_scan_dpp<NW>(A, b);
+      double sn[NW];
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+        double v = b[r];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) v += A[r * NW + q] * s0[q];
+        sn[r] = v;
+      }
+      if (on) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) c.sS[(k + 1) * NW + q] = sn[q];
+      }
+#pragma unroll
+      for (int q = 0; q < NW; ++q) s0[q] = __shfl(sn[q], 63, 64);
+    }
+  }
+#else
   __device__ static void forward_recur(Ctx& c, const double* th) {
     // every row of 16 lanes repeats the computation of lanes 0..NW-1 (the broadcast below is per row); row 0 stores
     const int lane = c.lane, N = c.N, l16 = lane & 15, r = l16 < NW ? l16 : 0;
@@ -1370,6 +1538,8 @@ struct HsWave {
       }
     }
   }
+
+#endif
 
   // ---- phase 9: lanes over intervals -- step for midpoint / end point variables ---------------------------------
   __device__ static void intervals_dz(Ctx& c, const double* th) {

@@ -315,47 +315,6 @@ struct ShootWave {
     return nreg;
   }
 
-  // Affine maps x -> A x + b (n x n) in registers, one per lane: composition and the two wave scans built on it.
-  // `wv_down(v, d)` = value of lane + d (own value beyond the wave), `wv_up` = lane - d.
-  __device__ static inline double wv_down(double v, int d) { return __shfl_down(v, d, 64); }
-  __device__ static inline double wv_up(double v, int d) { return __shfl_up(v, d, 64); }
-  template <int n>
-  __device__ static inline void affine_after(double* A, double* b, const double* A2, const double* b2) {   // (A,b) <- (A,b) o (A2,b2)
-    double R[n * n], r[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      double v = b[i];
-#pragma unroll
-      for (int k = 0; k < n; ++k) v += A[i * n + k] * b2[k];
-      r[i] = v;
-#pragma unroll
-      for (int j = 0; j < n; ++j) {
-        double w = 0.0;
-#pragma unroll
-        for (int k = 0; k < n; ++k) w += A[i * n + k] * A2[k * n + j];
-        R[i * n + j] = w;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < n * n; ++i) A[i] = R[i];
-#pragma unroll
-    for (int i = 0; i < n; ++i) b[i] = r[i];
-  }
-  // suffix scan: lane l <- T_l o T_{l+1} o .. o T_63        prefix scan: lane l <- T_l o T_{l-1} o .. o T_0
-  template <int n, bool SUFFIX>
-  __device__ static inline void affine_scan(double* A, double* b) {
-    const int lane = threadIdx.x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      double A2[n * n], b2[n];
-#pragma unroll
-      for (int i = 0; i < n * n; ++i) A2[i] = SUFFIX ? wv_down(A[i], d) : wv_up(A[i], d);
-#pragma unroll
-      for (int i = 0; i < n; ++i) b2[i] = SUFFIX ? wv_down(b[i], d) : wv_up(b[i], d);
-      if (SUFFIX ? (lane + d < 64) : (lane >= d)) affine_after<n>(A, b, A2, b2);
-    }
-  }
-
   // ---- backward sweep (ShootCore::backward): linearisation at the current iterate (once per iterate), Riccati recursion ----
   __device__ static void backward(const HsWork& w, const HsSolveOpts& o, const double* p, const double* nuT, double delta, SweepOut& so) {
     using namespace detail;
