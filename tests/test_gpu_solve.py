@@ -178,6 +178,7 @@ def _shoot_opt(system, intervals, cpi, method):
     ("CARTPOLE", 4, 10, "HEUN"),         # NS = 4
     ("CARTPOLE", 20, 10, "HEUN"),        # 200 steps: 105 KB of LDS per trajectory, one workgroup per CU
     ("CANCERTREATMENT", 1, 100, "HEUN"),
+    ("BEARPOPULATIONS", 1, 40, "HEUN"),  # two controls: the one-lane recursion
 ])
 def test_shooting_wave_and_lane_kernels_agree(monkeypatch, system, intervals, cpi, method):
   """shoot_solver_wave.h (one trajectory per wavefront, iterate in LDS) and ShootCore in the lane kernel are two mappings
