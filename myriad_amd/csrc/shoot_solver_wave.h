@@ -249,8 +249,7 @@ struct ShootWave {
     const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
     sw_lds* k_ptr = k_off >= 0 ? l.kg + (long)(S - 1) * KG + k_off : l.ex + X_Z + 1;
     const int k_step = k_off >= 0 ? KG : 0;
-    double reg_floor = o.reg_floor;
-    asm volatile("" : "+v"(reg_floor));
+    const double reg_floor = o.reg_floor;
     int nreg = 0;
     aborted = false;
     constexpr int PF = MYR_SHOOT_RICCATI_PF;
@@ -284,11 +283,12 @@ struct ShootWave {
         C2[0] = H0; C2[1] = fma(D3[1], f_t1, H1); C2[2] = fma(D3[2], f_t23, D1[1]) + H2; C2[3] = D3[3] * f_t23;
         const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
         const double q11 = HW::rdlane(D2[2], 8);
-        double d = q11;
-        if (!(d > reg_floor)) {                                        // wave-uniform, rare (same pivot rule as chol_reg)
-          d = dmax(fabs(d), reg_floor); ++nreg;
+        const bool bad = !(q11 > reg_floor);                           // wave-uniform, rare (same pivot rule as chol_reg)
+        if (bad) {
+          ++nreg;
           if (abort_on_reg) { aborted = true; return nreg; }
         }
+        const double d = bad ? dmax(fabs(q11), reg_floor) : q11;
         const double kk = D2[2] * fast_rcp(d);
         k_ptr[0] = kk;
         k_ptr -= k_step;
