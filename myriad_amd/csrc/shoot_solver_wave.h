@@ -803,14 +803,21 @@ void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, dou
     if (threadIdx.x < 8) l.ex[W::X_T + threadIdx.x] = 0.0;
     const long long tall_ = wall_clock64();
 #endif
-    IpLoop<W>::run(w, o, pp.get(), r);
+    // first start: an eighth of the iteration limit (at least 100) -- a solve that has not converged by then is almost
+    // always one that crawls to the limit (config 3: p99 56 iterations, slowest converging solve 180, stuck ones 1000),
+    // a second start typically needs 30 .. 50 iterations, and a stuck trajectory is what the launch otherwise waits for
+    // (seeds 2020 / 2021 of config 3: 170 / 105 ms against 20 ms for the other 8191 trajectories)
+    HsSolveOpts o1 = o;
+    o1.max_iter = o.max_iter / 8 > 100 ? o.max_iter / 8 : (o.max_iter < 100 ? o.max_iter : 100);
+    IpLoop<W>::run(w, MYR_SHOOT_RESTARTS > 0 ? o1 : o, pp.get(), r);
     __syncthreads();
     // A solve that ends without a KKT point (line search stalled on a non-descent direction, iteration limit, non-finite
     // values) is restarted from the caller's point with another initial barrier parameter (x3, then /3): the iterates of
     // single shooting over a long horizon are sensitive enough that the slowest 0.01 % of a batch depend on rounding --
     // config 3's trajectory 3985 stalls after 58 iterations from mu = 0.1 with this kernel's summation order and needs
     // 31 .. 49 iterations from any of 0.01, 0.03, 0.3, 0.5, 1.  There is no restoration phase to fall back on;
-    // a second start is the cheap substitute.  Iterations and sweeps of all attempts are reported.
+    // a second start is the cheap substitute.  The restarts get the full iteration limit; iterations and sweeps of all
+    // attempts are reported (so `iters` can exceed max_iter).
     for (int attempt = 0; attempt < MYR_SHOOT_RESTARTS && r.status != 0; ++attempt) {
       for (int i = threadIdx.x; i < n; i += 64) l.z[i] = l.z0[i];
       __syncthreads();

@@ -4,7 +4,11 @@ Seen with ROCm 7.2 hipcc (round 2, shoot_solver_wave.h): a wave-uniform f64 comp
 one-lane region became  v_cmp_nlt_f64 vcc, ...  ;  s_cselect_b32 s, 0x3ff00000, 0  -- the s_cselect reads SCC, which a
 vector compare does not write, so the flag took whatever the previous scalar instruction left there.  The pattern flagged:
 an s_cselect / s_cbranch_scc whose most recent SCC-writing scalar instruction lies BEFORE the most recent v_cmp .. vcc
-(within 6 lines) and is not itself a scalar compare.  __graft_entry__.build() runs this on every translation unit.
+(within 6 lines), and either that instruction is neither a scalar compare nor the mask-to-SCC idiom
+`s_and_b64 d, mask, exec` (how a wave-uniform condition held as a lane mask legitimately reaches SCC), or the select is
+between two literals (the `cond ? 1.0 : 0.0` shape: with two flags in a row the second select re-used the SCC of the
+first -- tools/dev/repro/scc_select.hip reproduces exactly that in 25 lines).  A heuristic: it finds the real instances
+and nothing else in this library.  __graft_entry__.build() runs it on every translation unit.
 Usage: hipcc -S --cuda-device-only ... -o x.s ; python tools/dev/scan_scc.py x.s"""
 import re
 import sys
@@ -26,8 +30,14 @@ def scan(path):
     if _W.match(l):
       last_scc = i; last_scc_txt = t
     if t.startswith('s_cselect') or t.startswith('s_cbranch_scc'):
-      if (last_vcmp is not None and last_scc is not None and last_scc < last_vcmp and i - last_vcmp <= 6
-          and not last_scc_txt.startswith(('s_cmp', 's_bitcmp', 's_cmpk'))):
+      if last_vcmp is not None and last_scc is not None and last_scc < last_vcmp and i - last_vcmp <= 6:
+        ops = [o.strip() for o in t.split(None, 1)[1].split(',')][1:] if t.startswith('s_cselect_b32') else []
+        # `cond ? 1.0 : 0.0`: the high word of a double constant against 0
+        fp_literal_select = len(ops) == 2 and any(o.startswith('0x') for o in ops) and not any(o.startswith(('s', 'v', 'exec', 'm0')) for o in ops)
+        scalar_compare = last_scc_txt.startswith(('s_cmp', 's_bitcmp', 's_cmpk'))
+        mask_idiom = last_scc_txt.startswith(('s_and_b64', 's_andn2_b64', 's_or_b64')) and re.search(r',\s*exec\b', last_scc_txt) is not None
+        if scalar_compare or (mask_idiom and not fp_literal_select):
+          continue
         hits.append(f"{func} line {i + 1} | {last_scc_txt} ... {lines[last_vcmp].strip()} -> {t}")
   return hits
 
