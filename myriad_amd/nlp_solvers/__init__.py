@@ -23,8 +23,8 @@ def solve(hp: HParams, cfg: Config, opt_dict: Dict) -> Dict[str, np.ndarray]:
     eng = opt.engine
     o = eng.default_opts()
     o.max_iter = hp.max_iter
-    res = eng.solve(np.asarray(opt_dict['guess'], dtype=np.float64)[None], opt_dict['bounds'][None, :, 0],
-                    opt_dict['bounds'][None, :, 1], params=opt_dict.get('params'), opts=o)
+    res = opt.device_solve(np.asarray(opt_dict['guess'], dtype=np.float64)[None], opt_dict['bounds'][None, :, 0],
+                           opt_dict['bounds'][None, :, 1], opt_dict.get('params'), o)      # + second starts (see there)
     solution = {'x': res["z"][0], 'fun': float(res["cost"][0]), 'success': bool(res["status"][0] == 0), 'v': res["lam"][0],
                 'nit': int(res["iters"][0])}
   elif hp.nlpsolver in (NLPSolverType.SLSQP, NLPSolverType.TRUST):
