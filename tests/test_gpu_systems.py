@@ -308,3 +308,19 @@ def test_pendulum_needs_and_gets_a_second_start(monkeypatch):
   assert abs(x[-1, 0] - np.pi) < 1e-9 and np.abs(x[:, 0]).max() > 0.5 * np.pi and (np.diff(np.sign(x[:, 1])) != 0).sum() >= 2   # swings
   sol = opt.solve()                                             # the reference-shaped call takes the same path
   assert sol['cost'] == pytest.approx(r['cost'][0], rel=1e-9)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.TRAPEZOIDAL, intervals=60),
+    dict(optimizer=OptimizerType.SHOOTING, intervals=1, controls_per_interval=60),
+    dict(optimizer=OptimizerType.SHOOTING, intervals=6, controls_per_interval=10),
+], ids=["trapezoidal", "single-shooting", "multiple-shooting"])
+def test_pendulum_swing_up_converges_under_every_transcription(kw):
+  """The collocation transcriptions need the second start (iters > max_iter), shooting does not; the discretisations agree
+  on the optimum to their order (25.4 .. 25.7)."""
+  hp = HParams(system=SystemType.PENDULUM, nlpsolver=NLPSolverType.SQP, **kw)
+  opt = get_optimizer(hp, CFG, hp.system())
+  r = opt.solve_batch()
+  assert r['status'][0] == 0
+  assert np.abs(opt.constraints(r['xs_and_us'][0])).max() <= 1e-8
+  assert 25.3 < r['cost'][0] < 25.8
