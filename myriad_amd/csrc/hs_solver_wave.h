@@ -29,6 +29,14 @@ template <class True, int ID_> struct NodeTraits<SysNODE<True, 64, 64, ID_>> {
   static constexpr int lds_doubles = mlp ? NodeMfma64::L_N : 0;
 };
 
+// Barrier of the phases of ONE wavefront.  A workgroup of a single wavefront uses the hardware barrier; network systems pack
+// several independent wavefronts into a workgroup (they share the weights in LDS) and may not meet at a workgroup barrier:
+// there the phases of a wavefront are ordered by a fence (all its LDS / global accesses retired) + the wave barrier.
+template <bool MULTI>
+__device__ inline void wave_sync() {
+  if constexpr (MULTI) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+  else __syncthreads();
+}
 __device__ inline double wv_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -145,7 +153,7 @@ __device__ inline void affine_after(double* A, double* b, const double* A2, cons
 // suffix scan: lane l <- T_l o T_{l+1} o .. o T_63        prefix scan: lane l <- T_l o T_{l-1} o .. o T_0
 template <int n, bool SUFFIX>
 __device__ inline void affine_scan(double* A, double* b) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     double A2[n * n], b2[n];
@@ -179,7 +187,7 @@ __device__ inline double dpp_scan_src(double v) {
 }
 template <int n, int STEP>
 __device__ inline void affine_prefix_round(double* A, double* b) {
-  const int lane = threadIdx.x, l16 = lane & 15;
+  const int lane = threadIdx.x & 63, l16 = lane & 15;
   double A2[n * n], b2[n];
 #pragma unroll
   for (int i = 0; i < n * n; ++i) A2[i] = dpp_scan_src<STEP>(A[i]);
@@ -208,6 +216,9 @@ struct HsWave {
   static constexpr int MLAM = TRAP ? 1 : 2;        // multiplier blocks (NS each) per interval
   static constexpr bool MLP = NodeTraits<Sys>::mlp;
   static_assert(!(MLP && TRAP), "network dynamics are built for the Hermite-Simpson transcription");
+  // wavefronts per workgroup: network systems share their weights (40 KB of LDS) between WPB_MAX independent solves
+  static constexpr int WPB_MAX = MLP ? 3 : 1;
+  __device__ static inline void wsync() { wave_sync<MLP>(); }
   static constexpr int ND2 = MLP ? NodeMfma64::NPAIR : Sys::NNZ2;   // stored second-derivative data per point
   __host__ __device__ static constexpr int npoints(int N) { return TRAP ? N + 1 : 2 * N + 1; }
   // quadrature weight and time of point j (hermite_simpson.py:212-214 / trapezoidal.py:80-94)
@@ -303,7 +314,7 @@ struct HsWave {
   struct Step { bool on; double ap, ad, mu, ksig; };
   __device__ static void points_lin(Ctx& c, P1& o, const Step& st) {
     if constexpr (MLP) {       // the network pass reads z from memory: apply the step first
-      if (st.on) { update(c, st.ap, st.ad, st.mu, st.ksig); __syncthreads(); }
+      if (st.on) { update(c, st.ap, st.ad, st.mu, st.ksig); wsync(); }
     }
     node_pass<1>(c, 0.0);
     double f = 0, cmax = 0, cmin = INFINITY, sm = 0, lg = 0; int nm = 0;
@@ -886,7 +897,7 @@ struct HsWave {
       }
       nreg += chol_reg<NU>(Puu, o.reg_floor);
       chol_solve<NU, NC>(Puu, ku);
-      __syncthreads();
+      wsync();
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < NS; ++i)
@@ -900,7 +911,7 @@ struct HsWave {
 #pragma unroll
         for (int i = 0; i < NU * NC; ++i) c.sKu[i] = ku[i];
       }
-      __syncthreads();
+      wsync();
     }
     return nreg;
   }
@@ -975,7 +986,7 @@ struct HsWave {
 #pragma unroll
         for (int t = 0; t < NGL; ++t) { const int e = lane + 64 * t; g_pre[t] = st[SG_GE + (e < NGE ? e : NGE - 1)]; }
       }
-      __syncthreads();
+      wsync();
       // (b) tv = P' v + (pc' on the right-hand-side lanes),  v = own column of [Ge^ | ge^]
       double v[NW], tv[NW];
 #pragma unroll
@@ -1044,7 +1055,7 @@ struct HsWave {
         for (int t = 0; t < NQ; ++t) s += rdlane(col[NW + t], NY + 2 + i) * kk[t];
         tnuB[i] -= s;
       }
-      __syncthreads();
+      wsync();
     }
     // hand P, pc, Tnu to the first-point step through LDS
     if (isP) {
@@ -1057,9 +1068,9 @@ struct HsWave {
 #pragma unroll
       for (int i = 0; i < NS; ++i) c.sTnu[i * NC + cc] = tnuB[i];
     }
-    __syncthreads();
+    wsync();
     if (isC && cc >= 2) c.sTnu[(cc - 2) * NC + 0] += tnuA;
-    __syncthreads();
+    wsync();
     return riccati_first_point(c, o, delta, nreg);
   }
 
@@ -1307,9 +1318,9 @@ struct HsWave {
       if (g >= 2 && g - 2 < NS) c.sTnu[(g - 2) * NC + rcc] = T2;
       if (g >= 2 && g < NS) c.sTnu[g * NC + rcc] = T3;
     }
-    __syncthreads();
+    wsync();
     if (g == 2 && rcc >= 2) c.sTnu[(rcc - 2) * NC + 0] += T1;       // row 6: ge^T pc'[:, nu_i], summed over the stages
-    __syncthreads();
+    wsync();
     return riccati_first_point(c, o, delta, nreg);
   }
 
@@ -1403,9 +1414,9 @@ struct HsWave {
       if (g >= 2 && g - 2 < NS) c.sTnu[(g - 2) * NC + rcc] = T2;
       if (g >= 2 && g < NS) c.sTnu[g * NC + rcc] = T3;
     }
-    __syncthreads();
+    wsync();
     if (g == 2 && rcc >= 2) c.sTnu[(rcc - 2) * NC + 0] += T1;
-    __syncthreads();
+    wsync();
     return riccati_first_point(c, o, delta, nreg);
   }
 
@@ -1636,7 +1647,7 @@ struct HsWave {
 #pragma unroll
       for (int q = 0; q < NS; ++q) { sX[j * NS + q] = x[q]; if constexpr (!MLP) sF[j * NS + q] = ff[q]; }
     }
-    __syncthreads();
+    wsync();
     double ca = 0;
     for (int k = c.lane; k < N; k += 64) {
       if constexpr (TRAP) {
@@ -1653,7 +1664,7 @@ struct HsWave {
         ca += fabs(xm - 0.5 * (xs + xe) - c.h8 * (fs - fe));
       }
     }
-    __syncthreads();
+    wsync();
     f = wv_sum(fa); bar = mu * wv_sum(ba); c1 = wv_sum(ca);
     bad = wv_isum(bad);
     if (bad != 0) return false;
@@ -1702,7 +1713,7 @@ struct HsWave {
   __device__ static void solve(Ctx& c, const HsSolveOpts& o, HsSolveResult& res) {
     using namespace detail;
     init(c);
-    __syncthreads();
+    wsync();
 #pragma unroll
     for (int q = 0; q < NS; ++q) { const long i = zi(c, c.K - 1, q); c.term_pinned[q] = !(c.lb[i] < c.ub[i]); }
     double mu = o.mu_init, pen = 1.0;
@@ -1721,20 +1732,20 @@ struct HsWave {
       P1 p1;
       points_lin(c, p1, pending);
       pending.on = false;
-      __syncthreads();
+      wsync();
       MYR_PH(0)
       double c1, cinf, lam_inf, sum_mult, stat_raw;
       intervals_elim(c, c1, cinf);
-      __syncthreads();
+      wsync();
       MYR_PH(1)
       adjoint_recur(c, nuT);
-      __syncthreads();
+      wsync();
       MYR_PH(2)
       intervals_lambda(c, lam_inf, sum_mult);
-      __syncthreads();
+      wsync();
       MYR_PH(3)
       points_hess(c, stat_raw);
-      __syncthreads();
+      wsync();
       MYR_PH(4)
       // inertia correction with retries (only the delta-dependent phases are redone)
       double delta = lm;
@@ -1747,20 +1758,20 @@ struct HsWave {
 #else
         if constexpr (!MFMA_RICCATI && !TRAP) intervals_qm(c, delta);   // the matrix-core sweep forms the midpoint terms itself
 #endif
-        __syncthreads();
+        wsync();
         MYR_PH(5)
 #ifdef MYR_RICCATI_CHECK   // dev self-check: both forms on the same inputs, differences of every output printed
         if constexpr (MFMA_RICCATI) {
           const int nv = riccati(c, o, delta, abort_on_reg);
-          __syncthreads();
+          wsync();
           const int nk = c.N * KST, nl = NW * NW + NW * NC + NS * NY1 + NS * NC + NU * NC;
           for (int i = c.lane; i < nk; i += 64) c.r0[i] = c.kg[i];
           for (int i = c.lane; i < nl; i += 64) c.r0[nk + i] = c.sP[i];
-          __syncthreads();
+          wsync();
           for (int i = c.lane; i < nk; i += 64) c.kg[i] = -7.0;
-          __syncthreads();
+          wsync();
           const int nm = riccati_mfma(c, o, delta, false);
-          __syncthreads();
+          wsync();
           double dk = 0, dP = 0, dPc = 0, dT = 0, dKu = 0, mk = 0;
           int worst = -1;
           for (int i = c.lane; i < nk; i += 64) { const double d = fabs(c.r0[i] - c.kg[i]); if (d > dk) { dk = d; worst = i; } mk = dmax(mk, fabs(c.r0[i])); }
@@ -1789,7 +1800,7 @@ struct HsWave {
 #endif
           nreg = riccati(c, o, delta, abort_on_reg);
 #endif
-        __syncthreads();
+        wsync();
         MYR_PH(6)
         if (nreg == 0) break;
         if (!abort_on_reg) break;
@@ -1826,13 +1837,13 @@ struct HsWave {
       for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
       MYR_PH(7)
       intervals_phi(c, th);
-      __syncthreads();
+      wsync();
       MYR_PH(13)
       forward_recur(c, th);
-      __syncthreads();
+      wsync();
       MYR_PH(8)
       intervals_dz(c, th);
-      __syncthreads();
+      wsync();
       MYR_PH(9)
       typename S::FwdOut fo;
       points_limits(c, o, mu, fo);
@@ -1884,7 +1895,7 @@ struct HsWave {
         small_steps = (a < o.recenter_alpha) ? small_steps + 1 : 0;
         if (small_steps >= o.recenter && mu < o.mu_init) { mu = dmin(o.mu_init, 10.0 * mu); small_steps = 0; }
       }
-      __syncthreads();
+      wsync();
     }
     res.status = 1; res.iters = o.max_iter;
   }
@@ -1893,11 +1904,12 @@ struct HsWave {
 #ifndef MYR_WAVE_MIN_WAVES
 #define MYR_WAVE_MIN_WAVES 1   // waves per SIMD the register allocation must allow (occupancy)
 #endif
-// Persistent: grid = the wavefronts the device keeps resident (one 64-thread workgroup each, dynamic LDS =
-// HsWave<Sys>::lds_bytes(N)); every workgroup pulls trajectories from `ticket` until the batch is done and owns ONE
-// scratch block (slot blockIdx.x) that it re-uses for all of them.
+// Persistent: grid = the wavefronts the device keeps resident (blockDim.x / 64 per workgroup: 1, or up to WPB_MAX for network
+// systems, whose wavefronts share the weights in LDS; dynamic LDS = waves x lds_solver_doubles + weights); every wavefront
+// pulls trajectories from `ticket` until the batch is done and owns ONE scratch block (slot blockIdx.x * waves + wave) that
+// it re-uses for all of them.
 template <class Sys, int SCHEME = 0>
-__global__ __launch_bounds__(64, MYR_WAVE_MIN_WAVES)
+__global__ __launch_bounds__((64 * HsWave<Sys, SCHEME>::WPB_MAX), MYR_WAVE_MIN_WAVES)
 void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                           const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                           const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
@@ -1905,9 +1917,10 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
   using W = HsWave<Sys, SCHEME>;
   extern __shared__ __attribute__((aligned(16))) char smem_wave[];
   typename W::Ctx c;
-  c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x;
+  const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x & 63;
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
-  double* s = scratch + (long)blockIdx.x * scratch_stride;
+  double* s = scratch + ((long)blockIdx.x * waves + wave) * scratch_stride;
   c.zL = s; s += c.n; c.zU = s; s += c.n; c.dz = s; s += c.n;
   c.pt = s; s += (long)W::PF_N * c.K;
   c.hr = c.pt + (long)W::PF_F * c.K;                            // overlaid on the f | A fields (see PF_*)
@@ -1917,7 +1930,7 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
   else { c.kg = s; s += (long)W::KST * c.N; }
   c.zr = s; s += W::ZR + 2;
   double* const lam_own = s;
-  double* l = reinterpret_cast<double*>(smem_wave);
+  double* l = reinterpret_cast<double*>(smem_wave) + (long)wave * W::lds_solver_doubles(c.N);
   c.r0 = l; l += W::r0_doubles(c.N);
   c.sPi = l; l += c.N * W::NS;
   c.sS = l; l += (c.N + 1) * W::NW;
@@ -1926,22 +1939,28 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
   c.sGe = l; l += W::NS * W::NY1;
   c.sTnu = l; l += W::NS * W::NC;
   c.sKu = l; l += W::NU * W::NC;
-  c.wl = reinterpret_cast<double*>(smem_wave) + W::lds_solver_doubles(c.N);
-  bool weights_loaded = false;
+  c.wl = reinterpret_cast<double*>(smem_wave) + (long)waves * W::lds_solver_doubles(c.N);
+  if constexpr (W::MLP) {        // weights shared by the batch: wavefront 0 loads them once, the ONE workgroup barrier of the kernel
+    if (params_stride == 0) {
+      SysParams<Sys> pw;
+      pw.load(params, 0, 0);
+      if (wave == 0) NodeMfma64::load_weights(pw.get(), c.wl, c.lane);
+      __syncthreads();
+    }
+  }
   for (;;) {
     int t = 0;
-    if (threadIdx.x == 0) t = atomicAdd(ticket, 1);
+    if (c.lane == 0) t = atomicAdd(ticket, 1);
     const long b = __builtin_amdgcn_readfirstlane(t);
     if (b >= B) break;
     c.z = z + b * (long)c.n; c.lb = lb + b * (long)c.n; c.ub = ub + b * (long)c.n;
     c.lam = lam ? lam + b * (long)(W::MLAM * c.N * W::NS) : lam_own;
     c.pp.load(params, b, params_stride);
     c.pp.set_scale(vs.s);
-    if constexpr (W::MLP) {      // network weights -> LDS: once per workgroup when the batch shares them, else per trajectory
-      if (!weights_loaded || params_stride != 0) {
+    if constexpr (W::MLP) {      // per-trajectory weights (launched with one wavefront per workgroup): loaded per trajectory
+      if (params_stride != 0) {
         NodeMfma64::load_weights(c.pp.get(), c.wl, c.lane);
-        weights_loaded = true;
-        __syncthreads();
+        W::wsync();
       }
     }
     HsSolveResult r;
@@ -1951,19 +1970,19 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
 #endif
     W::solve(c, o, r);
 #ifdef MYR_PHASE_TIMING
-    if (threadIdx.x == 0 && b < 4) {
+    if (c.lane == 0 && b < 4) {
       printf("traj %ld it %d: lin %lld elim %lld adj %lld lam %lld hess %lld qm %lld ricc %lld nu %lld fwd %lld dz %lld lim %lld ls %lld upd %lld\n",
              b, r.iters, c.tph[0], c.tph[1], c.tph[2], c.tph[3], c.tph[4], c.tph[5], c.tph[6], c.tph[7], c.tph[8], c.tph[9],
              c.tph[10], c.tph[11], c.tph[12]);
     }
 #endif
-    if (threadIdx.x == 0) {
+    if (c.lane == 0) {
       if (cost) cost[b] = r.cost;
       if (status) status[b] = r.status;
       if (iters) iters[b] = r.iters;
       if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
     }
-    __syncthreads();      // the slot's scratch and LDS are handed to the next trajectory
+    W::wsync();      // the slot's scratch and LDS are handed to the next trajectory
   }
 }
 

@@ -402,22 +402,31 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   // lane-per-trajectory form, which keeps everything in global scratch, takes over
   if (h->solve_mode == 1 && HsWave<Sys, SCHEME>::lds_bytes(N) <= 160 * 1024) {
     using W = HsWave<Sys, SCHEME>;
-    const size_t lds = W::lds_bytes(N);
+    // wavefronts per workgroup: 1, except network systems whose batch shares one set of weights -- their wavefronts share
+    // the 40 KB of weights in LDS, three to a workgroup (3 x 33 + 40 = 140 KB: three resident wavefronts per CU instead of two)
+    int wpb = 1;
+    if (W::MLP && pstride == 0) {
+      wpb = W::WPB_MAX;
+      if (const char* e = getenv("MYRIAD_NODE_WPB")) { wpb = atoi(e); if (wpb < 1) wpb = 1; if (wpb > W::WPB_MAX) wpb = W::WPB_MAX; }
+      while (wpb > 1 && ((size_t)wpb * W::lds_solver_doubles(N) + NodeTraits<Sys>::lds_doubles) * 8 > 160 * 1024) --wpb;
+    }
+    const size_t lds = ((size_t)wpb * W::lds_solver_doubles(N) + NodeTraits<Sys>::lds_doubles) * 8;
     auto kern = hs_solve_wave_kernel<Sys, SCHEME>;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // Persistent form: as many workgroups as the device keeps resident (registers and LDS allow 4 wavefronts per CU), each
     // pulling trajectories from a ticket counter.  Scratch belongs to the SLOT, not to the trajectory: the working set of
     // a launch is slots x 273 KB (280 MB for CARTPOLE N=100) instead of B x 273 KB (1.1 GB at B = 4096) and is re-used
     // trajectory after trajectory, i.e. it stays in the 256 MB Infinity Cache instead of streaming through HBM.
-    int slots = h->solve_slots;
+    int slots = h->solve_slots;              // wavefronts
     if (slots <= 0) {
       int per_cu = 0, dev = 0, cus = 0;
-      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64, lds));
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * wpb, lds));
       HIPCHK(hipGetDevice(&dev));
       HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      slots = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256);
+      slots = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256) * wpb;
     }
     if (slots > B) slots = B;
+    slots = (slots + wpb - 1) / wpb * wpb;                       // whole workgroups (surplus wavefronts find the ticket counter exhausted)
     long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
     if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate slots over HBM channels
     const size_t need = (size_t)slots * (size_t)stride * 8;
@@ -432,7 +441,7 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     HsSolveOpts o = make_opts(h, so);
     KTimer& kt = h->kt[MYR_K_SOLVE];
     HIPCHK(hipEventRecord(kt.a, h->stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(slots / wpb)), dim3(64 * wpb), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
                        params, pstride, cost, status, iters, kkt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(kt.b, h->stream));

@@ -17,3 +17,8 @@ for B in [int(a) for a in sys.argv[1:]] or [128, 1024]:
   ms, n = opt.engine.kernel_time(_lib.K_SOLVE)
   print(json.dumps(dict(config="5 CARTPOLE+NODE(64,64) HS N=100", B=B, converged=float((res['status'] == 0).mean()), kernel_ms=ms,
                         solves_per_s_kernel=B / ms * 1e3, its_median=float(np.median(res['iters'])), status=np.bincount(res['status']).tolist())))
+  if os.environ.get("NODE_EVAL"):
+    opt.engine.kernel_time_reset()
+    ev = opt.engine.eval(res["xs_and_us"], params=opt.system.device_params(), want=("c", "jblk", "f", "gradf"))
+    ms, n = opt.engine.kernel_time(_lib.K_EVAL)
+    print(json.dumps(dict(eval_kernel_ms=ms, launches=n, B=B, max_c=float(np.abs(ev["c"]).max()))))
