@@ -217,7 +217,8 @@ struct HsWave {
   static constexpr bool MLP = NodeTraits<Sys>::mlp;
   static_assert(!(MLP && TRAP), "network dynamics are built for the Hermite-Simpson transcription");
   // wavefronts per workgroup: network systems share their weights (40 KB of LDS) between WPB_MAX independent solves
-  static constexpr int WPB_MAX = MLP ? 3 : 1;
+  // (4 x 24 KB + 40 KB = 138 KB of LDS: one wavefront per SIMD, which is what 512 registers allow anyway)
+  static constexpr int WPB_MAX = MLP ? 4 : 1;
   __device__ static inline void wsync() { wave_sync<MLP>(); }
   static constexpr int ND2 = MLP ? NodeMfma64::NPAIR : Sys::NNZ2;   // stored second-derivative data per point
   __host__ __device__ static constexpr int npoints(int N) { return TRAP ? N + 1 : 2 * N + 1; }
@@ -264,7 +265,12 @@ struct HsWave {
   }
   // LDS doubles: region R0 (adjoint M|v, later Phi|phi, later trial x|f), Pi, S, exchange
   __host__ __device__ static int r0_doubles(int N) {
-    const int a = N * (NS * NS + NS), b = N * PHI, c = 2 * npoints(N) * NS;
+#if defined(MYR_RECUR_SEQ) || defined(MYR_RECUR_SEQ_FWD)
+    const int b = N * PHI;
+#else
+    const int b = NodeTraits<Sys>::mlp ? 0 : N * PHI;     // (network systems: the closed-loop maps are not staged, see PHI_IN_LDS)
+#endif
+    const int a = N * (NS * NS + NS), c = 2 * npoints(N) * NS;
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
   }
   static constexpr int EXCH = NW * NW + NW * NC + NS * NY1 + NS * NC + NU * NC + 8;
@@ -1422,45 +1428,65 @@ struct HsWave {
 
   // ---- phase 8a: lanes over intervals -- closed-loop stage maps  s_{k+1} = Phi_k s_k + phi_k, s = (dx, du) of a knot
   // (the gains applied to the elimination rows, for the multipliers theta = (1, mu, nu)); rows -> LDS region R0
+  // closed-loop map of stage k as an affine map in registers: A (NW x NW, row-major), b (NW)
+  __device__ static inline void stage_phi(const Ctx& c, const double* th, int k, double* A, double* b) {
+    const int N = c.N;
+    const double* Kst = c.kg + (long)k * KSTR;
+    const double* st = c.st + (long)k * SG_N;
+    double Kk[NQ * NW], kq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ * NW; ++q) Kk[q] = Kst[q];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+      double v = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) v += Kst[NQ * NW + t * NC + cc] * th[cc];
+      kq[t] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      double g[NY1];
+#pragma unroll
+      for (int q = 0; q <= NY; ++q) g[q] = st[SG_GE + i * NY1 + q];
+      const bool pin = (k == N - 1) && c.term_pinned[i];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        double v = g[q];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) v -= g[NW + t] * Kk[t * NW + q];
+        A[i * NW + q] = pin ? 0.0 : v;
+      }
+      double v = g[NY];
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) v -= g[NW + t] * kq[t];
+      b[i] = pin ? 0.0 : v;
+    }
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) A[(NS + a) * NW + q] = -Kk[(QE + a) * NW + q];
+      b[NS + a] = -kq[QE + a];
+    }
+  }
+  // Staged through LDS for the closed-form systems (computing the maps inside the scan phase costs them more in registers
+  // than the LDS round trip: 195.6 k against 200.0 k solves/s on the bench); network systems compute them in the scan phase
+  // and give the 24 KB back (PHI_IN_LDS: four wavefronts per workgroup instead of three).
+#if defined(MYR_RECUR_SEQ) || defined(MYR_RECUR_SEQ_FWD)
+  static constexpr bool PHI_IN_LDS = true;       // (the sequential form of the recursion reads the maps row by row from LDS)
+#else
+  static constexpr bool PHI_IN_LDS = !MLP;
+#endif
   __device__ static void intervals_phi(Ctx& c, const double* th) {
     const int N = c.N;
     for (int k = c.lane; k < N; k += 64) {
-      const double* Kst = c.kg + (long)k * KSTR;
-      const double* st = c.st + (long)k * SG_N;
-      double Kk[NQ * NW], kq[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ * NW; ++q) Kk[q] = Kst[q];
-#pragma unroll
-      for (int t = 0; t < NQ; ++t) {
-        double v = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) v += Kst[NQ * NW + t * NC + cc] * th[cc];
-        kq[t] = v;
-      }
+      double A[NW * NW], b[NW];
+      stage_phi(c, th, k, A, b);
       double* P = c.r0 + (long)k * PHI;
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        double g[NY1];
+      for (int i = 0; i < NW; ++i) {
 #pragma unroll
-        for (int q = 0; q <= NY; ++q) g[q] = st[SG_GE + i * NY1 + q];
-        const bool pin = (k == N - 1) && c.term_pinned[i];
-#pragma unroll
-        for (int q = 0; q < NW; ++q) {
-          double v = g[q];
-#pragma unroll
-          for (int t = 0; t < NQ; ++t) v -= g[NW + t] * Kk[t * NW + q];
-          P[i * (NW + 1) + q] = pin ? 0.0 : v;
-        }
-        double v = g[NY];
-#pragma unroll
-        for (int t = 0; t < NQ; ++t) v -= g[NW + t] * kq[t];
-        P[i * (NW + 1) + NW] = pin ? 0.0 : v;
-      }
-#pragma unroll
-      for (int a = 0; a < NU; ++a) {
-#pragma unroll
-        for (int q = 0; q < NW; ++q) P[(NS + a) * (NW + 1) + q] = -Kk[(QE + a) * NW + q];
-        P[(NS + a) * (NW + 1) + NW] = -kq[QE + a];
+        for (int q = 0; q < NW; ++q) P[i * (NW + 1) + q] = A[i * NW + q];
+        P[i * (NW + 1) + NW] = b[i];
       }
     }
   }
@@ -1491,12 +1517,20 @@ struct HsWave {
       const int k = base + lane;
       const bool on = k < N;
       double A[NW * NW], b[NW];
-      const double* P = c.r0 + (long)(on ? k : 0) * PHI;
+      if constexpr (PHI_IN_LDS) {
+        const double* P = c.r0 + (long)(on ? k : 0) * PHI;
 #pragma unroll
-      for (int r = 0; r < NW; ++r) {
+        for (int r = 0; r < NW; ++r) {
 #pragma unroll
-        for (int q = 0; q < NW; ++q) A[r * NW + q] = on ? P[r * (NW + 1) + q] : ((r == q) ? 1.0 : 0.0);
-        b[r] = on ? P[r * (NW + 1) + NW] : 0.0;
+          for (int q = 0; q < NW; ++q) A[r * NW + q] = on ? P[r * (NW + 1) + q] : ((r == q) ? 1.0 : 0.0);
+          b[r] = on ? P[r * (NW + 1) + NW] : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NW * NW; ++q) A[q] = ((q / NW) == (q % NW)) ? 1.0 : 0.0;      // identity beyond the last stage
+#pragma unroll
+        for (int q = 0; q < NW; ++q) b[q] = 0.0;
+        if (on) stage_phi(c, th, k, A, b);
       }
       affine_prefix_scan_dpp<NW>(A, b);
       double sn[NW];
@@ -1836,8 +1870,10 @@ struct HsWave {
 #pragma unroll
       for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
       MYR_PH(7)
-      intervals_phi(c, th);
-      wsync();
+      if constexpr (PHI_IN_LDS) {
+        intervals_phi(c, th);
+        wsync();
+      }
       MYR_PH(13)
       forward_recur(c, th);
       wsync();
