@@ -287,6 +287,8 @@ struct HsWave {
     // LDS
     double *r0, *sPi, *sS, *sP, *sPc, *sGe, *sTnu, *sKu;
     double* wl;           // network weights in LDS (node_mfma.h), network systems only
+    int coop = 0;         // > 1: that many wavefronts of the workgroup share THIS trajectory's network passes (see the kernel)
+    double* cmd = nullptr;   // LDS mailbox of the cooperative mode
 #ifdef MYR_PHASE_TIMING
     long long tph[16], t0;
 #endif
@@ -300,6 +302,10 @@ struct HsWave {
   __device__ static inline long zi(const Ctx& c, int j, int comp) { return S::zi(c.K, j, comp); }
 
   // ---- network systems: matrix-core passes over all points (node_mfma.h) ---------------------------------------------
+  // Cooperative mode (small batches: fewer trajectories than CUs): the solver runs in wavefront 0 of a workgroup, and for
+  // every network pass it posts the arguments in LDS and meets the other wavefronts at a workgroup barrier; the tiles of 16
+  // points are dealt round-robin, a second barrier ends the pass.  The helpers spend the rest of the solve at the barrier.
+  struct CoopCmd { int mode; NodeMfma64::Args a; };
   template <int MODE>
   __device__ static inline void node_pass(Ctx& c, double alpha) {
     if constexpr (MLP) {
@@ -308,9 +314,33 @@ struct HsWave {
       a.sF = (nd_lds*)(c.r0 + (long)c.K * NS);
       a.alpha = alpha; a.h6 = c.h6; a.h8 = c.h8; a.K = c.K; a.N = c.N;
       a.pf_f = PF_F; a.pf_a = PF_A; a.pf_b = PF_B; a.pf_d2 = PF_D2;
-      NodeMfma64::pass<MODE>((const nd_lds*)c.wl, a, c.lane);
+      if (c.coop > 1) {
+        a.ts = c.coop;
+        if (c.lane == 0) { CoopCmd* m = reinterpret_cast<CoopCmd*>(c.cmd); m->mode = MODE; m->a = a; }
+        __syncthreads();
+        NodeMfma64::pass<MODE>((const nd_lds*)c.wl, a, c.lane);          // (t0 = 0: wavefront 0's share)
+        __syncthreads();
+      } else
+        NodeMfma64::pass<MODE>((const nd_lds*)c.wl, a, c.lane);
     } else { (void)c; (void)alpha; }
   }
+  __device__ static void coop_helper(const double* wl, double* cmd, int wave, int lane) {
+    if constexpr (MLP) {
+      for (;;) {
+        __syncthreads();
+        const CoopCmd* m = reinterpret_cast<const CoopCmd*>(cmd);
+        const int mode = m->mode;
+        if (mode < 0) break;
+        NodeMfma64::Args a = m->a;
+        a.t0 = wave;
+        if (mode == 0) NodeMfma64::pass<0>((const nd_lds*)wl, a, lane);
+        else if (mode == 1) NodeMfma64::pass<1>((const nd_lds*)wl, a, lane);
+        else NodeMfma64::pass<2>((const nd_lds*)wl, a, lane);
+        __syncthreads();
+      }
+    } else { (void)wl; (void)cmd; (void)wave; (void)lane; }
+  }
+  static constexpr int COOP_CMD_DOUBLES = (sizeof(CoopCmd) + 7) / 8 + 1;
 
   // ---- phase 1: lanes over points -- linearisation, bound terms ----------------------------------------------
   struct P1 { double f, cmax, cmin, sm, lg; int nm; };   // lg = -sum log(slack): barrier term of the merit function / mu
@@ -1949,11 +1979,13 @@ __global__ __launch_bounds__((64 * HsWave<Sys, SCHEME>::WPB_MAX), MYR_WAVE_MIN_W
 void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                           const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                           const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
-                          int32_t* iters, double* kkt) {
+                          int32_t* iters, double* kkt, int coop) {
   using W = HsWave<Sys, SCHEME>;
   extern __shared__ __attribute__((aligned(16))) char smem_wave[];
   typename W::Ctx c;
-  const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  // coop (network systems, small batches): the workgroup's wavefronts share ONE trajectory -- wavefront 0 solves, the others
+  // help with the network passes (node_pass); otherwise every wavefront of the workgroup is an independent solve
+  const int wave = coop ? 0 : (int)(threadIdx.x >> 6), waves = coop ? 1 : (int)(blockDim.x >> 6);
   c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x & 63;
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
   double* s = scratch + ((long)blockIdx.x * waves + wave) * scratch_stride;
@@ -1976,12 +2008,17 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
   c.sTnu = l; l += W::NS * W::NC;
   c.sKu = l; l += W::NU * W::NC;
   c.wl = reinterpret_cast<double*>(smem_wave) + (long)waves * W::lds_solver_doubles(c.N);
+  if (coop) { c.coop = blockDim.x >> 6; c.cmd = c.wl + NodeTraits<Sys>::lds_doubles; }
   if constexpr (W::MLP) {        // weights shared by the batch: wavefront 0 loads them once, the ONE workgroup barrier of the kernel
     if (params_stride == 0) {
       SysParams<Sys> pw;
       pw.load(params, 0, 0);
-      if (wave == 0) NodeMfma64::load_weights(pw.get(), c.wl, c.lane);
+      if ((threadIdx.x >> 6) == 0) NodeMfma64::load_weights(pw.get(), c.wl, c.lane);
       __syncthreads();
+    }
+    if (coop && (threadIdx.x >> 6) != 0) {       // helper wavefronts of the cooperative mode
+      W::coop_helper(c.wl, c.cmd, (int)(threadIdx.x >> 6), c.lane);
+      return;
     }
   }
   for (;;) {
@@ -2019,6 +2056,12 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
       if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
     }
     W::wsync();      // the slot's scratch and LDS are handed to the next trajectory
+  }
+  if constexpr (W::MLP) {
+    if (coop) {          // release the helper wavefronts
+      if (c.lane == 0) reinterpret_cast<typename W::CoopCmd*>(c.cmd)->mode = -1;
+      __syncthreads();
+    }
   }
 }
 

@@ -402,15 +402,25 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   // lane-per-trajectory form, which keeps everything in global scratch, takes over
   if (h->solve_mode == 1 && HsWave<Sys, SCHEME>::lds_bytes(N) <= 160 * 1024) {
     using W = HsWave<Sys, SCHEME>;
-    // wavefronts per workgroup: 1, except network systems whose batch shares one set of weights -- their wavefronts share
-    // the 40 KB of weights in LDS, three to a workgroup (3 x 33 + 40 = 140 KB: three resident wavefronts per CU instead of two)
-    int wpb = 1;
-    if (W::MLP && pstride == 0) {
-      wpb = W::WPB_MAX;
-      if (const char* e = getenv("MYRIAD_NODE_WPB")) { wpb = atoi(e); if (wpb < 1) wpb = 1; if (wpb > W::WPB_MAX) wpb = W::WPB_MAX; }
-      while (wpb > 1 && ((size_t)wpb * W::lds_solver_doubles(N) + NodeTraits<Sys>::lds_doubles) * 8 > 160 * 1024) --wpb;
+    // wavefronts per workgroup: 1, except network systems -- independent solves that share the 40 KB of weights in LDS, four to a
+    // workgroup (4 x 24 + 40 KB), or, for batches smaller than the number of CUs, ONE solve whose network passes the four share
+    int wpb = 1, coop = 0;
+    if (W::MLP) {
+      int dev = 0, cus = 256;
+      HIPCHK(hipGetDevice(&dev));
+      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      // fewer trajectories than CUs: the wavefronts of a workgroup share one trajectory's network passes (cooperative mode)
+      coop = (B <= cus) ? 1 : 0;
+      if (const char* e = getenv("MYRIAD_NODE_COOP")) coop = atoi(e) != 0;
+      if (coop || pstride == 0) {
+        wpb = W::WPB_MAX;
+        if (const char* e = getenv("MYRIAD_NODE_WPB")) { wpb = atoi(e); if (wpb < 1) wpb = 1; if (wpb > W::WPB_MAX) wpb = W::WPB_MAX; }
+        while (!coop && wpb > 1 && ((size_t)wpb * W::lds_solver_doubles(N) + NodeTraits<Sys>::lds_doubles) * 8 > 160 * 1024) --wpb;
+      }
+      if (wpb == 1) coop = 0;
     }
-    const size_t lds = ((size_t)wpb * W::lds_solver_doubles(N) + NodeTraits<Sys>::lds_doubles) * 8;
+    const int lwaves = coop ? 1 : wpb;                          // solves per workgroup
+    const size_t lds = ((size_t)lwaves * W::lds_solver_doubles(N) + NodeTraits<Sys>::lds_doubles + (coop ? W::COOP_CMD_DOUBLES : 0)) * 8;
     auto kern = hs_solve_wave_kernel<Sys, SCHEME>;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // Persistent form: as many workgroups as the device keeps resident (registers and LDS allow 4 wavefronts per CU), each
@@ -423,10 +433,10 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
       HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * wpb, lds));
       HIPCHK(hipGetDevice(&dev));
       HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      slots = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256) * wpb;
+      slots = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256) * lwaves;
     }
     if (slots > B) slots = B;
-    slots = (slots + wpb - 1) / wpb * wpb;                       // whole workgroups (surplus wavefronts find the ticket counter exhausted)
+    slots = (slots + lwaves - 1) / lwaves * lwaves;              // whole workgroups (surplus wavefronts find the ticket counter exhausted)
     long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
     if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate slots over HBM channels
     const size_t need = (size_t)slots * (size_t)stride * 8;
@@ -441,8 +451,8 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     HsSolveOpts o = make_opts(h, so);
     KTimer& kt = h->kt[MYR_K_SOLVE];
     HIPCHK(hipEventRecord(kt.a, h->stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(slots / wpb)), dim3(64 * wpb), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
-                       params, pstride, cost, status, iters, kkt);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(slots / lwaves)), dim3(64 * wpb), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
+                       params, pstride, cost, status, iters, kkt, coop);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(kt.b, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -95,12 +95,13 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
     nd_lds* sF;                                             // MODE 0: f of point j at sF[j * NS + r]
     double alpha, h6, h8;
     int K, N, pf_f, pf_a, pf_b, pf_d2;
+    int t0 = 0, ts = 1;                                     // this wavefront's tiles of 16 points: t0, t0 + ts, ...
   };
 
   template <int MODE>
   __device__ __attribute__((noinline)) static void pass(const nd_lds* wl, Args a, int lane) {
     const int g = lane >> 4, i = lane & 15, K = a.K;
-    for (int j0 = 0; j0 < K; j0 += 16) {
+    for (int j0 = 16 * a.t0; j0 < K; j0 += 16 * a.ts) {
       const bool valid = j0 + i < K;
       const int j = valid ? j0 + i : K - 1;
       // inputs in B-operand layout: state component g of point i, and the control in lane group 0 of the second k-step
