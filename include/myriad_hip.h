@@ -145,8 +145,13 @@ int myr_eval(myr_handle h, int32_t B, const double* z, const double* params, int
  *   lam    [B][m]  out: equality multipliers, sign convention of scipy/ipopt `mult_g`
  *                  (stationarity: grad f + J^T lam - zL + zU = 0)
  *   cost   [B]     out: objective at the solution
- *   status [B], iters [B]  out (int32)
+ *   status [B], iters [B]  out (int32): MYR_STATUS_* per instance (non-convergence is a status, never an error return);
+ *                  iterations spent.  SHOOTING on the wavefront kernel gives the first start max(100, max_iter / 8) iterations
+ *                  and restarts a solve that ended without a KKT point from the caller's point with another initial barrier
+ *                  parameter (x3, then /3, each with the full max_iter): `iters` sums the attempts and may exceed max_iter.
  *   kkt    [B][3]  out (may be NULL): final {max|c|, stationarity, complementarity}
+ * There is no feasibility-restoration phase: a binding that wants IPOPT's robustness against a poor starting point re-solves
+ * the instances with status != MYR_STATUS_CONVERGED from another guess ("What replaces IPOPT's restoration phase").
  */
 int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, const double* ub,
               const double* params, int32_t params_stride, const myr_solve_opts* opts,
