@@ -67,3 +67,25 @@ def test_node_batch_config5_shape():
   assert (res['status'] == 0).mean() >= 0.98, np.bincount(res['status'])
   ev = opt.engine.eval(res['xs_and_us'], params=opt.system.device_params(), want=("c",))
   assert np.abs(ev["c"][res['status'] == 0]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("B,knob,values", [
+    (12, "MYRIAD_NODE_COOP", ("1", "0")),     # fewer trajectories than CUs: four wavefronts share one trajectory's network passes / one wavefront does them
+    (300, "MYRIAD_NODE_WPB", ("4", "1")),     # more trajectories than CUs: four independent solves per workgroup sharing the weights / one
+])
+def test_node_workgroup_modes_agree(monkeypatch, B, knob, values):
+  """The three ways the network solver occupies a workgroup (hs_solver_wave.h: cooperative, four independent wavefronts, one
+  wavefront) run the same arithmetic per trajectory: identical iteration counts, costs equal to rounding."""
+  N = 20
+  rng = np.random.default_rng(5)
+  x0 = np.clip(0.1 * rng.standard_normal((B, 4)), -2, 2)
+  out = []
+  for v in values:
+    monkeypatch.setenv(knob, v)
+    hp, node, opt = _setup(N)
+    out.append(opt.solve_batch(x0s=x0, params=opt.system.device_params()))
+  a, b = out
+  assert (a["status"] == 0).all() and (b["status"] == 0).all()
+  assert (a["iters"] == b["iters"]).all()
+  np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-12)
+  np.testing.assert_allclose(a["xs_and_us"], b["xs_and_us"], rtol=0, atol=1e-9)
