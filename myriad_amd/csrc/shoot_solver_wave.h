@@ -7,18 +7,21 @@
 // records, gains -- 18 KB for VANDERPOL 1 x 50, eight workgroups per CU), and the workgroups are persistent (ticket
 // counter, as hs_solver_wave.h):
 //   * lanes over VARIABLES: starting point, bound terms, step limits, trial point + barrier, update;
-//   * lanes over STEPS: the step linearisations (first order, then -- with the costates known -- the step Hessians),
-//     the closed-loop step maps and the step itself once the state recursion has run;
-//   * lanes over INTERVALS: rollouts (states, continuity defects, objective) of the sweep and of every trial point;
-//   * sequential over the steps: the costate recursion and the closed-loop state recursion (one lane, small affine
-//     maps out of LDS, operands fetched one step ahead) and the Riccati recursion -- on the matrix cores (three
-//     v_mfma_f64_16x16x4_f64 per step, riccati_mfma below) for one-control systems with NS <= 4, else os_riccati_stage (the code of
-//     the lane kernel) in one lane.  An inertia-correction retry (W + delta I) repeats only the Riccati recursion: the
-//     rollout, both linearisation passes and the costates do not depend on delta.
+//   * lanes over STEPS (64 at a time): linearise -> costates -> step Hessians in one pass -- the costate recursion is affine and
+//     runs as a suffix scan of map compositions across the wave (affine_scan, hs_solver_wave.h), after which every lane
+//     evaluates its step Hessian with the costate it received; and the forward sweep in one pass -- closed-loop map of the
+//     step, prefix scan, the lane's own step and its share of the directional derivative;
+//   * lanes over INTERVALS: rollouts (states, continuity defects, objective) of every trial point; the accepted trial point
+//     IS the next iterate and its rollout is kept for the next sweep;
+//   * sequential over the steps: only the Riccati recursion -- on the matrix cores (three v_mfma_f64_16x16x4_f64 per step,
+//     riccati_mfma below) for one-control systems with NS <= 4, else os_riccati_stage (the code of the lane kernel) in
+//     one lane out of LDS.  An inertia-correction retry (W + delta I) repeats only that recursion: the rollout, the
+//     linearisation and the costates do not depend on delta.
+//   * a solve that ends without a KKT point is started again (another initial barrier parameter), see the kernel.
 // The algorithm, its constants and its control flow are ShootCore's: the outer loop IS IpLoop<> (hs_solver.h), executed
 // redundantly by all 64 lanes on wave-uniform scalars, with this struct as its `Core`.  Only the association of the sums
-// (objective, defect norms, barrier, directional derivative: wave reductions instead of one running sum) and of the
-// forward recursion (closed-loop map applied in one product) differ from the lane kernel, against which -- and against
+// (objective, defect norms, barrier, directional derivative: wave reductions instead of one running sum) and of the two
+// recursions (compositions of affine maps instead of step-by-step application) differ from the lane kernel, against which -- and against
 // the same oracle / golden solutions -- it is tested.
 //
 // Replaces, per trajectory, IPOPT on /root/reference/myriad/trajectory_optimizers/shooting.py:169-241 (objective :169-210,
