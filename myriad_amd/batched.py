@@ -43,6 +43,12 @@ def gather_solutions(local: Dict[str, "torch.Tensor"], counts: Sequence[int], gr
       bufs = [torch.empty_like(pad) for _ in range(world)]
       dist.all_gather(bufs, pad, group=group)
     else:
+      if equal:     # receive straight into the slices of the result (no per-rank buffers, no concatenation pass)
+        res = t.new_empty((world * mx,) + tuple(t.shape[1:])) if rank == dst else None
+        dist.gather(pad, [res[r * mx:(r + 1) * mx] for r in range(world)] if rank == dst else None, dst=dst, group=group)
+        if rank == dst:
+          out[k] = res
+        continue
       bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
       dist.gather(pad, bufs, dst=dst, group=group)
       if rank != dst:
