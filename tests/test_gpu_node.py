@@ -89,3 +89,19 @@ def test_node_workgroup_modes_agree(monkeypatch, B, knob, values):
   assert (a["iters"] == b["iters"]).all()
   np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-12)
   np.testing.assert_allclose(a["xs_and_us"], b["xs_and_us"], rtol=0, atol=1e-9)
+
+
+def test_node_cooperative_mode_with_per_trajectory_weights(monkeypatch):
+  """params [B, np] (a weight set per trajectory): the solving wavefront reloads the weights per trajectory while its helpers
+  wait at the mailbox barrier."""
+  rng = np.random.default_rng(6)
+  B = 6
+  x0 = np.clip(0.1 * rng.standard_normal((B, 4)), -2, 2)
+  out = []
+  for v in ("1", "0"):
+    monkeypatch.setenv("MYRIAD_NODE_COOP", v)
+    hp, node, opt = _setup(20)
+    out.append(opt.solve_batch(x0s=x0, params=np.tile(opt.system.device_params(), (B, 1))))
+  a, b = out
+  assert (a["status"] == 0).all() and (a["iters"] == b["iters"]).all()
+  np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-12)
