@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "systems_gen.h"
+#include "node_mfma.h"
 
 namespace myriad {
 
@@ -112,6 +113,10 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
   double* rec = reinterpret_cast<double*>(smem_raw);                       // K*REC
   HsStencil* tab = reinterpret_cast<HsStencil*>(rec + ((K * REC + 1) & ~1));  // JPI entries, 16-B aligned
   double* red = reinterpret_cast<double*>(tab + JPI);                      // WPT partial sums
+  // network systems (Hermite-Simpson): f, A, B of all points by the matrix-core pass of node_mfma.h, 16 points per tile, the
+  // tiles dealt over the workgroup's wavefronts; the weights (40 KB) sit in LDS behind the reduction scratch
+  constexpr bool MLP = NodeTraits<Sys>::mlp && SCHEME == EVAL_HS;
+  double* wl = red + ((WPT + 1) & ~1);
 
   const int tid = threadIdx.x;
   const long b = blockIdx.x;
@@ -121,6 +126,16 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
   const double* p = pp.get();
 
   hs_build_stencil<Sys, SCHEME>(tab, h, tid, NT);
+  if constexpr (MLP) {
+    NodeMfma64::load_weights(p, wl, tid, NT);
+    __syncthreads();
+    NodeMfma64::Args a;
+    a.z = (const nd_glb*)zb; a.dz = nullptr; a.lam = nullptr; a.pt = nullptr; a.sF = nullptr;
+    a.alpha = 0.0; a.h6 = 0.0; a.h8 = 0.0; a.K = K; a.N = N; a.pf_f = a.pf_a = a.pf_b = a.pf_d2 = 0;
+    a.t0 = tid >> 6; a.ts = WPT;
+    a.rec = (nd_lds*)rec; a.use_rec = 1; a.rec_stride = REC; a.rec_f = L::OFF_F; a.rec_a = L::OFF_A; a.rec_b = L::OFF_B;
+    NodeMfma64::pass<1>((const nd_lds*)wl, a, tid & 63);
+  }
 
   // ---- phase 1: per-point dynamics, Jacobians, cost ----
   const double h6 = h / 6.0;
@@ -132,14 +147,21 @@ void hs_eval_kernel(int N, double h, const double* __restrict__ z, const double*
 #pragma unroll
     for (int i = 0; i < NU; ++i) u[i] = zb[K * NS + j * NU + i];
     set_time<Sys>(p, (SCHEME == EVAL_HS ? 0.5 * h : h) * j);      // t_j of linspace(0, T, K) (hermite_simpson.py:252, trapezoidal.py:124)
-    Sys::lin(x, u, p, f, A, Bm, &g, gw);
     double* r = rec + j * REC;
+    if constexpr (MLP) {          // dynamics and Jacobians are already in the record; only the (closed-form) cost is per lane
+      Sys::cost_grad(x, u, p, &g, gw);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) { r[L::OFF_X + i] = x[i]; r[L::OFF_F + i] = f[i]; }
+      for (int i = 0; i < NS; ++i) r[L::OFF_X + i] = x[i];
+      (void)f; (void)A; (void)Bm;
+    } else {
+      Sys::lin(x, u, p, f, A, Bm, &g, gw);
 #pragma unroll
-    for (int i = 0; i < NS * NS; ++i) r[L::OFF_A + i] = A[i];
+      for (int i = 0; i < NS; ++i) { r[L::OFF_X + i] = x[i]; r[L::OFF_F + i] = f[i]; }
 #pragma unroll
-    for (int i = 0; i < NS * NU; ++i) r[L::OFF_B + i] = Bm[i];
+      for (int i = 0; i < NS * NS; ++i) r[L::OFF_A + i] = A[i];
+#pragma unroll
+      for (int i = 0; i < NS * NU; ++i) r[L::OFF_B + i] = Bm[i];
+    }
     // Simpson weight of point j in  sum_k h/6 (g_s + 4 g_m + g_e)   (hermite_simpson.py:212-214)
     const double w = SCHEME == EVAL_HS ? ((j & 1) ? 4.0 * h6 : ((j == 0 || j == K - 1) ? h6 : 2.0 * h6))
                                        : ((j == 0 || j == K - 1) ? 0.5 * h : h);      // trapezoidal.py:80-94
@@ -230,7 +252,8 @@ template <class Sys, int SCHEME = EVAL_HS>
 inline size_t hs_eval_lds_bytes(int N, int wpt) {
   using L = HsLayout<Sys, SCHEME>;
   const int K = L::PPI * N + 1;
-  return (size_t)((K * L::REC + 1) & ~1) * 8 + (size_t)L::JPI * sizeof(HsStencil) + (size_t)wpt * 8 + 16;
+  const size_t weights = (NodeTraits<Sys>::mlp && SCHEME == EVAL_HS) ? (size_t)NodeTraits<Sys>::lds_doubles * 8 + 16 : 0;
+  return (size_t)((K * L::REC + 1) & ~1) * 8 + (size_t)L::JPI * sizeof(HsStencil) + (size_t)wpt * 8 + 16 + weights;
 }
 
 }  // namespace myriad

@@ -21,13 +21,7 @@
 
 namespace myriad {
 
-// network dynamics (node_system.h) are evaluated by the matrix-core passes of node_mfma.h inside the wavefront solver
-template <class True, int H1, int H2, int ID_> struct SysNODE;
-template <class Sys> struct NodeTraits { static constexpr bool mlp = false; static constexpr int lds_doubles = 0; };
-template <class True, int ID_> struct NodeTraits<SysNODE<True, 64, 64, ID_>> {
-  static constexpr bool mlp = (True::NS == 4 && True::NU == 1);
-  static constexpr int lds_doubles = mlp ? NodeMfma64::L_N : 0;
-};
+// network dynamics (node_system.h) are evaluated by the matrix-core passes of node_mfma.h inside the wavefront solver (NodeTraits there)
 
 // Barrier of the phases of ONE wavefront.  A workgroup of a single wavefront uses the hardware barrier; network systems pack
 // several independent wavefronts into a workgroup (they share the weights in LDS) and may not meet at a workgroup barrier:

@@ -36,13 +36,13 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
   static constexpr int O_W1 = 0, O_B1 = O_W1 + NW * H, O_W2 = O_B1 + H, O_B2 = O_W2 + H * H, O_W3 = O_B2 + H, O_B3 = O_W3 + H * NS;
   static constexpr int NPAIR = NW * (NW + 1) / 2;       // entries of the symmetric 5 x 5 contraction
 
-  __device__ static inline void load_weights(const double* p, double* wl, int lane) {
-    for (int e = lane; e < 8 * H; e += 64) wl[L_W1 + e] = e < NW * H ? p[O_W1 + e] : 0.0;
-    for (int e = lane; e < H * H; e += 64) wl[L_W2 + (e >> 6) * LD2 + (e & 63)] = p[O_W2 + e];
-    for (int e = lane; e < H * NS; e += 64) wl[L_W3 + e] = p[O_W3 + e];
-    wl[L_B1 + lane] = p[O_B1 + lane];
-    wl[L_B2 + lane] = p[O_B2 + lane];
-    if (lane < NS) wl[L_B3 + lane] = p[O_B3 + lane];
+  // (by `nt` threads, thread `t`: one wavefront in the solver, the whole workgroup in the evaluation kernel)
+  __device__ static inline void load_weights(const double* p, double* wl, int t, int nt = 64) {
+    for (int e = t; e < 8 * H; e += nt) wl[L_W1 + e] = e < NW * H ? p[O_W1 + e] : 0.0;
+    for (int e = t; e < H * H; e += nt) wl[L_W2 + (e >> 6) * LD2 + (e & 63)] = p[O_W2 + e];
+    for (int e = t; e < H * NS; e += nt) wl[L_W3 + e] = p[O_W3 + e];
+    if (t < H) { wl[L_B1 + t] = p[O_B1 + t]; wl[L_B2 + t] = p[O_B2 + t]; }
+    if (t < NS) wl[L_B3 + t] = p[O_B3 + t];
   }
 
   __device__ static inline nd4 mm(double a, double b, nd4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
@@ -96,6 +96,9 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
     double alpha, h6, h8;
     int K, N, pf_f, pf_a, pf_b, pf_d2;
     int t0 = 0, ts = 1;                                     // this wavefront's tiles of 16 points: t0, t0 + ts, ...
+    nd_lds* rec = nullptr;                                  // MODE 1, evaluation kernel: F / A / B go to the LDS record of point j
+    int use_rec = 0;                                        //   (an explicit flag: the record may sit at LDS offset 0)
+    int rec_stride = 0, rec_f = 0, rec_a = 0, rec_b = 0;    //   rec[j * rec_stride + rec_f + r], + rec_a + r * NS + c, + rec_b + r * NU
   };
 
   template <int MODE>
@@ -130,7 +133,7 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
       if (MODE == 0 || MODE == 1) {
         const double F = layer3<true>(wl, g, i, h2);
         if (MODE == 0) { if (valid) a.sF[j * NS + g] = F; }
-        else if (valid) a.pt[(long)(a.pf_f + g) * K + j] = F;
+        else if (valid) { if (a.use_rec) a.rec[j * a.rec_stride + a.rec_f + g] = F; else a.pt[(long)(a.pf_f + g) * K + j] = F; }
       }
       if (MODE == 1) {
         // forward tangents: d A1 / d w_c = W1[c, :] (constant), so d H1 = s'(A1) * W1[c, :], then the two upper layers
@@ -147,7 +150,10 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
 #pragma unroll
             for (int s = 0; s < 4; ++s) d2[mt][s] *= sp2[mt][s];
           const double dF = layer3<false>(wl, g, i, d2);      // d F_g / d w_c at point i
-          if (valid) a.pt[(long)(c < NS ? a.pf_a + g * NS + c : a.pf_b + g * NU) * K + j] = dF;
+          if (valid) {
+            if (a.use_rec) a.rec[j * a.rec_stride + (c < NS ? a.rec_a + g * NS + c : a.rec_b + g * NU)] = dF;
+            else a.pt[(long)(c < NS ? a.pf_a + g * NS + c : a.pf_b + g * NU) * K + j] = dF;
+          }
         }
       }
       if (MODE == 2) {
@@ -215,6 +221,14 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
       }
     }
   }
+};
+
+// network dynamics (node_system.h) that the matrix-core passes above implement
+template <class True, int H1, int H2, int ID_> struct SysNODE;
+template <class Sys> struct NodeTraits { static constexpr bool mlp = false; static constexpr int lds_doubles = 0; };
+template <class True, int ID_> struct NodeTraits<SysNODE<True, 64, 64, ID_>> {
+  static constexpr bool mlp = (True::NS == 4 && True::NU == 1);
+  static constexpr int lds_doubles = mlp ? NodeMfma64::L_N : 0;
 };
 
 }  // namespace myriad
