@@ -223,3 +223,58 @@ def _gather_dst_worker(rank, world, port, q):
     ok = out == {}
   q.put((rank, bool(ok)))
   dist.destroy_process_group()
+
+
+class _SecondStartEngine:
+  """CPU stand-in for _lib.Engine: `solve` reports MAXITER for every instance whose control guess is all zero (the reference
+  guess) and success otherwise -- enough to exercise TrajectoryOptimizer.device_solve / excitation_guess without a GPU."""
+  ns, nu = 2, 1
+
+  def __init__(self):
+    self.calls = []
+
+  def rollout(self, x0, us, steps, params=None):
+    assert us.shape[1] in (steps + 1, 2 * steps + 1)
+    xs = np.cumsum(np.concatenate([x0[:, None, :], 0.01 * np.ones((x0.shape[0], steps, x0.shape[1]))], axis=1), axis=1)
+    xs[:, 3, 0] = 1e9                       # a rollout that leaves the box: the guess must be clipped into the bounds
+    return xs, np.zeros(x0.shape[0])
+
+  def solve(self, z0, lb, ub, params=None, opts=None):
+    z0 = np.asarray(z0); B = z0.shape[0]
+    self.calls.append(z0.copy())
+    nx = z0.shape[1] - self.rows_u
+    fail = np.all(z0[:, nx:] == 0.0, axis=1)
+    return {"z": z0.copy(), "lam": np.zeros((B, 1)), "cost": np.where(fail, 9.0, 1.0), "status": fail.astype(np.int32),
+            "iters": np.full(B, 10, np.int32), "kkt": np.zeros((B, 3))}
+
+
+def test_second_starts_resolve_only_failed_instances_from_an_excitation_guess(monkeypatch):
+  """device_solve: instances with status != 0 are solved again from oscillating controls + the states of their rollout
+  (clipped into the bounds, pinned rows untouched); converged instances are left alone; iters accumulates;
+  MYRIAD_SECOND_STARTS=0 switches it off."""
+  from myriad_amd.config import Config, HParams, IntegrationMethod, OptimizerType, QuadratureRule
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = HParams(system=SystemType.PENDULUM, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
+               integration_method=IntegrationMethod.HEUN, intervals=6)
+  opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+  eng = _SecondStartEngine(); eng.rows_u = opt._u_shape[0]
+  opt._engine = eng
+  B = 3
+  x0s = np.tile(opt.system.x_0, (B, 1))
+  z0, lb, ub = opt.batch_inputs(x0s, None)
+  z0[1, -1] = 0.1                          # instance 1 has a non-zero control guess: "converges" at the first attempt
+  res = opt.device_solve(z0, lb, ub, None, None)
+  assert (res["status"] == 0).all() and list(res["iters"]) == [20, 10, 20] and list(res["cost"]) == [1.0, 1.0, 1.0]
+  assert len(eng.calls) == 2 and eng.calls[1].shape[0] == 2            # one second start, for the two failed instances only
+  g = eng.calls[1]
+  assert (g >= lb[[0, 2]]).all() and (g <= ub[[0, 2]]).all()           # clipped (the rollout left the box at row 3)
+  nx = z0.shape[1] - eng.rows_u
+  assert np.array_equal(g[:, :2], x0s[[0, 2]])                          # pinned first state
+  u = g[0, nx:]
+  umax = opt.system.bounds[2][1]
+  assert abs(u[0]) < 1e-12 and 0.7 * umax < np.abs(u).max() <= 0.95 * umax + 1e-12 and (np.diff(np.sign(u[1:-1])) != 0).sum() >= 3
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0")
+  eng.calls.clear()
+  res = opt.device_solve(z0, lb, ub, None, None)
+  assert list(res["status"]) == [1, 0, 1] and len(eng.calls) == 1
