@@ -71,7 +71,8 @@ def test_node_batch_config5_shape():
 
 @pytest.mark.parametrize("B,knob,values", [
     (12, "MYRIAD_NODE_COOP", ("1", "0")),     # fewer trajectories than CUs: four wavefronts share one trajectory's network passes / one wavefront does them
-    (300, "MYRIAD_NODE_WPB", ("4", "1")),     # more trajectories than CUs: four independent solves per workgroup sharing the weights / one
+    (300, "MYRIAD_NODE_WPB", ("4", "1")),     # between one and two trajectories per CU: cooperative with four wavefronts / one wavefront alone
+    (1100, "MYRIAD_NODE_COOP", ("0", "1")),   # four independent solves per workgroup sharing the weights / cooperative
 ])
 def test_node_workgroup_modes_agree(monkeypatch, B, knob, values):
   """The three ways the network solver occupies a workgroup (hs_solver_wave.h: cooperative, four independent wavefronts, one
