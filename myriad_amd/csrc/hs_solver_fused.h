@@ -1,0 +1,1011 @@
+// hs_solver_fused.h -- the wavefront-per-trajectory Hermite-Simpson interior-point SQP of hs_solver_wave.h with the phases
+// of an iteration FUSED so that the per-point / per-stage records stay on the CU.
+//
+// Round 2's kernel (HsWave) ran an iteration as thirteen phases that handed 223 KB of records per trajectory to each other
+// through global memory: 80 GB per 4096-trajectory launch, 3.9 TB/s, 500 x the algorithmic I/O -- and it was that traffic, not
+// the occupancy, that bound it (profiles/r03/exp01_noinline_two_waves.md: twice the resident wavefronts, no gain).  Here:
+//   * the iterate (z, zL, zU) lives in LDS for the whole solve (24 KB for CARTPOLE N = 100); bounds that are the same for
+//     every interior point (the reference's transcriptions never produce anything else, hermite_simpson.py:55-81) are
+//     detected once and served from a 30-double LDS table;
+//   * BACKWARD phase (lanes over intervals, one pass): apply the accepted step -> linearise the interval's knot and
+//     midpoint -> take the end knot's linearisation from the neighbouring lane (registers, not memory) -> eliminate ->
+//     adjoint recursion as a wave scan on the rows still in registers -> multipliers.  Only the elimination maps
+//     Ge | Gm (64 doubles per stage) are written; f, A, B, the adjoint maps and the M | v rows never leave the lane;
+//   * HESSIAN phase (lanes over points): second derivatives are RECOMPUTED from the iterate (one more sin / cos per point
+//     is cheaper than a 54-field record written and read back), records are symmetric-packed (25 instead of 35 doubles);
+//   * the Riccati sweep on the fp64 matrix cores is HsWave's (same tile, same chaining), reading the packed records;
+//   * FORWARD phase (lanes over intervals, one pass): closed-loop maps -> wave scan -> step of the interval's midpoint and
+//     end knot -> fraction-to-the-boundary limits and merit slope of those points, on the values just computed.
+// Per iteration and trajectory: ~40 k doubles of global traffic instead of ~100 k, and six dependent memory round trips
+// instead of thirty.  The algorithm, its constants and its control flow are those of HsWave::solve / HsSolver::solve; the
+// kernels are tested against each other (tests/test_gpu_solve.py).
+// Reference: the problem is the one /root/reference/myriad/trajectory_optimizers/collocation/hermite_simpson.py builds
+// (constraints :325-335, objective :243-257, bounds :55-81); the solve replaces myriad/nlp_solvers/__init__.py:57-58.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hs_solver_wave.h"
+
+namespace myriad {
+
+// lane l <- lane l - 1 (lane 0: unspecified, the callers overwrite it)
+__device__ inline double lane_up1(double v) { return __shfl_up(v, 1, 64); }
+
+template <class Sys>
+struct HsFused {
+  using W0 = HsWave<Sys, 0>;
+  using S = HsSolver<Sys>;
+  using D = HsSol<Sys>;
+  static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = NY + 1;
+  static constexpr int QE = NQ - NU;
+  static constexpr bool SUPPORTED = (NU == 1 && NS <= 4) && !NodeTraits<Sys>::mlp;
+  static constexpr int HSYM = NW * (NW + 1) / 2;
+  // per-point Hessian record, AoS: upper triangle of H (row-major), g0 (NW), g1 (NW)
+  static constexpr int HR_H = 0, HR_G0 = HSYM, HR_G1 = HR_G0 + NW, HR_N = HR_G1 + NW;
+  // per-stage record, AoS: Ge | ge, Gm | gm
+  static constexpr int SG_GE = 0, SG_GM = NS * NY1, SG_N = 2 * NS * NY1;
+  static constexpr int KST = NQ * NW + NQ * NC, KSTR = KST;      // gains K | kc per stage
+  static constexpr int ZR = 32;                                  // block of zeros (masked sweep lanes read it) + 2 write-only slots
+  static constexpr int PF = MYR_RICCATI_PF;
+  static constexpr int PADH = PF * 2 * HR_N, PADS = PF * SG_N;   // the sweep's prefetch ring reads PF stages below stage 0
+  __host__ __device__ static constexpr int symidx(int r, int c) { return r <= c ? r * NW - r * (r - 1) / 2 + (c - r) : c * NW - c * (c - 1) / 2 + (r - c); }
+  __host__ __device__ static constexpr int npoints(int N) { return 2 * N + 1; }
+  __host__ __device__ static inline double wq(int K, int j, double h) { return S::wsimp(K, j, h); }
+  __host__ __device__ static inline double tq(int j, double h) { return 0.5 * h * j; }
+
+  // global scratch per resident wavefront (doubles): zeros | dz | pad | hr | pad | st | gains | multipliers
+  __host__ __device__ static long off_dz(int) { return ZR; }
+  __host__ __device__ static long off_hr(int N) { return off_dz(N) + (long)npoints(N) * NW + PADH; }
+  __host__ __device__ static long off_st(int N) { return off_hr(N) + (long)npoints(N) * HR_N + PADS; }
+  __host__ __device__ static long off_kg(int N) { return off_st(N) + (long)N * SG_N; }
+  __host__ __device__ static long off_lam(int N) { return off_kg(N) + (long)N * KST; }
+  __host__ __device__ static long scratch_doubles(int N) { return off_lam(N) + 2L * N * NS; }
+  // LDS (doubles): z | zL | zU | R0 (multipliers, later the trial's x | f) | bound table | neighbour stash | first-point exchange
+  static constexpr int NREC = NS + NS + NS * NS + NS * NU + NS;   // x, f, A, B, own: what an interval takes from its end knot
+  static constexpr int EXCH = NW * NW + NW * NC + NS * NC + NU * NC;
+  __host__ __device__ static int r0_doubles(int N) { const int a = 2 * npoints(N) * NS, b = 2 * N * NS; return a > b ? a : b; }
+  __host__ __device__ static int lds_doubles(int N) { return 3 * npoints(N) * NW + r0_doubles(N) + 6 * NW + NREC + EXCH + 8; }
+  __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
+
+  struct Ctx {
+    int N, K, n, lane;
+    double h, h6, h8;
+    double *z, *zL, *zU;                  // the iterate (LDS)
+    double *dz, *hr, *st, *kg, *zr;       // global scratch of this wavefront
+    const double *lb, *ub;                // the caller's bounds (global)
+    bool uni;                             // interior points share one bound per component: served from sB
+    SysParams<Sys> pp;
+    bool term_pinned[NS];
+    double *r0, *sLam, *sB, *sStash, *sP, *sPc, *sTnu, *sKu;   // LDS
+#ifdef MYR_PHASE_TIMING
+    long long tph[16], t0;
+#endif
+  };
+  __device__ static inline long zi(const Ctx& c, int j, int comp) { return S::zi(c.K, j, comp); }
+  __device__ static inline void wsync() { __syncthreads(); }
+
+  // bounds of the NW variables of point j
+  __device__ static inline void load_bounds(const Ctx& c, int j, double* l, double* u) {
+    if (c.uni) {
+      const double* b = c.sB + ((j == 0) ? 0 : ((j == c.K - 1) ? 2 * NW : 4 * NW));
+#pragma unroll
+      for (int q = 0; q < NW; ++q) { l[q] = b[q]; u[q] = b[NW + q]; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) { const long i = zi(c, j, q); l[q] = c.lb[i]; u[q] = c.ub[i]; }
+    }
+  }
+
+  struct Step { bool on; double ap, ad, mu, ksig; };
+  struct Acc { double f, cmax, cmin, sm, lg; int nm; };
+  struct PRec { double x[NS], f[NS], A[NS * NS], B[NS * NU], own[NS]; };   // own = w_j dg/dx + (zU - zL)_x of the point
+
+  // One point of the backward phase: the accepted step of the previous iteration is applied on the values loaded anyway
+  // (same formulas, same order of operations as HsWave::points_lin), then dynamics + first derivatives, bound sums.
+  // Every lane runs it (uniform control flow: the callers use cross-lane moves); `live` gates stores and sums.
+  __device__ static inline void lin_at(Ctx& c, const Step& st, int j, bool live, PRec& R, Acc& a) {
+    typename S::VarBlk V;
+    load_bounds(c, j, V.l, V.u);
+    const double iks = 1.0 / st.ksig;
+    double dv[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const long i = zi(c, j, q);
+      V.z[q] = c.z[i]; V.zl[q] = c.zL[i]; V.zu[q] = c.zU[i];
+      dv[q] = st.on ? c.dz[i] : 0.0;
+    }
+    if (st.on) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const long i = zi(c, j, q);
+        const double l = V.l[q], u = V.u[q], zv = V.z[q], d = dv[q], zl = V.zl[q], zu = V.zu[q];
+        const bool fr = l < u;
+        const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+        const double zn = fr ? zv + st.ap * d : zv;
+        const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
+        const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
+        double vl = zl + st.ad * (-zl + (st.mu - zl * d) * detail::rcp_(sl));
+        double vu = zu + st.ad * (-zu + (st.mu + zu * d) * detail::rcp_(su));
+        const double ml = st.mu * detail::rcp_(snl), mu_ = st.mu * detail::rcp_(snu);
+        vl = detail::dmax(detail::dmin(vl, st.ksig * ml), ml * iks);
+        vu = detail::dmax(detail::dmin(vu, st.ksig * mu_), mu_ * iks);
+        V.z[q] = zn; V.zl[q] = hl ? vl : 0.0; V.zu[q] = hu ? vu : 0.0;
+        if (live) { c.z[i] = V.z[q]; c.zL[i] = V.zl[q]; c.zU[i] = V.zu[q]; }
+      }
+    }
+    double u_[NU], g, gw[NW];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) R.x[q] = V.z[q];
+#pragma unroll
+    for (int q = 0; q < NU; ++q) u_[q] = V.z[NS + q];
+    set_time<Sys>(c.pp.get(), tq(j, c.h));
+    Sys::lin(R.x, u_, c.pp.get(), R.f, R.A, R.B, &g, gw);
+    const double wj = wq(c.K, j, c.h);
+    double cmax = a.cmax, cmin = a.cmin, sm = 0.0, slk = 1.0; int nm = 0, sexp = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      typename S::BV b = S::bound_terms(V.z[q], V.l[q], V.u[q], V.zl[q], V.zu[q], cmax, cmin);
+      if (q < NS) R.own[q < NS ? q : 0] = wj * gw[q] + b.zlu;
+      const bool fr = V.l[q] < V.u[q];
+      const bool hl = fr && (V.l[q] > -INFINITY), hu = fr && (V.u[q] < INFINITY);
+      sm += (hl ? V.zl[q] : 0.0) + (hu ? V.zu[q] : 0.0);
+      nm += (hl ? 1 : 0) + (hu ? 1 : 0);
+      const double sl = hl ? V.z[q] - V.l[q] : 1.0, su = hu ? V.u[q] - V.z[q] : 1.0;
+      { int e_; slk *= frexp((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0), &e_); sexp += e_; }
+    }
+    if (live) {
+      a.cmax = cmax; a.cmin = cmin; a.sm += sm; a.nm += nm;
+      a.lg -= log(slk) + sexp * 0.6931471805599453;
+      a.f += wj * g;
+    }
+  }
+
+  // ---- BACKWARD phase -------------------------------------------------------------------------------------------------------
+  // Lane l of a block takes stage k = kb + 63 - l (descending: the suffix recursion over the stages becomes the prefix scan
+  // over the lanes that the DPP idiom provides, and the end knot of stage k is the start knot of the lane below).  The top
+  // block starts at the virtual stage N, whose start knot is the terminal point.
+  struct BOut { double f, cmax, cmin, sm, lg, c1, cinf, lam_inf, sum_mult; int nm; };
+  __device__ static void backward(Ctx& c, const Step& stp, const double* nuT, BOut& o) {
+    using namespace detail;
+    const int N = c.N, K = c.K, lane = c.lane;
+    const double h6 = c.h6, h8 = c.h8;
+    Acc acc{0.0, 0.0, INFINITY, 0.0, 0.0, 0};
+    double c1 = 0, cinf = 0, li_ = 0, smu = 0;
+    double piS[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) piS[q] = c.term_pinned[q] ? nuT[q] : 0.0;
+    for (int kb = (N / 64) * 64; kb >= 0; kb -= 64) {
+      const int kr = kb + 63 - lane;
+      const bool on_s = kr <= N, on = kr < N;
+      const int k = on_s ? kr : N;                 // (lanes above the horizon repeat the terminal point; nothing is stored)
+      PRec Rs, Rm, Re;
+      lin_at(c, stp, 2 * k, on_s, Rs, acc);
+      lin_at(c, stp, on ? 2 * k + 1 : 2 * k, on, Rm, acc);
+      // end knot of the stage = start knot of stage k + 1: the lane below; lane 0 takes what the previous block left
+      {
+        double* rs = reinterpret_cast<double*>(&Rs); double* re = reinterpret_cast<double*>(&Re);
+#pragma unroll
+        for (int q = 0; q < NREC; ++q) {
+          const double t = lane_up1(rs[q]);
+          re[q] = (lane == 0) ? c.sStash[q] : t;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 63) {
+#pragma unroll
+          for (int q = 0; q < NREC; ++q) c.sStash[q] = rs[q];
+        }
+      }
+      const double* xs = Rs.x; const double* fs = Rs.f; const double* As = Rs.A; const double* Bs = Rs.B;
+      const double* xm = Rm.x; const double* fm = Rm.f; const double* Am = Rm.A; const double* Bm = Rm.B;
+      const double* xe = Re.x; const double* fe = Re.f; const double* Ae = Re.A; const double* Be = Re.B;
+      double dk[NS], ik[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        dk[q] = (xe[q] - xs[q]) - h6 * (fs[q] + 4.0 * fm[q] + fe[q]);
+        ik[q] = xm[q] - 0.5 * (xs[q] + xe[q]) - h8 * (fs[q] - fe[q]);
+        if (on) {
+          c1 += fabs(dk[q]) + fabs(ik[q]);
+          cinf = dmax(cinf, dmax(fabs(dk[q]), fabs(ik[q])));
+        }
+      }
+      double Cm[NS * NS], Ne[NS * NS], Nsm[NS * NS], E[NS * NS];
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const double id = (r == q) ? 1.0 : 0.0;
+          Cm[r * NS + q] = 4.0 * h6 * Am[r * NS + q];
+          Ne[r * NS + q] = 0.5 * id - h8 * Ae[r * NS + q];
+          Nsm[r * NS + q] = 0.5 * id + h8 * As[r * NS + q];
+        }
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = ((r == q) ? 1.0 : 0.0) - h6 * Ae[r * NS + q];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s -= Cm[r * NS + t] * Ne[t * NS + q];
+          E[r * NS + q] = s;
+        }
+      lu_factor<NS>(E);
+      double rm[NS], owne[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        rm[q] = Rm.own[q];
+        owne[q] = (k == N - 1 && c.term_pinned[q]) ? 0.0 : Re.own[q];
+      }
+      double* sg = c.st + (long)(on ? k : 0) * SG_N;
+      // Ge | ge
+      double Ge[NS * NY1];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = ((r == q) ? 1.0 : 0.0) + h6 * As[r * NS + q];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Cm[r * NS + t] * Nsm[t * NS + q];
+          Ge[r * NY1 + q] = s;
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          double cbs = 0.0, cbe = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) { cbs += Cm[r * NS + t] * Bs[t * NU + a]; cbe += Cm[r * NS + t] * Be[t * NU + a]; }
+          Ge[r * NY1 + NS + a] = h6 * Bs[r * NU + a] + h8 * cbs;
+          Ge[r * NY1 + NS + NU + a] = 4.0 * h6 * Bm[r * NU + a];
+          Ge[r * NY1 + NS + 2 * NU + a] = h6 * Be[r * NU + a] - h8 * cbe;
+        }
+        double s = -dk[r];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s -= Cm[r * NS + t] * ik[t];
+        Ge[r * NY1 + NY] = s;
+      }
+      lu_solve<NS, NY1>(E, Ge);
+      if (on) {
+#pragma unroll
+        for (int q = 0; q < NS * NY1; ++q) sg[SG_GE + q] = Ge[q];
+      }
+      // Gm | gm
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double row[NY1];
+#pragma unroll
+        for (int q = 0; q <= NY; ++q) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Ne[r * NS + t] * Ge[t * NY1 + q];
+          row[q] = s;
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) row[q] += Nsm[r * NS + q];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { row[NS + a] += h8 * Bs[r * NU + a]; row[NS + 2 * NU + a] -= h8 * Be[r * NU + a]; }
+        row[NY] -= ik[r];
+        if (on) {
+#pragma unroll
+          for (int q = 0; q <= NY; ++q) sg[SG_GM + r * NY1 + q] = row[q];
+        }
+      }
+      // adjoint maps: lam_d = Ld Pi + ld0, lam_i = Li Pi + li0, Pi_prev = M Pi + v
+      double Ld[NS * NS], ld0[NS], Li[NS * NS], li0[NS];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        double y[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) y[q] = (q == i) ? 1.0 : 0.0;
+        lu_solve_t<NS>(E, y);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) Ld[q * NS + i] = -y[q];
+      }
+      {
+        double t0[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = owne[q];
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Ne[t * NS + q] * rm[t];
+          t0[q] = s;
+        }
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+          double s = 0.0;
+#pragma unroll
+          for (int q = 0; q < NS; ++q) s += Ld[r * NS + q] * t0[q];
+          ld0[r] = s;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) s += Cm[t * NS + r] * Ld[t * NS + q];
+          Li[r * NS + q] = s;
+        }
+        double s = -rm[r];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) s += Cm[t * NS + r] * ld0[t];
+        li0[r] = s;
+      }
+      // Pi_prev = (-I - h6 As^T) lam_d + (-I/2 - h8 As^T) lam_i  ->  the lane's affine map (identity above the horizon)
+      double MA[NS * NS], Mb[NS];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+#pragma unroll
+        for (int q = 0; q <= NS; ++q) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) {
+            const double sd = ((r == t) ? -1.0 : 0.0) - h6 * As[t * NS + r];
+            const double si = ((r == t) ? -0.5 : 0.0) - h8 * As[t * NS + r];
+            s += sd * (q < NS ? Ld[t * NS + q] : ld0[t]) + si * (q < NS ? Li[t * NS + q] : li0[t]);
+          }
+          if (q < NS) MA[r * NS + q] = on ? s : ((r == q) ? 1.0 : 0.0); else Mb[r] = on ? s : 0.0;
+        }
+      }
+      affine_prefix_scan_dpp<NS>(MA, Mb);
+      double lo[NS], pi[NS];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double v = Mb[r];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) v += MA[r * NS + q] * piS[q];
+        lo[r] = v;                              // Pi_{k-1}
+      }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const double t = lane_up1(lo[q]);       // Pi_k = Pi_{k'-1} of the lane below, whose stage is k' = k + 1
+        pi[q] = (lane == 0) ? piS[q] : t;
+      }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) piS[q] = __shfl(lo[q], 63, 64);
+      // multipliers of the stage
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double d = ld0[r], i2 = li0[r];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { d += Ld[r * NS + q] * pi[q]; i2 += Li[r * NS + q] * pi[q]; }
+        if (on) {
+          c.sLam[k * NS + r] = d;
+          c.sLam[N * NS + k * NS + r] = i2;
+          li_ = dmax(li_, dmax(fabs(d), fabs(i2)));
+          smu += fabs(d) + fabs(i2);
+        }
+      }
+    }
+    o.f = wv_sum(acc.f); o.cmax = wv_max(acc.cmax); o.cmin = wv_min(acc.cmin); o.sm = wv_sum(acc.sm); o.nm = wv_isum(acc.nm);
+    o.lg = wv_sum(acc.lg); o.c1 = wv_sum(c1); o.cinf = wv_max(cinf); o.lam_inf = wv_max(li_); o.sum_mult = wv_sum(smu);
+  }
+
+  // ---- HESSIAN phase: lanes over points -- Lagrangian Hessian, gradient columns, control-row stationarity ----------------------
+  __device__ static void hessian(Ctx& c, double& stat) {
+    const int N = c.N, K = c.K;
+    const double h6 = c.h6, h8 = c.h8;
+    double st_ = 0;
+    for (int j = c.lane; j < K; j += 64) {
+      double a[NS];
+      if (j & 1) {
+        const int k = (j - 1) >> 1;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) a[q] = -4.0 * h6 * c.sLam[k * NS + q];
+      } else {
+        const int kL = (j >> 1) - 1, kR = j >> 1;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double s = 0.0;
+          if (kL >= 0) s += -h6 * c.sLam[kL * NS + q] + h8 * c.sLam[N * NS + kL * NS + q];
+          if (kR < N) s += -h6 * c.sLam[kR * NS + q] - h8 * c.sLam[N * NS + kR * NS + q];
+          a[q] = s;
+        }
+      }
+      const double wj = wq(K, j, c.h);
+      typename S::VarBlk V;
+      load_bounds(c, j, V.l, V.u);
+#pragma unroll
+      for (int q = 0; q < NW; ++q) { const long i = zi(c, j, q); V.z[q] = c.z[i]; V.zl[q] = c.zL[i]; V.zu[q] = c.zU[i]; }
+      HsPoint<Sys> P;
+      set_time<Sys>(c.pp.get(), tq(j, c.h));
+      S::lin_point(V, c.pp.get(), P);
+      double sig[NW], g1v[NW], zlu[NW], cmx = 0.0, cmn = INFINITY;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        typename S::BV b = S::bound_terms(V.z[q], V.l[q], V.u[q], V.zl[q], V.zu[q], cmx, cmn);
+        sig[q] = b.sigma; g1v[q] = b.g1; zlu[q] = b.zlu;
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        double r = wj * P.gw[NS + u] + zlu[NS + u];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) r += P.B[t * NU + u] * a[t];
+        st_ = detail::dmax(st_, fabs(r));
+      }
+      double W[NW * NW];
+      Sys::hessian(P.x, P.u, c.pp.get(), P.D2, a, wj, W);
+      double* hr = c.hr + (long)j * HR_N;
+      const bool last = (j == K - 1);
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+        const bool zr = last && r < NS && c.term_pinned[r < NS ? r : 0];
+#pragma unroll
+        for (int q = r; q < NW; ++q) {
+          const bool zq = last && q < NS && c.term_pinned[q < NS ? q : 0];
+          hr[HR_H + symidx(r, q)] = (zr || zq) ? 0.0 : (W[r * NW + q] + ((r == q) ? sig[r] : 0.0));
+        }
+        hr[HR_G0 + r] = zr ? 0.0 : wj * P.gw[r];
+        hr[HR_G1 + r] = zr ? 0.0 : g1v[r];
+      }
+    }
+    stat = wv_max(st_);
+  }
+
+  // ---- first point of the sweep: dx_0 = 0, eliminate du_0 (HsWave::riccati_first_point on the packed record) ----------------------
+  __device__ static int riccati_first_point(Ctx& c, const HsSolveOpts& o, double delta, int nreg) {
+    using namespace detail;
+    const int lane = c.lane;
+    const double* hr = c.hr;   // point 0
+    double Puu[NU * NU], ku[NU * NC], pun[NU * NS];
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+#pragma unroll
+      for (int b = 0; b < NU; ++b) Puu[a * NU + b] = c.sP[(NS + a) * NW + NS + b] + hr[HR_H + symidx(NS + a, NS + b)] + ((a == b) ? delta : 0.0);
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+        ku[a * NC + cc] = c.sPc[(NS + a) * NC + cc] + (cc == 0 ? hr[HR_G0 + NS + a] : (cc == 1 ? hr[HR_G1 + NS + a] : 0.0));
+#pragma unroll
+      for (int i = 0; i < NS; ++i) pun[a * NS + i] = ku[a * NC + 2 + i];
+    }
+    nreg += chol_reg<NU>(Puu, o.reg_floor);
+    chol_solve<NU, NC>(Puu, ku);
+    wsync();
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+          double s = 0.0;
+#pragma unroll
+          for (int a = 0; a < NU; ++a) s += pun[a * NS + i] * ku[a * NC + cc];
+          c.sTnu[i * NC + cc] -= s;
+        }
+#pragma unroll
+      for (int i = 0; i < NU * NC; ++i) c.sKu[i] = ku[i];
+    }
+    wsync();
+    return nreg;
+  }
+
+  // ---- Riccati sweep on v_mfma_f64_16x16x4_f64: HsWave::riccati_mfma (tile slots, chaining, pivot rule: see there), reading
+  // the symmetric-packed point records; the prefetch ring reads PF stages below stage 0 into the padding in front of hr / st ----
+  typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+  __device__ static int riccati_mfma(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
+    using namespace detail;
+    const int lane = c.lane, N = c.N;
+    const int g = lane >> 4, j = lane & 15;
+    const int scol = j < 4 ? (j < NS ? j : -1) : (j < 6 ? NS : -1);
+    const int ycol = scol >= 0 ? scol : ((j == 12 || j == 13) ? NS + 1 : ((j == 8 || j == 9) ? NS + 2 : -1));
+    const int cc = j == 6 ? 0 : (j == 7 ? 1 : (j == 10 ? 2 : (j == 11 ? 3 : (j == 14 ? 4 : (j == 15 ? 5 : -1)))));
+    const int rcc = (cc >= 0 && cc < NC) ? cc : -1;
+    const bool rowx = g < NS;
+    const double* he = c.hr + (long)(2 * (N - 1) + 2) * HR_N;
+    const double* hm = he - HR_N;
+    const double* st = c.st + (long)(N - 1) * SG_N;
+    auto hsel = [&](const double* rec, int row, bool on) -> const double* {
+      if (!on) return c.zr;
+      if (scol >= 0) return rec + HR_H + (scol <= row ? scol * NW - scol * (scol - 1) / 2 + (row - scol) : row * NW - row * (row - 1) / 2 + (scol - row));
+      if (rcc == 0) return rec + HR_G0 + row;
+      if (rcc == 1) return rec + HR_G1 + row;
+      return c.zr;
+    };
+    auto gsel = [&](int off) -> const double* {
+      if (!rowx) return c.zr;
+      if (ycol >= 0) return st + off + g * NY1 + ycol;
+      if (rcc == 0) return st + off + g * NY1 + NY;
+      return c.zr;
+    };
+    const double* ptr[6] = {hsel(he, g, rowx), hsel(he, NS, g < 2), gsel(SG_GE), hsel(hm, g, rowx), hsel(hm, NS, g < 2), gsel(SG_GM)};
+    long stp[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) stp[q] = (ptr[q] == c.zr) ? 0 : ((q == 2 || q == 5) ? (long)SG_N : 2L * HR_N);
+    const bool pinr = rowx && c.term_pinned[rowx ? g : 0];
+    double X0 = (pinr && scol == g) ? o.rho_term - delta : ((pinr && rcc == 2 + g) ? 1.0 : 0.0), X1 = 0.0;
+    const double dv0 = (rowx && scol == g) ? delta : 0.0, dv1 = (g < 2 && scol == NS) ? delta : 0.0;
+    const double f_a1 = j < 6 ? 1.0 : 0.0;
+    const double f_keep = rcc >= 0 ? 1.0 : 0.0;
+    const double f_she = (j == 8 || j == 9) ? 1.0 : 0.0, f_shm = (j == 12 || j == 13) ? 1.0 : 0.0;
+    const double f_x1 = g < 2 ? 1.0 : 0.0, f_t1 = g == 2 ? 1.0 : 0.0, f_t23 = g >= 2 ? 1.0 : 0.0;
+    const bool a3_on = g < 2 && (j < 6 || j == 10 || j == 11 || j == 14 || j == 15);
+    const double f_a3m = (a3_on && g == 0) ? -1.0 : 0.0, f_a3e = (a3_on && g == 1) ? -1.0 : 0.0;
+    const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
+    const int k_str = k_off < 0 ? 1 : ((scol >= 0) ? NW : NC);
+    double* k_ptr = k_off >= 0 ? c.kg + (long)(N - 1) * KSTR + k_off : c.zr + ZR - 2;
+    const long k_step = k_off >= 0 ? KSTR : 0;
+    double reg_floor = o.reg_floor;
+    asm volatile("" : "+v"(reg_floor));
+    int nreg = 0;
+    double in[PF][6];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
+    }
+    auto mid_part = [&](double n0, double n1, double Gm) -> mfma_d4 {
+      n0 += dv0; n1 += dv1;
+      const double s0 = W0::dpp_row_shr8(n0), s1 = W0::dpp_row_shr8(n1);
+      mfma_d4 C;
+      C[0] = fma(s0, f_shm, n0 * f_keep);
+      C[1] = fma(s1, f_shm, n1 * f_keep);
+      C[2] = 0.0; C[3] = 0.0;
+      const mfma_d4 R = __builtin_amdgcn_mfma_f64_16x16x4f64(n0 * f_a1, Gm, C, 0, 0, 0);
+      mfma_d4 C2;
+      C2[0] = 0.0; C2[1] = 0.0; C2[2] = 0.0; C2[3] = R[1];
+      return __builtin_amdgcn_mfma_f64_16x16x4f64(Gm, R[0], C2, 0, 0, 0);
+    };
+    mfma_d4 Qm = mid_part(in[0][3], in[0][4], in[0][5]);
+    mfma_d4 D3 = {X0, X1, 0.0, 0.0};
+    for (int kb = N - 1; kb >= 0; kb -= PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int k = kb - u;
+        if (k < 0) break;
+        X0 = D3[0] + (in[u][0] + dv0); X1 = fma(D3[1], f_x1, in[u][1] + dv1);
+        const double G = in[u][2];
+        const double nn0 = in[(u + 1) % PF][3], nn1 = in[(u + 1) % PF][4], nGm = in[(u + 1) % PF][5];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
+        const double sh0 = W0::dpp_row_shr4(X0), sh1 = W0::dpp_row_shr4(X1);
+        mfma_d4 C1;
+        C1[0] = fma(sh0, f_she, X0 * f_keep);
+        C1[1] = fma(sh1, f_she, X1 * f_keep);
+        C1[2] = 0.0; C1[3] = 0.0;
+        const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X0 * f_a1, G, C1, 0, 0, 0);
+        mfma_d4 C2;
+        C2[0] = Qm[0]; C2[1] = fma(D3[1], f_t1, Qm[1]); C2[2] = fma(D3[2], f_t23, Qm[2]) + D1[1]; C2[3] = fma(D3[3], f_t23, Qm[3]);
+        const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
+        const double q00 = W0::rdlane(D2[3], 12), q10 = W0::rdlane(D2[2], 12), q11 = W0::rdlane(D2[2], 8);
+        const double det = fma(q00, q11, -(q10 * q10));
+        const double rdet = fast_rcp(det);
+        const double b0 = D2[3], b1 = D2[2];
+        double kk0 = fma(q11, b0, -(q10 * b1)) * rdet;
+        double kk1 = fma(q00, b1, -(q10 * b0)) * rdet;
+        if (!(q00 > reg_floor) || !(det > reg_floor * q00)) {          // wave-uniform, rare
+          const double u00 = q00, u10 = q10, u11 = q11;
+          double d0 = u00;
+          if (!(d0 > reg_floor)) { d0 = dmax(fabs(d0), reg_floor); ++nreg; }
+          const double i0 = fast_rcp(d0);
+          const double l10 = u10 * i0;
+          double d1 = u11 - l10 * l10 * d0;
+          if (!(d1 > reg_floor)) { d1 = dmax(fabs(d1), reg_floor); ++nreg; }
+          if (nreg > 0 && abort_on_reg) return nreg;
+          const double i1 = fast_rcp(d1);
+          kk0 = b0; kk1 = b1;
+          kk1 -= l10 * kk0;
+          kk0 *= i0; kk1 *= i1;
+          kk0 -= l10 * kk1;
+        }
+        k_ptr[0] = kk0; k_ptr[k_str] = kk1;
+        k_ptr -= k_step;
+        const double A3 = fma(D2[3], f_a3m, D2[2] * f_a3e);
+        const double B3 = g == 0 ? kk0 : (g == 1 ? kk1 : 0.0);
+        D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, B3, D2, 0, 0, 0);
+        double m0 = nn0 + dv0, m1 = nn1 + dv1;
+        const double ms0 = W0::dpp_row_shr8(m0), ms1 = W0::dpp_row_shr8(m1);
+        mfma_d4 Cm;
+        Cm[0] = fma(ms0, f_shm, m0 * f_keep);
+        Cm[1] = fma(ms1, f_shm, m1 * f_keep);
+        Cm[2] = 0.0; Cm[3] = 0.0;
+        const mfma_d4 Rm = __builtin_amdgcn_mfma_f64_16x16x4f64(m0 * f_a1, nGm, Cm, 0, 0, 0);
+        mfma_d4 Cq;
+        Cq[0] = 0.0; Cq[1] = 0.0; Cq[2] = 0.0; Cq[3] = Rm[1];
+        Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(nGm, Rm[0], Cq, 0, 0, 0);
+      }
+    }
+    X0 = D3[0]; X1 = D3[1];
+    const double T1 = D3[1], T2 = D3[2], T3 = D3[3];
+    if (scol >= 0 && j != 5) {
+      if (rowx) c.sP[g * NW + scol] = X0;
+      if (g == 0) c.sP[NS * NW + scol] = X1;
+    }
+    if (rcc >= 0) {
+      if (rowx) c.sPc[g * NC + rcc] = X0;
+      if (g == 0) c.sPc[NS * NC + rcc] = X1;
+      if (g >= 2 && g - 2 < NS) c.sTnu[(g - 2) * NC + rcc] = T2;
+      if (g >= 2 && g < NS) c.sTnu[g * NC + rcc] = T3;
+    }
+    wsync();
+    if (g == 2 && rcc >= 2) c.sTnu[(rcc - 2) * NC + 0] += T1;
+    wsync();
+    return riccati_first_point(c, o, delta, nreg);
+  }
+
+  // ---- FORWARD phase: closed-loop maps -> wave scan -> step of the stage's midpoint and end knot -> their step limits ----------
+  __device__ static void forward(Ctx& c, const HsSolveOpts& o, double mu, const double* th, typename S::FwdOut& fo) {
+    const int N = c.N, K = c.K, lane = c.lane;
+    const double tau = detail::dmax(o.tau_min, 1.0 - mu);
+    typename S::FwdOut l; l.alpha_p = 1.0; l.alpha_d = 1.0; l.gphi = 0.0;
+    // step limits / merit slope of the NW variables of point j with step d; stores the step
+    auto apply = [&](int j, const double* d, bool live) {
+      typename S::VarBlk V;
+      load_bounds(c, j, V.l, V.u);
+      double gg, gw[NW];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) { const long i = zi(c, j, q); V.z[q] = c.z[i]; V.zl[q] = c.zL[i]; V.zu[q] = c.zU[i]; }
+      set_time<Sys>(c.pp.get(), tq(j, c.h));
+      Sys::cost_grad(V.z, V.z + NS, c.pp.get(), &gg, gw);
+      const double wj = wq(K, j, c.h);
+      typename S::FwdOut t = l;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        if (live) c.dz[zi(c, j, q)] = d[q];
+        S::step_limits(V.z[q], V.l[q], V.u[q], V.zl[q], V.zu[q], d[q], mu, wj * gw[q], tau, t);
+      }
+      if (live) l = t;
+    };
+    double s0[NW];                           // state in front of the block (uniform)
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s0[q] = 0.0;
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+      double v = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) v -= c.sKu[a * NC + cc] * th[cc];
+      s0[NS + a] = v;
+    }
+    apply(0, s0, lane == 0);
+    for (int base = 0; base < N; base += 64) {
+      const int kr = base + lane;
+      const bool on = kr < N;
+      const int k = on ? kr : N - 1;
+      const double* Kst = c.kg + (long)k * KSTR;
+      const double* sg = c.st + (long)k * SG_N;
+      double Kk[NQ * NW], kq[NQ], Ge[NS * NY1], Gm[NS * NY1];
+#pragma unroll
+      for (int q = 0; q < NQ * NW; ++q) Kk[q] = Kst[q];
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) {
+        double v = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) v += Kst[NQ * NW + t * NC + cc] * th[cc];
+        kq[t] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < NS * NY1; ++q) { Ge[q] = sg[SG_GE + q]; Gm[q] = sg[SG_GM + q]; }
+      // closed-loop map of the stage (HsWave::stage_phi), identity beyond the last stage
+      double A[NW * NW], b[NW];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const bool pin = (k == N - 1) && c.term_pinned[i];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+          double v = Ge[i * NY1 + q];
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) v -= Ge[i * NY1 + NW + t] * Kk[t * NW + q];
+          A[i * NW + q] = on ? (pin ? 0.0 : v) : ((i == q) ? 1.0 : 0.0);
+        }
+        double v = Ge[i * NY1 + NY];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) v -= Ge[i * NY1 + NW + t] * kq[t];
+        b[i] = (on && !pin) ? v : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) A[(NS + a) * NW + q] = on ? -Kk[(QE + a) * NW + q] : ((NS + a == q) ? 1.0 : 0.0);
+        b[NS + a] = on ? -kq[QE + a] : 0.0;
+      }
+      affine_prefix_scan_dpp<NW>(A, b);
+      double sn[NW], y[NY];
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+        double v = b[r];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) v += A[r * NW + q] * s0[q];
+        sn[r] = v;                               // s_{k+1}
+      }
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const double t = lane_up1(sn[q]);
+        y[q] = (lane == 0) ? s0[q] : t;          // s_k
+      }
+#pragma unroll
+      for (int q = 0; q < NW; ++q) s0[q] = __shfl(sn[q], 63, 64);
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) {
+        double v = -kq[t];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) v -= Kk[t * NW + q] * y[q];
+        y[NW + t] = v;
+      }
+      double dm[NW], de[NW];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        double vm = Gm[r * NY1 + NY];
+#pragma unroll
+        for (int q = 0; q < NY; ++q) vm += Gm[r * NY1 + q] * y[q];
+        dm[r] = vm;
+        de[r] = sn[r];                           // = Ge y + ge (0 on a pinned terminal state)
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { dm[NS + a] = y[NW + a]; de[NS + a] = y[NW + NU + a]; }
+      apply(2 * k + 1, dm, on);
+      apply(2 * k + 2, de, on);
+    }
+    fo.alpha_p = wv_min(l.alpha_p); fo.alpha_d = wv_min(l.alpha_d); fo.gphi = wv_sum(l.gphi);
+  }
+
+  // ---- merit trial at z + alpha dz (HsWave::trial on the LDS iterate) --------------------------------------------------------
+  __device__ static bool trial(Ctx& c, double alpha, double mu, double& f, double& bar, double& c1) {
+    const int N = c.N, K = c.K;
+    double* sX = c.r0; double* sF = c.r0 + (long)K * NS;
+    double fa = 0, ba = 0; int bad = 0;
+    for (int j = c.lane; j < K; j += 64) {
+      double x[NS], u[NU], ff[NS], bl[NW], bu[NW];
+      load_bounds(c, j, bl, bu);
+      double slk = 1.0; int sexp = 0;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const long i = zi(c, j, q);
+        const double v = c.z[i] + alpha * c.dz[i];
+        const double l = bl[q], ub = bu[q];
+        const bool fr = l < ub;
+        const bool hl = fr && (l > -INFINITY), hu = fr && (ub < INFINITY);
+        const double sl = hl ? v - l : 1.0, su = hu ? ub - v : 1.0;
+        bad += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
+        { int e_; slk *= frexp((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0), &e_); sexp += e_; }
+        if (q < NS) x[q] = v; else u[q - NS] = v;
+      }
+      ba -= log(slk) + sexp * 0.6931471805599453;
+      Sys::f(x, u, c.pp.get(), ff);
+      set_time<Sys>(c.pp.get(), tq(j, c.h));
+      const double gj = Sys::g(x, u, c.pp.get());
+      fa += wq(K, j, c.h) * gj;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) { sX[j * NS + q] = x[q]; sF[j * NS + q] = ff[q]; }
+    }
+    wsync();
+    double ca = 0;
+    for (int k = c.lane; k < N; k += 64) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const double xs = sX[(2 * k) * NS + q], xm = sX[(2 * k + 1) * NS + q], xe = sX[(2 * k + 2) * NS + q];
+        const double fs = sF[(2 * k) * NS + q], fm = sF[(2 * k + 1) * NS + q], fe = sF[(2 * k + 2) * NS + q];
+        ca += fabs((xe - xs) - c.h6 * (fs + 4.0 * fm + fe));
+        ca += fabs(xm - 0.5 * (xs + xe) - c.h8 * (fs - fe));
+      }
+    }
+    wsync();
+    f = wv_sum(fa); bar = mu * wv_sum(ba); c1 = wv_sum(ca);
+    bad = wv_isum(bad);
+    if (bad != 0) return false;
+    if (!detail::finite_(f)) return false;
+    if (!detail::finite_(c1)) return false;
+    return detail::finite_(bar);
+  }
+
+  // ---- start: the caller's point pushed inside its bounds (HsWave::init), into LDS; bound table ---------------------------------
+  __device__ static void init(Ctx& c, const double* zg) {
+    const double k1 = 1e-2, k2 = 1e-2;
+    const int K = c.K;
+    int same = 1;
+    for (int i = c.lane; i < c.n; i += 64) {
+      const double l = c.lb[i], u = c.ub[i], v0 = zg[i];
+      const bool fr = l < u;
+      const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+      const double width = (hl && hu) ? (u - l) : INFINITY;
+      const double pl = detail::dmin(k1 * detail::dmax(1.0, fabs(l)), k2 * width);
+      const double pu = detail::dmin(k1 * detail::dmax(1.0, fabs(u)), k2 * width);
+      double v = v0;
+      v = hl ? detail::dmax(v, l + pl) : v;
+      v = hu ? detail::dmin(v, u - pu) : v;
+      v = fr ? v : l;
+      c.z[i] = v; c.zL[i] = hl ? 1.0 : 0.0; c.zU[i] = hu ? 1.0 : 0.0;
+      // does every interior point have the bounds of point 1?  (variable i = component q of point j)
+      const int j = i < K * NS ? i / NS : (i - K * NS) / NU;
+      const int q = i < K * NS ? i - j * NS : NS + (i - K * NS) - j * NU;
+      if (j >= 1 && j <= K - 2) {
+        const long i1 = S::zi(K, 1, q);
+        const double l1 = c.lb[i1], u1 = c.ub[i1];
+        same &= ((l == l1) && (u == u1)) ? 1 : 0;      // (infinities compare equal; a NaN bound switches the table off)
+      }
+    }
+    same = (wv_isum(same) == 64) ? 1 : 0;
+    c.uni = __builtin_amdgcn_readfirstlane(same) != 0;
+    if (c.lane < NW) {
+      const int q = c.lane;
+      const long i0 = S::zi(K, 0, q), iT = S::zi(K, K - 1, q), i1 = S::zi(K, 1, q);
+      c.sB[q] = c.lb[i0]; c.sB[NW + q] = c.ub[i0];
+      c.sB[2 * NW + q] = c.lb[iT]; c.sB[3 * NW + q] = c.ub[iT];
+      c.sB[4 * NW + q] = c.lb[i1]; c.sB[5 * NW + q] = c.ub[i1];
+    }
+    if (c.lane < ZR) c.zr[c.lane] = 0.0;
+  }
+
+  // ---- the solve (control flow identical to HsWave::solve / HsSolver::solve) -----------------------------------------------------
+  __device__ static void solve(Ctx& c, const HsSolveOpts& o, const double* zg, HsSolveResult& res) {
+    using namespace detail;
+    init(c, zg);
+    wsync();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) c.term_pinned[q] = !(c.sB[2 * NW + q] < c.sB[3 * NW + q]);
+    double mu = o.mu_init, pen = 1.0;
+    int pen_over = 0, pen_cuts = 0;
+    double nuT[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) nuT[i] = 0.0;
+    const double mu_min = dmin(o.tol_compl, o.tol_stat) * 0.1;
+    res.status = 1; res.iters = o.max_iter;
+    int stall = 0, small_steps = 0;
+    double delta_last = 0.0, lm = 0.0;
+    constexpr int NMMAX = 8;
+    double hist[NMMAX]; int nhist = 0, hpos = 0; double hist_mu = -1.0, hist_pen = -1.0;
+    Step pending{false, 0.0, 0.0, 0.0, o.kappa_sigma};
+    for (int it = 0; it <= o.max_iter; ++it) {
+      BOut p1;
+      backward(c, pending, nuT, p1);
+      pending.on = false;
+      wsync();
+      MYR_PH(0)
+      double stat_raw;
+      hessian(c, stat_raw);
+      wsync();
+      MYR_PH(4)
+      const double c1 = p1.c1, cinf = p1.cinf, sum_mult = p1.sum_mult;
+      double delta = lm;
+      if (o.delta_warm && delta_last > o.delta_warm_min) delta = dmax(delta, delta_last / DELTA_WARM_DIV);
+      int nreg = 0;
+      for (int tr_ = 0; tr_ < 12; ++tr_) {
+        const bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
+        nreg = riccati_mfma(c, o, delta, abort_on_reg);
+        wsync();
+        MYR_PH(6)
+        if (nreg == 0) break;
+        if (!abort_on_reg) break;
+        if (delta == 0.0) delta = (delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4;
+        else delta *= (delta_last > 0.0) ? 8.0 : 100.0;
+      }
+      delta_last = (delta > lm) ? delta : 0.0;
+      const int nm = 2 * c.N * NS + p1.nm;
+      const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
+      const double stat = stat_raw / sd, comp = p1.cmax / sd;
+      res.cost = p1.f; res.feas = cinf; res.stat = stat; res.compl_ = comp;
+      if (!(finite_(p1.f) && finite_(cinf) && finite_(stat_raw))) { res.status = 2; res.iters = it; return; }
+      if (cinf <= o.tol_feas && stat <= o.tol_stat && comp <= o.tol_compl) { res.status = 0; res.iters = it; return; }
+      if (it == o.max_iter) break;
+      for (int guard = 0; guard < 8; ++guard) {
+        const double cerr = (p1.cmin <= p1.cmax) ? dmax(fabs(p1.cmax - mu), fabs(p1.cmin - mu)) : 0.0;
+        const double emu = dmax(dmax(stat, cinf), cerr / sd);
+        if (emu <= o.kappa_eps * mu && mu > mu_min) {
+          const double nmu = dmax(mu_min, dmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+          mu = nmu;
+        } else break;
+      }
+      typename S::SweepOut so;
+#pragma unroll
+      for (int i = 0; i < NS * NC; ++i) so.Tnu[i] = c.sTnu[i];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) so.term_pinned[i] = c.term_pinned[i];
+      double nu[NS];
+      S::solve_nu(so, mu, nu);
+      double th[NC];
+      th[0] = 1.0; th[1] = mu;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
+      MYR_PH(7)
+      typename S::FwdOut fo;
+      forward(c, o, mu, th, fo);
+      wsync();
+      MYR_PH(8)
+      if (!(finite_(fo.gphi) && finite_(fo.alpha_p))) { res.status = 2; res.iters = it; return; }
+      if (c1 > 0.0) {
+        const double need = fo.gphi / (0.9 * c1);
+        if (pen < need) pen = need + 1.0;
+        if (PEN_RELAX > 0) {
+          const double want = 2.0 * dmax(need, 0.0) + 1.0;
+          pen_over = (pen > PEN_RELAX_RATIO * want) ? pen_over + 1 : 0;
+          if (pen_over >= PEN_RELAX && pen_cuts < PEN_RELAX_MAX) { pen = want; pen_over = 0; ++pen_cuts; }
+        }
+      }
+      const double Dphi = fo.gphi - pen * c1;
+      const double f0 = p1.f, bar0 = mu * p1.lg, c10 = c1;
+      const double phi0 = f0 + bar0 + pen * c10;
+      if (mu != hist_mu || pen != hist_pen) { nhist = 0; hpos = 0; hist_mu = mu; hist_pen = pen; }
+      double phiref = phi0;
+      for (int j = 0; j < nhist; ++j) phiref = dmax(phiref, hist[j]);
+      if (o.nonmono > 0) { hist[hpos % o.nonmono] = phi0; ++hpos; if (nhist < o.nonmono) ++nhist; }
+      double a = fo.alpha_p;
+      bool ok = false;
+      for (int ls = 0; ls < 40; ++ls) {
+        double ft, bt, ct;
+        if (trial(c, a, mu, ft, bt, ct)) {
+          const double phit = ft + bt + pen * ct;
+          if (phit <= phiref + 1e-8 * a * Dphi + 1e-13 * fabs(phi0)) { ok = true; break; }
+        }
+        a *= 0.5;
+      }
+      if (!ok) {
+        if (++stall > 5) {       // the multipliers in R0 were overwritten by the trials: rebuild them for the caller
+          Step none{false, 0.0, 0.0, 0.0, o.kappa_sigma};
+          BOut t_;
+          backward(c, none, nuT, t_);
+          wsync();
+          res.status = 3; res.iters = it; return;
+        }
+      } else stall = 0;
+      MYR_PH(11)
+      pending.on = true; pending.ap = a; pending.ad = o.dual_follow ? fo.alpha_d * (a / fo.alpha_p) : fo.alpha_d; pending.mu = mu;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
+      if (o.lm_init > 0.0) {
+        const double ratio = o.lm_abs ? a : a / fo.alpha_p;
+        if (ratio <= 0.25) lm = dmin(1e2, dmax(o.lm_init, 4.0 * lm));
+        else if (ratio >= 0.99) { lm *= 0.25; if (lm < 0.1 * o.lm_init) lm = 0.0; }
+      }
+      if (o.recenter > 0) {
+        small_steps = (a < o.recenter_alpha) ? small_steps + 1 : 0;
+        if (small_steps >= o.recenter && mu < o.mu_init) { mu = dmin(o.mu_init, 10.0 * mu); small_steps = 0; }
+      }
+      wsync();
+    }
+    res.status = 1; res.iters = o.max_iter;
+  }
+};
+
+// Persistent, one trajectory per wavefront (workgroup = one wavefront): every workgroup pulls trajectories from `ticket` until the
+// batch is done and owns ONE scratch block that it re-uses for all of them.
+template <class Sys>
+__global__ __launch_bounds__(64, 1)
+void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
+                           const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
+                           const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
+                           int32_t* iters, double* kkt) {
+  using W = HsFused<Sys>;
+  extern __shared__ __attribute__((aligned(16))) char smem_fused[];
+  typename W::Ctx c;
+  c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x & 63;
+  c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
+  double* s = scratch + (long)blockIdx.x * scratch_stride;
+  c.zr = s; c.dz = s + W::off_dz(c.N); c.hr = s + W::off_hr(c.N); c.st = s + W::off_st(c.N); c.kg = s + W::off_kg(c.N);
+  double* const lam_own = s + W::off_lam(c.N);
+  double* l = reinterpret_cast<double*>(smem_fused);
+  c.z = l; l += c.n; c.zL = l; l += c.n; c.zU = l; l += c.n;
+  c.r0 = l; c.sLam = l; l += W::r0_doubles(c.N);
+  c.sB = l; l += 6 * W::NW;
+  c.sStash = l; l += W::NREC;
+  c.sP = l; l += W::NW * W::NW;
+  c.sPc = l; l += W::NW * W::NC;
+  c.sTnu = l; l += W::NS * W::NC;
+  c.sKu = l; l += W::NU * W::NC;
+  for (;;) {
+    int t = 0;
+    if (c.lane == 0) t = atomicAdd(ticket, 1);
+    const long b = __builtin_amdgcn_readfirstlane(t);
+    if (b >= B) break;
+    double* zg = z + b * (long)c.n;
+    c.lb = lb + b * (long)c.n; c.ub = ub + b * (long)c.n;
+    double* lamg = lam ? lam + b * (long)(2 * c.N * W::NS) : lam_own;
+    c.pp.load(params, b, params_stride);
+    c.pp.set_scale(vs.s);
+    HsSolveResult r;
+#ifdef MYR_PHASE_TIMING
+    for (int i = 0; i < 16; ++i) c.tph[i] = 0;
+    c.t0 = clock64();
+#endif
+    W::solve(c, o, zg, r);
+    for (int i = c.lane; i < c.n; i += 64) zg[i] = c.z[i];
+    for (int i = c.lane; i < 2 * c.N * W::NS; i += 64) lamg[i] = c.sLam[i];
+#ifdef MYR_PHASE_TIMING
+    if (c.lane == 0 && b < 4) {
+      printf("traj %ld it %d: backward %lld hess %lld ricc %lld nu %lld forward %lld ls %lld\n",
+             b, r.iters, c.tph[0], c.tph[4], c.tph[6], c.tph[7], c.tph[8], c.tph[11]);
+    }
+#endif
+    if (c.lane == 0) {
+      if (cost) cost[b] = r.cost;
+      if (status) status[b] = r.status;
+      if (iters) iters[b] = r.iters;
+      if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
+    }
+    W::wsync();      // the slot's scratch and LDS are handed to the next trajectory
+  }
+}
+
+}  // namespace myriad

@@ -12,6 +12,7 @@
 #include "colloc_products.h"
 #include "hs_solver.h"
 #include "hs_solver_wave.h"
+#include "hs_solver_fused.h"
 #include "shoot_solver_wave.h"
 #include "os_solver.h"
 #include "shoot_eval.h"
@@ -77,13 +78,16 @@ struct myr_handle_s {
   size_t dbuf_bytes = 0;
   int eval_wpt = 8;
   int eval_nt = 1;      // non-temporal stores for the c / J-block streams
-  int solve_mode = 1;   // 1: one trajectory per wavefront (hs_solver_wave.h); 0: one trajectory per lane (hs_solver.h)
+  int solve_mode = 1;   // 1: one trajectory per wavefront (hs_solver_fused.h / hs_solver_wave.h); 0: one trajectory per lane (hs_solver.h)
+  int solve_fused = 1;  // 1: the fused-phase wavefront kernel where it is built (MYRIAD_SOLVE_MODE=wave1 selects round 2's HsWave)
   int solve_lpw = 16;   // trajectories (active lanes) per wavefront in the solve kernel
   // solver scratch (batch-minor / SoA)
   void* sbuf = nullptr;
   size_t sbuf_bytes = 0;
   int* ticket = nullptr;      // work counter of the persistent solve kernel (one int)
   int solve_slots = 0;        // MYRIAD_SOLVE_SLOTS: resident wavefronts of the solve kernel (0 = what the device holds)
+  bool fused_ready = false;   // launch_hs_fused: kernel attributes set, occupancy known (for fused_N intervals)
+  int fused_N = 0, fused_slots = 0;
   // variable scaling of the solve path (myr_set_var_scale): the solver kernels see z/s, lb/s, ub/s
   VarScale vscale{{1, 1, 1, 1, 1, 1, 1, 1}};
   bool vscale_on = false;
@@ -392,6 +396,52 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
                              int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                              int32_t* iters, double* kkt);
 
+// fused-phase wavefront kernel (hs_solver_fused.h): Hermite-Simpson, closed-form systems with one control and <= 4 states
+template <class Sys>
+static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
+                           int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
+                           int32_t* iters, double* kkt) {
+  using W = HsFused<Sys>;
+  const int N = h->d.intervals;
+  const size_t lds = W::lds_bytes(N);
+  auto kern = hs_solve_fused_kernel<Sys>;
+  if (!h->fused_ready || h->fused_N != N) {      // attributes and occupancy once per handle and grid size, not per call
+    int per_cu = 0, dev = 0, cus = 0;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64, lds));
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    h->fused_slots = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256);
+    h->fused_ready = true; h->fused_N = N;
+  }
+  int slots = h->solve_slots > 0 ? h->solve_slots : h->fused_slots;
+  if (slots > B) slots = B;
+  long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
+  if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate slots over HBM channels
+  const size_t need = (size_t)slots * (size_t)stride * 8;
+  if (need > h->sbuf_bytes) {
+    if (h->sbuf) HIPCHK(hipFree(h->sbuf));
+    h->sbuf = nullptr; h->sbuf_bytes = 0;
+    HIPCHK(hipMalloc(&h->sbuf, need));
+    h->sbuf_bytes = need;
+  }
+  if (!h->ticket) HIPCHK(hipMalloc(&h->ticket, sizeof(int)));
+  HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int), h->stream));
+  HsSolveOpts o = make_opts(h, so);
+  KTimer& kt = h->kt[MYR_K_SOLVE];
+  HIPCHK(hipEventRecord(kt.a, h->stream));
+  hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
+                     params, pstride, cost, status, iters, kkt);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(kt.b, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
+  kt.sum_ms += ms;
+  kt.launches += 1;
+  return MYR_OK;
+}
+
 template <class Sys, int SCHEME = 0>
 static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                            int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
@@ -400,6 +450,10 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   const myr_dims& dm = h->dims;
   // one trajectory per wavefront while its LDS working set fits a CU (N <= ~480 for CARTPOLE); beyond that the
   // lane-per-trajectory form, which keeps everything in global scratch, takes over
+  if constexpr (SCHEME == 0 && HsFused<Sys>::SUPPORTED) {
+    if (h->solve_mode == 1 && h->solve_fused && HsFused<Sys>::lds_bytes(N) <= 160 * 1024)
+      return launch_hs_fused<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  }
   if (h->solve_mode == 1 && HsWave<Sys, SCHEME>::lds_bytes(N) <= 160 * 1024) {
     using W = HsWave<Sys, SCHEME>;
     // wavefronts per workgroup: 1, except network systems -- independent solves that share the 40 KB of weights in LDS, four to a
@@ -727,7 +781,7 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
   if (w) { int v = atoi(w); if (v == 1 || v == 4 || v == 8) h->eval_wpt = v; }
   if (const char* e = getenv("MYRIAD_EVAL_NT")) h->eval_nt = atoi(e);
   const char* md = getenv("MYRIAD_SOLVE_MODE");
-  if (md) h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1;
+  if (md) { h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1; h->solve_fused = (strcmp(md, "wave1") == 0) ? 0 : 1; }
   const char* l = getenv("MYRIAD_SOLVE_LPW");
   if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
   if (const char* e = getenv("MYRIAD_SOLVE_SLOTS")) h->solve_slots = atoi(e);   // developer knob: resident wavefronts of the solve kernel
