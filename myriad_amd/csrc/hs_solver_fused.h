@@ -30,8 +30,12 @@ namespace myriad {
 // lane l <- lane l - 1 (lane 0: unspecified, the callers overwrite it)
 __device__ inline double lane_up1(double v) { return __shfl_up(v, 1, 64); }
 
-template <class Sys>
+// W wavefronts share one trajectory (W = 1: the throughput form, four trajectories per CU; W = 2: the small-batch form, each
+// wavefront takes every other block of 64 stages / points and they meet at workgroup barriers -- the carries of the two wave
+// scans and the neighbour records cross through LDS; the Riccati sweep runs in wavefront 0).
+template <class Sys, int W = 1>
 struct HsFused {
+  static constexpr int NT = 64 * W;
   using W0 = HsWave<Sys, 0>;
   using S = HsSolver<Sys>;
   using D = HsSol<Sys>;
@@ -52,41 +56,64 @@ struct HsFused {
   __host__ __device__ static inline double wq(int K, int j, double h) { return S::wsimp(K, j, h); }
   __host__ __device__ static inline double tq(int j, double h) { return 0.5 * h * j; }
 
-  // global scratch per resident wavefront (doubles): zeros | dz | pad | hr | pad | st | gains | multipliers
-  __host__ __device__ static long off_dz(int) { return ZR; }
-  __host__ __device__ static long off_hr(int N) { return off_dz(N) + (long)npoints(N) * NW + PADH; }
+  // global scratch per resident wavefront (doubles): zeros | pad | hr | pad | st | gains | multipliers
+  __host__ __device__ static long off_hr(int) { return ZR + PADH; }
   __host__ __device__ static long off_st(int N) { return off_hr(N) + (long)npoints(N) * HR_N + PADS; }
   __host__ __device__ static long off_kg(int N) { return off_st(N) + (long)N * SG_N; }
   __host__ __device__ static long off_lam(int N) { return off_kg(N) + (long)N * KST; }
   __host__ __device__ static long scratch_doubles(int N) { return off_lam(N) + 2L * N * NS; }
-  // LDS (doubles): z | zL | zU | R0 (multipliers, later the trial's x | f) | bound table | neighbour stash | first-point exchange
+  // LDS (doubles): z | zL | zU | dz | multipliers | bound table | neighbour stash | first-point exchange
   static constexpr int NREC = NS + NS + NS * NS + NS * NU + NS;   // x, f, A, B, own: what an interval takes from its end knot
   static constexpr int EXCH = NW * NW + NW * NC + NS * NC + NU * NC;
-  __host__ __device__ static int r0_doubles(int N) { const int a = 2 * npoints(N) * NS, b = 2 * N * NS; return a > b ? a : b; }
-  __host__ __device__ static int lds_doubles(int N) { return 3 * npoints(N) * NW + r0_doubles(N) + 6 * NW + NREC + EXCH + 8; }
+  // exchange between blocks / wavefronts (double-buffered by round): neighbour record, block total of a scan, trial knot; partial sums
+  static constexpr int NTOT = NW * NW + NW, NRED = 12;
+  static constexpr int XCH = 2 * W * NREC + 2 * W * NTOT + 2 * W * 2 * NS + W * NRED + 4;
+  __host__ __device__ static int lds_doubles(int N) { return 4 * npoints(N) * NW + 2 * N * NS + 6 * NW + XCH + EXCH + 8; }
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
 
   struct Ctx {
-    int N, K, n, lane;
+    int N, K, n, lane, wave, tid;
     double h, h6, h8;
-    double *z, *zL, *zU;                  // the iterate (LDS)
-    double *dz, *hr, *st, *kg, *zr;       // global scratch of this wavefront
+    double *z, *zL, *zU, *dz;             // the iterate and the step (LDS)
+    double *hr, *st, *kg, *zr;            // global scratch of this wavefront
     const double *lb, *ub;                // the caller's bounds (global)
     bool uni;                             // interior points share one bound per component: served from sB
     SysParams<Sys> pp;
     bool term_pinned[NS];
-    double *r0, *sLam, *sB, *sStash, *sP, *sPc, *sTnu, *sKu;   // LDS
+    double *sLam, *sB, *sStash, *sTot, *sTr, *sRed, *sMisc, *sP, *sPc, *sTnu, *sKu;   // LDS
 #ifdef MYR_PHASE_TIMING
     long long tph[16], t0;
 #endif
   };
   __device__ static inline long zi(const Ctx& c, int j, int comp) { return S::zi(c.K, j, comp); }
   __device__ static inline void wsync() { __syncthreads(); }
+  // partial results of the W wavefronts -> the workgroup's (op: 0 sum, 1 max, 2 min); every wavefront ends with the same values
+  template <int NV>
+  __device__ static inline void wg_combine(Ctx& c, double* v, const int (&op)[NV]) {
+    static_assert(NV <= NRED, "partial-sum slots");
+    if constexpr (W > 1) {
+      if (c.lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) c.sRed[c.wave * NRED + i] = v[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        double r = c.sRed[i];
+#pragma unroll
+        for (int w = 1; w < W; ++w) {
+          const double t = c.sRed[w * NRED + i];
+          r = op[i] == 0 ? r + t : (op[i] == 1 ? (r > t ? r : t) : (r < t ? r : t));
+        }
+        v[i] = r;
+      }
+    } else { (void)c; (void)v; (void)op; }
+  }
 
   // bounds of the NW variables of point j
   __device__ static inline void load_bounds(const Ctx& c, int j, double* l, double* u) {
     if (c.uni) {
-      const double* b = c.sB + ((j == 0) ? 0 : ((j == c.K - 1) ? 2 * NW : 4 * NW));
+      const nd_lds* b = (const nd_lds*)c.sB + ((j == 0) ? 0 : ((j == c.K - 1) ? 2 * NW : 4 * NW));
 #pragma unroll
       for (int q = 0; q < NW; ++q) { l[q] = b[q]; u[q] = b[NW + q]; }
     } else {
@@ -173,25 +200,31 @@ struct HsFused {
     double piS[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) piS[q] = c.term_pinned[q] ? nuT[q] : 0.0;
-    for (int kb = (N / 64) * 64; kb >= 0; kb -= 64) {
-      const int kr = kb + 63 - lane;
+    // rounds of W blocks from the top: wavefront w takes block r0 - w of the round
+    int round = 0;
+    for (int r0 = N / 64; r0 >= 0; r0 -= W, ++round) {
+      const int blk = r0 - c.wave;
+      const int kr = blk >= 0 ? blk * 64 + 63 - lane : N + 1;
       const bool on_s = kr <= N, on = kr < N;
       const int k = on_s ? kr : N;                 // (lanes above the horizon repeat the terminal point; nothing is stored)
       PRec Rs, Rm, Re;
       lin_at(c, stp, 2 * k, on_s, Rs, acc);
       lin_at(c, stp, on ? 2 * k + 1 : 2 * k, on, Rm, acc);
-      // end knot of the stage = start knot of stage k + 1: the lane below; lane 0 takes what the previous block left
+      // end knot of the stage = start knot of stage k + 1: the lane below; lane 0 takes what the block above left (the
+      // wavefront above of this round, or the last wavefront of the previous round)
       {
         double* rs = reinterpret_cast<double*>(&Rs); double* re = reinterpret_cast<double*>(&Re);
+        double* mine = c.sStash + ((round & 1) * W + c.wave) * NREC;
+        const double* theirs = c.sStash + (c.wave > 0 ? ((round & 1) * W + c.wave - 1) : (((round + 1) & 1) * W + W - 1)) * NREC;
+        if (lane == 63) {
+#pragma unroll
+          for (int q = 0; q < NREC; ++q) mine[q] = rs[q];
+        }
+        wsync();
 #pragma unroll
         for (int q = 0; q < NREC; ++q) {
           const double t = lane_up1(rs[q]);
-          re[q] = (lane == 0) ? c.sStash[q] : t;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 63) {
-#pragma unroll
-          for (int q = 0; q < NREC; ++q) c.sStash[q] = rs[q];
+          re[q] = (lane == 0) ? theirs[q] : t;
         }
       }
       const double* xs = Rs.x; const double* fs = Rs.f; const double* As = Rs.A; const double* Bs = Rs.B;
@@ -344,6 +377,38 @@ struct HsFused {
         }
       }
       affine_prefix_scan_dpp<NS>(MA, Mb);
+      double piN[NS];                          // Pi below the round (the next round's carry), by every wavefront alike
+#pragma unroll
+      for (int q = 0; q < NS; ++q) piN[q] = piS[q];
+      if constexpr (W > 1) {      // the blocks above in this round: their totals (lane 63's composite map) carry Pi down to this block
+        double* tot = c.sTot + ((round & 1) * W + c.wave) * NTOT;
+        if (lane == 63) {
+#pragma unroll
+          for (int q = 0; q < NS * NS; ++q) tot[q] = MA[q];
+#pragma unroll
+          for (int q = 0; q < NS; ++q) tot[NS * NS + q] = Mb[q];
+        }
+        wsync();
+        double pw[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) pw[q] = piS[q];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const double* tw = c.sTot + ((round & 1) * W + w) * NTOT;
+          double t[NS];
+#pragma unroll
+          for (int r = 0; r < NS; ++r) {
+            double v = tw[NS * NS + r];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) v += tw[r * NS + q] * piN[q];
+            t[r] = v;
+          }
+#pragma unroll
+          for (int q = 0; q < NS; ++q) { piN[q] = t[q]; if (w < c.wave) pw[q] = t[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) piS[q] = pw[q];      // Pi above THIS wavefront's block
+      }
       double lo[NS], pi[NS];
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
@@ -358,7 +423,7 @@ struct HsFused {
         pi[q] = (lane == 0) ? piS[q] : t;
       }
 #pragma unroll
-      for (int q = 0; q < NS; ++q) piS[q] = __shfl(lo[q], 63, 64);
+      for (int q = 0; q < NS; ++q) piS[q] = (W > 1) ? piN[q] : __shfl(lo[q], 63, 64);
       // multipliers of the stage
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
@@ -373,8 +438,12 @@ struct HsFused {
         }
       }
     }
-    o.f = wv_sum(acc.f); o.cmax = wv_max(acc.cmax); o.cmin = wv_min(acc.cmin); o.sm = wv_sum(acc.sm); o.nm = wv_isum(acc.nm);
-    o.lg = wv_sum(acc.lg); o.c1 = wv_sum(c1); o.cinf = wv_max(cinf); o.lam_inf = wv_max(li_); o.sum_mult = wv_sum(smu);
+    double v[10] = {wv_sum(acc.f), wv_max(acc.cmax), wv_min(acc.cmin), wv_sum(acc.sm), (double)wv_isum(acc.nm),
+                    wv_sum(acc.lg), wv_sum(c1), wv_max(cinf), wv_max(li_), wv_sum(smu)};
+    const int op[10] = {0, 1, 2, 0, 0, 0, 0, 1, 1, 0};
+    wg_combine<10>(c, v, op);
+    o.f = v[0]; o.cmax = v[1]; o.cmin = v[2]; o.sm = v[3]; o.nm = (int)v[4]; o.lg = v[5]; o.c1 = v[6]; o.cinf = v[7];
+    o.lam_inf = v[8]; o.sum_mult = v[9];
   }
 
   // ---- HESSIAN phase: lanes over points -- Lagrangian Hessian, gradient columns, control-row stationarity ----------------------
@@ -382,7 +451,7 @@ struct HsFused {
     const int N = c.N, K = c.K;
     const double h6 = c.h6, h8 = c.h8;
     double st_ = 0;
-    for (int j = c.lane; j < K; j += 64) {
+    for (int j = c.tid; j < K; j += NT) {
       double a[NS];
       if (j & 1) {
         const int k = (j - 1) >> 1;
@@ -419,8 +488,8 @@ struct HsFused {
         for (int t = 0; t < NS; ++t) r += P.B[t * NU + u] * a[t];
         st_ = detail::dmax(st_, fabs(r));
       }
-      double W[NW * NW];
-      Sys::hessian(P.x, P.u, c.pp.get(), P.D2, a, wj, W);
+      double Wh[NW * NW];
+      Sys::hessian(P.x, P.u, c.pp.get(), P.D2, a, wj, Wh);
       double* hr = c.hr + (long)j * HR_N;
       const bool last = (j == K - 1);
 #pragma unroll
@@ -429,13 +498,16 @@ struct HsFused {
 #pragma unroll
         for (int q = r; q < NW; ++q) {
           const bool zq = last && q < NS && c.term_pinned[q < NS ? q : 0];
-          hr[HR_H + symidx(r, q)] = (zr || zq) ? 0.0 : (W[r * NW + q] + ((r == q) ? sig[r] : 0.0));
+          hr[HR_H + symidx(r, q)] = (zr || zq) ? 0.0 : (Wh[r * NW + q] + ((r == q) ? sig[r] : 0.0));
         }
         hr[HR_G0 + r] = zr ? 0.0 : wj * P.gw[r];
         hr[HR_G1 + r] = zr ? 0.0 : g1v[r];
       }
     }
-    stat = wv_max(st_);
+    double v[1] = {wv_max(st_)};
+    const int op[1] = {1};
+    wg_combine<1>(c, v, op);
+    stat = v[0];
   }
 
   // ---- first point of the sweep: dx_0 = 0, eliminate du_0 (HsWave::riccati_first_point on the packed record) ----------------------
@@ -456,7 +528,7 @@ struct HsFused {
     }
     nreg += chol_reg<NU>(Puu, o.reg_floor);
     chol_solve<NU, NC>(Puu, ku);
-    wsync();
+    wave_sync<true>();
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < NS; ++i)
@@ -470,7 +542,7 @@ struct HsFused {
 #pragma unroll
       for (int i = 0; i < NU * NC; ++i) c.sKu[i] = ku[i];
     }
-    wsync();
+    wave_sync<true>();
     return nreg;
   }
 
@@ -561,6 +633,18 @@ struct HsFused {
         mfma_d4 C2;
         C2[0] = Qm[0]; C2[1] = fma(D3[1], f_t1, Qm[1]); C2[2] = fma(D3[2], f_t23, Qm[2]) + D1[1]; C2[3] = fma(D3[3], f_t23, Qm[3]);
         const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
+        // midpoint part of stage k-1 (independent of the recursion): issued HERE, so that its two dependent products run on
+        // the matrix pipe while the vector pipe waits for D2 and computes the gains -- behind D3 they delayed the next stage's D1
+        double m0 = nn0 + dv0, m1 = nn1 + dv1;
+        const double ms0 = W0::dpp_row_shr8(m0), ms1 = W0::dpp_row_shr8(m1);
+        mfma_d4 Cm;
+        Cm[0] = fma(ms0, f_shm, m0 * f_keep);
+        Cm[1] = fma(ms1, f_shm, m1 * f_keep);
+        Cm[2] = 0.0; Cm[3] = 0.0;
+        const mfma_d4 Rm = __builtin_amdgcn_mfma_f64_16x16x4f64(m0 * f_a1, nGm, Cm, 0, 0, 0);
+        mfma_d4 Cq;
+        Cq[0] = 0.0; Cq[1] = 0.0; Cq[2] = 0.0; Cq[3] = Rm[1];
+        Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(nGm, Rm[0], Cq, 0, 0, 0);
         const double q00 = W0::rdlane(D2[3], 12), q10 = W0::rdlane(D2[2], 12), q11 = W0::rdlane(D2[2], 8);
         const double det = fma(q00, q11, -(q10 * q10));
         const double rdet = fast_rcp(det);
@@ -587,16 +671,6 @@ struct HsFused {
         const double A3 = fma(D2[3], f_a3m, D2[2] * f_a3e);
         const double B3 = g == 0 ? kk0 : (g == 1 ? kk1 : 0.0);
         D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, B3, D2, 0, 0, 0);
-        double m0 = nn0 + dv0, m1 = nn1 + dv1;
-        const double ms0 = W0::dpp_row_shr8(m0), ms1 = W0::dpp_row_shr8(m1);
-        mfma_d4 Cm;
-        Cm[0] = fma(ms0, f_shm, m0 * f_keep);
-        Cm[1] = fma(ms1, f_shm, m1 * f_keep);
-        Cm[2] = 0.0; Cm[3] = 0.0;
-        const mfma_d4 Rm = __builtin_amdgcn_mfma_f64_16x16x4f64(m0 * f_a1, nGm, Cm, 0, 0, 0);
-        mfma_d4 Cq;
-        Cq[0] = 0.0; Cq[1] = 0.0; Cq[2] = 0.0; Cq[3] = Rm[1];
-        Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(nGm, Rm[0], Cq, 0, 0, 0);
       }
     }
     X0 = D3[0]; X1 = D3[1];
@@ -611,9 +685,9 @@ struct HsFused {
       if (g >= 2 && g - 2 < NS) c.sTnu[(g - 2) * NC + rcc] = T2;
       if (g >= 2 && g < NS) c.sTnu[g * NC + rcc] = T3;
     }
-    wsync();
+    wave_sync<true>();
     if (g == 2 && rcc >= 2) c.sTnu[(rcc - 2) * NC + 0] += T1;
-    wsync();
+    wave_sync<true>();
     return riccati_first_point(c, o, delta, nreg);
   }
 
@@ -650,9 +724,10 @@ struct HsFused {
       for (int cc = 0; cc < NC; ++cc) v -= c.sKu[a * NC + cc] * th[cc];
       s0[NS + a] = v;
     }
-    apply(0, s0, lane == 0);
-    for (int base = 0; base < N; base += 64) {
-      const int kr = base + lane;
+    apply(0, s0, c.tid == 0);
+    int round = 0;
+    for (int base0 = 0; base0 < N; base0 += NT, ++round) {
+      const int kr = base0 + c.tid;             // (wavefront w takes block base0 / 64 + w of the round)
       const bool on = kr < N;
       const int k = on ? kr : N - 1;
       const double* Kst = c.kg + (long)k * KSTR;
@@ -693,6 +768,38 @@ struct HsFused {
         b[NS + a] = on ? -kq[QE + a] : 0.0;
       }
       affine_prefix_scan_dpp<NW>(A, b);
+      double sN[NW];                            // state behind the round, by every wavefront alike
+#pragma unroll
+      for (int q = 0; q < NW; ++q) sN[q] = s0[q];
+      if constexpr (W > 1) {
+        double* tot = c.sTot + ((round & 1) * W + c.wave) * NTOT;
+        if (lane == 63) {
+#pragma unroll
+          for (int q = 0; q < NW * NW; ++q) tot[q] = A[q];
+#pragma unroll
+          for (int q = 0; q < NW; ++q) tot[NW * NW + q] = b[q];
+        }
+        wsync();
+        double sw[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) sw[q] = s0[q];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const double* tw = c.sTot + ((round & 1) * W + w) * NTOT;
+          double t[NW];
+#pragma unroll
+          for (int r = 0; r < NW; ++r) {
+            double v = tw[NW * NW + r];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) v += tw[r * NW + q] * sN[q];
+            t[r] = v;
+          }
+#pragma unroll
+          for (int q = 0; q < NW; ++q) { sN[q] = t[q]; if (w < c.wave) sw[q] = t[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < NW; ++q) s0[q] = sw[q];       // state in front of THIS wavefront's block
+      }
       double sn[NW], y[NY];
 #pragma unroll
       for (int r = 0; r < NW; ++r) {
@@ -707,7 +814,7 @@ struct HsFused {
         y[q] = (lane == 0) ? s0[q] : t;          // s_k
       }
 #pragma unroll
-      for (int q = 0; q < NW; ++q) s0[q] = __shfl(sn[q], 63, 64);
+      for (int q = 0; q < NW; ++q) s0[q] = (W > 1) ? sN[q] : __shfl(sn[q], 63, 64);
 #pragma unroll
       for (int t = 0; t < NQ; ++t) {
         double v = -kq[t];
@@ -729,53 +836,92 @@ struct HsFused {
       apply(2 * k + 1, dm, on);
       apply(2 * k + 2, de, on);
     }
-    fo.alpha_p = wv_min(l.alpha_p); fo.alpha_d = wv_min(l.alpha_d); fo.gphi = wv_sum(l.gphi);
+    double v[3] = {wv_min(l.alpha_p), wv_min(l.alpha_d), wv_sum(l.gphi)};
+    const int op[3] = {2, 2, 0};
+    wg_combine<3>(c, v, op);
+    fo.alpha_p = v[0]; fo.alpha_d = v[1]; fo.gphi = v[2];
   }
 
-  // ---- merit trial at z + alpha dz (HsWave::trial on the LDS iterate) --------------------------------------------------------
-  __device__ static bool trial(Ctx& c, double alpha, double mu, double& f, double& bar, double& c1) {
-    const int N = c.N, K = c.K;
-    double* sX = c.r0; double* sF = c.r0 + (long)K * NS;
-    double fa = 0, ba = 0; int bad = 0;
-    for (int j = c.lane; j < K; j += 64) {
-      double x[NS], u[NU], ff[NS], bl[NW], bu[NW];
-      load_bounds(c, j, bl, bu);
-      double slk = 1.0; int sexp = 0;
+  // ---- merit trial at z + alpha dz: lanes over intervals, each evaluating its midpoint and end knot; the start knot's (x, f)
+  // come from the lane below (registers), so nothing is staged -- same sums as HsWave::trial ----------------------------------------
+  struct TPt { double x[NS], f[NS]; };
+  __device__ static inline void trial_point(Ctx& c, int j, double alpha, bool live, TPt& P, double& fa, double& ba, int& bad) {
+    double u[NU], bl[NW], bu[NW];
+    load_bounds(c, j, bl, bu);
+    double slk = 1.0; int sexp = 0, bd = 0;
 #pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        const long i = zi(c, j, q);
-        const double v = c.z[i] + alpha * c.dz[i];
-        const double l = bl[q], ub = bu[q];
-        const bool fr = l < ub;
-        const bool hl = fr && (l > -INFINITY), hu = fr && (ub < INFINITY);
-        const double sl = hl ? v - l : 1.0, su = hu ? ub - v : 1.0;
-        bad += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
-        { int e_; slk *= frexp((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0), &e_); sexp += e_; }
-        if (q < NS) x[q] = v; else u[q - NS] = v;
-      }
-      ba -= log(slk) + sexp * 0.6931471805599453;
-      Sys::f(x, u, c.pp.get(), ff);
-      set_time<Sys>(c.pp.get(), tq(j, c.h));
-      const double gj = Sys::g(x, u, c.pp.get());
-      fa += wq(K, j, c.h) * gj;
-#pragma unroll
-      for (int q = 0; q < NS; ++q) { sX[j * NS + q] = x[q]; sF[j * NS + q] = ff[q]; }
+    for (int q = 0; q < NW; ++q) {
+      const long i = zi(c, j, q);
+      const double v = c.z[i] + alpha * c.dz[i];
+      const double l = bl[q], ub = bu[q];
+      const bool fr = l < ub;
+      const bool hl = fr && (l > -INFINITY), hu = fr && (ub < INFINITY);
+      const double sl = hl ? v - l : 1.0, su = hu ? ub - v : 1.0;
+      bd += (sl > 0.0 ? 0 : 1) + (su > 0.0 ? 0 : 1);
+      { int e_; slk *= frexp((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0), &e_); sexp += e_; }
+      if (q < NS) P.x[q < NS ? q : 0] = v; else u[q - NS] = v;
     }
-    wsync();
-    double ca = 0;
-    for (int k = c.lane; k < N; k += 64) {
+    Sys::f(P.x, u, c.pp.get(), P.f);
+    set_time<Sys>(c.pp.get(), tq(j, c.h));
+    const double gj = Sys::g(P.x, u, c.pp.get());
+    if (live) {
+      ba -= log(slk) + sexp * 0.6931471805599453;
+      fa += wq(c.K, j, c.h) * gj;
+      bad += bd;
+    }
+  }
+  __device__ static bool trial(Ctx& c, double alpha, double mu, double& f, double& bar, double& c1) {
+    const int N = c.N, lane = c.lane;
+    double fa = 0, ba = 0, ca = 0; int bad = 0;
+    TPt Pc;                                   // knot in front of the block (uniform)
+    trial_point(c, 0, alpha, c.tid == 0, Pc, fa, ba, bad);
+    int round = 0;
+    for (int base0 = 0; base0 < N; base0 += NT, ++round) {
+      const int kr = base0 + c.tid;
+      const bool on = kr < N;
+      const int k = on ? kr : N - 1;
+      TPt Pm, Pe, Ps;
+      trial_point(c, 2 * k + 1, alpha, on, Pm, fa, ba, bad);
+      trial_point(c, 2 * k + 2, alpha, on, Pe, fa, ba, bad);
+      if constexpr (W > 1) {      // the knot in front of this wavefront's block is the end knot of the block below
+        double* mine = c.sTr + ((round & 1) * W + c.wave) * 2 * NS;
+        if (lane == 63) {
+#pragma unroll
+          for (int q = 0; q < NS; ++q) { mine[q] = Pe.x[q]; mine[NS + q] = Pe.f[q]; }
+        }
+        wsync();
+        if (c.wave > 0) {
+          const double* theirs = c.sTr + ((round & 1) * W + c.wave - 1) * 2 * NS;
+#pragma unroll
+          for (int q = 0; q < NS; ++q) { Pc.x[q] = theirs[q]; Pc.f[q] = theirs[NS + q]; }
+        }
+      }
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
-        const double xs = sX[(2 * k) * NS + q], xm = sX[(2 * k + 1) * NS + q], xe = sX[(2 * k + 2) * NS + q];
-        const double fs = sF[(2 * k) * NS + q], fm = sF[(2 * k + 1) * NS + q], fe = sF[(2 * k + 2) * NS + q];
-        ca += fabs((xe - xs) - c.h6 * (fs + 4.0 * fm + fe));
-        ca += fabs(xm - 0.5 * (xs + xe) - c.h8 * (fs - fe));
+        const double tx = lane_up1(Pe.x[q]), tf = lane_up1(Pe.f[q]);
+        Ps.x[q] = (lane == 0) ? Pc.x[q] : tx; Ps.f[q] = (lane == 0) ? Pc.f[q] : tf;
+      }
+      if constexpr (W > 1) {
+        const double* last = c.sTr + ((round & 1) * W + W - 1) * 2 * NS;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { Pc.x[q] = last[q]; Pc.f[q] = last[NS + q]; }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { Pc.x[q] = __shfl(Pe.x[q], 63, 64); Pc.f[q] = __shfl(Pe.f[q], 63, 64); }
+      }
+      if (on) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          ca += fabs((Pe.x[q] - Ps.x[q]) - c.h6 * (Ps.f[q] + 4.0 * Pm.f[q] + Pe.f[q]));
+          ca += fabs(Pm.x[q] - 0.5 * (Ps.x[q] + Pe.x[q]) - c.h8 * (Ps.f[q] - Pe.f[q]));
+        }
       }
     }
-    wsync();
-    f = wv_sum(fa); bar = mu * wv_sum(ba); c1 = wv_sum(ca);
-    bad = wv_isum(bad);
-    if (bad != 0) return false;
+    double v[4] = {wv_sum(fa), wv_sum(ba), wv_sum(ca), (double)wv_isum(bad)};
+    const int op[4] = {0, 0, 0, 0};
+    wg_combine<4>(c, v, op);
+    f = v[0]; bar = mu * v[1]; c1 = v[2];
+    if (v[3] != 0.0) return false;
     if (!detail::finite_(f)) return false;
     if (!detail::finite_(c1)) return false;
     return detail::finite_(bar);
@@ -786,7 +932,7 @@ struct HsFused {
     const double k1 = 1e-2, k2 = 1e-2;
     const int K = c.K;
     int same = 1;
-    for (int i = c.lane; i < c.n; i += 64) {
+    for (int i = c.tid; i < c.n; i += NT) {
       const double l = c.lb[i], u = c.ub[i], v0 = zg[i];
       const bool fr = l < u;
       const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
@@ -807,16 +953,19 @@ struct HsFused {
         same &= ((l == l1) && (u == u1)) ? 1 : 0;      // (infinities compare equal; a NaN bound switches the table off)
       }
     }
-    same = (wv_isum(same) == 64) ? 1 : 0;
+    double sv[1] = {(double)wv_isum(same)};
+    const int sop[1] = {0};
+    wg_combine<1>(c, sv, sop);
+    same = (sv[0] == (double)NT) ? 1 : 0;
     c.uni = __builtin_amdgcn_readfirstlane(same) != 0;
-    if (c.lane < NW) {
-      const int q = c.lane;
+    if (c.tid < NW) {
+      const int q = c.tid;
       const long i0 = S::zi(K, 0, q), iT = S::zi(K, K - 1, q), i1 = S::zi(K, 1, q);
       c.sB[q] = c.lb[i0]; c.sB[NW + q] = c.ub[i0];
       c.sB[2 * NW + q] = c.lb[iT]; c.sB[3 * NW + q] = c.ub[iT];
       c.sB[4 * NW + q] = c.lb[i1]; c.sB[5 * NW + q] = c.ub[i1];
     }
-    if (c.lane < ZR) c.zr[c.lane] = 0.0;
+    if (c.tid < ZR) c.zr[c.tid] = 0.0;
   }
 
   // ---- the solve (control flow identical to HsWave::solve / HsSolver::solve) -----------------------------------------------------
@@ -854,7 +1003,14 @@ struct HsFused {
       int nreg = 0;
       for (int tr_ = 0; tr_ < 12; ++tr_) {
         const bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
-        nreg = riccati_mfma(c, o, delta, abort_on_reg);
+        if constexpr (W > 1) {
+          if (c.wave == 0) {
+            nreg = riccati_mfma(c, o, delta, abort_on_reg);
+            if (c.lane == 0) c.sMisc[1] = (double)nreg;
+          }
+          wsync();
+          nreg = (int)c.sMisc[1];
+        } else nreg = riccati_mfma(c, o, delta, abort_on_reg);
         wsync();
         MYR_PH(6)
         if (nreg == 0) break;
@@ -922,13 +1078,7 @@ struct HsFused {
         a *= 0.5;
       }
       if (!ok) {
-        if (++stall > 5) {       // the multipliers in R0 were overwritten by the trials: rebuild them for the caller
-          Step none{false, 0.0, 0.0, 0.0, o.kappa_sigma};
-          BOut t_;
-          backward(c, none, nuT, t_);
-          wsync();
-          res.status = 3; res.iters = it; return;
-        }
+        if (++stall > 5) { res.status = 3; res.iters = it; return; }
       } else stall = 0;
       MYR_PH(11)
       pending.on = true; pending.ap = a; pending.ad = o.dual_follow ? fo.alpha_d * (a / fo.alpha_p) : fo.alpha_d; pending.mu = mu;
@@ -951,32 +1101,41 @@ struct HsFused {
 
 // Persistent, one trajectory per wavefront (workgroup = one wavefront): every workgroup pulls trajectories from `ticket` until the
 // batch is done and owns ONE scratch block that it re-uses for all of them.
-template <class Sys>
-__global__ __launch_bounds__(64, 1)
+template <class Sys, int NWAVES = 1>
+__global__ __launch_bounds__(64 * NWAVES, 1)
 void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                            const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                            const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
                            int32_t* iters, double* kkt) {
-  using W = HsFused<Sys>;
+  using W = HsFused<Sys, NWAVES>;
   extern __shared__ __attribute__((aligned(16))) char smem_fused[];
   typename W::Ctx c;
-  c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x & 63;
+  c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x & 63; c.tid = threadIdx.x; c.wave = threadIdx.x >> 6;
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
   double* s = scratch + (long)blockIdx.x * scratch_stride;
-  c.zr = s; c.dz = s + W::off_dz(c.N); c.hr = s + W::off_hr(c.N); c.st = s + W::off_st(c.N); c.kg = s + W::off_kg(c.N);
+  c.zr = s; c.hr = s + W::off_hr(c.N); c.st = s + W::off_st(c.N); c.kg = s + W::off_kg(c.N);
   double* const lam_own = s + W::off_lam(c.N);
   double* l = reinterpret_cast<double*>(smem_fused);
-  c.z = l; l += c.n; c.zL = l; l += c.n; c.zU = l; l += c.n;
-  c.r0 = l; c.sLam = l; l += W::r0_doubles(c.N);
+  c.z = l; l += c.n; c.zL = l; l += c.n; c.zU = l; l += c.n; c.dz = l; l += c.n;
+  c.sLam = l; l += 2 * c.N * W::NS;
   c.sB = l; l += 6 * W::NW;
-  c.sStash = l; l += W::NREC;
+  c.sStash = l; l += 2 * NWAVES * W::NREC;
+  c.sTot = l; l += 2 * NWAVES * W::NTOT;
+  c.sTr = l; l += 2 * NWAVES * 2 * W::NS;
+  c.sRed = l; l += NWAVES * W::NRED;
+  c.sMisc = l; l += 4;
   c.sP = l; l += W::NW * W::NW;
   c.sPc = l; l += W::NW * W::NC;
   c.sTnu = l; l += W::NS * W::NC;
   c.sKu = l; l += W::NU * W::NC;
   for (;;) {
     int t = 0;
-    if (c.lane == 0) t = atomicAdd(ticket, 1);
+    if (c.tid == 0) t = atomicAdd(ticket, 1);
+    if constexpr (NWAVES > 1) {
+      if (c.tid == 0) reinterpret_cast<int*>(c.sMisc)[0] = t;
+      __syncthreads();
+      t = reinterpret_cast<int*>(c.sMisc)[0];
+    }
     const long b = __builtin_amdgcn_readfirstlane(t);
     if (b >= B) break;
     double* zg = z + b * (long)c.n;
@@ -990,15 +1149,15 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     c.t0 = clock64();
 #endif
     W::solve(c, o, zg, r);
-    for (int i = c.lane; i < c.n; i += 64) zg[i] = c.z[i];
-    for (int i = c.lane; i < 2 * c.N * W::NS; i += 64) lamg[i] = c.sLam[i];
+    for (int i = c.tid; i < c.n; i += W::NT) zg[i] = c.z[i];
+    for (int i = c.tid; i < 2 * c.N * W::NS; i += W::NT) lamg[i] = c.sLam[i];
 #ifdef MYR_PHASE_TIMING
     if (c.lane == 0 && b < 4) {
       printf("traj %ld it %d: backward %lld hess %lld ricc %lld nu %lld forward %lld ls %lld\n",
              b, r.iters, c.tph[0], c.tph[4], c.tph[6], c.tph[7], c.tph[8], c.tph[11]);
     }
 #endif
-    if (c.lane == 0) {
+    if (c.tid == 0) {
       if (cost) cost[b] = r.cost;
       if (status) status[b] = r.status;
       if (iters) iters[b] = r.iters;

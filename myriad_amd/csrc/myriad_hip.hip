@@ -67,6 +67,7 @@ struct KTimer {
   int launches = 0;
 };
 
+struct FusedLaunch { bool ready = false; int N = 0, slots = 0; };
 struct myr_handle_s {
   myr_problem_desc d;
   myr_dims dims;
@@ -86,14 +87,24 @@ struct myr_handle_s {
   size_t sbuf_bytes = 0;
   int* ticket = nullptr;      // work counter of the persistent solve kernel (one int)
   int solve_slots = 0;        // MYRIAD_SOLVE_SLOTS: resident wavefronts of the solve kernel (0 = what the device holds)
-  bool fused_ready = false;   // launch_hs_fused: kernel attributes set, occupancy known (for fused_N intervals)
-  int fused_N = 0, fused_slots = 0;
+  FusedLaunch fused[2];       // launch_hs_fused_w<Sys, 1 | 2>: kernel attributes set, occupancy known
+  int fused_waves = 0;        // MYRIAD_FUSED_WAVES: wavefronts per trajectory (0 = by batch size)
+  int cus = 0;                // compute units of the device (cached)
   // variable scaling of the solve path (myr_set_var_scale): the solver kernels see z/s, lb/s, ub/s
   VarScale vscale{{1, 1, 1, 1, 1, 1, 1, 1}};
   bool vscale_on = false;
   void* vbuf = nullptr;       // scaled copies of lb, ub
   size_t vbuf_bytes = 0;
 };
+
+static int device_cus(myr_handle h) {
+  if (h->cus <= 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->cus = cus;
+    else h->cus = 256;
+  }
+  return h->cus;
+}
 
 static int ensure_dbuf(myr_handle h, size_t bytes) {
   if (bytes <= h->dbuf_bytes) return 0;
@@ -396,25 +407,26 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
                              int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                              int32_t* iters, double* kkt);
 
-// fused-phase wavefront kernel (hs_solver_fused.h): Hermite-Simpson, closed-form systems with one control and <= 4 states
-template <class Sys>
-static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
-                           int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
-                           int32_t* iters, double* kkt) {
-  using W = HsFused<Sys>;
+// fused-phase wavefront kernel (hs_solver_fused.h): Hermite-Simpson, closed-form systems with one control and <= 4 states.
+// NWAVES wavefronts per trajectory: 1 for throughput (four trajectories per CU), 2 when the batch leaves CUs idle otherwise
+// (B <= 2 trajectories per CU: the parallel phases of an iteration take half the time, the launch lasts as long as one solve).
+template <class Sys, int NWAVES>
+static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
+                             int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
+                             int32_t* iters, double* kkt) {
+  using W = HsFused<Sys, NWAVES>;
   const int N = h->d.intervals;
   const size_t lds = W::lds_bytes(N);
-  auto kern = hs_solve_fused_kernel<Sys>;
-  if (!h->fused_ready || h->fused_N != N) {      // attributes and occupancy once per handle and grid size, not per call
-    int per_cu = 0, dev = 0, cus = 0;
+  auto kern = hs_solve_fused_kernel<Sys, NWAVES>;
+  FusedLaunch& fl = h->fused[NWAVES - 1];
+  if (!fl.ready || fl.N != N) {      // attributes and occupancy once per handle and grid size, not per call
+    int per_cu = 0;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64, lds));
-    HIPCHK(hipGetDevice(&dev));
-    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    h->fused_slots = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256);
-    h->fused_ready = true; h->fused_N = N;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * NWAVES, lds));
+    fl.slots = (per_cu > 0 ? per_cu : 4 / NWAVES) * device_cus(h);
+    fl.ready = true; fl.N = N;
   }
-  int slots = h->solve_slots > 0 ? h->solve_slots : h->fused_slots;
+  int slots = h->solve_slots > 0 ? h->solve_slots : fl.slots;
   if (slots > B) slots = B;
   long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
   if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate slots over HBM channels
@@ -430,7 +442,7 @@ static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, con
   HsSolveOpts o = make_opts(h, so);
   KTimer& kt = h->kt[MYR_K_SOLVE];
   HIPCHK(hipEventRecord(kt.a, h->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
+  hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
                      params, pstride, cost, status, iters, kkt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
@@ -440,6 +452,16 @@ static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, con
   kt.sum_ms += ms;
   kt.launches += 1;
   return MYR_OK;
+}
+template <class Sys>
+static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
+                           int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
+                           int32_t* iters, double* kkt) {
+  int waves = (B <= 2 * device_cus(h)) ? 2 : 1;
+  if (h->fused_waves > 0) waves = h->fused_waves;
+  if (waves == 2 && HsFused<Sys, 2>::lds_bytes(h->d.intervals) <= 160 * 1024)
+    return launch_hs_fused_w<Sys, 2>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  return launch_hs_fused_w<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
 }
 
 template <class Sys, int SCHEME = 0>
@@ -784,6 +806,7 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
   if (md) { h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1; h->solve_fused = (strcmp(md, "wave1") == 0) ? 0 : 1; }
   const char* l = getenv("MYRIAD_SOLVE_LPW");
   if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
+  if (const char* e = getenv("MYRIAD_FUSED_WAVES")) h->fused_waves = atoi(e);     // developer knob: wavefronts per trajectory of the fused kernel
   if (const char* e = getenv("MYRIAD_SOLVE_SLOTS")) h->solve_slots = atoi(e);   // developer knob: resident wavefronts of the solve kernel
   *out = h;
   return MYR_OK;

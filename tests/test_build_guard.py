@@ -26,7 +26,10 @@ def test_scanner_flags_the_pattern_and_passes_the_legitimate_idioms(tmp_path):
   good = tmp_path / "good.s"
   good.write_text("_Z1gv:\n\ts_cmp_lg_u32 s50, 11\n\tv_cmp_nlt_f64_e32 vcc, s[4:5], v[66:67]\n\ts_cselect_b64 s[4:5], -1, 0\n\ts_endpgm\n"
                   "_Z2g2v:\n\ts_and_b64 s[14:15], s[76:77], exec\n\tv_cmp_gt_f64_e64 vcc, v[10:11], |v[94:95]|\n\ts_cselect_b32 s53, s3, s17\n\ts_endpgm\n"
-                  "_Z2g3v:\n\tv_cmp_nlt_f64_e64 s[0:1], v[10:11], v[12:13]\n\ts_and_b64 s[0:1], s[0:1], exec\n\ts_cselect_b32 s0, 0x3ff00000, 0\n\ts_endpgm\n")
+                  "_Z2g3v:\n\tv_cmp_nlt_f64_e64 s[0:1], v[10:11], v[12:13]\n\ts_and_b64 s[0:1], s[0:1], exec\n\ts_cselect_b32 s0, 0x3ff00000, 0\n\ts_endpgm\n"
+                  # ocml pow(): the mask-to-SCC idiom and its literal select interleaved with an unrelated compare whose vcc is consumed
+                  "_Z2g4v:\n\ts_and_b64 s[4:5], s[4:5], exec\n\tv_cndmask_b32_e32 v14, v16, v14, vcc\n\tv_cmp_class_f64_e32 vcc, s[14:15], v15\n"
+                  "\ts_cselect_b32 s4, 0, 0x7ff00000\n\tv_mov_b32_e32 v15, s4\n\tv_cndmask_b32_e32 v12, v12, v13, vcc\n\ts_endpgm\n")
   sc = _scanner()
   assert len(sc.scan(str(bad))) == 2
   assert sc.scan(str(good)) == []
