@@ -265,14 +265,16 @@ def run(a, rank, world, dev, make_engine):
   # HBM traffic: NOT measured in this run (PMC counters need rocprofv3 passes of their own); cited from the committed
   # summaries of the same command, per launch, with the file named
   prof = {}
-  for rnd in ("r02", "r01"):
+  fused = os.environ.get("MYRIAD_SOLVE_MODE", "wave") == "wave"
+  skey = "hs_solve_fused_kernel" if fused else "hs_solve_wave_kernel"
+  for rnd in ("r03", "r02", "r01"):
     tp = os.path.join(ROOT, "profiles", rnd, "hs_eval_traffic.json")
     if "eval" not in prof and os.path.exists(tp) and B == 4096 and N == 100:
       prof["eval"] = (json.load(open(tp)).get("traffic_bytes_per_launch"), os.path.relpath(tp, ROOT))
     sp = os.path.join(ROOT, "profiles", rnd, "pmc_bench_n1.json")
     if "solver" not in prof and os.path.exists(sp) and B == 4096 and N == 100:
       try:
-        d = json.load(open(sp))["hs_solve_wave_kernel"]["derived_traffic_bytes"]
+        d = json.load(open(sp))[skey]["derived_traffic_bytes"]
         prof["solver"] = (float(d["fetch_x2"]) + float(d["write"]), os.path.relpath(sp, ROOT))
       except Exception:
         pass
@@ -298,10 +300,12 @@ def run(a, rank, world, dev, make_engine):
                  "achieved": alg / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": alg / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from_profile": traffic_src,
                  "alg_bytes_per_launch": alg, "avg_ms": ev_ms, "launches": ev_n},
-    "solver_kernel": {"kernel": ("hs_solve_wave_kernel<CARTPOLE> (persistent, one trajectory per wavefront, Riccati sweep on fp64 MFMA, whole SQP in one launch)"
-                                 if os.environ.get("MYRIAD_SOLVE_MODE", "wave") != "lane" else
-                                 "hs_solve_kernel<CARTPOLE> (one trajectory per lane, whole SQP in one launch)"),
-                      "avg_ms": sv_ms, "launches": sv_n, "bound": "memory latency + HBM-side record traffic at 1 wave/SIMD (see DESIGN.md section 4)",
+    "solver_kernel": {"kernel": ("hs_solve_fused_kernel<CARTPOLE> (persistent, one trajectory per wavefront, iterate in LDS, fused backward / forward phases, Riccati sweep on fp64 MFMA, whole SQP in one launch)"
+                                 if fused else
+                                 ("hs_solve_wave_kernel<CARTPOLE> (round-2 kernel: persistent, one trajectory per wavefront, thirteen phases through global records)"
+                                  if os.environ.get("MYRIAD_SOLVE_MODE") == "wave1" else
+                                  "hs_solve_kernel<CARTPOLE> (one trajectory per lane, whole SQP in one launch)")),
+                      "avg_ms": sv_ms, "launches": sv_n, "bound": "dependent-instruction latency of one wavefront per SIMD (the Riccati sweep is 45 % of an iteration; see DESIGN.md section 4)",
                       "alg_io_bytes_per_launch": B * 8 * (3 * (2 * N + 1) * 5 + (2 * N + 1) * 5 + 2 * N * 4),
                       "hbm_bytes_per_launch_from_profile": sol_bytes, "hbm_profile": sol_src,
                       "hbm_GBps": (sol_bytes / (sv_ms * 1e-3) / 1e9) if (sol_bytes and sv_ms) else None,

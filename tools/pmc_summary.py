@@ -7,7 +7,7 @@ acc = {}
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
   for r in csv.DictReader(open(path)):
     name = r["Kernel_Name"]
-    key = next((k_ for k_ in ("hs_solve_wave_kernel", "shoot_solve_wave_kernel", "lane_solve_kernel", "hs_eval_kernel") if k_ in name), None)
+    key = next((k_ for k_ in ("hs_solve_fused_kernel", "hs_solve_wave_kernel", "shoot_solve_wave_kernel", "lane_solve_kernel", "hs_eval_kernel") if k_ in name), None)
     if key is None:
       continue
     k = acc.setdefault(key, {"launch": {"grid": r.get("Grid_Size"), "wg": r.get("Workgroup_Size"), "vgpr": r.get("VGPR_Count"),
