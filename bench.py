@@ -96,18 +96,86 @@ def cpu_baseline(N, budget_s):
   dt25, it25, ok25, cost25 = timed_solve(25, None)
   dt, nit, done, _ = timed_solve(N, budget_s)
   its_per_s = nit / dt
-  full_its = 110
+  full_its, measured = 110, None
+  for rnd in ("r03",):                       # a whole solve measured on a GPU-box host by `bench.py --cpu-full` (committed)
+    fp = os.path.join(ROOT, "profiles", rnd, "cpu_baseline_full.json")
+    if N == 100 and os.path.exists(fp):
+      try:
+        m = json.load(open(fp))["slsqp_full_solve"]
+        full_its = int(m["iterations"])
+        measured = {"file": os.path.relpath(fp, ROOT), "seconds": m["seconds"], "iterations": m["iterations"], "value": m["value"],
+                    "trust_constr": json.load(open(fp)).get("trust_constr_subsample", {}).get("value")}
+      except Exception:
+        pass
   value = (1.0 / dt) if done else its_per_s / full_its
   return {"value": value, "unit": "solves/s", "cores": 1, "torch_threads": int(torch.get_num_threads()),
-          "host_cores": os.cpu_count() or 1, "kind": "port", "extrapolated": (not done),
+          "host_cores": os.cpu_count() or 1, "kind": "port", "extrapolated": (not done), "measured_full_solve": measured,
           "full_solve": {"workload": "CARTPOLE HS N=25, default x0, SLSQP to its default tolerance", "seconds": dt25,
                          "iterations": it25, "converged": bool(ok25), "cost": cost25, "value": 1.0 / dt25, "unit": "solves/s"},
           "sample": f"oracle SciPy-SLSQP path (serial Fortran SLSQP + torch-autodiff callbacks), CARTPOLE HS N={N} instance 0 "
                     f"(default x0): {nit} SLSQP iterations in {dt:.1f} s ({its_per_s:.3f} it/s)" +
                     ("; ran to convergence" if done else
-                     f"; a converged solve needs {full_its} iterations at the reference's default tolerance (BASELINE.md: "
-                     f"546 s measured for the reference), so value = it/s / {full_its} (EXTRAPOLATED); the measured "
-                     f"full solve is `full_solve` (N=25)")}
+                     f"; a converged solve needs {full_its} iterations at the reference's default tolerance (" +
+                     (f"measured: {measured['file']}, {measured['seconds']:.0f} s on a GPU-box host" if measured else "BASELINE.md: 546 s measured for the reference") +
+                     f"), so value = this run's it/s / {full_its}; whole measured solves: `measured_full_solve` (N=100) and `full_solve` (N=25)")}
+
+
+def cpu_full(N, out_path, trust_budget_s=600.0):
+  """`python bench.py --cpu-full FILE`: the MEASURED legs of the CPU baseline, on the host cores of the box it
+  runs on (no GPU involved): (1) ONE whole SLSQP solve of the metric's problem (CARTPOLE HS N intervals, default x0) to SciPy's default
+  tolerance -- the reference's NLPSolverType.SLSQP branch (/root/reference/myriad/nlp_solvers/__init__.py:50-52) on the oracle's restated
+  callbacks; about nine minutes at N=100; (2) the trust-constr branch (:53-55) on up to 8 instances of the workload's start-state
+  rule at N=25 with the reference's maxiter=1000 inside `trust_budget_s` of wall time (at N=100 one trust-constr solve ran into
+  maxiter after 24 minutes, SURVEY.md App. C -- a subsample at that size does not fit any bench budget; the N=100 rate is sampled
+  for 60 s instead).  The default run cites the file this writes."""
+  from oracle import myriad_oracle as O
+  import torch
+  res = {"host_cores": os.cpu_count() or 1, "torch_threads": int(torch.get_num_threads()), "kind": "port",
+         "what": "oracle SciPy path (serial SLSQP / trust-constr + torch-autodiff callbacks) = the reference's SciPy branches minus JAX"}
+  s = O.CartPole()
+  tr = O.hermite_simpson(s, N)
+  cb = O.Callbacks(tr); cb.jac(tr.guess); cb.grad(tr.guess)
+  t0 = time.time()
+  r = O.solve(tr, "SLSQP", max_iter=1000, cb=cb)
+  dt = time.time() - t0
+  res["slsqp_full_solve"] = {"workload": f"CARTPOLE HS N={N}, default x0, SLSQP to its default tolerance (ftol=1e-6), maxiter=1000",
+                             "seconds": dt, "iterations": int(r["scipy"].nit), "converged": bool(r["scipy"].success), "cost": float(r["cost"]),
+                             "max_abs_c": float(np.abs(cb.cons(r["xs_and_us"])).max()), "value": 1.0 / dt, "unit": "solves/s", "cores": 1}
+  print("[cpu-full] SLSQP", json.dumps(res["slsqp_full_solve"]), file=sys.stderr, flush=True)
+  x0s = np.vstack([s.x_0[None], O.random_x0(s, 7, seed=2019)])
+  rows, t_all = [], time.time()
+  for b in range(8):
+    if time.time() - t_all > trust_budget_s:
+      break
+    sb = O.CartPole(); sb.x_0 = x0s[b].copy()
+    trb = O.hermite_simpson(sb, 25)
+    t0 = time.time()
+    rb = O.solve(trb, "TRUST", max_iter=1000)
+    rows.append({"instance": b, "seconds": time.time() - t0, "iterations": int(rb["scipy"].nit), "converged": bool(rb["scipy"].success),
+                 "cost": float(rb["cost"]), "max_abs_c": float(np.abs(O.Callbacks(trb).cons(rb["xs_and_us"])).max())})
+    print("[cpu-full] trust-constr", json.dumps(rows[-1]), file=sys.stderr, flush=True)
+  tt = sum(r_["seconds"] for r_ in rows)
+  res["trust_constr_subsample"] = {"workload": "CARTPOLE HS N=25, x0 = default + clip(x_0 + 0.1 N(0,I)) from default_rng(2019), trust-constr, maxiter=1000",
+                                   "instances": rows, "value": (len(rows) / tt) if rows else None, "unit": "solves/s (finished or at maxiter)", "cores": 1}
+
+  class _Stop(Exception):
+    pass
+  t0 = time.time(); nit = [0]
+  def cbk(xk, state=None):
+    nit[0] += 1
+    if time.time() - t0 > 60.0:
+      raise _Stop()
+  try:
+    from scipy.optimize import minimize
+    minimize(fun=cb.fun, x0=tr.guess, method="trust-constr", jac=cb.grad, constraints=({"type": "eq", "fun": cb.cons, "jac": cb.jac}),
+             bounds=tr.bounds, options={"maxiter": 1000}, callback=cbk)
+  except _Stop:
+    pass
+  res["trust_constr_rate_at_N"] = {"workload": f"CARTPOLE HS N={N}, default x0, trust-constr sampled for 60 s", "iterations": nit[0],
+                                   "seconds": time.time() - t0, "its_per_s": nit[0] / (time.time() - t0)}
+  with open(out_path, "w") as f:
+    json.dump(res, f, indent=1)
+  print(json.dumps(res))
 
 
 def cpu_same_algorithm(z0, lb, ub, N, T, nsample):
@@ -331,7 +399,12 @@ def main():
   ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
   ap.add_argument("--intervals", type=int, default=100)
   ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the N=100 cpu_baseline sample (0 = skip)")
+  ap.add_argument("--cpu-full", metavar="FILE", default=None,
+                  help="measure the whole CPU baseline (one full N-interval SLSQP solve, ~9 min, + a trust-constr subsample) on this host, write FILE, exit")
   a = ap.parse_args()
+  if a.cpu_full:
+    cpu_full(a.intervals, a.cpu_full)
+    return
 
   if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
     sys.exit(self_launch(a.gpus))

@@ -180,7 +180,8 @@ int myr_rollout(myr_handle h, int32_t B, int32_t num_steps, int32_t u_rows, cons
  *   myr_vjp:  out[B][n] = J(z)^T lam   (+ grad f(z) when add_gradf != 0: the gradient of the Lagrangian in z)
  *   myr_jvp:  out[B][m] = J(z) v
  * z [B][n], lam [B][m], v [B][n]; layouts and row order as in myr_eval.  Collocation: pointwise / intervalwise kernels;
- * SHOOTING (EULER, HEUN, MIDPOINT): reverse sweep seeded with lam / forward tangents through the steps.
+ * SHOOTING (EULER, HEUN, MIDPOINT, RK4 -- whatever hp.integration_method selects, utils.py:91-96, shooting.py:230-241): reverse
+ * sweep seeded with lam / forward tangents through the steps (RK4: two control rows per step, u[2i], u[2i+1], u[2i+2]).
  */
 int myr_vjp(myr_handle h, int32_t B, const double* z, const double* lam, const double* params, int32_t params_stride,
             double* out, int32_t add_gradf, int32_t mem);
@@ -217,6 +218,11 @@ int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, const double*
 /* Average device time (HIP events on the handle's stream) of the launches of one kernel since the last reset. */
 int myr_kernel_time(myr_handle h, int32_t kernel_id, double* avg_ms, int32_t* launches);
 int myr_kernel_time_reset(myr_handle h);
+
+/* Devices the library can create handles on (hipGetDeviceCount; 0 when there is none or the runtime fails).  The reference
+ * has no multi-device code; the host mirror uses it to fan a batch out over the GPUs of a node beneath the
+ * unchanged TrajectoryOptimizer API (myriad/trajectory_optimizers/base.py:69-93): one handle and one host thread per device. */
+int myr_device_count(void);
 
 const char* myr_last_error(void);
 const char* myr_version(void);

@@ -28,7 +28,7 @@ STATUS_NAMES = {0: "CONVERGED", 1: "MAXITER", 2: "NAN", 3: "STALLED"}
 
 EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve",
            "myr_set_var_scale", "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_fbsm", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",
-           "myr_version"]
+           "myr_version", "myr_device_count"]
 
 
 class ProblemDesc(C.Structure):
@@ -81,6 +81,8 @@ def load() -> C.CDLL:
   lib.myr_get_dims.restype = C.c_int
   lib.myr_default_solve_opts.argtypes = [C.POINTER(SolveOpts)]
   lib.myr_default_solve_opts.restype = None
+  lib.myr_device_count.argtypes = []
+  lib.myr_device_count.restype = C.c_int
   lib.myr_eval.argtypes = [vp, C.c_int32, dp, dp, C.c_int32, dp, dp, dp, dp, C.c_int32]
   lib.myr_eval.restype = C.c_int
   lib.myr_solve.argtypes = [vp, C.c_int32, dp, dp, dp, dp, C.c_int32, C.POINTER(SolveOpts), dp, dp, ip, ip, dp, C.c_int32]
@@ -136,6 +138,11 @@ def _f64(a, shape=None):
   if shape is not None and tuple(a.shape) != tuple(shape):
     raise ValueError(f"expected shape {shape}, got {a.shape}")
   return a
+
+
+def device_count() -> int:
+  """Devices the library can create handles on (0 without a GPU)."""
+  return int(load().myr_device_count())
 
 
 class Engine:

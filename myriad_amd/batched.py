@@ -55,3 +55,48 @@ def gather_solutions(local: Dict[str, "torch.Tensor"], counts: Sequence[int], gr
         continue
     out[k] = torch.cat([b[:counts[r]] for r, b in enumerate(bufs)], dim=0)
   return out
+
+
+def fan_out_solve(engines: Sequence, z0, lb, ub, params=None, opts=None) -> Dict:
+  """One batch over several handles (one per device) beneath an unchanged caller: contiguous `shard_range` chunks, one host
+  thread per engine (the C-ABI call releases the GIL and every handle binds its own device and stream), results concatenated
+  in instance order.  The reference's API solves one instance per call on one device (trajectory_optimizers/base.py:69-93);
+  this is the internal fan-out SURVEY.md 8(b) "Threading" asks for.  `engines[i].solve(z0, lb, ub, params=, opts=)` must
+  return a dict of arrays with the batch in the first dimension.  An engine may appear twice (two shards queue on one
+  device)."""
+  import threading
+  import numpy as np
+  z0 = np.asarray(z0, dtype=np.float64)
+  if z0.ndim == 1:
+    z0 = z0[None]
+  B = z0.shape[0]
+  lb = np.broadcast_to(np.asarray(lb, dtype=np.float64), z0.shape)
+  ub = np.broadcast_to(np.asarray(ub, dtype=np.float64), z0.shape)
+  p = None if params is None else np.asarray(params, dtype=np.float64)
+  world = max(1, min(len(engines), B))
+  if world == 1:
+    return engines[0].solve(z0, lb, ub, params=p, opts=opts)
+  out = [None] * world
+  err = [None] * world
+  locks = {}
+  for e in engines[:world]:
+    locks.setdefault(id(e), threading.Lock())        # a handle owns one scratch buffer and one stream: one call at a time
+
+  def work(r):
+    lo, hi = shard_range(B, r, world)
+    pr = p if (p is None or p.ndim == 1) else p[lo:hi]
+    try:
+      with locks[id(engines[r])]:
+        out[r] = engines[r].solve(z0[lo:hi], lb[lo:hi], ub[lo:hi], params=pr, opts=opts)
+    except BaseException as e:   # re-raised in the caller's thread
+      err[r] = e
+
+  ts = [threading.Thread(target=work, args=(r,), name=f"myriad-dev{r}") for r in range(world)]
+  for t in ts:
+    t.start()
+  for t in ts:
+    t.join()
+  for e in err:
+    if e is not None:
+      raise e
+  return {k: np.concatenate([o[k] for o in out], axis=0) for k in out[0]}

@@ -735,6 +735,11 @@ MYR_SYSTEM_ENTRY_POINTS(extern, SysNODE_CARTPOLE)
 #if !defined(MYR_TU_SYSTEM)   // ===== C-ABI and dispatch: the main object only ============================================
 extern "C" const char* myr_last_error(void) { return g_err.c_str(); }
 extern "C" const char* myr_version(void) { return "myriad_hip 0.1 (gfx950)"; }
+extern "C" int myr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
 
 extern "C" void myr_default_solve_opts(myr_solve_opts* o) {
   if (!o) return;

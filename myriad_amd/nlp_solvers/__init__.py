@@ -24,7 +24,8 @@ def solve(hp: HParams, cfg: Config, opt_dict: Dict) -> Dict[str, np.ndarray]:
     o = eng.default_opts()
     o.max_iter = hp.max_iter
     res = opt.device_solve(np.asarray(opt_dict['guess'], dtype=np.float64)[None], opt_dict['bounds'][None, :, 0],
-                           opt_dict['bounds'][None, :, 1], opt_dict.get('params'), o)      # + second starts (see there)
+                           opt_dict['bounds'][None, :, 1], opt_dict.get('params'), o,
+                           second_starts=not opt_dict.get('explicit_guess', False))         # second starts: the reference guess only
     solution = {'x': res["z"][0], 'fun': float(res["cost"][0]), 'success': bool(res["status"][0] == 0), 'v': res["lam"][0],
                 'nit': int(res["iters"][0])}
   elif hp.nlpsolver in (NLPSolverType.SLSQP, NLPSolverType.TRUST):

@@ -69,6 +69,10 @@ class TrajectoryOptimizer(object):
     self.bounds = np.vstack((x_bounds, u_bounds))
     self._x_shape, self._u_shape = x_guess.shape, u_guess.shape
     self._engine: Optional[_lib.Engine] = None
+    self._engines: Dict[int, _lib.Engine] = {}
+    # devices a batch is fanned out over (one handle + one host thread each; `devices=[0, 0]` queues two shards on one GPU).
+    # None = every visible device, except under a torch.distributed launch (one process per GPU: that rank's device)
+    self.devices = None
     if cfg.verbose:                                                        # base.py:53-63
       print("hp opt type", hp.optimizer)
       print("hp quadrature rule", hp.quadrature_rule)
@@ -78,17 +82,52 @@ class TrajectoryOptimizer(object):
       raise NotImplementedError("Discrete systems are not compatible with Trajectory trajectory_optimizers")
 
   # ---- device engine ------------------------------------------------------------------------------
+  def _make_engine(self, device: int) -> _lib.Engine:
+    eng = _lib.Engine(self.system.name, self.transcription, self.hp.intervals, self.system.T,
+                      controls_per_interval=self.hp.controls_per_interval,
+                      integration_method=self.hp.integration_method.name, device=device)
+    scale = getattr(self.system, "var_scale", None)
+    if scale is not None and os.environ.get("MYRIAD_VAR_SCALE", "1") != "0":
+      s = scale()
+      if s is not None and np.any(s != 1.0):
+        eng.set_var_scale(s)
+    return eng
+
+  def _device_list(self):
+    """Device ordinals of the fan-out: `self.devices`, else MYRIAD_DEVICES ("all" | "0,1,.."), else every visible device --
+    but only this rank's device under a one-process-per-GPU launch (bench.py, torchrun)."""
+    if self.devices is not None:
+      return [int(d) for d in self.devices]
+    env = os.environ.get("MYRIAD_DEVICES")
+    if env and env != "all":
+      return [int(d) for d in env.replace(",", " ").split()]
+    if env is None and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+      return [int(os.environ.get("LOCAL_RANK", "0"))]
+    return list(range(max(1, _lib.device_count())))
+
+  def engines_for(self, B: int):
+    """Handles a batch of B instances is sharded over: one per device of `_device_list()`, as many as leave every shard at
+    least `min_shard` instances (a launch lasts as long as one solve: smaller shards do not finish sooner)."""
+    devs = self._device_list()
+    k = max(1, min(len(devs), B // self.min_shard if B >= self.min_shard else 1))
+    out = []
+    for d in devs[:k]:
+      if d not in self._engines:
+        self._engines[d] = self.engine if (d == self._primary_device() and self._engine is not None) else self._make_engine(d)
+      out.append(self._engines[d])
+    return out
+
+  min_shard = 256
+
+  def _primary_device(self) -> int:
+    return self._device_list()[0]
+
   @property
   def engine(self) -> _lib.Engine:
     if self._engine is None:
-      self._engine = _lib.Engine(self.system.name, self.transcription, self.hp.intervals, self.system.T,
-                                 controls_per_interval=self.hp.controls_per_interval,
-                                 integration_method=self.hp.integration_method.name)
-      scale = getattr(self.system, "var_scale", None)
-      if scale is not None and os.environ.get("MYRIAD_VAR_SCALE", "1") != "0":
-        s = scale()
-        if s is not None and np.any(s != 1.0):
-          self._engine.set_var_scale(s)
+      d = self._primary_device()
+      self._engine = self._engines[d] if d in self._engines else self._make_engine(d)
+      self._engines[d] = self._engine
     return self._engine
 
   def unravel(self, z):
@@ -190,27 +229,44 @@ class TrajectoryOptimizer(object):
     z = np.concatenate([xs.reshape(B, -1), us[:, ::(rr - 1) // (rows_u - 1)].reshape(B, -1)], axis=1)
     return np.clip(z, lb, ub)
 
-  def device_solve(self, z0, lb, ub, params, opts):
-    """`engine.solve` + second starts for the instances that did not reach a KKT point."""
-    import os
-    eng = self.engine
-    res = eng.solve(z0, lb, ub, params=params, opts=opts)
+  def _solve_sharded(self, z0, lb, ub, params, opts):
+    """One device call per handle of `engines_for(B)`, concurrently (myriad_amd.batched.fan_out_solve)."""
+    from myriad_amd.batched import fan_out_solve
+    B = 1 if np.ndim(z0) == 1 else np.shape(z0)[0]
+    return fan_out_solve(self.engines_for(B), z0, lb, ub, params=params, opts=opts)
+
+  def device_solve(self, z0, lb, ub, params, opts, second_starts=True):
+    """The device solve (fanned out over `engines_for(B)`) + second starts for the instances that did not reach a KKT point.
+    The result says which start produced each instance: `start` = 0 for the caller's point, c for the excitation guess with c
+    cycles; `attempts` = device solves the instance went through (its `iters` are summed over them).  `second_starts=False`
+    (what solve_with_params / solve_batch pass when the caller gave an explicit guess) returns the first attempt as it is."""
+    res = self._solve_sharded(z0, lb, ub, params, opts)
+    B = res["status"].shape[0]
+    res["start"] = np.zeros(B, dtype=np.int32)
+    res["attempts"] = np.ones(B, dtype=np.int32)
     env = os.environ.get("MYRIAD_SECOND_STARTS")
     cycles = self.second_start_cycles if env is None else tuple(int(c) for c in env.replace(",", " ").split() if int(c) > 0)
+    if not second_starts:
+      cycles = ()
     fail = np.nonzero(res["status"] != 0)[0]
     p = None if params is None else np.asarray(params, dtype=np.float64)
+    z0 = np.asarray(z0, dtype=np.float64).reshape(B, -1)
+    lb = np.broadcast_to(np.asarray(lb, dtype=np.float64), z0.shape)
+    ub = np.broadcast_to(np.asarray(ub, dtype=np.float64), z0.shape)
     for c in cycles:
       if fail.size == 0:
         break
-      lbf, ubf = np.asarray(lb)[fail], np.asarray(ub)[fail]
+      lbf, ubf = lb[fail], ub[fail]
       ns = self._x_shape[1]
-      x0f = np.where(lbf[:, :ns] == ubf[:, :ns], lbf[:, :ns], np.asarray(z0)[fail][:, :ns])
+      x0f = np.where(lbf[:, :ns] == ubf[:, :ns], lbf[:, :ns], z0[fail][:, :ns])
       pf = p if (p is None or p.ndim == 1) else p[fail]
-      r2 = eng.solve(self.excitation_guess(x0f, lbf, ubf, pf, c), lbf, ubf, params=pf, opts=opts)
+      r2 = self._solve_sharded(self.excitation_guess(x0f, lbf, ubf, pf, c), lbf, ubf, pf, opts)
       r2["iters"] = r2["iters"] + res["iters"][fail]
       ok = r2["status"] == 0
-      for k in res:
+      for k in r2:
         res[k][fail[ok]] = r2[k][ok]
+      res["start"][fail[ok]] = c
+      res["attempts"][fail] += 1
       res["iters"][fail[~ok]] = r2["iters"][~ok]
       fail = fail[~ok]
     return res
@@ -227,7 +283,7 @@ class TrajectoryOptimizer(object):
     return {'objective': objective, 'guess': self.guess if guess is None else np.asarray(guess),
             'constraints': constraints, 'bounds': self.bounds, 'unravel': self.unravel,
             # descriptor for the device solver, which owns the transcription (SURVEY.md 8(b) inner boundary)
-            'optimizer': self, 'params_map': params,
+            'optimizer': self, 'params_map': params, 'explicit_guess': guess is not None,
             'params': self.system.device_params() if params is None else self.system.params_from_mapping(params)}
 
   def solve(self) -> Dict[str, np.ndarray]:
@@ -242,10 +298,12 @@ class TrajectoryOptimizer(object):
     """Per-instance (z0, lb, ub) for start states x0s [B,ns], by the reference's own guess / bounds rules."""
     raise NotImplementedError
 
-  def solve_batch(self, x0s=None, params=None, guess=None, max_iter=None) -> Dict[str, np.ndarray]:
+  def solve_batch(self, x0s=None, params=None, guess=None, max_iter=None, second_starts=None) -> Dict[str, np.ndarray]:
     """EXTENSION (the reference solves one instance per call): B independent instances -- random x0 and/or parameter
-    sweeps -- in one device call.  x0s [B,ns] replaces x_0 per instance (bounds row 0 and the guess rule);
-    params [B,np] are per-instance model parameters in device order (system.param_names)."""
+    sweeps -- in one call, sharded over `self.devices` (default: every visible GPU; one handle + host thread per device).
+    x0s [B,ns] replaces x_0 per instance (bounds row 0 and the guess rule); params [B,np] are per-instance model
+    parameters in device order (system.param_names).  Second starts (see device_solve) apply to the reference's guess only:
+    with an explicit `guess` the first attempt is returned unless second_starts=True."""
     eng = self.engine
     if x0s is None:
       B = 1 if params is None or np.ndim(params) == 1 else np.shape(params)[0]
@@ -257,10 +315,10 @@ class TrajectoryOptimizer(object):
       z0 = np.broadcast_to(np.asarray(guess, dtype=np.float64), z0.shape).copy()
     o = eng.default_opts()
     o.max_iter = self.hp.max_iter if max_iter is None else max_iter
-    res = self.device_solve(z0, lb, ub, p, o)
+    res = self.device_solve(z0, lb, ub, p, o, second_starts=(guess is None) if second_starts is None else bool(second_starts))
     x, u = self.unravel(res["z"])
     return {'x': x, 'u': u, 'xs_and_us': res["z"], 'cost': res["cost"], 'lambda': res["lam"],
-            'status': res["status"], 'iters': res["iters"], 'kkt': res["kkt"]}
+            'status': res["status"], 'iters': res["iters"], 'kkt': res["kkt"], 'start': res["start"], 'attempts': res["attempts"]}
 
   def _batch_bounds(self, x0s):
     B, ns = x0s.shape

@@ -142,3 +142,28 @@ def test_gather_solutions_over_rccl_single_rank():
     assert torch.equal(out["z"], z) and torch.equal(out["status"], st)
   finally:
     dist.destroy_process_group()
+
+
+def test_solve_batch_fan_out_over_two_handles_of_one_device_matches_one_handle():
+  """SURVEY.md 8(b) Threading: the batch axis fans out beneath the unchanged API -- one handle + one host thread per listed
+  device.  `devices=[0, 0]` runs the two shards on one GPU (a 1-GPU box): same result, instance by instance, as one handle."""
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = _hp(25)
+  rng = np.random.default_rng(3)
+  opt1 = get_optimizer(hp, CFG, hp.system()); opt1.devices = [0]
+  x0s = np.clip(np.array(opt1.system.x_0)[None] + 0.1 * rng.standard_normal((48, 4)), -2, 2)
+  a = opt1.solve_batch(x0s=x0s)
+  opt2 = get_optimizer(hp, CFG, hp.system()); opt2.devices = [0, 0]; opt2.min_shard = 8
+  assert len(opt2.engines_for(48)) == 2
+  b = opt2.solve_batch(x0s=x0s)
+  assert (a["status"] == 0).all() and (b["status"] == 0).all()
+  for k in ("xs_and_us", "cost", "lambda", "iters", "status", "start", "attempts"):
+    assert np.array_equal(a[k], b[k]), k
+  # default device list: every visible device (1 here), never more shards than min_shard allows
+  opt3 = get_optimizer(hp, CFG, hp.system())
+  assert opt3._device_list() == list(range(_lib_device_count())) and len(opt3.engines_for(48)) == 1
+
+
+def _lib_device_count():
+  from myriad_amd import _lib
+  return max(1, _lib.device_count())

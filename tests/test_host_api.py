@@ -267,6 +267,12 @@ def test_second_starts_resolve_only_failed_instances_from_an_excitation_guess(mo
   res = opt.device_solve(z0, lb, ub, None, None)
   assert (res["status"] == 0).all() and list(res["iters"]) == [20, 10, 20] and list(res["cost"]) == [1.0, 1.0, 1.0]
   assert len(eng.calls) == 2 and eng.calls[1].shape[0] == 2            # one second start, for the two failed instances only
+  assert list(res["start"]) == [2, 0, 2] and list(res["attempts"]) == [2, 1, 2]   # which start produced each instance
+  eng.calls.clear()
+  r1 = opt.device_solve(z0, lb, ub, None, None, second_starts=False)   # an explicit guess: the first attempt is returned as it is
+  assert list(r1["status"]) == [1, 0, 1] and len(eng.calls) == 1 and list(r1["attempts"]) == [1, 1, 1]
+  eng.calls.clear()
+  res = opt.device_solve(z0, lb, ub, None, None)
   g = eng.calls[1]
   assert (g >= lb[[0, 2]]).all() and (g <= ub[[0, 2]]).all()           # clipped (the rollout left the box at row 3)
   nx = z0.shape[1] - eng.rows_u
@@ -278,3 +284,76 @@ def test_second_starts_resolve_only_failed_instances_from_an_excitation_guess(mo
   eng.calls.clear()
   res = opt.device_solve(z0, lb, ub, None, None)
   assert list(res["status"]) == [1, 0, 1] and len(eng.calls) == 1
+
+
+class _ShardEngine:
+  """CPU stand-in for _lib.Engine that records which rows it was given and on which thread."""
+
+  def __init__(self, tag, fail_on=None):
+    self.tag, self.fail_on, self.calls = tag, fail_on, []
+
+  def solve(self, z0, lb, ub, params=None, opts=None):
+    import threading
+    import time
+    z0 = np.asarray(z0); B = z0.shape[0]
+    assert lb.shape == z0.shape and ub.shape == z0.shape and (params is None or np.ndim(params) == 1 or len(params) == B)
+    self.calls.append((z0[:, 0].copy(), threading.current_thread().name, None if params is None else np.array(params, copy=True)))
+    time.sleep(0.05)
+    if self.fail_on is not None and (z0[:, 0] == self.fail_on).any():
+      raise RuntimeError("device fault")
+    return {"z": z0 + 1.0, "lam": np.zeros((B, 2)), "cost": z0[:, 0] * 10.0, "status": np.zeros(B, np.int32),
+            "iters": np.full(B, self.tag, np.int32), "kkt": np.zeros((B, 3))}
+
+
+def test_fan_out_shards_a_batch_over_engines_in_order():
+  """batched.fan_out_solve: contiguous shards, one thread per engine, results concatenated in instance order, per-instance
+  parameters follow their rows, an engine listed twice gets both shards (serialised), errors reach the caller."""
+  from myriad_amd.batched import fan_out_solve, shard_range
+  B, n = 11, 4
+  z0 = np.arange(B, dtype=np.float64)[:, None] * np.ones((1, n))
+  lb, ub = -np.ones(n), np.ones((B, n))
+  p = np.arange(B * 3, dtype=np.float64).reshape(B, 3)
+  engs = [_ShardEngine(1), _ShardEngine(2), _ShardEngine(3)]
+  res = fan_out_solve(engs, z0, lb, ub, params=p)
+  assert np.array_equal(res["z"], z0 + 1.0) and np.array_equal(res["cost"], 10.0 * np.arange(B))
+  for r, e in enumerate(engs):
+    lo, hi = shard_range(B, r, 3)
+    rows, thread, pp = e.calls[0]
+    assert np.array_equal(rows, np.arange(lo, hi)) and thread == f"myriad-dev{r}" and np.array_equal(pp, p[lo:hi])
+    assert (res["iters"][lo:hi] == r + 1).all()
+  one = _ShardEngine(7)
+  res = fan_out_solve([one, one], z0, lb, ub, params=p[0])          # `devices=[0, 0]`: two shards queue on one handle
+  assert len(one.calls) == 2 and np.array_equal(res["z"], z0 + 1.0) and one.calls[0][2].shape == (3,)
+  res = fan_out_solve(engs, z0[:2], lb, ub[:2])                       # fewer instances than engines
+  assert res["z"].shape == (2, n)
+  with pytest.raises(RuntimeError, match="device fault"):
+    fan_out_solve([_ShardEngine(1), _ShardEngine(2, fail_on=9.0)], z0, lb, ub)
+
+
+def test_solve_batch_fans_out_beneath_the_unchanged_api(monkeypatch):
+  """TrajectoryOptimizer.solve_batch with `devices` set: the batch is split over one handle per listed device (stub engines
+  here), the result dict keeps the reference's keys plus status / iters / start / attempts, in instance order."""
+  from myriad_amd.config import Config, HParams, IntegrationMethod, OptimizerType, QuadratureRule
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
+               integration_method=IntegrationMethod.RK4, intervals=4)
+  opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+
+  class E(_ShardEngine):
+    def default_opts(self):
+      class O: max_iter = 0
+      return O()
+  e0, e1 = E(1), E(2)
+  opt._engine = e0; opt._engines = {0: e0, 1: e1}
+  opt.devices = [0, 1]; opt.min_shard = 2
+  B = 6
+  x0s = np.tile(opt.system.x_0, (B, 1)) + 0.01 * np.arange(B)[:, None]
+  out = opt.solve_batch(x0s=x0s)
+  assert len(e0.calls) == 1 and len(e1.calls) == 1 and np.allclose(e0.calls[0][0], x0s[:3, 0]) and np.allclose(e1.calls[0][0], x0s[3:, 0])
+  assert out["x"].shape == (B, 9, 4) and list(out["iters"]) == [1, 1, 1, 2, 2, 2] and list(out["attempts"]) == [1] * B
+  assert set(out) >= {"x", "u", "xs_and_us", "cost", "lambda", "status", "iters", "start", "attempts"}
+  opt.devices = [0]
+  e0.calls.clear(); e1.calls.clear()
+  opt.solve_batch(x0s=x0s)
+  assert len(e0.calls) == 1 and e0.calls[0][0].shape[0] == B and not e1.calls
