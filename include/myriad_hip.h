@@ -99,8 +99,14 @@ typedef struct {
 } myr_dims;
 
 typedef struct {
-  int32_t max_iter;     /* hp.max_iter (config.py:70)                                     */
-  int32_t reserved;
+  int32_t max_iter;     /* hp.max_iter (config.py:70): bounds the iterations of ONE attempt   */
+  int32_t restarts;     /* attempts after a first one that ends without a KKT point: -1 = the library's default (2 for the
+                           shooting wavefront kernel, 0 for every other kernel), 0 = a single attempt of at most max_iter
+                           iterations -- `iters` <= max_iter then holds --, k > 0 = up to k more (at most 4).  With restarts
+                           the first attempt is cut at max(100, max_iter / 8) iterations, a restart takes the caller's point
+                           again with another initial barrier parameter (mu_init x 3, then / 3) and the full max_iter, and
+                           `iters` reports the sum over the attempts.  Only the shooting wavefront kernel restarts; the lane
+                           kernels (MYRIAD_SOLVE_MODE=lane, iterates too large for LDS) ignore the field. */
   double  tol_feas;     /* converged: max|c| <= tol_feas                  (default 1e-8)  */
   double  tol_stat;     /* converged: scaled ||grad f + J^T lam - zL + zU||_inf <= tol_stat (1e-6) */
   double  tol_compl;    /* converged: complementarity <= tol_compl        (default 1e-7)  */

@@ -41,6 +41,7 @@ struct HsSolveOpts {
   double tol_feas, tol_stat, tol_compl, mu_init;
   int cpi = 1;             // controls per interval (shooting)
   int method = 1;          // integration method id (shooting): 0 Euler, 1 Heun, 2 midpoint, 3 RK4
+  int restarts = 0;        // shooting wavefront kernel: further attempts of a solve that ends without a KKT point (myr_solve_opts.restarts)
   double kappa_mu = 0.2, theta_mu = 1.5, kappa_eps = 10.0;   // barrier update: mu <- max(mu_min, min(kappa_mu mu, mu^theta_mu)) when E_mu <= kappa_eps mu
   double delta_warm_min = 3e-3;   // ... only while the previous delta was at least this large (early, non-convex phase)
   int delta_warm = 0;      // 1: start the inertia correction from the previous delta / 3 instead of 0 (set per problem

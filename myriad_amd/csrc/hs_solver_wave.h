@@ -251,10 +251,13 @@ struct HsWave {
   static constexpr int ZR = 2 * NY + 2;           // block of zeros (masked stage inputs of the Riccati lanes read it)
   static constexpr int PHI = NW * (NW + 1);       // closed-loop stage map Phi | phi per stage (LDS)
 
+  // The sweeps' prefetch rings read MYR_RICCATI_PF stages below stage 0 (never used): PADF doubles in front of every slot keep
+  // those reads inside the allocation whatever the system's sizes (VANDERPOL, N = 1: 105 doubles back from 84 in front).
+  static constexpr int PADF = 8 * ((2 * HR_N > SG_N ? 2 * HR_N : SG_N) + 1);
   __host__ __device__ static long scratch_doubles(int N) {
     const long K = npoints(N), n = K * NW;
     const long fa = (long)(NS + NS * NS) * K, hrn = (long)HR_N * K;        // hr overlays the f | A fields at the end of pt
-    return 3 * n + (long)PF_N * K + (hrn > fa ? hrn - fa : 0) + (long)SG_N * N + (OVERLAY_K ? 0 : (long)KST * N) + ZR + 2 /* write-only slot */ +
+    return PADF + 3 * n + (long)PF_N * K + (hrn > fa ? hrn - fa : 0) + (long)SG_N * N + (OVERLAY_K ? 0 : (long)KST * N) + ZR + 2 /* write-only slot */ +
            (long)MLAM * N * NS /* lambda when the caller passes none */;
   }
   // LDS doubles: region R0 (adjoint M|v, later Phi|phi, later trial x|f), Pi, S, exchange
@@ -1128,7 +1131,7 @@ struct HsWave {
 #ifndef MYR_RICCATI_INLINE
 #define MYR_RICCATI_INLINE
 #endif
-  static_assert(MYR_RICCATI_PF >= 2, "the prefetch ring needs two slots");
+  static_assert(MYR_RICCATI_PF >= 2 && MYR_RICCATI_PF <= 8, "the prefetch ring needs two slots; PADF covers eight");
   static constexpr bool MFMA_RICCATI = (NU == 1 && NS <= 4);
   typedef double mfma_d4 __attribute__((ext_vector_type(4)));
   // lane l <- lane l-4 within its row of 16 lanes (0 where l%16 < 4).  Inline asm on purpose: the compiler sinks the
@@ -1982,7 +1985,7 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
   const int wave = coop ? 0 : (int)(threadIdx.x >> 6), waves = coop ? 1 : (int)(blockDim.x >> 6);
   c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x & 63;
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
-  double* s = scratch + ((long)blockIdx.x * waves + wave) * scratch_stride;
+  double* s = scratch + ((long)blockIdx.x * waves + wave) * scratch_stride + W::PADF;
   c.zL = s; s += c.n; c.zU = s; s += c.n; c.dz = s; s += c.n;
   c.pt = s; s += (long)W::PF_N * c.K;
   c.hr = c.pt + (long)W::PF_F * c.K;                            // overlaid on the f | A fields (see PF_*)

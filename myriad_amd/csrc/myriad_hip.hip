@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/myriad_hip.h"
@@ -67,7 +69,6 @@ struct KTimer {
   int launches = 0;
 };
 
-struct FusedLaunch { bool ready = false; int N = 0, slots = 0; };
 struct myr_handle_s {
   myr_problem_desc d;
   myr_dims dims;
@@ -87,7 +88,8 @@ struct myr_handle_s {
   size_t sbuf_bytes = 0;
   int* ticket = nullptr;      // work counter of the persistent solve kernel (one int)
   int solve_slots = 0;        // MYRIAD_SOLVE_SLOTS: resident wavefronts of the solve kernel (0 = what the device holds)
-  FusedLaunch fused[2];       // launch_hs_fused_w<Sys, 1 | 2>: kernel attributes set, occupancy known
+  std::map<std::tuple<const void*, int, size_t>, int> occ;   // kernel_slots(): workgroups per CU of (kernel, block size, dynamic LDS)
+  size_t eval_attr_lds[6] = {0, 0, 0, 0, 0, 0};   // dynamic-LDS attribute already set for the eval kernel variants (W = 1 / 4 / 8, nt)
   int fused_waves = 0;        // MYRIAD_FUSED_WAVES: wavefronts per trajectory (0 = by batch size)
   int cus = 0;                // compute units of the device (cached)
   // variable scaling of the solve path (myr_set_var_scale): the solver kernels see z/s, lb/s, ub/s
@@ -104,6 +106,21 @@ static int device_cus(myr_handle h) {
     else h->cus = 256;
   }
   return h->cus;
+}
+
+// Workgroups of `kern` a CU keeps resident at this block size and dynamic-LDS size; sets the kernel's dynamic-LDS limit on the
+// way.  Asked of the runtime once per handle and configuration, not on every solve call.
+static int kernel_blocks_per_cu(myr_handle h, const void* kern, int threads, size_t lds, int* out) {
+  auto key = std::make_tuple(kern, threads, lds);
+  auto it = h->occ.find(key);
+  if (it == h->occ.end()) {
+    int per_cu = 0;
+    HIPCHK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
+    it = h->occ.emplace(key, per_cu).first;
+  }
+  *out = it->second;
+  return MYR_OK;
 }
 
 static int ensure_dbuf(myr_handle h, size_t bytes) {
@@ -123,9 +140,13 @@ static int launch_hs_eval(myr_handle h, int B, const double* z, const double* pa
                           double* f, double* g, double* c, double* j) {
   const int N = h->d.intervals;
   const double hstep = h->d.T / N;
-  const int wpt = h->eval_wpt;
-  // LDS is sized for the number of wavefronts ACTUALLY launched (the non-NT fallback always runs 4 per workgroup)
-  if (hs_eval_lds_bytes<Sys, SCHEME>(N, 8) > 160 * 1024) return fail(MYR_E_CAPACITY, "hs_eval: intervals too large for the 160 KiB LDS record");
+  int wpt = h->eval_wpt;
+  // LDS is sized for the number of wavefronts ACTUALLY launched (the non-NT fallback always runs 4 per workgroup): when the
+  // preferred width does not fit a CU the launch steps down (8 -> 4 -> 1) before it gives up
+  const bool nt_ = h->eval_nt != 0;
+  auto launched = [&](int w) { return nt_ ? (w == 1 ? 1 : (w == 8 ? 8 : 4)) : 4; };
+  while (hs_eval_lds_bytes<Sys, SCHEME>(N, launched(wpt)) > 160 * 1024 && nt_ && wpt > 1) wpt = wpt == 8 ? 4 : 1;
+  if (hs_eval_lds_bytes<Sys, SCHEME>(N, launched(wpt)) > 160 * 1024) return fail(MYR_E_CAPACITY, "hs_eval: intervals too large for the 160 KiB LDS record");
   KTimer& kt = h->kt[MYR_K_EVAL];
   // the start event is recorded after the host-side attribute call, directly in front of the launch: the interval
   // between the two events is the kernel plus its dispatch, not host work
@@ -133,7 +154,10 @@ static int launch_hs_eval(myr_handle h, int B, const double* z, const double* pa
   {                                                                                                               \
     auto kern = hs_eval_kernel<Sys, W, NTV, SCHEME>;                                                                   \
     const size_t lds = hs_eval_lds_bytes<Sys, SCHEME>(N, W);                                                      \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    if (h->eval_attr_lds[(W == 1 ? 0 : (W == 4 ? 1 : 2)) + (NTV ? 3 : 0)] != lds) {                             \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      h->eval_attr_lds[(W == 1 ? 0 : (W == 4 ? 1 : 2)) + (NTV ? 3 : 0)] = lds;                                   \
+    }                                                                                                             \
     HIPCHK(hipEventRecord(kt.a, h->stream));                                                                      \
     hipLaunchKernelGGL(kern, dim3(B), dim3(64 * W), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);    \
   }
@@ -385,6 +409,7 @@ static HsSolveOpts make_opts(myr_handle h, const myr_solve_opts& so) {
   o.N = h->d.intervals; o.h = h->d.T / h->d.intervals; o.max_iter = so.max_iter; o.tol_feas = so.tol_feas;
   o.tol_stat = so.tol_stat; o.tol_compl = so.tol_compl; o.mu_init = so.mu_init;
   o.cpi = h->d.controls_per_interval; o.method = h->d.integration_method;
+  o.restarts = so.restarts < 0 ? MYR_SHOOT_RESTARTS : (so.restarts > 4 ? 4 : so.restarts);
   // warm-started inertia correction: trades factorisation sweeps for (slightly more) iterations, which pays when a
   // sweep costs more than a linearisation -- collocation with closed-form dynamics; not shooting (the rollout
   // linearisation dominates, and the correction decays too slowly for its stragglers) nor network dynamics
@@ -418,15 +443,9 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   const int N = h->d.intervals;
   const size_t lds = W::lds_bytes(N);
   auto kern = hs_solve_fused_kernel<Sys, NWAVES>;
-  FusedLaunch& fl = h->fused[NWAVES - 1];
-  if (!fl.ready || fl.N != N) {      // attributes and occupancy once per handle and grid size, not per call
-    int per_cu = 0;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * NWAVES, lds));
-    fl.slots = (per_cu > 0 ? per_cu : 4 / NWAVES) * device_cus(h);
-    fl.ready = true; fl.N = N;
-  }
-  int slots = h->solve_slots > 0 ? h->solve_slots : fl.slots;
+  int per_cu = 0;       // (attributes and occupancy once per handle and configuration, not per call)
+  if (int rc = kernel_blocks_per_cu(h, reinterpret_cast<const void*>(kern), 64 * NWAVES, lds, &per_cu)) return rc;
+  int slots = h->solve_slots > 0 ? h->solve_slots : (per_cu > 0 ? per_cu : 4 / NWAVES) * device_cus(h);
   if (slots > B) slots = B;
   long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
   if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate slots over HBM channels
@@ -503,19 +522,14 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     const int lwaves = coop ? 1 : wpb;                          // solves per workgroup
     const size_t lds = ((size_t)lwaves * W::lds_solver_doubles(N) + NodeTraits<Sys>::lds_doubles + (coop ? W::COOP_CMD_DOUBLES : 0)) * 8;
     auto kern = hs_solve_wave_kernel<Sys, SCHEME>;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    if (int rc = kernel_blocks_per_cu(h, reinterpret_cast<const void*>(kern), 64 * wpb, lds, &per_cu)) return rc;
     // Persistent form: as many workgroups as the device keeps resident (registers and LDS allow 4 wavefronts per CU), each
     // pulling trajectories from a ticket counter.  Scratch belongs to the SLOT, not to the trajectory: the working set of
     // a launch is slots x 273 KB (280 MB for CARTPOLE N=100) instead of B x 273 KB (1.1 GB at B = 4096) and is re-used
     // trajectory after trajectory, i.e. it stays in the 256 MB Infinity Cache instead of streaming through HBM.
     int slots = h->solve_slots;              // wavefronts
-    if (slots <= 0) {
-      int per_cu = 0, dev = 0, cus = 0;
-      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64 * wpb, lds));
-      HIPCHK(hipGetDevice(&dev));
-      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      slots = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256) * lwaves;
-    }
+    if (slots <= 0) slots = (per_cu > 0 ? per_cu : 4) * device_cus(h) * lwaves;
     if (slots > B) slots = B;
     slots = (slots + lwaves - 1) / lwaves * lwaves;              // whole workgroups (surplus wavefronts find the ticket counter exhausted)
     long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
@@ -614,15 +628,10 @@ static int launch_shoot_solve(myr_handle h, int B, double* z, const double* lb, 
   if (h->solve_mode != 1 || lds > 160 * 1024)
     return launch_lane_solve<ShootCore<Sys, M>, Sys>(h, B, ShootCore<Sys, M>::stage_doubles(N, cpi), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   auto kern = shoot_solve_wave_kernel<Sys, M>;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  if (int rc = kernel_blocks_per_cu(h, reinterpret_cast<const void*>(kern), 64, lds, &per_cu)) return rc;
   int slots = h->solve_slots;
-  if (slots <= 0) {
-    int per_cu = 0, dev = 0, cus = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 64, lds));
-    HIPCHK(hipGetDevice(&dev));
-    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    slots = (per_cu > 0 ? per_cu : 4) * (cus > 0 ? cus : 256);
-  }
+  if (slots <= 0) slots = (per_cu > 0 ? per_cu : 4) * device_cus(h);
   if (slots > B) slots = B;
   if (!h->ticket) HIPCHK(hipMalloc(&h->ticket, sizeof(int)));
   HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int), h->stream));
@@ -744,7 +753,7 @@ extern "C" int myr_device_count(void) {
 extern "C" void myr_default_solve_opts(myr_solve_opts* o) {
   if (!o) return;
   o->max_iter = 1000;   // config.py:70
-  o->reserved = 0;
+  o->restarts = -1;     // library default, see the header
   o->tol_feas = 1e-8;
   o->tol_stat = 1e-6;
   o->tol_compl = 1e-7;

@@ -36,7 +36,7 @@ namespace myriad {
 typedef __attribute__((address_space(3))) double sw_lds;     // LDS-typed pointers: ds_read / ds_write instead of flat accesses
 
 #ifndef MYR_SHOOT_RESTARTS
-#define MYR_SHOOT_RESTARTS 2       // second / third start of a failed solve (see the kernel)
+#define MYR_SHOOT_RESTARTS 2       // default of myr_solve_opts.restarts for this kernel: second / third start of a failed solve
 #endif
 #ifndef MYR_SHOOT_MIN_WAVES
 #define MYR_SHOOT_MIN_WAVES 2     // waves per SIMD the register allocation must allow (LDS allows 8 workgroups per CU)
@@ -812,7 +812,7 @@ void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, dou
     // (seeds 2020 / 2021 of config 3: 170 / 105 ms against 20 ms for the other 8191 trajectories)
     HsSolveOpts o1 = o;
     o1.max_iter = o.max_iter / 8 > 100 ? o.max_iter / 8 : (o.max_iter < 100 ? o.max_iter : 100);
-    IpLoop<W>::run(w, MYR_SHOOT_RESTARTS > 0 ? o1 : o, pp.get(), r);
+    IpLoop<W>::run(w, o.restarts > 0 ? o1 : o, pp.get(), r);
     __syncthreads();
     // A solve that ends without a KKT point (line search stalled on a non-descent direction, iteration limit, non-finite
     // values) is restarted from the caller's point with another initial barrier parameter (x3, then /3): the iterates of
@@ -821,11 +821,11 @@ void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, dou
     // 31 .. 49 iterations from any of 0.01, 0.03, 0.3, 0.5, 1.  There is no restoration phase to fall back on;
     // a second start is the cheap substitute.  The restarts get the full iteration limit; iterations and sweeps of all
     // attempts are reported (so `iters` can exceed max_iter).
-    for (int attempt = 0; attempt < MYR_SHOOT_RESTARTS && r.status != 0; ++attempt) {
+    for (int attempt = 0; attempt < o.restarts && r.status != 0; ++attempt) {
       for (int i = threadIdx.x; i < n; i += 64) l.z[i] = l.z0[i];
       __syncthreads();
       HsSolveOpts o2 = o;
-      o2.mu_init = o.mu_init * (attempt == 0 ? 3.0 : 1.0 / 3.0);
+      o2.mu_init = o.mu_init * ((attempt & 1) == 0 ? 3.0 : 1.0 / 3.0);
       HsSolveResult r2;
       IpLoop<W>::run(w, o2, pp.get(), r2);
       __syncthreads();

@@ -192,7 +192,12 @@ def test_shooting_solve_matches_golden_fixtures(tag, name, golden_dir):
   o.tol_feas, o.tol_stat, o.tol_compl, o.mu_init = 1e-11, 1e-10, 1e-12, 1e-9
   r2 = eng.solve(r["z"], d["lb"], d["ub"], params=d["params"], opts=o)
   assert (r2["status"] == 0).all(), (r2["status"], r2["iters"], r2["kkt"])
-  assert np.abs(r2["z"] - d["z"]).max() < 1e-6, np.abs(r2["z"] - d["z"]).max(axis=1)
+  # a WEAKLY active bound (fixture multiplier < 1e-4: the last control of a Heun rollout hardly enters the objective) keeps an
+  # interior-point iterate at slack = mu / multiplier from it (1.5e-6 at the smallest barrier parameter): 1e-5 there, 1e-6 elsewhere
+  on_bound = (d["z"] == d["lb"]) | (d["z"] == d["ub"])
+  weak = on_bound & (d["lb"] < d["ub"]) & ((d["zL"] + d["zU"]) < 1e-4)
+  err = np.abs(r2["z"] - d["z"])
+  assert err[~weak].max() < 1e-6 and err.max() < 1e-5, (err[~weak].max(), err.max())
   np.testing.assert_allclose(r2["cost"], d["cost"], rtol=1e-10)
   lam_err = np.abs(r2["lam"] - d["lam"]).max(axis=1) / np.maximum(1.0, np.abs(d["lam"]).max(axis=1))
   assert lam_err.max() < 1e-6, lam_err            # sign convention of the reference's mult_g (nlp_solvers/__init__.py:82-86)
