@@ -61,14 +61,15 @@ struct HsFused {
   __host__ __device__ static long off_st(int N) { return off_hr(N) + (long)npoints(N) * HR_N + PADS; }
   __host__ __device__ static long off_kg(int N) { return off_st(N) + (long)N * SG_N; }
   __host__ __device__ static long off_lam(int N) { return off_kg(N) + (long)N * KST; }
-  __host__ __device__ static long scratch_doubles(int N) { return off_lam(N) + 2L * N * NS; }
+  __host__ __device__ static long off_kg2(int N) { return off_lam(N) + 2L * N * NS; }      // W = 2: gains of the speculative second sweep
+  __host__ __device__ static long scratch_doubles(int N) { return off_kg2(N) + (W > 1 ? (long)N * KST : 0); }
   // LDS (doubles): z | zL | zU | dz | multipliers | bound table | neighbour stash | first-point exchange
   static constexpr int NREC = NS + NS + NS * NS + NS * NU + NS;   // x, f, A, B, own: what an interval takes from its end knot
   static constexpr int EXCH = NW * NW + NW * NC + NS * NC + NU * NC;
   // exchange between blocks / wavefronts (double-buffered by round): neighbour record, block total of a scan, trial knot; partial sums
   static constexpr int NTOT = NW * NW + NW, NRED = 12;
   static constexpr int XCH = 2 * W * NREC + 2 * W * NTOT + 2 * W * 2 * NS + W * NRED + 4;
-  __host__ __device__ static int lds_doubles(int N) { return 4 * npoints(N) * NW + 2 * N * NS + 6 * NW + XCH + EXCH + 8; }
+  __host__ __device__ static int lds_doubles(int N) { return 4 * npoints(N) * NW + 2 * N * NS + 6 * NW + XCH + (W > 1 ? 2 : 1) * EXCH + 8; }
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
 
   struct Ctx {
@@ -76,6 +77,7 @@ struct HsFused {
     double h, h6, h8;
     double *z, *zL, *zU, *dz;             // the iterate and the step (LDS)
     double *hr, *st, *kg, *zr;            // global scratch of this wavefront
+    double *kgA, *kgB, *xA, *xB;          // W = 2: the two sets of sweep outputs (gains in global scratch, first-point exchange in LDS)
     const double *lb, *ub;                // the caller's bounds (global)
     bool uni;                             // interior points share one bound per component: served from sB
     SysParams<Sys> pp;
@@ -86,6 +88,10 @@ struct HsFused {
 #endif
   };
   __device__ static inline long zi(const Ctx& c, int j, int comp) { return S::zi(c.K, j, comp); }
+  // point the sweep outputs (gains, P | pc | Tnu | Ku exchange) of a context at one of the two sets
+  __device__ static inline void use_set(Ctx& c, double* kg, double* x) {
+    c.kg = kg; c.sP = x; c.sPc = x + NW * NW; c.sTnu = c.sPc + NW * NC; c.sKu = c.sTnu + NS * NC;
+  }
   __device__ static inline void wsync() { __syncthreads(); }
   // partial results of the W wavefronts -> the workgroup's (op: 0 sum, 1 max, 2 min); every wavefront ends with the same values
   template <int NV>
@@ -1001,22 +1007,48 @@ struct HsFused {
       double delta = lm;
       if (o.delta_warm && delta_last > o.delta_warm_min) delta = dmax(delta, delta_last / DELTA_WARM_DIV);
       int nreg = 0;
-      for (int tr_ = 0; tr_ < 12; ++tr_) {
-        const bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
-        if constexpr (W > 1) {
-          if (c.wave == 0) {
-            nreg = riccati_mfma(c, o, delta, abort_on_reg);
-            if (c.lane == 0) c.sMisc[1] = (double)nreg;
+      auto next_delta = [&](double d) {       // the inertia-correction ladder (IPOPT's: first 1e-4 or a third of the last one, then x 100 / x 8)
+        return d == 0.0 ? ((delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4) : d * ((delta_last > 0.0) ? 8.0 : 100.0);
+      };
+      if constexpr (W > 1) {
+        // Two rungs of the ladder at a time: wavefront 0 sweeps with delta, wavefront 1 -- idle otherwise -- with the NEXT candidate
+        // into a second set of outputs.  A failed first sweep costs a whole sweep (the bad pivot shows up near stage 0: 5 of 22
+        // sweeps of a typical solve); its successor is then already there.  Same sequence of candidates, first success wins: the
+        // iterates are those of the one-wavefront form.
+        use_set(c, c.kgA, c.xA);
+        for (int tr_ = 0; tr_ < 12; tr_ += 2) {
+          const double delta_b = next_delta(delta);
+          const bool abort_a = (tr_ < 11) && !(delta > 1e8), abort_b = (tr_ + 1 < 11) && !(delta_b > 1e8);
+          {
+            Ctx cw = c;
+            if (c.wave == 1) use_set(cw, c.kgB, c.xB);
+            if (c.wave < 2) {
+              const int nr = riccati_mfma(cw, o, c.wave == 0 ? delta : delta_b, c.wave == 0 ? abort_a : abort_b);
+              if (c.lane == 0) c.sMisc[1 + c.wave] = (double)nr;
+            }
           }
           wsync();
-          nreg = (int)c.sMisc[1];
-        } else nreg = riccati_mfma(c, o, delta, abort_on_reg);
-        wsync();
-        MYR_PH(6)
-        if (nreg == 0) break;
-        if (!abort_on_reg) break;
-        if (delta == 0.0) delta = (delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4;
-        else delta *= (delta_last > 0.0) ? 8.0 : 100.0;
+          const int na = (int)c.sMisc[1], nb = (int)c.sMisc[2];
+          wsync();
+          MYR_PH(6)
+          nreg = na;
+          if (na == 0 || !abort_a) break;
+          delta = delta_b; nreg = nb;
+          use_set(c, c.kgB, c.xB);
+          if (nb == 0 || !abort_b) break;
+          use_set(c, c.kgA, c.xA);
+          delta = next_delta(delta_b);
+        }
+      } else {
+        for (int tr_ = 0; tr_ < 12; ++tr_) {
+          const bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
+          nreg = riccati_mfma(c, o, delta, abort_on_reg);
+          wsync();
+          MYR_PH(6)
+          if (nreg == 0) break;
+          if (!abort_on_reg) break;
+          delta = next_delta(delta);
+        }
       }
       delta_last = (delta > lm) ? delta : 0.0;
       const int nm = 2 * c.N * NS + p1.nm;
@@ -1114,6 +1146,7 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
   double* s = scratch + (long)blockIdx.x * scratch_stride;
   c.zr = s; c.hr = s + W::off_hr(c.N); c.st = s + W::off_st(c.N); c.kg = s + W::off_kg(c.N);
+  c.kgA = c.kg; c.kgB = s + W::off_kg2(c.N);
   double* const lam_own = s + W::off_lam(c.N);
   double* l = reinterpret_cast<double*>(smem_fused);
   c.z = l; l += c.n; c.zL = l; l += c.n; c.zU = l; l += c.n; c.dz = l; l += c.n;
@@ -1124,10 +1157,8 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   c.sTr = l; l += 2 * NWAVES * 2 * W::NS;
   c.sRed = l; l += NWAVES * W::NRED;
   c.sMisc = l; l += 4;
-  c.sP = l; l += W::NW * W::NW;
-  c.sPc = l; l += W::NW * W::NC;
-  c.sTnu = l; l += W::NS * W::NC;
-  c.sKu = l; l += W::NU * W::NC;
+  c.xA = l; c.xB = l + W::EXCH;
+  W::use_set(c, c.kgA, c.xA);
   for (;;) {
     int t = 0;
     if (c.tid == 0) t = atomicAdd(ticket, 1);

@@ -46,47 +46,76 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
   }
 
   __device__ static inline nd4 mm(double a, double b, nd4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-  __device__ static inline double sigm(double a) { return 1.0 / (1.0 + exp(-a)); }
+  // 1 / (1 + exp(-a)) with the reciprocal from v_rcp_f64 + two Newton steps (5 instructions instead of the ~35 of the IEEE
+  // division sequence: a tile of 16 points takes 32 sigmoids per lane); <= 1 ulp
+  __device__ static inline double sigm(double a) {
+    const double d = 1.0 + exp(-a);
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+  }
 
+  // The 64 x 64 products below are written k-step OUTER, output tile INNER: every k-step issues four INDEPENDENT matrix
+  // instructions (one per output tile of 16 rows).  On MI355X a v_mfma_f64_16x16x4_f64 occupies the matrix pipe 64 cycles and a
+  // dependent one can issue ~130 cycles after its producer -- the original nest (tile outer: sixteen dependent instructions in
+  // a row per tile) left the pipe idle half of the time and more, with four accumulators in flight it is fed back to back.
   // out = W2^T in (+ b2): row m = 16 mt + i of the A operand, k = n = 16 t + 4 s + g
+  // (the "memory" barrier in front of every product keeps the compiler from holding the 64 weight values of one product in
+  // registers for the next ones -- six products share W2 in MODE 2, and 128 registers of hoisted weights pushed that pass into
+  // 4.4 KB of scratch per lane; an LDS read per matrix instruction is what the layout was made for)
   template <bool BIAS>
   __device__ static inline void gemm_t(const nd_lds* wl, int g, int i, const nd4* in, nd4* out) {
+    asm volatile("" ::: "memory");
+    nd4 acc[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      nd4 acc;
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc[s] = BIAS ? wl[L_B2 + 16 * mt + 4 * s + g] : 0.0;
+      for (int s = 0; s < 4; ++s) acc[mt][s] = BIAS ? wl[L_B2 + 16 * mt + 4 * s + g] : 0.0;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mm(wl[L_W2 + (16 * t + 4 * s + g) * LD2 + 16 * mt + i], in[t][s], acc);
-      out[mt] = acc;
-    }
+      for (int s = 0; s < 4; ++s) {
+        const nd_lds* row = wl + L_W2 + (16 * t + 4 * s + g) * LD2 + i;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = mm(row[16 * mt], in[t][s], acc[mt]);
+      }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) out[mt] = acc[mt];
   }
   // out = W2 in: row n = 16 nt + i, k = m = 16 t + 4 s + g
   __device__ static inline void gemm_n(const nd_lds* wl, int g, int i, const nd4* in, nd4* out) {
+    asm volatile("" ::: "memory");
+    nd4 acc[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      nd4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = nd4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mm(wl[L_W2 + (16 * nt + i) * LD2 + 16 * t + 4 * s + g], in[t][s], acc);
-      out[nt] = acc;
-    }
+      for (int s = 0; s < 4; ++s) {
+        const nd_lds* col = wl + L_W2 + i * LD2 + 16 * t + 4 * s + g;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = mm(col[16 * nt * LD2], in[t][s], acc[nt]);
+      }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) out[nt] = acc[nt];
   }
-  // rows 0..3 of W3^T in (+ b3): result for output r of point i in lane 16 r + i
+  // rows 0..3 of W3^T in (+ b3): result for output r of point i in lane 16 r + i.  One output tile only: the sixteen k-steps go
+  // to four accumulators (one per s) that are added at the end.
   template <bool BIAS>
   __device__ static inline double layer3(const nd_lds* wl, int g, int i, const nd4* in) {
-    nd4 acc = {BIAS ? wl[L_B3 + g] : 0.0, 0.0, 0.0, 0.0};
+    nd4 acc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s] = nd4{(BIAS && s == 0) ? wl[L_B3 + g] : 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const double a = wl[L_W3 + (16 * t + 4 * s + g) * NS + (i & 3)];
-        acc = mm(i < NS ? a : 0.0, in[t][s], acc);
+        acc[s] = mm(i < NS ? a : 0.0, in[t][s], acc[s]);
       }
-    return acc[0];
+    return (acc[0][0] + acc[1][0]) + (acc[2][0] + acc[3][0]);
   }
 
   struct Args {
@@ -113,23 +142,30 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
         xg += a.alpha * a.dz[(long)j * NS + g];
         if (g == 0) ug += a.alpha * a.dz[(long)K * NS + j];
       }
-      nd4 h1[4], sp1[4];
+      // (s'(A) = h (1 - h) and s''(A) = s'(A) (1 - 2 h) are formed where they are used: keeping them as arrays next to h1, h2
+      // cost MODE 2 64 more live registers than it had)
+      nd4 h1[4];
+      {
+        nd4 a1[4];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        nd4 acc;
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[s] = wl[L_B1 + 16 * mt + 4 * s + g];
-        acc = mm(wl[L_W1 + g * H + 16 * mt + i], xg, acc);
-        acc = mm(wl[L_W1 + (4 + g) * H + 16 * mt + i], ug, acc);
+          for (int s = 0; s < 4; ++s) a1[mt][s] = wl[L_B1 + 16 * mt + 4 * s + g];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { const double hv = sigm(acc[s]); h1[mt][s] = hv; sp1[mt][s] = hv * (1.0 - hv); }
+        for (int mt = 0; mt < 4; ++mt) a1[mt] = mm(wl[L_W1 + g * H + 16 * mt + i], xg, a1[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a1[mt] = mm(wl[L_W1 + (4 + g) * H + 16 * mt + i], ug, a1[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) h1[mt][s] = sigm(a1[mt][s]);
       }
-      nd4 h2[4], sp2[4];
+      nd4 h2[4];
       gemm_t<true>(wl, g, i, h1, h2);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { const double hv = sigm(h2[mt][s]); h2[mt][s] = hv; sp2[mt][s] = hv * (1.0 - hv); }
+        for (int s = 0; s < 4; ++s) h2[mt][s] = sigm(h2[mt][s]);
       if (MODE == 0 || MODE == 1) {
         const double F = layer3<true>(wl, g, i, h2);
         if (MODE == 0) { if (valid) a.sF[j * NS + g] = F; }
@@ -143,12 +179,12 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) d1[mt][s] = sp1[mt][s] * wl[L_W1 + c * H + 16 * mt + 4 * s + g];
+            for (int s = 0; s < 4; ++s) d1[mt][s] = h1[mt][s] * (1.0 - h1[mt][s]) * wl[L_W1 + c * H + 16 * mt + 4 * s + g];
           gemm_t<false>(wl, g, i, d1, d2);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) d2[mt][s] *= sp2[mt][s];
+            for (int s = 0; s < 4; ++s) d2[mt][s] *= h2[mt][s] * (1.0 - h2[mt][s]);
           const double dF = layer3<false>(wl, g, i, d2);      // d F_g / d w_c at point i
           if (valid) {
             if (a.use_rec) a.rec[j * a.rec_stride + (c < NS ? a.rec_a + g * NS + c : a.rec_b + g * NU)] = dF;
@@ -169,19 +205,18 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
         // g2 = W3 a (one k-step: k = output r = lane group), e2 = g2 s'(A2), c2 = g2 s''(A2)
         nd4 e2[4], c2[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          nd4 acc = {0.0, 0.0, 0.0, 0.0};
-          acc = mm(wl[L_W3 + (16 * nt + i) * NS + g], ar, acc);
+        for (int nt = 0; nt < 4; ++nt) e2[nt] = mm(wl[L_W3 + (16 * nt + i) * NS + g], ar, nd4{0.0, 0.0, 0.0, 0.0});
 #pragma unroll
-          for (int s = 0; s < 4; ++s) { const double e = acc[s] * sp2[nt][s]; e2[nt][s] = e; c2[nt][s] = e * (1.0 - 2.0 * h2[nt][s]); }
-        }
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { const double e = e2[nt][s] * (h2[nt][s] * (1.0 - h2[nt][s])); e2[nt][s] = e; c2[nt][s] = e * (1.0 - 2.0 * h2[nt][s]); }
         // g1 = W2 e2, c1 = g1 s''(A1)
         nd4 c1[4];
         gemm_n(wl, g, i, e2, c1);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) c1[mt][s] *= sp1[mt][s] * (1.0 - 2.0 * h1[mt][s]);
+          for (int s = 0; s < 4; ++s) c1[mt][s] *= h1[mt][s] * (1.0 - h1[mt][s]) * (1.0 - 2.0 * h1[mt][s]);
         // m_c = W2^T (s'(A1) * W1[c, :]): the five tangents of A2
         nd4 m[NW][4];
 #pragma unroll
@@ -190,7 +225,7 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) d1[mt][s] = sp1[mt][s] * wl[L_W1 + c * H + 16 * mt + 4 * s + g];
+            for (int s = 0; s < 4; ++s) d1[mt][s] = h1[mt][s] * (1.0 - h1[mt][s]) * wl[L_W1 + c * H + 16 * mt + 4 * s + g];
           gemm_t<false>(wl, g, i, d1, m[c]);
         }
         // W[a][b] = sum_n c1_n W1[a][n] W1[b][n] + sum_n c2_n m_a[n] m_b[n]: 16 hidden units per lane, then over the 4 groups

@@ -36,7 +36,9 @@ def test_node_eval_matches_oracle_autodiff():
   np.testing.assert_allclose(opt.objective_grad(z, params=node.params), cb.grad(z), rtol=1e-12, atol=1e-13)
   # the network reproduces the true field where it was fitted (R^2 = 0.997): sanity of the committed weights
   true = get_optimizer(hp, CFG, hp.system())
-  assert np.abs(opt.parametrized_constraints(node.params, tr.guess) - true.constraints(tr.guess)).max() < 1.0   # h=1/3, rms field error 0.7
+  ct = true.constraints(tr.guess)
+  diff = np.abs(opt.parametrized_constraints(node.params, tr.guess) - ct).max()
+  assert diff < 0.6 and diff < 0.1 * np.abs(ct).max()      # measured 0.49 against constraints of size 6.4 (h = 1/3)
 
 
 def test_node_solve_with_params_converges_and_is_kkt_point():

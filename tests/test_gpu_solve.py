@@ -150,6 +150,33 @@ def test_wave_and_lane_kernels_agree(monkeypatch):
   assert np.abs(out["wave"]["lam"] - out["lane"]["lam"]).max() < 1e-4 * max(1.0, np.abs(out["lane"]["lam"]).max())
 
 
+def test_fused_kernel_wavefront_forms_and_round2_kernel_agree(monkeypatch):
+  """hs_solver_fused.h with one and with two wavefronts per trajectory (the small-batch form: blocks of 64 stages dealt to the
+  two wavefronts, scan carries and neighbour records through LDS, the second inertia candidate swept speculatively by wavefront 1)
+  and round 2's kernel (MYRIAD_SOLVE_MODE=wave1) run one algorithm: same optima, same iteration counts up to the order of the sums."""
+  from bench import build_workload
+  from myriad_amd import _lib
+  B, N = 96, 100
+  x0, z0, lb, ub, T = build_workload(B, N, 11)
+  out = {}
+  for tag, env in (("w1", {"MYRIAD_FUSED_WAVES": "1"}), ("w2", {"MYRIAD_FUSED_WAVES": "2"}), ("r2", {"MYRIAD_SOLVE_MODE": "wave1"})):
+    for k in ("MYRIAD_FUSED_WAVES", "MYRIAD_SOLVE_MODE"):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    eng = _lib.Engine("CARTPOLE", "HERMITE_SIMPSON", N, T, max_batch=B)
+    out[tag] = eng.solve(z0, lb, ub)
+    eng.close()
+  for tag in ("w2", "r2"):
+    a, b = out["w1"], out[tag]
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-9)
+    assert (a["iters"] == b["iters"]).mean() >= 0.9, (tag, np.bincount(np.abs(a["iters"] - b["iters"])))
+    same = a["iters"] == b["iters"]
+    assert np.abs(a["z"][same] - b["z"][same]).max() < 1e-6
+    assert np.abs(a["lam"][same] - b["lam"][same]).max() < 1e-4 * max(1.0, np.abs(a["lam"]).max())
+
+
 def test_long_horizon_falls_back_to_the_lane_solver():
   """N = 600 intervals: the wavefront solver's LDS working set (~200 KB) exceeds a CU, so the lane-per-trajectory form
   runs instead of an error; same optimum as a coarser grid to discretisation accuracy."""
