@@ -41,7 +41,14 @@ struct HsFused {
   using D = HsSol<Sys>;
   static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = D::NY, NQ = D::NQ, NC = D::NC, NY1 = NY + 1;
   static constexpr int QE = NQ - NU;
-  static constexpr bool SUPPORTED = (NU == 1 && NS <= 4) && !NodeTraits<Sys>::mlp;
+  static constexpr bool SUPPORTED = (NU == 1 && NS <= 4);
+  // Network dynamics (config 5, node_system.h): f, A, B of ALL points come from the matrix-core pass of node_mfma.h (MODE 1, every
+  // wavefront of the workgroup takes every W-th tile of 16 points) into a global record the backward pass reads instead of calling
+  // Sys::lin; MODE 2 delivers the multiplier-contracted second derivatives for the hessian pass, MODE 0 the values for the trials
+  // (into LDS).  The weights (40 KB) sit in LDS behind the iterate.  Round 2 ran these systems on HsWave with the three helper
+  // wavefronts of a workgroup idle outside the passes; here every parallel pass is shared by the W = 4 wavefronts.
+  static constexpr bool MLP = NodeTraits<Sys>::mlp;
+  static constexpr int PT_F = 0, PT_A = PT_F + NS, PT_B = PT_A + NS * NS, PT_D2 = PT_B + NS * NU, PT_N = PT_D2 + NW * (NW + 1) / 2;
   static constexpr int HSYM = NW * (NW + 1) / 2;
   // per-point Hessian record, AoS: upper triangle of H (row-major), g0 (NW), g1 (NW)
   static constexpr int HR_H = 0, HR_G0 = HSYM, HR_G1 = HR_G0 + NW, HR_N = HR_G1 + NW;
@@ -62,14 +69,16 @@ struct HsFused {
   __host__ __device__ static long off_kg(int N) { return off_st(N) + (long)N * SG_N; }
   __host__ __device__ static long off_lam(int N) { return off_kg(N) + (long)N * KST; }
   __host__ __device__ static long off_kg2(int N) { return off_lam(N) + 2L * N * NS; }      // W = 2: gains of the speculative second sweep
-  __host__ __device__ static long scratch_doubles(int N) { return off_kg2(N) + (W > 1 ? (long)N * KST : 0); }
+  __host__ __device__ static long off_pt(int N) { return off_kg2(N) + (W > 1 ? (long)N * KST : 0); }     // network systems: point records (SoA)
+  __host__ __device__ static long scratch_doubles(int N) { return off_pt(N) + (MLP ? (long)PT_N * npoints(N) : 0); }
   // LDS (doubles): z | zL | zU | dz | multipliers | bound table | neighbour stash | first-point exchange
   static constexpr int NREC = NS + NS + NS * NS + NS * NU + NS;   // x, f, A, B, own: what an interval takes from its end knot
   static constexpr int EXCH = NW * NW + NW * NC + NS * NC + NU * NC;
   // exchange between blocks / wavefronts (double-buffered by round): neighbour record, block total of a scan, trial knot; partial sums
   static constexpr int NTOT = NW * NW + NW, NRED = 12;
   static constexpr int XCH = 2 * W * NREC + 2 * W * NTOT + 2 * W * 2 * NS + W * NRED + 4;
-  __host__ __device__ static int lds_doubles(int N) { return 4 * npoints(N) * NW + 2 * N * NS + 6 * NW + XCH + (W > 1 ? 2 : 1) * EXCH + 8; }
+  __host__ __device__ static int lds_solver_doubles(int N) { return 4 * npoints(N) * NW + 2 * N * NS + 6 * NW + XCH + (W > 1 ? 2 : 1) * EXCH + 8; }
+  __host__ __device__ static int lds_doubles(int N) { return lds_solver_doubles(N) + (MLP ? npoints(N) * NS + NodeTraits<Sys>::lds_doubles : 0); }
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
 
   struct Ctx {
@@ -78,6 +87,7 @@ struct HsFused {
     double *z, *zL, *zU, *dz;             // the iterate and the step (LDS)
     double *hr, *st, *kg, *zr;            // global scratch of this wavefront
     double *kgA, *kgB, *xA, *xB;          // W = 2: the two sets of sweep outputs (gains in global scratch, first-point exchange in LDS)
+    double *pt, *sF, *wl;                 // network systems: point records (global), trial values and weights (LDS)
     const double *lb, *ub;                // the caller's bounds (global)
     bool uni;                             // interior points share one bound per component: served from sB
     SysParams<Sys> pp;
@@ -116,6 +126,20 @@ struct HsFused {
     } else { (void)c; (void)v; (void)op; }
   }
 
+  // network systems: one matrix-core pass over all points, tiles of 16 points dealt over the W wavefronts
+  template <int MODE>
+  __device__ static inline void node_pass(Ctx& c, double alpha) {
+    if constexpr (MLP) {
+      NodeMfma64::ArgsT<nd_lds> a;
+      a.z = (const nd_lds*)c.z; a.dz = (const nd_lds*)c.dz; a.lam = (const nd_lds*)c.sLam; a.pt = (nd_glb*)c.pt;
+      a.sF = (nd_lds*)c.sF;
+      a.alpha = alpha; a.h6 = c.h6; a.h8 = c.h8; a.K = c.K; a.N = c.N;
+      a.pf_f = PT_F; a.pf_a = PT_A; a.pf_b = PT_B; a.pf_d2 = PT_D2;
+      a.t0 = c.wave; a.ts = W;
+      NodeMfma64::pass<MODE, nd_lds>((const nd_lds*)c.wl, a, c.lane);
+    } else { (void)c; (void)alpha; }
+  }
+
   // bounds of the NW variables of point j
   __device__ static inline void load_bounds(const Ctx& c, int j, double* l, double* u) {
     if (c.uni) {
@@ -131,6 +155,30 @@ struct HsFused {
   struct Step { bool on; double ap, ad, mu, ksig; };
   struct Acc { double f, cmax, cmin, sm, lg; int nm; };
   struct PRec { double x[NS], f[NS], A[NS * NS], B[NS * NU], own[NS]; };   // own = w_j dg/dx + (zU - zL)_x of the point
+
+  // the accepted step applied to the NW variables of point j (network systems: a pass of its own in front of the matrix-core
+  // linearisation; same formulas as in lin_at)
+  __device__ static inline void step_at(Ctx& c, const Step& st, int j, PRec&) {
+    double bl[NW], bu[NW];
+    load_bounds(c, j, bl, bu);
+    const double iks = 1.0 / st.ksig;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const long i = zi(c, j, q);
+      const double l = bl[q], u = bu[q], zv = c.z[i], d = c.dz[i], zl = c.zL[i], zu = c.zU[i];
+      const bool fr = l < u;
+      const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
+      const double zn = fr ? zv + st.ap * d : zv;
+      const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
+      const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
+      double vl = zl + st.ad * (-zl + (st.mu - zl * d) * detail::rcp_(sl));
+      double vu = zu + st.ad * (-zu + (st.mu + zu * d) * detail::rcp_(su));
+      const double ml = st.mu * detail::rcp_(snl), mu_ = st.mu * detail::rcp_(snu);
+      vl = detail::dmax(detail::dmin(vl, st.ksig * ml), ml * iks);
+      vu = detail::dmax(detail::dmin(vu, st.ksig * mu_), mu_ * iks);
+      c.z[i] = zn; c.zL[i] = hl ? vl : 0.0; c.zU[i] = hu ? vu : 0.0;
+    }
+  }
 
   // One point of the backward phase: the accepted step of the previous iteration is applied on the values loaded anyway
   // (same formulas, same order of operations as HsWave::points_lin), then dynamics + first derivatives, bound sums.
@@ -171,7 +219,18 @@ struct HsFused {
 #pragma unroll
     for (int q = 0; q < NU; ++q) u_[q] = V.z[NS + q];
     set_time<Sys>(c.pp.get(), tq(j, c.h));
-    Sys::lin(R.x, u_, c.pp.get(), R.f, R.A, R.B, &g, gw);
+    if constexpr (MLP) {          // f, A, B from the matrix-core pass (the step was applied before it); the cost is closed form
+      const double* pt = c.pt + j;
+      const int K = c.K;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) R.f[q] = pt[(PT_F + q) * K];
+#pragma unroll
+      for (int q = 0; q < NS * NS; ++q) R.A[q] = pt[(PT_A + q) * K];
+#pragma unroll
+      for (int q = 0; q < NS * NU; ++q) R.B[q] = pt[(PT_B + q) * K];
+      Sys::cost_grad(R.x, u_, c.pp.get(), &g, gw);
+    } else
+      Sys::lin(R.x, u_, c.pp.get(), R.f, R.A, R.B, &g, gw);
     const double wj = wq(c.K, j, c.h);
     double cmax = a.cmax, cmin = a.cmin, sm = 0.0, slk = 1.0; int nm = 0, sexp = 0;
 #pragma unroll
@@ -206,6 +265,19 @@ struct HsFused {
     double piS[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) piS[q] = c.term_pinned[q] ? nuT[q] : 0.0;
+    Step stp_ = stp;
+    if constexpr (MLP) {          // the network pass reads the iterate: apply the step first (lanes over points), then linearise all points
+      if (stp.on) {
+        Acc dummy{0.0, 0.0, INFINITY, 0.0, 0.0, 0};
+        for (int j = c.tid; j < K; j += NT) { PRec R; step_at(c, stp, j, R); }
+        (void)dummy;
+        wsync();
+        stp_.on = false;
+      }
+      node_pass<1>(c, 0.0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      wsync();
+    }
     // rounds of W blocks from the top: wavefront w takes block r0 - w of the round
     int round = 0;
     for (int r0 = N / 64; r0 >= 0; r0 -= W, ++round) {
@@ -214,8 +286,8 @@ struct HsFused {
       const bool on_s = kr <= N, on = kr < N;
       const int k = on_s ? kr : N;                 // (lanes above the horizon repeat the terminal point; nothing is stored)
       PRec Rs, Rm, Re;
-      lin_at(c, stp, 2 * k, on_s, Rs, acc);
-      lin_at(c, stp, on ? 2 * k + 1 : 2 * k, on, Rm, acc);
+      lin_at(c, stp_, 2 * k, on_s, Rs, acc);
+      lin_at(c, stp_, on ? 2 * k + 1 : 2 * k, on, Rm, acc);
       // end knot of the stage = start knot of stage k + 1: the lane below; lane 0 takes what the block above left (the
       // wavefront above of this round, or the last wavefront of the previous round)
       {
@@ -457,6 +529,11 @@ struct HsFused {
     const int N = c.N, K = c.K;
     const double h6 = c.h6, h8 = c.h8;
     double st_ = 0;
+    if constexpr (MLP) {          // the network's multiplier-contracted second derivatives of all points (reads the multipliers in LDS)
+      node_pass<2>(c, 0.0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      wsync();
+    }
     for (int j = c.tid; j < K; j += NT) {
       double a[NS];
       if (j & 1) {
@@ -480,7 +557,16 @@ struct HsFused {
       for (int q = 0; q < NW; ++q) { const long i = zi(c, j, q); V.z[q] = c.z[i]; V.zl[q] = c.zL[i]; V.zu[q] = c.zU[i]; }
       HsPoint<Sys> P;
       set_time<Sys>(c.pp.get(), tq(j, c.h));
-      S::lin_point(V, c.pp.get(), P);
+      if constexpr (MLP) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) P.x[q] = V.z[q];
+#pragma unroll
+        for (int q = 0; q < NU; ++q) P.u[q] = V.z[NS + q];
+        Sys::cost_grad(P.x, P.u, c.pp.get(), &P.g, P.gw);
+#pragma unroll
+        for (int q = 0; q < NS * NU; ++q) P.B[q] = c.pt[(long)(PT_B + q) * K + j];
+      } else
+        S::lin_point(V, c.pp.get(), P);
       double sig[NW], g1v[NW], zlu[NW], cmx = 0.0, cmn = INFINITY;
 #pragma unroll
       for (int q = 0; q < NW; ++q) {
@@ -495,7 +581,13 @@ struct HsFused {
         st_ = detail::dmax(st_, fabs(r));
       }
       double Wh[NW * NW];
-      Sys::hessian(P.x, P.u, c.pp.get(), P.D2, a, wj, Wh);
+      if constexpr (MLP) {
+        double Wm[NW * (NW + 1) / 2];
+#pragma unroll
+        for (int q = 0; q < NW * (NW + 1) / 2; ++q) Wm[q] = c.pt[(long)(PT_D2 + q) * K + j];
+        Sys::hessian_packed(P.x, P.u, Wm, wj, Wh);
+      } else
+        Sys::hessian(P.x, P.u, c.pp.get(), P.D2, a, wj, Wh);
       double* hr = c.hr + (long)j * HR_N;
       const bool last = (j == K - 1);
 #pragma unroll
@@ -867,7 +959,11 @@ struct HsFused {
       { int e_; slk *= frexp((sl > 0.0 ? sl : 1.0) * (su > 0.0 ? su : 1.0), &e_); sexp += e_; }
       if (q < NS) P.x[q < NS ? q : 0] = v; else u[q - NS] = v;
     }
-    Sys::f(P.x, u, c.pp.get(), P.f);
+    if constexpr (MLP) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) P.f[q] = c.sF[j * NS + q];
+    } else
+      Sys::f(P.x, u, c.pp.get(), P.f);
     set_time<Sys>(c.pp.get(), tq(j, c.h));
     const double gj = Sys::g(P.x, u, c.pp.get());
     if (live) {
@@ -879,6 +975,10 @@ struct HsFused {
   __device__ static bool trial(Ctx& c, double alpha, double mu, double& f, double& bar, double& c1) {
     const int N = c.N, lane = c.lane;
     double fa = 0, ba = 0, ca = 0; int bad = 0;
+    if constexpr (MLP) {          // f of every trial point by the matrix-core pass -> LDS
+      node_pass<0>(c, alpha);
+      wsync();
+    }
     TPt Pc;                                   // knot in front of the block (uniform)
     trial_point(c, 0, alpha, c.tid == 0, Pc, fa, ba, bad);
     int round = 0;
@@ -1146,7 +1246,7 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
   double* s = scratch + (long)blockIdx.x * scratch_stride;
   c.zr = s; c.hr = s + W::off_hr(c.N); c.st = s + W::off_st(c.N); c.kg = s + W::off_kg(c.N);
-  c.kgA = c.kg; c.kgB = s + W::off_kg2(c.N);
+  c.kgA = c.kg; c.kgB = s + W::off_kg2(c.N); c.pt = s + W::off_pt(c.N);
   double* const lam_own = s + W::off_lam(c.N);
   double* l = reinterpret_cast<double*>(smem_fused);
   c.z = l; l += c.n; c.zL = l; l += c.n; c.zU = l; l += c.n; c.dz = l; l += c.n;
@@ -1159,6 +1259,16 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   c.sMisc = l; l += 4;
   c.xA = l; c.xB = l + W::EXCH;
   W::use_set(c, c.kgA, c.xA);
+  c.sF = reinterpret_cast<double*>(smem_fused) + W::lds_solver_doubles(c.N);
+  c.wl = c.sF + c.K * W::NS;
+  if constexpr (W::MLP) {        // weights shared by the batch: loaded once per workgroup
+    if (params_stride == 0) {
+      SysParams<Sys> pw;
+      pw.load(params, 0, 0);
+      NodeMfma64::load_weights(pw.get(), c.wl, c.tid, W::NT);
+      __syncthreads();
+    }
+  }
   for (;;) {
     int t = 0;
     if (c.tid == 0) t = atomicAdd(ticket, 1);
@@ -1174,6 +1284,12 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     double* lamg = lam ? lam + b * (long)(2 * c.N * W::NS) : lam_own;
     c.pp.load(params, b, params_stride);
     c.pp.set_scale(vs.s);
+    if constexpr (W::MLP) {      // a weight set per trajectory
+      if (params_stride != 0) {
+        NodeMfma64::load_weights(c.pp.get(), c.wl, c.tid, W::NT);
+        __syncthreads();
+      }
+    }
     HsSolveResult r;
 #ifdef MYR_PHASE_TIMING
     for (int i = 0; i < 16; ++i) c.tph[i] = 0;

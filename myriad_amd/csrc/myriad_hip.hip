@@ -476,11 +476,15 @@ template <class Sys>
 static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                            int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                            int32_t* iters, double* kkt) {
-  int waves = (B <= 2 * device_cus(h)) ? 2 : 1;
-  if (h->fused_waves > 0) waves = h->fused_waves;
-  if (waves == 2 && HsFused<Sys, 2>::lds_bytes(h->d.intervals) <= 160 * 1024)
-    return launch_hs_fused_w<Sys, 2>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-  return launch_hs_fused_w<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  if constexpr (NodeTraits<Sys>::mlp) {     // network dynamics: four wavefronts share a trajectory and the 40 KB of weights in LDS
+    return launch_hs_fused_w<Sys, 4>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  } else {
+    int waves = (B <= 2 * device_cus(h)) ? 2 : 1;
+    if (h->fused_waves > 0) waves = h->fused_waves;
+    if (waves == 2 && HsFused<Sys, 2>::lds_bytes(h->d.intervals) <= 160 * 1024)
+      return launch_hs_fused_w<Sys, 2>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    return launch_hs_fused_w<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  }
 }
 
 template <class Sys, int SCHEME = 0>
@@ -492,7 +496,7 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   // one trajectory per wavefront while its LDS working set fits a CU (N <= ~480 for CARTPOLE); beyond that the
   // lane-per-trajectory form, which keeps everything in global scratch, takes over
   if constexpr (SCHEME == 0 && HsFused<Sys>::SUPPORTED) {
-    if (h->solve_mode == 1 && h->solve_fused && HsFused<Sys>::lds_bytes(N) <= 160 * 1024)
+    if (h->solve_mode == 1 && h->solve_fused && HsFused<Sys, (NodeTraits<Sys>::mlp ? 4 : 1)>::lds_bytes(N) <= 160 * 1024)
       return launch_hs_fused<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   if (h->solve_mode == 1 && HsWave<Sys, SCHEME>::lds_bytes(N) <= 160 * 1024) {

@@ -118,8 +118,10 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
     return (acc[0][0] + acc[1][0]) + (acc[2][0] + acc[3][0]);
   }
 
-  struct Args {
-    const nd_glb* z; const nd_glb* dz; const nd_glb* lam;   // decision vector, step (MODE 0), multipliers (MODE 2)
+  // ZT: address space of the iterate, the step and the multipliers (global in HsWave, LDS in the fused kernel)
+  template <class ZT>
+  struct ArgsT {
+    const ZT* z; const ZT* dz; const ZT* lam;               // decision vector, step (MODE 0), multipliers (MODE 2)
     nd_glb* pt;                                             // per-point records, field f of point j at pt[f * K + j]
     nd_lds* sF;                                             // MODE 0: f of point j at sF[j * NS + r]
     double alpha, h6, h8;
@@ -129,9 +131,10 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
     int use_rec = 0;                                        //   (an explicit flag: the record may sit at LDS offset 0)
     int rec_stride = 0, rec_f = 0, rec_a = 0, rec_b = 0;    //   rec[j * rec_stride + rec_f + r], + rec_a + r * NS + c, + rec_b + r * NU
   };
+  using Args = ArgsT<nd_glb>;
 
-  template <int MODE>
-  __device__ __attribute__((noinline)) static void pass(const nd_lds* wl, Args a, int lane) {
+  template <int MODE, class ZT = nd_glb>
+  __device__ __attribute__((noinline)) static void pass(const nd_lds* wl, ArgsT<ZT> a, int lane) {
     const int g = lane >> 4, i = lane & 15, K = a.K;
     for (int j0 = 16 * a.t0; j0 < K; j0 += 16 * a.ts) {
       const bool valid = j0 + i < K;

@@ -83,6 +83,7 @@ def test_node_workgroup_modes_agree(monkeypatch, B, knob, values):
   rng = np.random.default_rng(5)
   x0 = np.clip(0.1 * rng.standard_normal((B, 4)), -2, 2)
   monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0")     # kernels are compared: no host-side rescue of a failed device solve
+  monkeypatch.setenv("MYRIAD_SOLVE_MODE", "wave1")    # round 2's kernel (the fused kernel, the default since round 3, has one form)
   out = []
   for v in values:
     monkeypatch.setenv(knob, v)
@@ -95,6 +96,27 @@ def test_node_workgroup_modes_agree(monkeypatch, B, knob, values):
   np.testing.assert_allclose(a["xs_and_us"], b["xs_and_us"], rtol=0, atol=1e-9)
 
 
+def test_node_fused_kernel_agrees_with_round2_kernel(monkeypatch):
+  """Network dynamics on the fused kernel (hs_solver_fused.h, four wavefronts per trajectory: matrix-core passes AND the
+  parallel phases shared) against round 2's HsWave: one algorithm, same optima, iteration counts equal up to the order of the sums."""
+  N = 40
+  rng = np.random.default_rng(8)
+  B = 24
+  x0 = np.clip(0.1 * rng.standard_normal((B, 4)), -2, 2)
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0")
+  out = {}
+  for mode in ("wave", "wave1"):
+    monkeypatch.setenv("MYRIAD_SOLVE_MODE", mode)
+    hp, node, opt = _setup(N)
+    out[mode] = opt.solve_batch(x0s=x0, params=opt.system.device_params())
+  a, b = out["wave"], out["wave1"]
+  assert (a["status"] == 0).all() and (b["status"] == 0).all()
+  np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-9)
+  assert (a["iters"] == b["iters"]).mean() >= 0.85, np.bincount(np.abs(a["iters"] - b["iters"]))
+  same = a["iters"] == b["iters"]
+  assert np.abs(a["xs_and_us"][same] - b["xs_and_us"][same]).max() < 1e-6
+
+
 def test_node_cooperative_mode_with_per_trajectory_weights(monkeypatch):
   """params [B, np] (a weight set per trajectory): the solving wavefront reloads the weights per trajectory while its helpers
   wait at the mailbox barrier."""
@@ -102,6 +124,7 @@ def test_node_cooperative_mode_with_per_trajectory_weights(monkeypatch):
   B = 6
   x0 = np.clip(0.1 * rng.standard_normal((B, 4)), -2, 2)
   out = []
+  monkeypatch.setenv("MYRIAD_SOLVE_MODE", "wave1")            # round 2's kernel: cooperative / one wavefront
   for v in ("1", "0"):
     monkeypatch.setenv("MYRIAD_NODE_COOP", v)
     hp, node, opt = _setup(20)
@@ -109,3 +132,11 @@ def test_node_cooperative_mode_with_per_trajectory_weights(monkeypatch):
   a, b = out
   assert (a["status"] == 0).all() and (a["iters"] == b["iters"]).all()
   np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-12)
+  # the fused kernel (default): a weight set per trajectory is reloaded into LDS per trajectory; same optima as shared weights
+  monkeypatch.setenv("MYRIAD_SOLVE_MODE", "wave")
+  hp, node, opt = _setup(20)
+  f1 = opt.solve_batch(x0s=x0, params=np.tile(opt.system.device_params(), (B, 1)))
+  f0 = opt.solve_batch(x0s=x0, params=opt.system.device_params())
+  assert (f1["status"] == 0).all() and (f1["iters"] == f0["iters"]).all()
+  np.testing.assert_allclose(f1["cost"], f0["cost"], rtol=1e-12)
+  np.testing.assert_allclose(f1["cost"], a["cost"], rtol=1e-9)
