@@ -115,7 +115,9 @@ static int kernel_blocks_per_cu(myr_handle h, const void* kern, int threads, siz
   auto it = h->occ.find(key);
   if (it == h->occ.end()) {
     int per_cu = 0;
-    HIPCHK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (the limit is a property of the FUNCTION, shared by every handle of the process: raise it to the hardware's 160 KB once
+    // instead of to this handle's size, which a handle with a shorter horizon would lower again)
+    HIPCHK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
     it = h->occ.emplace(key, per_cu).first;
   }
@@ -154,9 +156,9 @@ static int launch_hs_eval(myr_handle h, int B, const double* z, const double* pa
   {                                                                                                               \
     auto kern = hs_eval_kernel<Sys, W, NTV, SCHEME>;                                                                   \
     const size_t lds = hs_eval_lds_bytes<Sys, SCHEME>(N, W);                                                      \
-    if (h->eval_attr_lds[(W == 1 ? 0 : (W == 4 ? 1 : 2)) + (NTV ? 3 : 0)] != lds) {                             \
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      h->eval_attr_lds[(W == 1 ? 0 : (W == 4 ? 1 : 2)) + (NTV ? 3 : 0)] = lds;                                   \
+    if (h->eval_attr_lds[(W == 1 ? 0 : (W == 4 ? 1 : 2)) + (NTV ? 3 : 0)] == 0) {      /* function-wide limit: the hardware's, once */ \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      h->eval_attr_lds[(W == 1 ? 0 : (W == 4 ? 1 : 2)) + (NTV ? 3 : 0)] = 1;                                     \
     }                                                                                                             \
     HIPCHK(hipEventRecord(kt.a, h->stream));                                                                      \
     hipLaunchKernelGGL(kern, dim3(B), dim3(64 * W), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);    \
@@ -435,14 +437,14 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
 // fused-phase wavefront kernel (hs_solver_fused.h): Hermite-Simpson, closed-form systems with one control and <= 4 states.
 // NWAVES wavefronts per trajectory: 1 for throughput (four trajectories per CU), 2 when the batch leaves CUs idle otherwise
 // (B <= 2 trajectories per CU: the parallel phases of an iteration take half the time, the launch lasts as long as one solve).
-template <class Sys, int NWAVES>
+template <class Sys, int NWAVES, int SCHEME>
 static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                              int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                              int32_t* iters, double* kkt) {
-  using W = HsFused<Sys, NWAVES>;
+  using W = HsFused<Sys, NWAVES, SCHEME>;
   const int N = h->d.intervals;
   const size_t lds = W::lds_bytes(N);
-  auto kern = hs_solve_fused_kernel<Sys, NWAVES>;
+  auto kern = hs_solve_fused_kernel<Sys, NWAVES, SCHEME>;
   int per_cu = 0;       // (attributes and occupancy once per handle and configuration, not per call)
   if (int rc = kernel_blocks_per_cu(h, reinterpret_cast<const void*>(kern), 64 * NWAVES, lds, &per_cu)) return rc;
   int slots = h->solve_slots > 0 ? h->solve_slots : (per_cu > 0 ? per_cu : 4 / NWAVES) * device_cus(h);
@@ -472,18 +474,18 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   kt.launches += 1;
   return MYR_OK;
 }
-template <class Sys>
+template <class Sys, int SCHEME>
 static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                            int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                            int32_t* iters, double* kkt) {
   if constexpr (NodeTraits<Sys>::mlp) {     // network dynamics: four wavefronts share a trajectory and the 40 KB of weights in LDS
-    return launch_hs_fused_w<Sys, 4>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    return launch_hs_fused_w<Sys, 4, 0>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   } else {
     int waves = (B <= 2 * device_cus(h)) ? 2 : 1;
     if (h->fused_waves > 0) waves = h->fused_waves;
-    if (waves == 2 && HsFused<Sys, 2>::lds_bytes(h->d.intervals) <= 160 * 1024)
-      return launch_hs_fused_w<Sys, 2>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-    return launch_hs_fused_w<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    if (waves == 2 && HsFused<Sys, 2, SCHEME>::lds_bytes(h->d.intervals) <= 160 * 1024)
+      return launch_hs_fused_w<Sys, 2, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    return launch_hs_fused_w<Sys, 1, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
 }
 
@@ -495,9 +497,9 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   const myr_dims& dm = h->dims;
   // one trajectory per wavefront while its LDS working set fits a CU (N <= ~480 for CARTPOLE); beyond that the
   // lane-per-trajectory form, which keeps everything in global scratch, takes over
-  if constexpr (SCHEME == 0 && HsFused<Sys>::SUPPORTED) {
-    if (h->solve_mode == 1 && h->solve_fused && HsFused<Sys, (NodeTraits<Sys>::mlp ? 4 : 1)>::lds_bytes(N) <= 160 * 1024)
-      return launch_hs_fused<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  if constexpr (HsFused<Sys>::SUPPORTED && !(SCHEME == 1 && NodeTraits<Sys>::mlp)) {
+    if (h->solve_mode == 1 && h->solve_fused && HsFused<Sys, (NodeTraits<Sys>::mlp ? 4 : 1), SCHEME>::lds_bytes(N) <= 160 * 1024)
+      return launch_hs_fused<Sys, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   if (h->solve_mode == 1 && HsWave<Sys, SCHEME>::lds_bytes(N) <= 160 * 1024) {
     using W = HsWave<Sys, SCHEME>;
