@@ -964,9 +964,37 @@ struct HsFused {
     wave_sync<true>();
     return riccati_first_point(c, o, delta, nreg);
   }
+  // The sweep is a function of its own (-DMYR_SWEEP_INLINE folds it back): its register allocation is then independent of the ~20 k
+  // instructions around it (the masks of the tile trick stay in VGPRs instead of being re-read from AGPRs every stage; the kernel
+  // around it spills 120 values instead of 186).  Arguments by value -- the context itself must not escape into a call, or every pass
+  // would find it in scratch (profiles/r03, experiment 1).  Measured: B=256 3.70 -> 3.56 ms, B=4096 15.5 -> 15.0 ms, B=512 (W = 2)
+  // 3.37 -> 3.09 ms.
+  struct SwArgs { nd_glb *hr, *st, *zr, *kg; nd_lds* xs; int N, lane, pinned, abort; double reg_floor, rho_term, delta; };
+  __device__ __attribute__((noinline)) static int sweep_call(SwArgs a) {
+    Ctx c;
+    c.N = a.N; c.lane = a.lane; c.hr = (double*)a.hr; c.st = (double*)a.st; c.zr = (double*)a.zr;
+    use_set(c, (double*)a.kg, (double*)a.xs);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) c.term_pinned[q] = ((a.pinned >> q) & 1) != 0;
+    HsSolveOpts o;
+    o.reg_floor = a.reg_floor; o.rho_term = a.rho_term;
+    if constexpr (TRAP) return riccati_mfma_trap(c, o, a.delta, a.abort != 0);
+    else return riccati_mfma(c, o, a.delta, a.abort != 0);
+  }
   __device__ static inline int sweep(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
+#ifndef MYR_SWEEP_INLINE
+    SwArgs a;
+    a.hr = (nd_glb*)c.hr; a.st = (nd_glb*)c.st; a.zr = (nd_glb*)c.zr; a.kg = (nd_glb*)c.kg; a.xs = (nd_lds*)c.sP;
+    a.N = c.N; a.lane = c.lane; a.abort = abort_on_reg ? 1 : 0;
+    a.pinned = 0;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) a.pinned |= c.term_pinned[q] ? (1 << q) : 0;
+    a.reg_floor = o.reg_floor; a.rho_term = o.rho_term; a.delta = delta;
+    return sweep_call(a);
+#else
     if constexpr (TRAP) return riccati_mfma_trap(c, o, delta, abort_on_reg);
     else return riccati_mfma(c, o, delta, abort_on_reg);
+#endif
   }
 
   // ---- FORWARD phase: closed-loop maps -> wave scan -> step of the stage's midpoint and end knot -> their step limits ----------
@@ -1226,6 +1254,24 @@ struct HsFused {
     return detail::finite_(bar);
   }
 
+  // ---- the parallel passes as functions of their own (-DMYR_PASS_NOINLINE; measured SLOWER, off): the context travels BY VALUE (a copy
+  // on the stack; the caller's context does not escape), results come back by value.  Every pass then compiles without a single spill
+  // (backward 256 + 176 registers, hessian 248, forward 256 + 78, trial 248) -- and the launch takes 17.9 instead of 14.8 ms (B=256: 3.96
+  // against 3.58): the pointers arrive through scratch as per-lane values, so addresses are formed on the vector pipe and the LDS
+  // accesses lose their address space.  Only the sweep, whose inputs are a dozen values, gains from a frame of its own. ----------------
+#ifdef MYR_PASS_NOINLINE
+#define MYR_PASS_ATTR __attribute__((noinline))
+#else
+#define MYR_PASS_ATTR inline
+#endif
+  struct NuT { double v[NS]; };
+  __device__ MYR_PASS_ATTR static BOut backward_pass(Ctx c, Step stp, NuT nu) { BOut o; backward(c, stp, nu.v, o); return o; }
+  __device__ MYR_PASS_ATTR static double hessian_pass(Ctx c) { double st; hessian(c, st); return st; }
+  struct ThT { double v[NC]; };
+  __device__ MYR_PASS_ATTR static typename S::FwdOut forward_pass(Ctx c, HsSolveOpts o, double mu, ThT th) { typename S::FwdOut fo; forward(c, o, mu, th.v, fo); return fo; }
+  struct TrialOut { double f, bar, c1; bool ok; };
+  __device__ MYR_PASS_ATTR static TrialOut trial_pass(Ctx c, double alpha, double mu) { TrialOut t; t.ok = trial(c, alpha, mu, t.f, t.bar, t.c1); return t; }
+
   // ---- start: the caller's point pushed inside its bounds (HsWave::init), into LDS; bound table ---------------------------------
   __device__ static void init(Ctx& c, const double* zg) {
     const double k1 = 1e-2, k2 = 1e-2;
@@ -1288,12 +1334,12 @@ struct HsFused {
     Step pending{false, 0.0, 0.0, 0.0, o.kappa_sigma};
     for (int it = 0; it <= o.max_iter; ++it) {
       BOut p1;
-      backward(c, pending, nuT, p1);
+      { NuT nu_; for (int q = 0; q < NS; ++q) nu_.v[q] = nuT[q]; p1 = backward_pass(c, pending, nu_); }
       pending.on = false;
       wsync();
       MYR_PH(0)
       double stat_raw;
-      hessian(c, stat_raw);
+      stat_raw = hessian_pass(c);
       wsync();
       MYR_PH(4)
       const double c1 = p1.c1, cinf = p1.cinf, sum_mult = p1.sum_mult;
@@ -1390,7 +1436,7 @@ struct HsFused {
       for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
       MYR_PH(7)
       typename S::FwdOut fo;
-      forward(c, o, mu, th, fo);
+      { ThT th_; for (int q = 0; q < NC; ++q) th_.v[q] = th[q]; fo = forward_pass(c, o, mu, th_); }
       wsync();
       MYR_PH(8)
       if (!(finite_(fo.gphi) && finite_(fo.alpha_p))) { res.status = 2; res.iters = it; return; }
@@ -1414,7 +1460,9 @@ struct HsFused {
       bool ok = false;
       for (int ls = 0; ls < 40; ++ls) {
         double ft, bt, ct;
-        if (trial(c, a, mu, ft, bt, ct)) {
+        const TrialOut tr1 = trial_pass(c, a, mu);
+        ft = tr1.f; bt = tr1.bar; ct = tr1.c1;
+        if (tr1.ok) {
           const double phit = ft + bt + pen * ct;
           if (phit <= phiref + 1e-8 * a * Dphi + 1e-13 * fabs(phi0)) { ok = true; break; }
         }
