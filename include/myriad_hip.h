@@ -57,6 +57,10 @@ enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2,
        MYR_SYS_HARVEST = 18, MYR_SYS_TIMBERHARVEST = 19,
        /* lenhart/predator_prey.py: terminal cost and ONE pinned terminal state (x_T = [None, None, B]) */
        MYR_SYS_PREDATORPREY = 20,
+       /* ELASTIC twins (100 + id; no counterpart in the reference -- the feasibility-restoration device of the solver, DESIGN.md
+          "Elastic mode"): x' = f(x,u) + s with NS slack controls s appended to u and the running cost g + rho/2 |s|^2, rho the
+          LAST model parameter.  All entry points work on them like on any system (NU = nu + ns controls). */
+       MYR_SYS_PENDULUM_ELASTIC = 113, MYR_SYS_ROCKETLANDING_ELASTIC = 115,
        /* lenhart/invasive_plant.py: DISCRETE-time (five foci, five controls).  Only myr_fbsm (its discrete recurrences)
           accepts it; the direct-transcription entry points return MYR_E_UNSUPPORTED, as the reference's direct optimisers
           raise NotImplementedError for it (trajectory_optimizers/base.py:66-67) */

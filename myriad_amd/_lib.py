@@ -19,12 +19,14 @@ SYS_IDS = {"CARTPOLE": 0, "VANDERPOL": 1, "CANCERTREATMENT": 2, "SIMPLECASE": 3,
            "GLUCOSE": 6, "MOULDFUNGICIDE": 7, "SIMPLECASEWITHBOUNDS": 8, "HIVTREATMENT": 9, "EPIDEMICSEIRN": 10, "SEIR": 11,
            "BEARPOPULATIONS": 12, "PENDULUM": 13, "MOUNTAINCAR": 14, "ROCKETLANDING": 15,
            "BACTERIA": 16, "TUMOUR": 17, "HARVEST": 18, "TIMBERHARVEST": 19, "PREDATORPREY": 20,
-           "INVASIVEPLANT": 21}   # INVASIVEPLANT: discrete-time, myr_fbsm only
+           "INVASIVEPLANT": 21,   # INVASIVEPLANT: discrete-time, myr_fbsm only
+           "PENDULUM_ELASTIC": 113, "ROCKETLANDING_ELASTIC": 115}   # elastic twins (slack controls on the dynamics), see include/myriad_hip.h
 TR_IDS = {"HERMITE_SIMPSON": 0, "TRAPEZOIDAL": 1, "SHOOTING": 2}
 INT_IDS = {"EULER": 0, "HEUN": 1, "MIDPOINT": 2, "RK4": 3}
 MEM_HOST, MEM_DEVICE = 0, 1
 K_EVAL, K_SOLVE, K_ROLLOUT, K_RESID, K_PROD, K_FBSM = 0, 1, 2, 3, 4, 5
-STATUS_NAMES = {0: "CONVERGED", 1: "MAXITER", 2: "NAN", 3: "STALLED"}
+STATUS_NAMES = {0: "CONVERGED", 1: "MAXITER", 2: "NAN", 3: "STALLED", 4: "INFEASIBLE"}
+STATUS_INFEASIBLE = 4   # assigned by the host's elastic phase (TrajectoryOptimizer.device_solve), never by a kernel
 
 EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve",
            "myr_set_var_scale", "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_fbsm", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",

@@ -31,8 +31,8 @@
 namespace myriad {
 
 // variable scales of the scaled problem the solver kernels work on (by-value kernel argument; closed-form systems have
-// at most 8 variables per point)
-struct VarScale { double s[8]; };
+// at most 8 variables per point, the elastic twin of ROCKETLANDING 14)
+struct VarScale { double s[16]; };
 
 struct HsSolveOpts {
   int N;

@@ -983,6 +983,16 @@ struct HsFused {
   }
   __device__ static inline int sweep(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
 #ifndef MYR_SWEEP_INLINE
+    // (W > 1 keeps the sweep inline: called as a function from wavefront 0 alone -- the others wait at the barrier -- the kernel
+    // faulted on BIOREACTOR (N = 20, first iteration) and left VANDERPOL's trapezoidal solve infeasible, while the same call made
+    // by ALL wavefronts, or the inlined sweep, are fine.  Not understood; tools/dev/crash_probe2.py with -DMYR_SWEEP_CALL_W.)
+#ifndef MYR_SWEEP_CALL_W
+    if constexpr (W > 1) {
+      if constexpr (TRAP) return riccati_mfma_trap(c, o, delta, abort_on_reg);
+      else return riccati_mfma(c, o, delta, abort_on_reg);
+    } else
+#endif
+    {
     SwArgs a;
     a.hr = (nd_glb*)c.hr; a.st = (nd_glb*)c.st; a.zr = (nd_glb*)c.zr; a.kg = (nd_glb*)c.kg; a.xs = (nd_lds*)c.sP;
     a.N = c.N; a.lane = c.lane; a.abort = abort_on_reg ? 1 : 0;
@@ -991,6 +1001,7 @@ struct HsFused {
     for (int q = 0; q < NS; ++q) a.pinned |= c.term_pinned[q] ? (1 << q) : 0;
     a.reg_floor = o.reg_floor; a.rho_term = o.rho_term; a.delta = delta;
     return sweep_call(a);
+    }
 #else
     if constexpr (TRAP) return riccati_mfma_trap(c, o, delta, abort_on_reg);
     else return riccati_mfma(c, o, delta, abort_on_reg);

@@ -229,6 +229,61 @@ class TrajectoryOptimizer(object):
     z = np.concatenate([xs.reshape(B, -1), us[:, ::(rr - 1) // (rows_u - 1)].reshape(B, -1)], axis=1)
     return np.clip(z, lb, ub)
 
+  # ---- elastic mode: what stands in for a feasibility-restoration phase -----------------------------------------------
+  # An instance the solver leaves without a KKT point is handed to the system's ELASTIC TWIN (include/myriad_hip.h: the
+  # dynamics x' = f(x,u) + s with free slack controls s and the running cost g + rho/2 |s|^2): every state trajectory is
+  # feasible for the twin, so the iterate cannot jam against an infeasible stationary point of the merit function.  The twin
+  # is solved from the reference's guess for rho = elastic_rhos (each from the previous solution), and its last state / control
+  # trajectory starts the problem itself.  A twin that ends at a KKT point whose slack does not shrink as rho grows is a
+  # stationary point of the infeasibility: the instance is reported INFEASIBLE (status 4) unless a later start solves it.
+  # Twins exist for the systems listed in _lib.SYS_IDS as <NAME>_ELASTIC, under the collocation transcriptions.
+  elastic_rhos = (1.0, 1e2, 1e4)
+  elastic_slack_tol = 1e-3
+
+  def _twin_engine(self) -> Optional[_lib.Engine]:
+    name = self.system.name + "_ELASTIC"
+    if name not in _lib.SYS_IDS or self.transcription == "SHOOTING" or os.environ.get("MYRIAD_ELASTIC", "1") == "0":
+      return None
+    if getattr(self, "_twin", None) is None:
+      self._twin = _lib.Engine(name, self.transcription, self.hp.intervals, self.system.T, device=self._primary_device())
+      scale = getattr(self.system, "var_scale", None)
+      if scale is not None and os.environ.get("MYRIAD_VAR_SCALE", "1") != "0":
+        s = scale()
+        if s is not None and np.any(s != 1.0):
+          self._twin.set_var_scale(np.concatenate([s, s[:self._x_shape[1]]]))     # a slack is a rate of its state
+    return self._twin
+
+  def elastic_restoration(self, z0, lb, ub, params, opts):
+    """The elastic phase for the instances (z0, lb, ub, params) [B,..]: returns the result of the final solve of the problem
+    itself from the twin's trajectory, with `iters` summed over the phase, `attempts` = device solves, `slack` [B, len(rhos)]
+    = max |s| of the twin's solution per rho and `twin_status` [B] of the last twin solve."""
+    twin = self._twin_engine()
+    B = z0.shape[0]
+    (rows_x, ns), (rows_u, nu) = self._x_shape, self._u_shape
+    nx = rows_x * ns
+
+    def widen(a, fill):
+      U = a[:, nx:].reshape(B, rows_u, nu)
+      return np.concatenate([a[:, :nx], np.concatenate([U, np.full((B, rows_u, ns), fill)], axis=2).reshape(B, -1)], axis=1)
+
+    zt, lbt, ubt = widen(z0, 0.0), widen(lb, -np.inf), widen(ub, np.inf)
+    pb = self.system.device_params() if params is None else np.asarray(params, dtype=np.float64)
+    pb = np.broadcast_to(pb, (B, pb.shape[-1]))
+    iters = np.zeros(B, dtype=np.int64)
+    slack = np.zeros((B, len(self.elastic_rhos)))
+    for k, rho in enumerate(self.elastic_rhos):
+      r = twin.solve(zt, lbt, ubt, params=np.concatenate([pb, np.full((B, 1), float(rho))], axis=1), opts=opts)
+      zt = np.clip(np.nan_to_num(r["z"], nan=0.0, posinf=1e6, neginf=-1e6), lbt, ubt)
+      iters += r["iters"]
+      slack[:, k] = np.abs(zt[:, nx:].reshape(B, rows_u, nu + ns)[:, :, nu:]).max(axis=(1, 2))
+    z1 = np.concatenate([zt[:, :nx], zt[:, nx:].reshape(B, rows_u, nu + ns)[:, :, :nu].reshape(B, -1)], axis=1)
+    res = self._solve_sharded(z1, lb, ub, params, opts)
+    res["iters"] = (res["iters"] + iters).astype(res["iters"].dtype)
+    res["slack"] = slack
+    res["twin_status"] = r["status"].copy()
+    res["attempts"] = np.full(B, len(self.elastic_rhos) + 1, dtype=np.int32)
+    return res
+
   def _solve_sharded(self, z0, lb, ub, params, opts):
     """One device call per handle of `engines_for(B)`, concurrently (myriad_amd.batched.fan_out_solve)."""
     from myriad_amd.batched import fan_out_solve
@@ -253,6 +308,21 @@ class TrajectoryOptimizer(object):
     z0 = np.asarray(z0, dtype=np.float64).reshape(B, -1)
     lb = np.broadcast_to(np.asarray(lb, dtype=np.float64), z0.shape)
     ub = np.broadcast_to(np.asarray(ub, dtype=np.float64), z0.shape)
+    res["restored"] = np.zeros(B, dtype=np.int32)
+    if fail.size and second_starts and self._twin_engine() is not None:        # elastic mode first, other guesses after it
+      pf = p if (p is None or p.ndim == 1) else p[fail]
+      r2 = self.elastic_restoration(z0[fail], lb[fail], ub[fail], pf, opts)
+      ok = r2["status"] == 0
+      for k in ("z", "lam", "cost", "status", "kkt"):
+        res[k][fail[ok]] = r2[k][ok]
+      res["iters"][fail] += r2["iters"]
+      res["attempts"][fail] += r2["attempts"]
+      res["restored"][fail[ok]] = 1
+      # stationary point of the infeasibility: the twin converged for the largest rho and its slack neither vanished nor shrank
+      s = r2["slack"]
+      stuck = (~ok) & (r2["twin_status"] == 0) & (s[:, -1] > self.elastic_slack_tol) & (s[:, -1] > 0.1 * s[:, -2])
+      res["status"][fail[stuck]] = _lib.STATUS_INFEASIBLE
+      fail = fail[~ok]
     for c in cycles:
       if fail.size == 0:
         break
@@ -265,6 +335,7 @@ class TrajectoryOptimizer(object):
       ok = r2["status"] == 0
       for k in r2:
         res[k][fail[ok]] = r2[k][ok]
+      res["restored"][fail[ok]] = 0
       res["start"][fail[ok]] = c
       res["attempts"][fail] += 1
       res["iters"][fail[~ok]] = r2["iters"][~ok]
@@ -318,7 +389,8 @@ class TrajectoryOptimizer(object):
     res = self.device_solve(z0, lb, ub, p, o, second_starts=(guess is None) if second_starts is None else bool(second_starts))
     x, u = self.unravel(res["z"])
     return {'x': x, 'u': u, 'xs_and_us': res["z"], 'cost': res["cost"], 'lambda': res["lam"],
-            'status': res["status"], 'iters': res["iters"], 'kkt': res["kkt"], 'start': res["start"], 'attempts': res["attempts"]}
+            'status': res["status"], 'iters': res["iters"], 'kkt': res["kkt"], 'start': res["start"], 'attempts': res["attempts"],
+            'restored': res["restored"]}
 
   def _batch_bounds(self, x0s):
     B, ns = x0s.shape

@@ -771,6 +771,28 @@ class NodeCartPole(CartPole):
     return h @ w + b
 
 
+class Elastic(System):
+  """The ELASTIC TWIN of a system (no counterpart in the reference; include/myriad_hip.h MYR_SYS_*_ELASTIC): x' = f(x,u) + s with
+  ns free slack controls s appended to u, running cost g + rho/2 |s|^2.  The checker of the twins' device code."""
+
+  def __init__(self, base: System, rho: float = 1.0):
+    self.base, self.rho = base, float(rho)
+    self.name = base.name + "_ELASTIC"
+    self.param_names = tuple(base.param_names) + ("rho",)
+    self.x_0, self.x_T, self.T = base.x_0, base.x_T, base.T
+    self.bounds = np.vstack([base.bounds, np.tile([[-np.inf, np.inf]], (base.ns, 1))])
+    self._nu = base.nu
+
+  def params(self):
+    return np.concatenate([self.base.params(), [self.rho]])
+
+  def dynamics(self, x, u):
+    return self.base.dynamics(x, u[..., :self._nu]) + u[..., self._nu:]
+
+  def cost(self, x, u, t=None):
+    return self.base.cost(x, u[..., :self._nu], t) + 0.5 * self.rho * (u[..., self._nu:] ** 2).sum(-1)
+
+
 SYSTEMS = {c.name: c for c in (CartPole, VanDerPol, CancerTreatment, SimpleCase, Bioreactor, Glucose, MouldFungicide,
                                 SimpleCaseWithBounds, HIVTreatment, EpidemicSEIRN, SEIR, BearPopulations, Pendulum, MountainCar,
                                 RocketLanding, Bacteria, Tumour, Harvest, TimberHarvest, PredatorPrey)}

@@ -260,6 +260,7 @@ def test_second_starts_resolve_only_failed_instances_from_an_excitation_guess(mo
   opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
   eng = _SecondStartEngine(); eng.rows_u = opt._u_shape[0]
   opt._engine = eng
+  monkeypatch.setenv("MYRIAD_ELASTIC", "0")       # the elastic phase (next test) comes before the second starts
   B = 3
   x0s = np.tile(opt.system.x_0, (B, 1))
   z0, lb, ub = opt.batch_inputs(x0s, None)
@@ -284,6 +285,77 @@ def test_second_starts_resolve_only_failed_instances_from_an_excitation_guess(mo
   eng.calls.clear()
   res = opt.device_solve(z0, lb, ub, None, None)
   assert list(res["status"]) == [1, 0, 1] and len(eng.calls) == 1
+
+
+class _TwinEngine:
+  """CPU stand-in for the handle of an elastic twin (PENDULUM_ELASTIC: 2 states, 1 control + 2 slacks): returns the point it was
+  given with controls 0.5 and slacks `slack[k]` at the k-th call of a phase, status 0."""
+
+  def __init__(self, slack):
+    self.slack, self.calls = slack, []
+
+  def solve(self, z0, lb, ub, params=None, opts=None):
+    z = np.array(z0, copy=True); B = z.shape[0]
+    k = len(self.calls) % len(self.slack)
+    self.calls.append((z0.copy(), np.array(lb, copy=True), np.array(ub, copy=True), np.array(params, copy=True)))
+    U = z[:, self.nx:].reshape(B, -1, 3)
+    U[:, :, 0] = 0.5 * self.u_value
+    U[:, :, 1:] = self.slack[k]
+    return {"z": z, "lam": np.zeros((B, 1)), "cost": np.ones(B), "status": np.zeros(B, np.int32), "iters": np.full(B, 7, np.int32),
+            "kkt": np.zeros((B, 3))}
+
+
+def test_elastic_phase_restores_failed_instances_and_reports_infeasibility(monkeypatch):
+  """device_solve: an instance without a KKT point goes through its system's elastic twin (slack controls, rho = 1, 1e2, 1e4, each
+  from the previous solution) and is solved again from the twin's states and controls -- before any second start; a twin whose
+  slack does not shrink marks the instance INFEASIBLE (status 4) when the final solve fails as well."""
+  from myriad_amd import _lib
+  from myriad_amd.config import Config, HParams, IntegrationMethod, OptimizerType, QuadratureRule
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = HParams(system=SystemType.PENDULUM, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
+               integration_method=IntegrationMethod.HEUN, intervals=6)
+  opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+  eng = _SecondStartEngine(); eng.rows_u = opt._u_shape[0]
+  opt._engine = eng
+  rows_u = opt._u_shape[0]; nx = opt._x_shape[0] * 2
+  twin = _TwinEngine(slack=[1.0, 1e-2, 1e-4]); twin.nx = nx; twin.u_value = 1.0
+  opt._twin = twin
+  B = 3
+  z0, lb, ub = opt.batch_inputs(np.tile(opt.system.x_0, (B, 1)), None)
+  z0[1, -1] = 0.1                                            # instance 1 converges at the first attempt
+  res = opt.device_solve(z0, lb, ub, None, None)
+  assert (res["status"] == 0).all() and list(res["restored"]) == [1, 0, 1] and list(res["start"]) == [0, 0, 0]
+  assert list(res["attempts"]) == [5, 1, 5] and list(res["iters"]) == [10 + 3 * 7 + 10, 10, 10 + 3 * 7 + 10]
+  assert len(twin.calls) == 3 and len(eng.calls) == 2          # three twin solves, one final solve: no second start was needed
+  zt, lbt, ubt, pt = twin.calls[0]
+  assert zt.shape == (2, nx + rows_u * 3) and np.array_equal(zt[:, :nx], z0[[0, 2], :nx])      # the failed instances, from THEIR guess
+  Ut = zt[:, nx:].reshape(2, rows_u, 3)
+  assert (Ut[:, :, 1:] == 0).all() and np.array_equal(Ut[:, :, 0], z0[[0, 2], nx:])
+  assert np.isneginf(lbt[:, nx:].reshape(2, rows_u, 3)[:, :, 1:]).all() and np.isposinf(ubt[:, nx:].reshape(2, rows_u, 3)[:, :, 1:]).all()
+  assert np.array_equal(lbt[:, nx:].reshape(2, rows_u, 3)[:, :, 0], lb[[0, 2], nx:])
+  assert [c[3][0, -1] for c in twin.calls] == [1.0, 1e2, 1e4] and np.array_equal(twin.calls[0][3][0, :-1], opt.system.device_params())
+  assert np.array_equal(twin.calls[1][0], np.clip(twin.calls[1][0], lbt, ubt)) and (twin.calls[1][0][:, nx:].reshape(2, rows_u, 3)[:, :, 1:] == 1.0).all()
+  final = eng.calls[1]
+  assert final.shape == (2, nx + rows_u) and (final[:, nx:] == 0.5).all()                  # the twin's controls without the slacks
+  # a twin whose slack stays: the final solve fails (controls zero), second starts are off -> INFEASIBLE
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0")
+  twin2 = _TwinEngine(slack=[1.0, 0.9, 0.8]); twin2.nx = nx; twin2.u_value = 0.0
+  opt._twin = twin2
+  res = opt.device_solve(z0, lb, ub, None, None)
+  assert list(res["status"]) == [_lib.STATUS_INFEASIBLE, 0, _lib.STATUS_INFEASIBLE] and list(res["restored"]) == [0, 0, 0]
+  assert _lib.STATUS_NAMES[_lib.STATUS_INFEASIBLE] == "INFEASIBLE"
+  # a twin whose slack vanishes while the final solve still fails: no certificate, the solver's own status stays
+  twin3 = _TwinEngine(slack=[1.0, 1e-2, 1e-4]); twin3.nx = nx; twin3.u_value = 0.0
+  opt._twin = twin3
+  res = opt.device_solve(z0, lb, ub, None, None)
+  assert list(res["status"]) == [1, 0, 1]
+  # an explicit guess (second_starts=False) or MYRIAD_ELASTIC=0: the first attempt is returned as it is
+  n = len(twin3.calls)
+  opt.device_solve(z0, lb, ub, None, None, second_starts=False)
+  monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  opt.device_solve(z0, lb, ub, None, None)
+  assert len(twin3.calls) == n
 
 
 class _ShardEngine:

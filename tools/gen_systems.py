@@ -238,7 +238,23 @@ def systems():
                   f=[(1 - x[1]) * x[0] - p[0] * x[0] * u[0], (x[0] - 1) * x[1] - p[1] * x[1] * u[0], u[0]],
                   g=p[2] * sp.Rational(1, 2) * u[0] ** 2, gT=x[0],
                   pdefault=[0.1, 0.1, 1.0], pnames=["d_1", "d_2", "A"]))
+  # ==== ELASTIC twins (no counterpart in the reference: the solver's feasibility-restoration device, DESIGN.md "Elastic mode") ====
+  # x' = f(x, u) + s with NS slack "controls" s and the running cost g + rho/2 |s|^2: every state trajectory is feasible for the
+  # twin, and its optima approach those of the system as rho grows (quadratic penalty on the dynamics residual).  ids: 100 + id.
+  # Under the solver's variable scaling the penalty is rho/2 |s / sc|^2 (sc: the scale of the slack = that of its state).
+  base = {S["name"]: S for S in out}
+  for nm in ("PENDULUM", "ROCKETLANDING"):
+    out.append(elastic(base[nm]))
   return out
+
+
+def elastic(S):
+  ns, nu, npar = len(S["x"]), len(S["u"]), len(S["p"])
+  s = sp.symbols(f"u{nu}:{nu + ns}", real=True)
+  rho = sp.Symbol(f"p{npar}", real=True)
+  return dict(name=S["name"] + "_ELASTIC", id=100 + S["id"], x=S["x"], u=tuple(S["u"]) + tuple(s), p=tuple(S["p"]) + (rho,),
+              f=[S["f"][i] + s[i] for i in range(ns)], g=S["g"], g_scaled=rho / 2 * sum(v ** 2 for v in s),
+              pdefault=list(S["pdefault"]) + [1.0], pnames=list(S["pnames"]) + ["rho"])
 
 
 def emit_block(assigns, indent="  "):
@@ -268,6 +284,9 @@ def gen_system(S):
   smap = {v: sc[i] * v for i, v in enumerate(w)}
   f = [sp.sympify(e).subs(smap, simultaneous=True) * isc[i] for i, e in enumerate(S["f"])]
   g = sp.sympify(S["g"]).subs(smap, simultaneous=True)
+  # (elastic twins) a term of the running cost written in the SCALED variables: rho/2 |s / sc|^2 weighs every slack against the
+  # magnitude of its state, whatever the units; with unit scales (every entry point but the scaled solve) it is rho/2 |s|^2
+  g = g + sp.sympify(S.get("g_scaled", 0))
   tt = sp.Symbol("tt", nonnegative=True)                              # time of the point (cost only; the dynamics of all systems are autonomous)
   time_dep = g.has(tt)
   assert not any(e.has(tt) for e in f), "time-dependent dynamics are not generated"
