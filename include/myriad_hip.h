@@ -71,7 +71,10 @@ enum { MYR_TR_HERMITE_SIMPSON = 0, MYR_TR_TRAPEZOIDAL = 1, MYR_TR_SHOOTING = 2 }
 enum { MYR_INT_EULER = 0, MYR_INT_HEUN = 1, MYR_INT_MIDPOINT = 2, MYR_INT_RK4 = 3 };
 enum { MYR_MEM_HOST = 0, MYR_MEM_DEVICE = 1 };
 /* per-instance solve status */
-enum { MYR_STATUS_CONVERGED = 0, MYR_STATUS_MAXITER = 1, MYR_STATUS_NAN = 2, MYR_STATUS_STALLED = 3 };
+enum { MYR_STATUS_CONVERGED = 0, MYR_STATUS_MAXITER = 1, MYR_STATUS_NAN = 2, MYR_STATUS_STALLED = 3,
+       /* never written by myr_solve itself: the verdict of the host's elastic phase ("Elastic mode") on an instance
+          whose elastic twin converges with a slack that does not vanish as its penalty grows */
+       MYR_STATUS_INFEASIBLE = 4 };
 /* kernel ids for myr_kernel_time */
 enum { MYR_K_EVAL = 0, MYR_K_SOLVE = 1, MYR_K_ROLLOUT = 2, MYR_K_RESID = 3, MYR_K_PROD = 4, MYR_K_FBSM = 5, MYR_K_COUNT = 6 };
 /* error codes */
