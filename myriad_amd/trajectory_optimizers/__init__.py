@@ -239,6 +239,7 @@ class TrajectoryOptimizer(object):
   # Twins exist for the systems listed in _lib.SYS_IDS as <NAME>_ELASTIC, under the collocation transcriptions.
   elastic_rhos = (1.0, 1e2, 1e4)
   elastic_slack_tol = 1e-3
+  elastic_max_iter = 500      # per twin solve (the ones that help take 30-300 iterations; a twin on the lane kernel costs 16 ms an iteration)
 
   def _twin_engine(self) -> Optional[_lib.Engine]:
     name = self.system.name + "_ELASTIC"
@@ -271,8 +272,12 @@ class TrajectoryOptimizer(object):
     pb = np.broadcast_to(pb, (B, pb.shape[-1]))
     iters = np.zeros(B, dtype=np.int64)
     slack = np.zeros((B, len(self.elastic_rhos)))
+    topts = opts
+    if opts is not None and opts.max_iter > self.elastic_max_iter:
+      topts = type(opts).from_buffer_copy(opts)
+      topts.max_iter = self.elastic_max_iter
     for k, rho in enumerate(self.elastic_rhos):
-      r = twin.solve(zt, lbt, ubt, params=np.concatenate([pb, np.full((B, 1), float(rho))], axis=1), opts=opts)
+      r = twin.solve(zt, lbt, ubt, params=np.concatenate([pb, np.full((B, 1), float(rho))], axis=1), opts=topts)
       zt = np.clip(np.nan_to_num(r["z"], nan=0.0, posinf=1e6, neginf=-1e6), lbt, ubt)
       iters += r["iters"]
       slack[:, k] = np.abs(zt[:, nx:].reshape(B, rows_u, nu + ns)[:, :, nu:]).max(axis=(1, 2))
