@@ -245,6 +245,8 @@ class TrajectoryOptimizer(object):
     name = self.system.name + "_ELASTIC"
     if name not in _lib.SYS_IDS or self.transcription == "SHOOTING" or os.environ.get("MYRIAD_ELASTIC", "1") == "0":
       return None
+    if getattr(self, "_twin_unsupported", False):      # the library does not build this twin's solver for this transcription
+      return None
     if getattr(self, "_twin", None) is None:
       self._twin = _lib.Engine(name, self.transcription, self.hp.intervals, self.system.T, device=self._primary_device())
       scale = getattr(self.system, "var_scale", None)
@@ -314,9 +316,17 @@ class TrajectoryOptimizer(object):
     lb = np.broadcast_to(np.asarray(lb, dtype=np.float64), z0.shape)
     ub = np.broadcast_to(np.asarray(ub, dtype=np.float64), z0.shape)
     res["restored"] = np.zeros(B, dtype=np.int32)
+    r2 = None
     if fail.size and second_starts and self._twin_engine() is not None:        # elastic mode first, other guesses after it
       pf = p if (p is None or p.ndim == 1) else p[fail]
-      r2 = self.elastic_restoration(z0[fail], lb[fail], ub[fail], pf, opts)
+      try:
+        r2 = self.elastic_restoration(z0[fail], lb[fail], ub[fail], pf, opts)
+      except NotImplementedError as e:          # MYR_E_UNSUPPORTED (myriad_amd/_lib.py: _chk)
+        if "not built" not in str(e):
+          raise
+        self._twin_unsupported = True          # (ROCKETLANDING's twin under the trapezoidal scheme: include/myriad_hip.h)
+        r2 = None
+    if r2 is not None:
       ok = r2["status"] == 0
       for k in ("z", "lam", "cost", "status", "kkt"):
         res[k][fail[ok]] = r2[k][ok]

@@ -89,3 +89,15 @@ def test_rocketlanding_converges_or_is_reported_infeasible():
   assert np.isfinite(r["xs_and_us"]).all()
   if r["status"][0] == 0:
     assert np.abs(opt.constraints(r["xs_and_us"][0])).max() <= 1e-6
+
+
+def test_twin_without_a_trapezoidal_solver_is_skipped_not_raised():
+  """ROCKETLANDING's twin (14 variables per point) has no trapezoidal solver in the library (myr_solve: UNSUPPORTED, "not built");
+  the elastic phase is then skipped for that optimizer and the second starts take over -- nothing is raised."""
+  hp, opt = _opt("ROCKETLANDING", rule="TRAPEZOIDAL", N=20, max_iter=100)
+  r = opt.solve_batch()
+  assert opt._twin_unsupported and r["restored"][0] == 0 and r["status"][0] in (0, 1, 2, 3)
+  assert r["attempts"][0] == 1 + len(opt.second_start_cycles) and np.isfinite(r["xs_and_us"]).all()
+  eng = _lib.Engine("ROCKETLANDING_ELASTIC", "TRAPEZOIDAL", 20, 16.0)
+  with pytest.raises(NotImplementedError, match="not built"):
+    eng.solve(np.zeros((1, eng.n)), -np.ones((1, eng.n)), np.ones((1, eng.n)))
