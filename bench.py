@@ -393,6 +393,15 @@ def run(a, rank, world, dev, make_engine):
     twin = cpu_same_algorithm(z0h, lbh, ubh, N, T, B)
     if twin:
       out["cpu_same_algorithm"] = twin
+  if world == 1 and cuda and not getattr(a, "no_other_configs", False):
+    # the other BASELINE configs (3, 4, 5 at their per-GPU share and on one GPU, README:83's trapezoidal literal), a few solves
+    # each AFTER the timed region: informative lines under the same driver clock, not part of `value`
+    try:
+      sys.path.insert(0, os.path.join(ROOT, "tools"))
+      import bench_configs
+      out["other_configs"] = bench_configs.measure()
+    except Exception as e:
+      out["other_configs"] = {"failed": repr(e)}
   return out
 
 
@@ -405,6 +414,7 @@ def main():
   ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
   ap.add_argument("--intervals", type=int, default=100)
   ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the N=100 cpu_baseline sample (0 = skip)")
+  ap.add_argument("--no-other-configs", action="store_true", help="skip the informative solves of BASELINE configs 3/4/5 after the timed region")
   ap.add_argument("--cpu-full", metavar="FILE", default=None,
                   help="measure the whole CPU baseline (one full N-interval SLSQP solve, ~9 min, + a trust-constr subsample) on this host, write FILE, exit")
   a = ap.parse_args()

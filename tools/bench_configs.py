@@ -9,7 +9,6 @@ from myriad_amd.systems.neural_ode import NeuralODE, NodeSystem
 from myriad_amd.trajectory_optimizers import get_optimizer
 from myriad_amd import _lib
 CFG = Config(verbose=False, plot=False)
-rng = np.random.default_rng(2019)
 
 def timed(opt, reps=3, **kw):
   opt.solve_batch(**kw)                       # warm-up (allocations)
@@ -21,30 +20,40 @@ def timed(opt, reps=3, **kw):
   ms, n = opt.engine.kernel_time(_lib.K_SOLVE)
   return res, dt, ms
 
-out = []
-# config 3: VANDERPOL shooting 1x50, 8192 per GPU
-hp = HParams(system=SystemType.VANDERPOL, optimizer=OptimizerType.SHOOTING, intervals=1, controls_per_interval=50, nlpsolver=NLPSolverType.SQP)
-opt = get_optimizer(hp, CFG, hp.system()); B = 8192
-x0 = np.clip(np.array([0., 1.]) + 0.1 * rng.standard_normal((B, 2)), -4, 4)
-res, dt, ms = timed(opt, x0s=x0)
-out.append(dict(config="3 VANDERPOL shooting 1x50 Heun", B=B, converged=float((res['status'] == 0).mean()), kernel_ms=ms, solves_per_s_kernel=B / ms * 1e3, its_median=float(np.median(res['iters']))))
-# config 4: CANCERTREATMENT shooting 1x100, 2048 per GPU, parameter sweep
-hp = HParams(system=SystemType.CANCERTREATMENT, optimizer=OptimizerType.SHOOTING, max_iter=500, nlpsolver=NLPSolverType.SQP)
-opt = get_optimizer(hp, CFG, hp.system()); B = 2048
-params = np.stack([rng.uniform(0.1, 0.5, B), rng.uniform(1, 5, B), rng.uniform(0.2, 0.8, B)], axis=1)
-res, dt, ms = timed(opt, x0s=rng.uniform(0.5, 0.99, (B, 1)), params=params)
-out.append(dict(config="4 CANCERTREATMENT shooting 1x100 Heun sweep", B=B, converged=float((res['status'] == 0).mean()), kernel_ms=ms, solves_per_s_kernel=B / ms * 1e3, its_median=float(np.median(res['iters']))))
-# config 5: CARTPOLE + NODE HS N=100, 128 per GPU (1024 over 8) and 1024 on one GPU
-hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON, integration_method=IntegrationMethod.RK4, intervals=100, hidden_layers=(64, 64), nlpsolver=NLPSolverType.SQP)
-opt = get_optimizer(hp, CFG, NodeSystem(NeuralODE.load_fitted_cartpole(), hp.system()))
-for B in (128, 1024):
+
+
+def measure():
+  """One line per config: converged fraction, solve-kernel time (HIP events inside the library) and the wall clock of
+  solve_batch (host buffers in and out: PCIe-inclusive).  bench.py attaches the list to its JSON line as `other_configs`."""
+  rng = np.random.default_rng(2019)
+  out = []
+  # config 3: VANDERPOL shooting 1x50, 8192 per GPU
+  hp = HParams(system=SystemType.VANDERPOL, optimizer=OptimizerType.SHOOTING, intervals=1, controls_per_interval=50, nlpsolver=NLPSolverType.SQP)
+  opt = get_optimizer(hp, CFG, hp.system()); B = 8192
+  x0 = np.clip(np.array([0., 1.]) + 0.1 * rng.standard_normal((B, 2)), -4, 4)
+  res, dt, ms = timed(opt, x0s=x0)
+  out.append(dict(config="3 VANDERPOL shooting 1x50 Heun", B=B, converged=float((res['status'] == 0).mean()), kernel_ms=ms, wall_ms=1e3 * dt, solves_per_s_wall=B / dt, solves_per_s_kernel=B / ms * 1e3, its_median=float(np.median(res['iters']))))
+  # config 4: CANCERTREATMENT shooting 1x100, 2048 per GPU, parameter sweep
+  hp = HParams(system=SystemType.CANCERTREATMENT, optimizer=OptimizerType.SHOOTING, max_iter=500, nlpsolver=NLPSolverType.SQP)
+  opt = get_optimizer(hp, CFG, hp.system()); B = 2048
+  params = np.stack([rng.uniform(0.1, 0.5, B), rng.uniform(1, 5, B), rng.uniform(0.2, 0.8, B)], axis=1)
+  res, dt, ms = timed(opt, x0s=rng.uniform(0.5, 0.99, (B, 1)), params=params)
+  out.append(dict(config="4 CANCERTREATMENT shooting 1x100 Heun sweep", B=B, converged=float((res['status'] == 0).mean()), kernel_ms=ms, wall_ms=1e3 * dt, solves_per_s_wall=B / dt, solves_per_s_kernel=B / ms * 1e3, its_median=float(np.median(res['iters']))))
+  # config 5: CARTPOLE + NODE HS N=100, 128 per GPU (1024 over 8) and 1024 on one GPU
+  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON, integration_method=IntegrationMethod.RK4, intervals=100, hidden_layers=(64, 64), nlpsolver=NLPSolverType.SQP)
+  opt = get_optimizer(hp, CFG, NodeSystem(NeuralODE.load_fitted_cartpole(), hp.system()))
+  for B in (128, 1024):
+    x0 = np.clip(0.1 * rng.standard_normal((B, 4)), -2, 2)
+    res, dt, ms = timed(opt, reps=2, x0s=x0, params=opt.system.device_params())
+    out.append(dict(config="5 CARTPOLE+NODE(64,64) HS N=100", B=B, converged=float((res['status'] == 0).mean()), kernel_ms=ms, wall_ms=1e3 * dt, solves_per_s_wall=B / dt, solves_per_s_kernel=B / ms * 1e3, its_median=float(np.median(res['iters']))))
+  # README:83 literal: CARTPOLE trapezoidal N=100
+  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, intervals=100, nlpsolver=NLPSolverType.SQP)
+  opt = get_optimizer(hp, CFG, hp.system()); B = 4096
   x0 = np.clip(0.1 * rng.standard_normal((B, 4)), -2, 2)
-  res, dt, ms = timed(opt, reps=2, x0s=x0, params=opt.system.device_params())
-  out.append(dict(config="5 CARTPOLE+NODE(64,64) HS N=100", B=B, converged=float((res['status'] == 0).mean()), kernel_ms=ms, solves_per_s_kernel=B / ms * 1e3, its_median=float(np.median(res['iters']))))
-# README:83 literal: CARTPOLE trapezoidal N=100
-hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, intervals=100, nlpsolver=NLPSolverType.SQP)
-opt = get_optimizer(hp, CFG, hp.system()); B = 4096
-x0 = np.clip(0.1 * rng.standard_normal((B, 4)), -2, 2)
-res, dt, ms = timed(opt, x0s=x0)
-out.append(dict(config="README:83 CARTPOLE trapezoidal N=100", B=B, converged=float((res['status'] == 0).mean()), kernel_ms=ms, solves_per_s_kernel=B / ms * 1e3, its_median=float(np.median(res['iters']))))
-for o in out: print(json.dumps(o))
+  res, dt, ms = timed(opt, x0s=x0)
+  out.append(dict(config="README:83 CARTPOLE trapezoidal N=100", B=B, converged=float((res['status'] == 0).mean()), kernel_ms=ms, wall_ms=1e3 * dt, solves_per_s_wall=B / dt, solves_per_s_kernel=B / ms * 1e3, its_median=float(np.median(res['iters']))))
+  return out
+
+
+if __name__ == "__main__":
+  for o in measure(): print(json.dumps(o))
