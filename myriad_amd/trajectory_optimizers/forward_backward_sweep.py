@@ -43,43 +43,35 @@ class FBSM(IndirectMethodOptimizer):
       raise NotImplementedError("FBSM needs adjoint dynamics: an IndirectFHCS system (tests/test_smoke.py:34-37)")
     self.system = system
     self.discrete = bool(getattr(system, "discrete", False))
-    self.N = hp.fbsm_intervals                                   # :31
-    self.h = system.T / self.N
-    if self.discrete:                                            # :33-35
-      self.N = int(system.T)
-      self.h = 1
-    state_shape = system.x_0.shape[0]
-    control_shape = system.bounds.shape[0] - state_shape
-    self.x_guess = np.vstack((system.x_0, np.zeros((self.N, state_shape))))        # :38
-    self.u_guess = np.zeros((self.N if self.discrete else self.N + 1, control_shape))   # :39-42
-    if system.adj_T is not None:
-      self.adj_guess = np.vstack((np.zeros((self.N, state_shape)), system.adj_T))  # :44
-    else:
-      self.adj_guess = np.zeros((self.N + 1, state_shape))
+    # sweep grid (:31-35): fbsm_intervals steps of T/N, or one step per time unit for a discrete system
+    self.N, self.h = (int(system.T), 1) if self.discrete else (hp.fbsm_intervals, system.T / hp.fbsm_intervals)
     self.t_interval = np.linspace(0, system.T, num=self.N + 1).reshape(-1, 1)
-    sizes = (self.x_guess.size, self.u_guess.size, self.adj_guess.size)
-    guess = np.concatenate([self.x_guess.ravel(), self.u_guess.ravel(), self.adj_guess.ravel()])
+    ns = system.x_0.shape[0]
+    nu = system.bounds.shape[0] - ns
+    # the three trajectories the sweeps iterate on (:38-46): zero except the state's first and the adjoint's last row
+    rows = {"x": self.N + 1, "u": self.N + (0 if self.discrete else 1), "adj": self.N + 1}
+    cols = {"x": ns, "u": nu, "adj": ns}
+    tr = {k: np.zeros((rows[k], cols[k])) for k in rows}
+    tr["x"][0] = system.x_0
+    if system.adj_T is not None:
+      tr["adj"][-1] = system.adj_T
+    self.x_guess, self.u_guess, self.adj_guess = tr["x"], tr["u"], tr["adj"]
+    cuts = np.cumsum([tr[k].size for k in ("x", "u")])
+    shapes = [tr[k].shape for k in ("x", "u", "adj")]
 
     def unravel(v):
-      a, b = sizes[0], sizes[0] + sizes[1]
-      return (v[:a].reshape(self.x_guess.shape), v[a:b].reshape(self.u_guess.shape), v[b:].reshape(self.adj_guess.shape))
+      return tuple(part.reshape(sh) for part, sh in zip(np.split(v, cuts), shapes))
 
-    self.x_bounds = system.bounds[:-1]                           # :52-55
-    self.u_bounds = system.bounds[-1:]
-    bounds = np.vstack((self.x_bounds, self.u_bounds))
-    # additional condition if a terminal state is pinned (:58-70): solved by the secant method over adj(T) of that state
-    self.terminal_cdtion = False
-    if system.x_T is not None:
-      num_term_state = 0
-      for idx, x_Ti in enumerate(system.x_T):
-        if x_Ti is not None:
-          self.terminal_cdtion = True
-          self.term_cdtion_state = idx
-          self.term_value = float(x_Ti)
-          num_term_state += 1
-        if num_term_state > 1:
-          raise NotImplementedError("Multiple states with terminal condition not supported yet")
-    super().__init__(hp, cfg, bounds, guess, unravel)
+    self.x_bounds, self.u_bounds = system.bounds[:-1], system.bounds[-1:]                        # :52-55
+    # a pinned terminal state (:58-70, at most one) is met by the secant iteration of sequencesolver() over adj(T) of that state
+    pinned = [] if system.x_T is None else [i for i, v in enumerate(system.x_T) if v is not None]
+    if len(pinned) > 1:
+      raise NotImplementedError("Multiple states with terminal condition not supported yet")
+    self.terminal_cdtion = len(pinned) == 1
+    if self.terminal_cdtion:
+      self.term_cdtion_state = pinned[0]
+      self.term_value = float(system.x_T[pinned[0]])
+    super().__init__(hp, cfg, np.vstack((self.x_bounds, self.u_bounds)), np.concatenate([tr[k].ravel() for k in ("x", "u", "adj")]), unravel)
     self._engine: Optional[_lib.Engine] = None
 
   @property
