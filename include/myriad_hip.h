@@ -173,6 +173,24 @@ int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, const double
               double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt, int32_t mem);
 
 /*
+ * myr_solve for B instances that differ in their START STATE only (EXTENSION; the reference builds guess and bounds of an
+ * instance from system.x_0 in the optimiser's constructor: collocation/hermite_simpson.py:37-48 (guess), :55-81 (bounds);
+ * collocation/trapezoidal.py:36-50, 55-77; shooting.py:56-74, 247-275 -- this entry point applies that constructor to B start
+ * states ON THE DEVICE, so a caller sends B x ns doubles instead of three [B][n] arrays).
+ *   x0s    [B][ns]  start states
+ *   g0,g1  [n]      guess rule: z0[b][i] = g0[i] + g1[i] * x0s[b][i mod ns] for the state entries (i < x_rows*ns: the product and
+ *                   the sum are rounded separately, i.e. bit for bit numpy's x0*(1-lin) + x_T*lin with g1 = 1-lin, g0 = x_T*lin),
+ *                   z0[b][i] = g0[i] for the controls.  A guess that does not depend on x0 (ones*0.1) has g1 = 0.
+ *   lb,ub  [n]      bounds shared by the instances; the first point's state entries (i < ns) are replaced by x0s[b] (x[0] = x0)
+ *   z      [B][n]   out: solutions (NOT read on entry)
+ *   params, opts, lam, cost, status, iters, kkt, mem: as myr_solve.  MYR_MEM_DEVICE: every pointer is a device pointer.
+ * Results are those of myr_solve on the expanded arrays (tests/test_gpu_solve.py::test_solve_x0_matches_solve).
+ */
+int myr_solve_x0(myr_handle h, int32_t B, const double* x0s, const double* g0, const double* g1, const double* lb,
+                 const double* ub, const double* params, int32_t params_stride, const myr_solve_opts* opts,
+                 double* z, double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt, int32_t mem);
+
+/*
  * Variable scaling of the SOLVE path.  scale [ns+nu] (states, then controls; NULL = all 1): myr_solve then works on
  * z/s, lb/s, ub/s with the dynamics f(s x)/s -- the same optimisation problem in better-conditioned variables (IPOPT's
  * user scaling, which the reference reaches through `nlp_scaling_method`); inputs and outputs of myr_solve stay in the

@@ -28,7 +28,7 @@ K_EVAL, K_SOLVE, K_ROLLOUT, K_RESID, K_PROD, K_FBSM = 0, 1, 2, 3, 4, 5
 STATUS_NAMES = {0: "CONVERGED", 1: "MAXITER", 2: "NAN", 3: "STALLED", 4: "INFEASIBLE"}
 STATUS_INFEASIBLE = 4   # assigned by the host's elastic phase (TrajectoryOptimizer.device_solve), never by a kernel
 
-EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve",
+EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve", "myr_solve_x0",
            "myr_set_var_scale", "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_fbsm", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",
            "myr_version", "myr_device_count"]
 
@@ -89,6 +89,8 @@ def load() -> C.CDLL:
   lib.myr_eval.restype = C.c_int
   lib.myr_solve.argtypes = [vp, C.c_int32, dp, dp, dp, dp, C.c_int32, C.POINTER(SolveOpts), dp, dp, ip, ip, dp, C.c_int32]
   lib.myr_solve.restype = C.c_int
+  lib.myr_solve_x0.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_int32, C.POINTER(SolveOpts), dp, dp, dp, ip, ip, dp, C.c_int32]
+  lib.myr_solve_x0.restype = C.c_int
   lib.myr_rollout.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, dp, dp, C.c_int32]
   lib.myr_rollout.restype = C.c_int
   lib.myr_set_var_scale.argtypes = [vp, dp]
@@ -237,6 +239,26 @@ class Engine:
     status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); kkt = np.empty((B, 3))
     _chk(self.lib.myr_solve(self._h, B, _addr(z), _addr(lb), _addr(ub), _addr(p), ps, C.byref(o), _addr(lam),
                             _addr(cost), _addr(status), _addr(iters), _addr(kkt), MEM_HOST), "myr_solve")
+    return {"z": z, "lam": lam, "cost": cost, "status": status, "iters": iters, "kkt": kkt}
+
+  def solve_x0(self, x0s, g0, g1, lb, ub, params=None, opts: Optional[SolveOpts] = None):
+    """myr_solve_x0: the instances differ in their start state only; guess and bounds are expanded on the device
+    (z0[b] = g0 + g1 * tile(x0s[b]) on the state rows, lb/ub [n] with the first point pinned to x0s[b])."""
+    x0s = np.ascontiguousarray(_f64(x0s))
+    if x0s.ndim == 1:
+      x0s = x0s[None]
+    B = x0s.shape[0]
+    if x0s.shape[1] != self.ns:
+      raise ValueError(f"x0s must be [B,{self.ns}]")
+    tpl = [np.ascontiguousarray(_f64(a)).reshape(-1) for a in (g0, g1, lb, ub)]
+    if any(a.shape[0] != self.n for a in tpl):
+      raise ValueError(f"g0, g1, lb, ub must have {self.n} entries")
+    p, ps = self._params(params, B)
+    o = opts or self.default_opts()
+    z = np.empty((B, self.n)); lam = np.empty((B, self.m)); cost = np.empty(B)
+    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); kkt = np.empty((B, 3))
+    _chk(self.lib.myr_solve_x0(self._h, B, _addr(x0s), _addr(tpl[0]), _addr(tpl[1]), _addr(tpl[2]), _addr(tpl[3]), _addr(p), ps,
+                               C.byref(o), _addr(z), _addr(lam), _addr(cost), _addr(status), _addr(iters), _addr(kkt), MEM_HOST), "myr_solve_x0")
     return {"z": z, "lam": lam, "cost": cost, "status": status, "iters": iters, "kkt": kkt}
 
   def solve_device(self, B, z, lb, ub, params, params_stride, opts, lam, cost, status, iters, kkt=None):

@@ -64,7 +64,6 @@ def fan_out_solve(engines: Sequence, z0, lb, ub, params=None, opts=None) -> Dict
   this is the internal fan-out SURVEY.md 8(b) "Threading" asks for.  `engines[i].solve(z0, lb, ub, params=, opts=)` must
   return a dict of arrays with the batch in the first dimension.  An engine may appear twice (two shards queue on one
   device)."""
-  import threading
   import numpy as np
   z0 = np.asarray(z0, dtype=np.float64)
   if z0.ndim == 1:
@@ -73,9 +72,34 @@ def fan_out_solve(engines: Sequence, z0, lb, ub, params=None, opts=None) -> Dict
   lb = np.broadcast_to(np.asarray(lb, dtype=np.float64), z0.shape)
   ub = np.broadcast_to(np.asarray(ub, dtype=np.float64), z0.shape)
   p = None if params is None else np.asarray(params, dtype=np.float64)
+  def call(e, lo, hi):
+    pr = p if (p is None or p.ndim == 1) else p[lo:hi]
+    return e.solve(z0[lo:hi], lb[lo:hi], ub[lo:hi], params=pr, opts=opts)
+
+  return fan_out(engines, B, call)
+
+
+def fan_out_solve_x0(engines: Sequence, x0s, g0, g1, lb, ub, params=None, opts=None) -> Dict:
+  """fan_out_solve for instances that differ in their start state only (`engine.solve_x0`: guess and bounds are expanded on the
+  device from the templates g0, g1, lb, ub [n]); the shards carry x0s [B,ns] and, if given per instance, params."""
+  import numpy as np
+  x0s = np.asarray(x0s, dtype=np.float64)
+  p = None if params is None else np.asarray(params, dtype=np.float64)
+
+  def call(e, lo, hi):
+    pr = p if (p is None or p.ndim == 1) else p[lo:hi]
+    return e.solve_x0(x0s[lo:hi], g0, g1, lb, ub, params=pr, opts=opts)
+
+  return fan_out(engines, x0s.shape[0], call)
+
+
+def fan_out(engines: Sequence, B: int, call) -> Dict:
+  """`call(engine, lo, hi)` on contiguous shards of B instances, one host thread per engine; dict results concatenated."""
+  import threading
+  import numpy as np
   world = max(1, min(len(engines), B))
   if world == 1:
-    return engines[0].solve(z0, lb, ub, params=p, opts=opts)
+    return call(engines[0], 0, B)
   out = [None] * world
   err = [None] * world
   locks = {}
@@ -84,10 +108,9 @@ def fan_out_solve(engines: Sequence, z0, lb, ub, params=None, opts=None) -> Dict
 
   def work(r):
     lo, hi = shard_range(B, r, world)
-    pr = p if (p is None or p.ndim == 1) else p[lo:hi]
     try:
       with locks[id(engines[r])]:
-        out[r] = engines[r].solve(z0[lo:hi], lb[lo:hi], ub[lo:hi], params=pr, opts=opts)
+        out[r] = call(engines[r], lo, hi)
     except BaseException as e:   # re-raised in the caller's thread
       err[r] = e
 

@@ -1165,6 +1165,99 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
   return MYR_OK;
 }
 
+// ---- myr_solve_x0: B instances that differ in their START STATE only ------------------------------------------------
+// The reference builds guess and bounds of an instance from system.x_0 in the optimiser's constructor
+// (hermite_simpson.py:37-48 guess, :55-81 bounds; trapezoidal.py:36-50, 55-77; shooting.py:56-74, 247-275).  For a batch
+// of start states that is B x 3 n doubles of host packing and PCIe traffic carrying B x ns doubles of information: the
+// expansion runs on the device instead.  z0[b][i] = g0[i] + g1[i] * x0s[b][i mod ns] on the state rows (two roundings, the
+// product and the sum: bit for bit what numpy's x0 * (1 - lin) + x_T * lin gives with g1 = 1 - lin, g0 = x_T * lin), g0[i]
+// elsewhere; lb / ub = the templates with the first point's state rows replaced by x0s[b].
+__global__ void pack_x0_kernel(long total, int n, int ns, int xcount, const double* __restrict__ x0s, const double* __restrict__ g0,
+                               const double* __restrict__ g1, const double* __restrict__ lbt, const double* __restrict__ ubt,
+                               double* __restrict__ z, double* __restrict__ lb, double* __restrict__ ub) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long b = t / n;
+    const int i = (int)(t - b * n);
+    double zi = g0[i], l = lbt[i], u = ubt[i];
+    if (i < xcount) {
+      const double x = x0s[b * ns + i % ns];
+      double prod = x * g1[i];
+      asm volatile("" : "+v"(prod));     // a rounded product of its own: the compiler must not contract it into an fma with the sum
+      zi = prod + zi;
+      if (i < ns) { l = x; u = x; }
+    }
+    z[t] = zi; lb[t] = l; ub[t] = u;
+  }
+}
+
+extern "C" int myr_solve_x0(myr_handle h, int32_t B, const double* x0s, const double* g0, const double* g1, const double* lb,
+                            const double* ub, const double* params, int32_t params_stride, const myr_solve_opts* opts,
+                            double* z, double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt, int32_t mem) {
+  if (!h || !x0s || !g0 || !g1 || !lb || !ub || !z) return fail(MYR_E_ARG, "myr_solve_x0: null handle, x0s, g0, g1, lb, ub or z");
+  if (h->d.system_id == MYR_SYS_INVASIVEPLANT) return no_such_path(h, "myr_solve_x0");
+  if (B < 0) return fail(MYR_E_ARG, "myr_solve_x0: negative batch");
+  if (B == 0) return MYR_OK;
+  if (params && params_stride != 0 && params_stride != h->dims.np)
+    return fail(MYR_E_ARG, "myr_solve_x0: params_stride must be 0 (shared) or np");
+  if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, "myr_solve_x0: a NODE system needs its weights in `params`");
+  if (mem != MYR_MEM_HOST && mem != MYR_MEM_DEVICE) return fail(MYR_E_ARG, "myr_solve_x0: bad mem kind");
+  myr_solve_opts so;
+  if (opts) so = *opts; else myr_default_solve_opts(&so);
+  if (so.max_iter < 0 || !(so.tol_feas > 0) || !(so.tol_stat > 0) || !(so.tol_compl > 0) || !(so.mu_init > 0))
+    return fail(MYR_E_ARG, "myr_solve_x0: bad options");
+  HIPCHK(hipSetDevice(h->d.device));
+  const myr_dims& dm = h->dims;
+  const bool host = mem == MYR_MEM_HOST;
+  const size_t nz = (size_t)B * dm.n, nl = lam ? (size_t)B * dm.m : 0, nx0 = (size_t)B * dm.ns;
+  const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  // device scratch: the expanded bounds always; for host callers also the iterate, the inputs and the results
+  size_t total = 2 * al(nz);
+  if (host) total += al(nz) + al(nx0) + 4 * al((size_t)dm.n) + al(nl) + al(npar) + al(B) + al(B) + al(3 * (size_t)B);
+  int rc = ensure_dbuf(h, total * 8);
+  if (rc) return rc;
+  double* dlb = (double*)h->dbuf;
+  double* dub = dlb + al(nz);
+  double* dz = z; const double* dx0 = x0s; const double* dg0 = g0; const double* dg1 = g1; const double* dlt = lb; const double* dut = ub;
+  const double* dpar = params;
+  double* dlam = lam; double* dcost = cost; int32_t* dstat = status; int32_t* dit = iters; double* dkkt = kkt;
+  if (host) {
+    double* q = dub + al(nz);
+    dz = q; q += al(nz);
+    double* hx0 = q; q += al(nx0);
+    double* tpl = q; q += 4 * al((size_t)dm.n);
+    dlam = nl ? q : nullptr; q += al(nl);
+    double* hp = q; q += al(npar);
+    dcost = q; q += al(B);
+    dstat = (int32_t*)q; dit = dstat + B; q += al(B);
+    dkkt = q;
+    HIPCHK(hipMemcpyAsync(hx0, x0s, nx0 * 8, hipMemcpyHostToDevice, h->stream));
+    const double* src[4] = {g0, g1, lb, ub};
+    for (int k = 0; k < 4; ++k) HIPCHK(hipMemcpyAsync(tpl + k * al((size_t)dm.n), src[k], (size_t)dm.n * 8, hipMemcpyHostToDevice, h->stream));
+    if (npar) HIPCHK(hipMemcpyAsync(hp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
+    dx0 = hx0; dg0 = tpl; dg1 = tpl + al((size_t)dm.n); dlt = tpl + 2 * al((size_t)dm.n); dut = tpl + 3 * al((size_t)dm.n);
+    dpar = npar ? hp : nullptr;
+  }
+  {
+    const long tz = (long)nz;
+    long blocks = (tz + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pack_x0_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, tz, dm.n, dm.ns, dm.x_rows * dm.ns, dx0, dg0, dg1, dlt, dut, dz, dlb, dub);
+    HIPCHK(hipGetLastError());
+  }
+  rc = dispatch_solve_scaled(h, B, dz, dlb, dub, dpar, params_stride, so, dlam, dcost, dstat, dit, dkkt);
+  if (rc) return rc;
+  if (host) {
+    HIPCHK(hipMemcpyAsync(z, dz, nz * 8, hipMemcpyDeviceToHost, h->stream));
+    if (nl) HIPCHK(hipMemcpyAsync(lam, dlam, nl * 8, hipMemcpyDeviceToHost, h->stream));
+    if (cost) HIPCHK(hipMemcpyAsync(cost, dcost, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
+    if (status) HIPCHK(hipMemcpyAsync(status, dstat, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (iters) HIPCHK(hipMemcpyAsync(iters, dit, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (kkt) HIPCHK(hipMemcpyAsync(kkt, dkkt, (size_t)B * 24, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return MYR_OK;
+}
+
 static int dispatch_rollout(myr_handle h, int B, int num_steps, int u_rows, const double* x0, const double* us,
                             const double* params, int pstride, double* xs, double* cost) {
   KTimer& kt = h->kt[MYR_K_ROLLOUT];

@@ -297,12 +297,46 @@ class TrajectoryOptimizer(object):
     B = 1 if np.ndim(z0) == 1 else np.shape(z0)[0]
     return fan_out_solve(self.engines_for(B), z0, lb, ub, params=params, opts=opts)
 
-  def device_solve(self, z0, lb, ub, params, opts, second_starts=True):
+  def _solve_sharded_x0(self, x0s, rule, params, opts):
+    """The first attempt of a batch that differs in its start states only: guess and bounds are expanded on the device
+    (myr_solve_x0) -- B x ns doubles go over PCIe instead of three [B][n] arrays, and no host packing."""
+    from myriad_amd.batched import fan_out_solve_x0
+    g0, g1 = rule
+    return fan_out_solve_x0(self.engines_for(x0s.shape[0]), x0s, g0, g1, self.bounds[:, 0], self.bounds[:, 1], params=params, opts=opts)
+
+  def x0_rule(self):
+    """(g0, g1), each [n], when the reference's guess of this transcription is an affine function of the start state --
+    z0 = g0 + g1 * tile(x0) on the state rows (include/myriad_hip.h: myr_solve_x0) -- else None (a rollout guess)."""
+    return None
+
+  def _linspace_rule(self):
+    """linspace(x_0, x_T, rows) per instance as x0 * (1 - lin) + x_T * lin: the arithmetic of batch_inputs, rounding included."""
+    rows, ns = self._x_shape
+    lin = np.linspace(0.0, 1.0, rows)
+    xT = np.asarray(self.system.x_T, dtype=np.float64)
+    g0 = np.zeros(self.guess.size); g1 = np.zeros(self.guess.size)
+    g0[:rows * ns] = (xT[None, :] * lin[:, None]).ravel()
+    g1[:rows * ns] = np.repeat(1 - lin, ns)
+    return g0, g1
+
+  def _expand_x0(self, x0s, rule):
+    """Host-side expansion of the myr_solve_x0 inputs (for the instances the second starts take up again)."""
+    g0, g1 = rule
+    rows, ns = self._x_shape
+    z0 = np.tile(g0, (x0s.shape[0], 1))
+    z0[:, :rows * ns] += (np.tile(x0s, (1, rows)) * g1[None, :rows * ns])
+    lb, ub = self._batch_bounds(x0s)
+    return z0, lb, ub
+
+  def device_solve(self, z0, lb, ub, params, opts, second_starts=True, x0_form=None):
     """The device solve (fanned out over `engines_for(B)`) + second starts for the instances that did not reach a KKT point.
     The result says which start produced each instance: `start` = 0 for the caller's point, c for the excitation guess with c
     cycles; `attempts` = device solves the instance went through (its `iters` are summed over them).  `second_starts=False`
     (what solve_with_params / solve_batch pass when the caller gave an explicit guess) returns the first attempt as it is."""
-    res = self._solve_sharded(z0, lb, ub, params, opts)
+    if x0_form is not None:       # (x0s, rule): the arrays exist on the device only; expanded here for failed instances alone
+      res = self._solve_sharded_x0(x0_form[0], x0_form[1], params, opts)
+    else:
+      res = self._solve_sharded(z0, lb, ub, params, opts)
     B = res["status"].shape[0]
     res["start"] = np.zeros(B, dtype=np.int32)
     res["attempts"] = np.ones(B, dtype=np.int32)
@@ -312,15 +346,28 @@ class TrajectoryOptimizer(object):
       cycles = ()
     fail = np.nonzero(res["status"] != 0)[0]
     p = None if params is None else np.asarray(params, dtype=np.float64)
+    res["restored"] = np.zeros(B, dtype=np.int32)
+    if fail.size == 0 or not (second_starts and (cycles or self._twin_engine() is not None)):
+      return res
+    if x0_form is not None:
+      z0, lb, ub = self._expand_x0(x0_form[0][fail], x0_form[1])
+      if p is not None and p.ndim == 2:
+        p = p[fail]
+      return self.device_solve_retries(res, fail, z0, lb, ub, p, opts, cycles)
     z0 = np.asarray(z0, dtype=np.float64).reshape(B, -1)
     lb = np.broadcast_to(np.asarray(lb, dtype=np.float64), z0.shape)
     ub = np.broadcast_to(np.asarray(ub, dtype=np.float64), z0.shape)
-    res["restored"] = np.zeros(B, dtype=np.int32)
+    pf = p if (p is None or p.ndim == 1) else p[fail]
+    return self.device_solve_retries(res, fail, z0[fail], lb[fail], ub[fail], pf, opts, cycles)
+
+  def device_solve_retries(self, res, fail, z0, lb, ub, p, opts, cycles):
+    """The elastic phase and the second starts for the instances `fail` of `res` (rows of z0, lb, ub, p = those instances)."""
+    sel = np.arange(fail.size)          # rows of z0 / lb / ub / p still unsolved (fail[i] is the instance of row sel[i])
+    rows_p = lambda idx: p if (p is None or p.ndim == 1) else p[idx]
     r2 = None
-    if fail.size and second_starts and self._twin_engine() is not None:        # elastic mode first, other guesses after it
-      pf = p if (p is None or p.ndim == 1) else p[fail]
+    if self._twin_engine() is not None:        # elastic mode first, other guesses after it
       try:
-        r2 = self.elastic_restoration(z0[fail], lb[fail], ub[fail], pf, opts)
+        r2 = self.elastic_restoration(z0, lb, ub, rows_p(sel), opts)
       except NotImplementedError as e:          # MYR_E_UNSUPPORTED (myriad_amd/_lib.py: _chk)
         if "not built" not in str(e):
           raise
@@ -337,14 +384,14 @@ class TrajectoryOptimizer(object):
       s = r2["slack"]
       stuck = (~ok) & (r2["twin_status"] == 0) & (s[:, -1] > self.elastic_slack_tol) & (s[:, -1] > 0.1 * s[:, -2])
       res["status"][fail[stuck]] = _lib.STATUS_INFEASIBLE
-      fail = fail[~ok]
+      fail, sel = fail[~ok], sel[~ok]
     for c in cycles:
       if fail.size == 0:
         break
-      lbf, ubf = lb[fail], ub[fail]
+      lbf, ubf = lb[sel], ub[sel]
       ns = self._x_shape[1]
-      x0f = np.where(lbf[:, :ns] == ubf[:, :ns], lbf[:, :ns], z0[fail][:, :ns])
-      pf = p if (p is None or p.ndim == 1) else p[fail]
+      x0f = np.where(lbf[:, :ns] == ubf[:, :ns], lbf[:, :ns], z0[sel][:, :ns])
+      pf = rows_p(sel)
       r2 = self._solve_sharded(self.excitation_guess(x0f, lbf, ubf, pf, c), lbf, ubf, pf, opts)
       r2["iters"] = r2["iters"] + res["iters"][fail]
       ok = r2["status"] == 0
@@ -354,7 +401,7 @@ class TrajectoryOptimizer(object):
       res["start"][fail[ok]] = c
       res["attempts"][fail] += 1
       res["iters"][fail[~ok]] = r2["iters"][~ok]
-      fail = fail[~ok]
+      fail, sel = fail[~ok], sel[~ok]
     return res
 
   # ---- solve ---------------------------------------------------------------------------------------
@@ -396,12 +443,17 @@ class TrajectoryOptimizer(object):
       x0s = np.tile(self.system.x_0, (B, 1))
     x0s = np.asarray(x0s, dtype=np.float64)
     p = self.system.device_params() if params is None else np.asarray(params, dtype=np.float64)
-    z0, lb, ub = self.batch_inputs(x0s, p)
-    if guess is not None:
-      z0 = np.broadcast_to(np.asarray(guess, dtype=np.float64), z0.shape).copy()
     o = eng.default_opts()
     o.max_iter = self.hp.max_iter if max_iter is None else max_iter
-    res = self.device_solve(z0, lb, ub, p, o, second_starts=(guess is None) if second_starts is None else bool(second_starts))
+    ss = (guess is None) if second_starts is None else bool(second_starts)
+    rule = self.x0_rule() if (guess is None and os.environ.get("MYRIAD_SOLVE_X0", "1") != "0") else None
+    if rule is not None:       # start states only: guess and bounds are expanded on the device (myr_solve_x0)
+      res = self.device_solve(None, None, None, p, o, second_starts=ss, x0_form=(x0s, rule))
+    else:
+      z0, lb, ub = self.batch_inputs(x0s, p)
+      if guess is not None:
+        z0 = np.broadcast_to(np.asarray(guess, dtype=np.float64), z0.shape).copy()
+      res = self.device_solve(z0, lb, ub, p, o, second_starts=ss)
     x, u = self.unravel(res["z"])
     return {'x': x, 'u': u, 'xs_and_us': res["z"], 'cost': res["cost"], 'lambda': res["lam"],
             'status': res["status"], 'iters': res["iters"], 'kkt': res["kkt"], 'start': res["start"], 'attempts': res["attempts"],
@@ -441,6 +493,13 @@ class HermiteSimpsonCollocationOptimizer(TrajectoryOptimizer):
     xb, ub = _state_control_bounds(system, K, K)
     super().__init__(hp, cfg, system, "HERMITE_SIMPSON", x_guess, u_guess, xb, ub)
 
+  def x0_rule(self):
+    if self.system.x_T is not None:
+      return self._linspace_rule()
+    g0 = np.zeros(self.guess.size)
+    g0[:self._x_shape[0] * self._x_shape[1]] = 0.1             # hermite_simpson.py:41: ones * 0.1, whatever x_0 is
+    return g0, np.zeros(self.guess.size)
+
   def batch_inputs(self, x0s, params=None):
     """hermite_simpson.py:41,59 applied per instance."""
     x0s = np.asarray(x0s, dtype=np.float64)
@@ -469,6 +528,10 @@ class TrapezoidalCollocationOptimizer(TrajectoryOptimizer):
     xb, ub = _state_control_bounds(system, N + 1, N + 1, trap_quirk=True)
     super().__init__(hp, cfg, system, "TRAPEZOIDAL", x_guess, u_guess, xb, ub)
 
+  def x0_rule(self):
+    xT = self.system.x_T
+    return self._linspace_rule() if (xT is not None and all(v is not None for v in xT)) else None      # else: a rollout guess
+
   def batch_inputs(self, x0s, params=None):
     N = self.hp.intervals
     xs = self._batch_state_guess(x0s, params, N + 1, N + 1)
@@ -491,6 +554,10 @@ class MultipleShootingOptimizer(TrajectoryOptimizer):
     xb, ub = _state_control_bounds(system, I + 1, mc * I * cpi + 1)
     super().__init__(hp, cfg, system, "SHOOTING", x_guess, u_guess, xb, ub)
     self._mc = mc
+
+  def x0_rule(self):
+    xT = self.system.x_T
+    return self._linspace_rule() if (xT is not None and all(v is not None for v in xT)) else None      # else: a rollout guess
 
   def batch_inputs(self, x0s, params=None):
     I = self.hp.intervals

@@ -22,7 +22,7 @@ def lib():
 
 def test_exports_match_header(lib):
   hdr = open(os.path.join(ROOT, "include", "myriad_hip.h")).read()
-  declared = set(re.findall(r"\b(myr_[a-z_]+)\s*\(", hdr))
+  declared = set(re.findall(r"\b(myr_[a-z0-9_]+)\s*\(", hdr))
   assert declared == set(_lib.EXPORTS)
   for s in declared:
     assert hasattr(lib, s), s

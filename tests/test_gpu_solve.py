@@ -269,3 +269,74 @@ def test_shooting_wave_kernel_restarts_a_stalled_solve(monkeypatch):
   o.restarts = 2
   r2 = eng.solve(z0, lb, ub, params=opt.system.device_params(), opts=o)
   assert r2["status"][0] == 0                                     # first attempt cut at 100, then a second start
+
+
+@pytest.mark.parametrize("system,transcription,kw", [
+    ("CARTPOLE", "hs", dict(intervals=20)),                       # x_T given: linspace(x0, x_T) per instance
+    ("VANDERPOL", "hs", dict(intervals=16)),                      # no x_T: ones * 0.1 whatever x0 is (g1 = 0)
+    ("CARTPOLE", "trap", dict(intervals=30)),
+    ("CARTPOLE", "shoot", dict(intervals=10, controls_per_interval=2)),
+])
+def test_solve_x0_matches_solve(system, transcription, kw, monkeypatch):
+  """myr_solve_x0 (start states + guess rule + bound templates, expanded on the device) against myr_solve on the arrays
+  batch_inputs builds on the host: the SAME inputs reach the solver (the expansion rounds like numpy), so every output is bit
+  for bit the same -- host buffers, device buffers, and through solve_batch with MYRIAD_SOLVE_X0 on / off."""
+  import ctypes as C
+  import torch
+  from myriad_amd import _lib
+  from myriad_amd.config import Config, HParams, IntegrationMethod, NLPSolverType, OptimizerType, QuadratureRule
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  if transcription == "shoot":
+    hp = HParams(system=SystemType[system], optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, nlpsolver=NLPSolverType.SQP, **kw)
+  else:
+    hp = HParams(system=SystemType[system], optimizer=OptimizerType.COLLOCATION, nlpsolver=NLPSolverType.SQP,
+                 quadrature_rule=QuadratureRule.HERMITE_SIMPSON if transcription == "hs" else QuadratureRule.TRAPEZOIDAL, **kw)
+  opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+  rule = opt.x0_rule()
+  assert rule is not None
+  B = 96
+  rng = np.random.default_rng(5)
+  x0s = opt.system.x_0[None] + 0.1 * rng.standard_normal((B, opt.system.x_0.shape[0]))
+  p = opt.system.device_params()
+  eng = opt.engine
+  z0, lb, ub = opt.batch_inputs(x0s, p)
+  ref = eng.solve(z0, lb, ub, params=p)
+  assert (ref["status"] == 0).mean() > 0.9
+  got = eng.solve_x0(x0s, rule[0], rule[1], opt.bounds[:, 0], opt.bounds[:, 1], params=p)
+  for k in ("z", "lam", "cost", "status", "iters", "kkt"):
+    assert np.array_equal(ref[k], got[k]), k
+  # device buffers: every pointer a device pointer, z is output only
+  dev = torch.device("cuda", 0)
+  t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+  dx0, dg0, dg1, dl, du, dp = t(x0s), t(rule[0]), t(rule[1]), t(opt.bounds[:, 0]), t(opt.bounds[:, 1]), t(p)
+  dz = torch.full((B, eng.n), float("nan"), dtype=torch.float64, device=dev)
+  dlam = torch.empty(B, eng.m, dtype=torch.float64, device=dev); dcost = torch.empty(B, dtype=torch.float64, device=dev)
+  dst = torch.empty(B, dtype=torch.int32, device=dev); dit = torch.empty(B, dtype=torch.int32, device=dev)
+  dk = torch.empty(B, 3, dtype=torch.float64, device=dev)
+  torch.cuda.synchronize()
+  o = eng.default_opts()
+  a = lambda x: C.c_void_p(x.data_ptr())
+  _lib._chk(eng.lib.myr_solve_x0(eng._h, B, a(dx0), a(dg0), a(dg1), a(dl), a(du), a(dp), 0, C.byref(o), a(dz), a(dlam), a(dcost),
+                                 a(dst), a(dit), a(dk), _lib.MEM_DEVICE), "myr_solve_x0")
+  assert np.array_equal(dz.cpu().numpy(), ref["z"]) and np.array_equal(dst.cpu().numpy(), ref["status"]) and np.array_equal(dlam.cpu().numpy(), ref["lam"])
+  # through the reference-shaped API
+  r1 = opt.solve_batch(x0s=x0s)
+  monkeypatch.setenv("MYRIAD_SOLVE_X0", "0")
+  r0 = opt.solve_batch(x0s=x0s)
+  for k in ("xs_and_us", "cost", "lambda", "status", "iters"):
+    assert np.array_equal(r0[k], r1[k]), k
+  assert np.array_equal(r1["xs_and_us"], ref["z"])
+
+
+def test_solve_x0_rejects_bad_arguments():
+  from myriad_amd import _lib
+  eng = _engine(10)
+  g = np.zeros(eng.n)
+  with pytest.raises(ValueError):
+    eng.solve_x0(np.zeros((2, eng.ns + 1)), g, g, g, g)
+  with pytest.raises(ValueError):
+    eng.solve_x0(np.zeros((2, eng.ns)), g[:-1], g, g, g)
+  rc = eng.lib.myr_solve_x0(eng._h, 2, None, None, None, None, None, None, 0, None, None, None, None, None, None, None, _lib.MEM_HOST)
+  assert rc != 0 and b"myr_solve_x0" in eng.lib.myr_last_error()

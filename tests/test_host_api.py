@@ -376,6 +376,12 @@ class _ShardEngine:
     return {"z": z0 + 1.0, "lam": np.zeros((B, 2)), "cost": z0[:, 0] * 10.0, "status": np.zeros(B, np.int32),
             "iters": np.full(B, self.tag, np.int32), "kkt": np.zeros((B, 3))}
 
+  def solve_x0(self, x0s, g0, g1, lb, ub, params=None, opts=None):
+    """myr_solve_x0's shape: start states + templates (only the first point matters to this stand-in)."""
+    x0s = np.asarray(x0s); B, ns = x0s.shape
+    z0 = np.tile(np.asarray(g0), (B, 1)); z0[:, :ns] = x0s
+    return self.solve(z0, np.broadcast_to(lb, z0.shape), np.broadcast_to(ub, z0.shape), params=params, opts=opts)
+
 
 def test_fan_out_shards_a_batch_over_engines_in_order():
   """batched.fan_out_solve: contiguous shards, one thread per engine, results concatenated in instance order, per-instance
@@ -429,3 +435,53 @@ def test_solve_batch_fans_out_beneath_the_unchanged_api(monkeypatch):
   e0.calls.clear(); e1.calls.clear()
   opt.solve_batch(x0s=x0s)
   assert len(e0.calls) == 1 and e0.calls[0][0].shape[0] == B and not e1.calls
+
+
+def test_x0_form_takes_the_device_expansion_and_expands_only_failed_instances_on_the_host(monkeypatch):
+  """solve_batch without an explicit guess hands start states + the guess rule to the engine (myr_solve_x0: no [B][n] arrays on
+  the host); the instances that fail are expanded on the host -- bit for bit batch_inputs' arrays -- for the second starts.
+  MYRIAD_SOLVE_X0=0 and an explicit guess keep the array path."""
+  from myriad_amd.config import Config, HParams, IntegrationMethod, OptimizerType, QuadratureRule
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  hp = HParams(system=SystemType.PENDULUM, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
+               integration_method=IntegrationMethod.HEUN, intervals=6)
+  opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+  monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  x0_calls = []
+
+  class Eng(_SecondStartEngine):
+    def solve_x0(self, x0s, g0, g1, lb, ub, params=None, opts=None):
+      x0_calls.append((np.array(x0s), np.array(g0), np.array(g1), np.array(lb), np.array(ub)))
+      B = x0s.shape[0]
+      st = np.zeros(B, np.int32); st[1] = 1                       # instance 1 fails the first attempt
+      return {"z": np.zeros((B, g0.size)), "lam": np.zeros((B, 1)), "cost": np.ones(B), "status": st,
+              "iters": np.full(B, 10, np.int32), "kkt": np.zeros((B, 3))}
+
+    def default_opts(self):
+      class O: max_iter = 0
+      return O()
+
+  eng = Eng(); eng.rows_u = opt._u_shape[0]
+  opt._engine = eng
+  rng = np.random.default_rng(0)
+  x0s = opt.system.x_0[None] + 0.1 * rng.standard_normal((3, 2))
+  res = opt.solve_batch(x0s=x0s)
+  assert len(x0_calls) == 1 and np.array_equal(x0_calls[0][0], x0s)
+  z0, lb, ub = opt.batch_inputs(x0s, None)
+  g0, g1 = x0_calls[0][1], x0_calls[0][2]
+  rows, ns = opt._x_shape
+  ze = np.tile(g0, (3, 1)); ze[:, :rows * ns] += np.tile(x0s, (1, rows)) * g1[None, :rows * ns]
+  assert np.array_equal(ze, z0)                                    # the rule reproduces the reference guess bit for bit
+  assert np.array_equal(x0_calls[0][3], opt.bounds[:, 0]) and np.array_equal(x0_calls[0][4], opt.bounds[:, 1])
+  assert len(eng.calls) == 1 and eng.calls[0].shape[0] == 1        # one second start, for the failed instance only
+  assert np.array_equal(eng.calls[0][:, :ns], x0s[[1]])            # ... expanded from ITS start state
+  assert list(res["status"]) == [0, 0, 0] and list(res["start"]) == [0, 2, 0] and list(res["attempts"]) == [1, 2, 1]
+  monkeypatch.setenv("MYRIAD_SOLVE_X0", "0")
+  x0_calls.clear(); eng.calls.clear()
+  opt.solve_batch(x0s=x0s)
+  assert len(x0_calls) == 0 and np.array_equal(eng.calls[0], z0)   # the array path, same inputs
+  monkeypatch.delenv("MYRIAD_SOLVE_X0")
+  eng.calls.clear()
+  opt.solve_batch(x0s=x0s, guess=z0[0])
+  assert len(x0_calls) == 0 and len(eng.calls) == 1                # an explicit guess: arrays, no second start
