@@ -21,6 +21,13 @@ def _blocks():
   return stub[0], fbsm[0]
 
 
+def _starts_block():
+  txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+  blk = [b for b in re.findall(r"```python\n(.*?)```", txt, re.S) if "def hip_starts" in b]
+  assert len(blk) == 1
+  return blk[0]
+
+
 def _header_arity():
   hdr = open(os.path.join(ROOT, "include", "myriad_hip.h")).read()
   hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
@@ -55,8 +62,11 @@ def test_integration_stubs_compile_and_match_the_header():
   stub, fbsm = _blocks()
   compile(stub, "INTEGRATION.md:hip_sqp", "exec")
   compile(fbsm, "INTEGRATION.md:hip_fbsm", "exec")
+  starts = _starts_block()
+  compile(starts, "INTEGRATION.md:hip_starts", "exec")
   arity = _header_arity()
-  calls = _call_arity(stub) + _call_arity(fbsm)
+  calls = _call_arity(stub) + _call_arity(fbsm) + _call_arity(starts)
+  assert "myr_solve_x0" in {c for c, _ in calls}
   assert {"myr_create", "myr_solve", "myr_fbsm", "myr_destroy", "myr_get_dims", "myr_last_error"} <= {c for c, _ in calls}
   for name, n in calls:
     assert name in arity, f"{name} is not declared in include/myriad_hip.h"
@@ -70,6 +80,7 @@ def _namespace(monkeypatch):
   ns = {}
   exec(compile(stub, "INTEGRATION.md:hip_sqp", "exec"), ns)
   exec(compile(fbsm, "INTEGRATION.md:hip_fbsm", "exec"), ns)
+  exec(compile(_starts_block(), "INTEGRATION.md:hip_starts", "exec"), ns)
   return ns
 
 
@@ -113,3 +124,25 @@ def test_hip_fbsm_stub_matches_the_mirror(monkeypatch):
   xs, us, adjs, sweeps = ns["hip_fbsm"]("CANCERTREATMENT", s.T, 200, s.x_0, lo, hi, params=s.device_params(), adj_T=s.adj_T, bang=bang)
   assert int(sweeps[0]) == int(ref["sweeps"][0])
   np.testing.assert_array_equal(xs, ref["x"]); np.testing.assert_array_equal(us, ref["u"]); np.testing.assert_array_equal(adjs, ref["adj"])
+
+
+@pytest.mark.gpu
+def test_hip_starts_stub_matches_solve_batch(monkeypatch):
+  """The myr_solve_x0 binding of INTEGRATION.md as written: B start states of CARTPOLE (x_T given: linspace rule) and VANDERPOL (no
+  x_T: constant guess) against the package's solve_batch -- identical to the bit."""
+  from myriad_amd.config import Config, HParams, IntegrationMethod, NLPSolverType, OptimizerType, QuadratureRule
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  ns = _namespace(monkeypatch)
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  rng = np.random.default_rng(3)
+  for st in (SystemType.CARTPOLE, SystemType.VANDERPOL):
+    hp = HParams(system=st, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
+                 integration_method=IntegrationMethod.RK4, intervals=12, nlpsolver=NLPSolverType.SQP)
+    opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+    x0s = opt.system.x_0[None] + 0.05 * rng.standard_normal((7, opt.system.x_0.shape[0]))
+    ref = opt.solve_batch(x0s=x0s)
+    sol = ns["hip_starts"](hp, opt._opt_inputs(), x0s)
+    assert sol["success"].all()
+    np.testing.assert_array_equal(sol["x"], ref["xs_and_us"]); np.testing.assert_array_equal(sol["v"], ref["lambda"])
+    np.testing.assert_array_equal(sol["fun"], ref["cost"]); np.testing.assert_array_equal(sol["nit"], ref["iters"])
