@@ -66,7 +66,7 @@ def test_node_batch_config5_shape():
   hp, node, opt = _setup(100)
   x0 = O.random_x0(O.CartPole(), 128, seed=2019)
   res = opt.solve_batch(x0s=x0, params=opt.system.device_params())
-  assert (res['status'] == 0).mean() >= 0.98, np.bincount(res['status'])
+  assert (res['status'] == 0).all(), np.bincount(res['status'])          # every instance (round 2 tolerated 2 %)
   ev = opt.engine.eval(res['xs_and_us'], params=opt.system.device_params(), want=("c",))
   assert np.abs(ev["c"][res['status'] == 0]).max() <= 1e-8
 
