@@ -966,7 +966,9 @@ struct HsWave {
     const long m_step = m_on ? SG_N : 0;
     const bool h_on = isP || (isC && cc < 2);   // H_e column | g0 | g1 of the end point (point 2k+2 for stage k)
     const double* h_ptr = h_on ? c.hr + (isP ? HR_H + lane * NW : (cc == 1 ? HR_G1 : HR_G0)) : c.zr;
-    const long h_step = h_on ? 2 * HR_N : 0;
+    // the end point of stage k is point 2k + 2 (Hermite-Simpson: knots at the even points) or k + 1 (trapezoidal: K = N + 1 points)
+    constexpr long H_PTS = TRAP ? 1 : 2;
+    const long h_step = h_on ? H_PTS * HR_N : 0;
     const int v_col = isY ? lane : NY;          // own column of Ge^ (Q lanes), ge^ (gradient column), none otherwise
     const double v_on = (isY || cc == 0) ? 1.0 : 0.0;
     const double c_on = isC ? 1.0 : 0.0;
@@ -986,7 +988,7 @@ struct HsWave {
     double m_pre[NY], h_pre[NW], g_pre[NGL];
     {
       const double* mp = m_ptr + (long)(N - 1) * m_step;
-      const double* hp = h_ptr + (long)(N - 1) * h_step + (h_on ? 2 * HR_N : 0);
+      const double* hp = h_ptr + (long)(N - 1) * h_step + (h_on ? H_PTS * HR_N : 0);
       const double* st = c.st + (long)(N - 1) * SG_N;
 #pragma unroll
       for (int r = 0; r < NY; ++r) m_pre[r] = mp[r * m_str];
@@ -1010,7 +1012,7 @@ struct HsWave {
       for (int t = 0; t < NGL; ++t) { const int e = lane + 64 * t; if (e < NGE) c.sGe[e] = g_pre[t]; }
       if (k > 0) {       // prefetch the next stage while this one is processed
         const double* mp = m_ptr + (long)(k - 1) * m_step;
-        const double* hp = h_ptr + (long)(k - 1) * h_step + (h_on ? 2 * HR_N : 0);
+        const double* hp = h_ptr + (long)(k - 1) * h_step + (h_on ? H_PTS * HR_N : 0);
         const double* st = c.st + (long)(k - 1) * SG_N;
 #pragma unroll
         for (int r = 0; r < NY; ++r) m_pre[r] = mp[r * m_str];

@@ -502,11 +502,12 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     if (h->solve_mode == 1 && h->solve_fused && HsFused<Sys, (NodeTraits<Sys>::mlp ? 4 : 1), SCHEME>::lds_bytes(N) <= 160 * 1024)
       return launch_hs_fused<Sys, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
-  // (Trapezoidal scheme with more than one control or more than four states: the wavefront kernel's general sweep does not converge
-  // there -- BEARPOPULATIONS ends in NaN after 186 iterations where the lane form needs 14 (tools/dev/trap_probe.py); until that is
-  // understood those systems take the lane form.  Its matrix-core sweep, one control and up to four states, is the tested one.)
-  constexpr bool wave_ok = !(SCHEME == 1 && !(Sys::NU == 1 && Sys::NS <= 4));
-  if constexpr (wave_ok)
+  // (Round 3 kept the trapezoidal scheme with more than one control or more than four states off the wavefront kernel: its general
+  // sweep read the end point's Hessian record at the Hermite-Simpson stride -- point 2k + 2 instead of k + 1 -- and BEARPOPULATIONS
+  // ended in NaN.  Fixed in HsWave::riccati (H_PTS); MYRIAD_TRAP_GENERAL_WAVE=0 sends those systems to the lane form again.)
+  static const bool trap_general_wave = [] { const char* e = getenv("MYRIAD_TRAP_GENERAL_WAVE"); return !(e && atoi(e) == 0); }();
+  const bool wave_ok = !(SCHEME == 1 && !(Sys::NU == 1 && Sys::NS <= 4)) || trap_general_wave;
+  if (wave_ok)
   if (h->solve_mode == 1 && HsWave<Sys, SCHEME>::lds_bytes(N) <= 160 * 1024) {
     using W = HsWave<Sys, SCHEME>;
     // wavefronts per workgroup: 1, except network systems -- independent solves that share the 40 KB of weights in LDS, four to a
