@@ -17,7 +17,10 @@ Prints ONE JSON line on rank 0 (see the task contract), including
                   HIP-event duration measured on the library's own stream inside the timed region;
   cpu_baseline -- the oracle's SciPy SLSQP path (the reference's NLPSolverType.SLSQP branch on restated callbacks)
                   timed on this box's host cores: one FULL converged solve at N=25 (measured) and a time-bounded sample
-                  of the N=100 solve (iteration rate measured, solve rate extrapolated -- labelled so).
+                  of the N=100 solve (iteration rate measured, solve rate extrapolated -- labelled so);
+  other_configs -- (N = 1, after the timed region, not part of `value`) the other BASELINE configs on one GPU and the headline
+                  workload through the host-buffer API solve_batch (numpy in, numpy out: the PCIe-inclusive rate),
+                  tools/bench_configs.py; --no-other-configs skips them.
 """
 import argparse
 import json

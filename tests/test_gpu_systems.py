@@ -319,7 +319,7 @@ def test_pendulum_needs_and_gets_a_second_start(monkeypatch):
 def test_trapezoidal_solve_is_a_kkt_point_of_the_oracle_problem(sysname):
   """The trapezoidal solver on a system with two controls (BEARPOPULATIONS) and on two with one: feasibility, cost and
   stationarity against the oracle's callbacks.  (Regression: the wavefront kernel's general sweep produced NaN for
-  BEARPOPULATIONS; systems outside its matrix-core form -- more than one control or four states -- take the lane kernel.)"""
+  BEARPOPULATIONS -- it addressed the Hessian records at the Hermite-Simpson stride; fixed, see the agreement test below.)"""
   hp = HParams(system=SystemType[sysname], optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.TRAPEZOIDAL,
                intervals=30, nlpsolver=NLPSolverType.SQP)
   O, s, tr, cb = _oracle(sysname, "COLLOCATION", hp)
@@ -335,6 +335,28 @@ def test_trapezoidal_solve_is_a_kkt_point_of_the_oracle_problem(sysname):
   inact = (lb < ub) & (z - lb > 1e-3 * width) & (ub - z > 1e-3 * width)
   sd = max(1.0, np.abs(lam).mean() / 100.0)
   assert np.abs(rr[inact]).max() < 1e-4 * sd * max(1.0, np.abs(cb.grad(z)).max())
+
+
+@pytest.mark.parametrize("sysname", ["BEARPOPULATIONS"])      # (the other closed-form system outside the matrix-core form, ROCKETLANDING, has no optimum to agree on; PENDULUM's elastic twin, three controls, is covered by the swing-up test below)
+def test_trapezoidal_general_sweep_agrees_with_the_lane_kernel(sysname, monkeypatch):
+  """A system outside the matrix-core sweep (BEARPOPULATIONS: two controls) under the trapezoidal scheme on
+  the wavefront kernel's GENERAL sweep -- which read the end point's Hessian record at the Hermite-Simpson stride (point 2k + 2
+  instead of k + 1) until round 3 and ended in NaN -- against the lane kernel: same status, same iteration count, same optimum."""
+  hp = HParams(system=SystemType[sysname], optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.TRAPEZOIDAL,
+               intervals=30, nlpsolver=NLPSolverType.SQP)
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  s0 = hp.system()
+  rng = np.random.default_rng(1)
+  x0s = s0.x_0[None] * (1.0 + 0.02 * rng.standard_normal((5, s0.x_0.shape[0])))
+  res = {}
+  for mode in ("wave", "lane"):
+    monkeypatch.setenv("MYRIAD_SOLVE_MODE", mode)
+    res[mode] = get_optimizer(hp, CFG, hp.system()).solve_batch(x0s=x0s)
+  w, l = res["wave"], res["lane"]
+  assert (w["status"] == 0).all() and (l["status"] == 0).all(), (w["status"], w["iters"], l["status"], l["iters"])
+  assert np.array_equal(w["iters"], l["iters"])
+  np.testing.assert_allclose(w["cost"], l["cost"], rtol=1e-9)
+  np.testing.assert_allclose(w["xs_and_us"], l["xs_and_us"], rtol=1e-6, atol=1e-8)
 
 
 @pytest.mark.parametrize("kw", [
