@@ -359,6 +359,23 @@ def test_trapezoidal_general_sweep_agrees_with_the_lane_kernel(sysname, monkeypa
   np.testing.assert_allclose(w["xs_and_us"], l["xs_and_us"], rtol=1e-6, atol=1e-8)
 
 
+def test_small_batches_take_the_one_wavefront_kernel(monkeypatch):
+  """Cases on which the two-wavefront fused kernel (W = 2, round 3's small-batch mode) went wrong -- tools/dev/w2_probe.py:
+  MOULDFUNGICIDE N = 100 stalled at cost 560, N = 6 ended in NaN; the first of three CANCERTREATMENT instances at N = 100 stalled at
+  17.1 -- solve by default (W = 1 for every batch size since then; MYRIAD_FUSED_WAVES=2 is a development switch)."""
+  monkeypatch.delenv("MYRIAD_FUSED_WAVES", raising=False)
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  for name, N, B, cost in (("MOULDFUNGICIDE", 100, 1, 85.35321226), ("MOULDFUNGICIDE", 6, 1, 85.47233574), ("CANCERTREATMENT", 100, 3, 20.57331484)):
+    hp = HParams(system=SystemType[name], optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
+                 intervals=N, nlpsolver=NLPSolverType.SQP)
+    opt = get_optimizer(hp, CFG, hp.system())
+    x0 = np.tile(opt.system.x_0, (B, 1)) * (1.0 + 0.01 * np.arange(B)[:, None])
+    r = opt.solve_batch(x0s=x0, max_iter=300)
+    assert (r["status"] == 0).all(), (name, N, r["status"], r["iters"], r["cost"])
+    assert r["cost"][0] == pytest.approx(cost, rel=1e-8)
+    assert np.abs(opt.constraints(r["xs_and_us"][0])).max() <= 1e-8
+
+
 def test_rocketlanding_wave_and_lane_kernels_take_the_same_iterations(monkeypatch):
   """ROCKETLANDING (six states, two controls: the only closed-form system with more than four states) has no optimum to compare --
   no solver reaches feasibility -- but the wavefront kernel's general sweep and the lane kernel must walk the same path: after a
