@@ -106,6 +106,9 @@ struct HsFused {
 #ifdef MYR_PHASE_TIMING
     long long tph[16], t0;
 #endif
+#ifdef MYR_TRACE
+    int traj;
+#endif
   };
   __device__ static inline long zi(const Ctx& c, int j, int comp) { return S::zi(c.K, j, comp); }
   // point the sweep outputs (gains, P | pc | Tnu | Ku exchange) of a context at one of the two sets
@@ -1419,6 +1422,11 @@ struct HsFused {
         }
       }
       delta_last = (delta > lm) ? delta : 0.0;
+#ifdef MYR_TRACE
+      if (c.lane == 0 && c.traj < MYR_TRACE)
+        printf("T b%d w%d it%d f=%.17g c1=%.17g cinf=%.17g stat=%.17g sm=%.17g lg=%.17g nreg=%d delta=%.9g mu=%.9g pen=%.9g\n", c.traj, c.wave, it,
+               p1.f, p1.c1, p1.cinf, stat_raw, p1.sum_mult, p1.lg, nreg, delta, mu, pen);
+#endif
       const int nm = MLAM * c.N * NS + p1.nm;
       const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
       const double stat = stat_raw / sd, comp = p1.cmax / sd;
@@ -1483,6 +1491,10 @@ struct HsFused {
         if (++stall > 5) { res.status = 3; res.iters = it; return; }
       } else stall = 0;
       MYR_PH(11)
+#ifdef MYR_TRACE
+      if (c.lane == 0 && c.traj < MYR_TRACE)
+        printf("S b%d w%d it%d ap=%.17g ad=%.17g gphi=%.17g a=%.17g ok=%d nu0=%.17g\n", c.traj, c.wave, it, fo.alpha_p, fo.alpha_d, fo.gphi, a, (int)ok, nu[0]);
+#endif
       pending.on = true; pending.ap = a; pending.ad = o.dual_follow ? fo.alpha_d * (a / fo.alpha_p) : fo.alpha_d; pending.mu = mu;
 #pragma unroll
       for (int i = 0; i < NS; ++i) nuT[i] += a * (nu[i] - nuT[i]);
@@ -1508,7 +1520,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1)
 void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                            const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                            const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
-                           int32_t* iters, double* kkt) {
+                           int32_t* iters, double* kkt, unsigned long long poison) {
   using W = HsFused<Sys, NWAVES, SCHEME>;
   extern __shared__ __attribute__((aligned(16))) char smem_fused[];
   typename W::Ctx c;
@@ -1552,6 +1564,21 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     double* zg = z + b * (long)c.n;
     c.lb = lb + b * (long)c.n; c.ub = ub + b * (long)c.n;
     double* lamg = lam ? lam + b * (long)(W::MLAM * c.N * W::NS) : lam_own;
+    if (poison) {
+      // MYRIAD_POISON (tests/test_gpu_poison.py): everything a trajectory inherits from its predecessor in this slot -- the solver's
+      // LDS and the slot's global scratch -- is overwritten with one bit pattern (a signalling NaN, or plain garbage).  A solve
+      // whose result depends on the pattern reads something before it writes it.
+      const double pv = __longlong_as_double((long long)poison);
+      __syncthreads();           // (every wavefront has read the ticket from sMisc)
+      double* l0 = reinterpret_cast<double*>(smem_fused);
+      const int nl = W::lds_solver_doubles(c.N) + (W::MLP ? c.K * W::NS : 0);
+      for (int i = c.tid; i < nl; i += W::NT) l0[i] = pv;
+      for (long i = c.tid; i < scratch_stride; i += W::NT) s[i] = pv;
+      __syncthreads();
+    }
+#ifdef MYR_TRACE
+    c.traj = (int)b;
+#endif
     c.pp.load(params, b, params_stride);
     c.pp.set_scale(vs.s);
     if constexpr (W::MLP) {      // a weight set per trajectory

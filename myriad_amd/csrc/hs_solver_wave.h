@@ -1978,7 +1978,7 @@ __global__ __launch_bounds__((64 * HsWave<Sys, SCHEME>::WPB_MAX), MYR_WAVE_MIN_W
 void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                           const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                           const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
-                          int32_t* iters, double* kkt, int coop) {
+                          int32_t* iters, double* kkt, int coop, unsigned long long poison) {
   using W = HsWave<Sys, SCHEME>;
   extern __shared__ __attribute__((aligned(16))) char smem_wave[];
   typename W::Ctx c;
@@ -2027,6 +2027,14 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
     if (b >= B) break;
     c.z = z + b * (long)c.n; c.lb = lb + b * (long)c.n; c.ub = ub + b * (long)c.n;
     c.lam = lam ? lam + b * (long)(W::MLAM * c.N * W::NS) : lam_own;
+    if (poison) {      // MYRIAD_POISON (tests/test_gpu_poison.py): what this wavefront inherits from its previous trajectory -- its LDS, its scratch slot
+      const double pv = __longlong_as_double((long long)poison);
+      double* l0 = reinterpret_cast<double*>(smem_wave) + (long)wave * W::lds_solver_doubles(c.N);
+      for (int i = c.lane; i < W::lds_solver_doubles(c.N); i += 64) l0[i] = pv;
+      double* s0 = scratch + ((long)blockIdx.x * waves + wave) * scratch_stride;
+      for (long i = c.lane; i < scratch_stride; i += 64) s0[i] = pv;
+      W::wsync();
+    }
     c.pp.load(params, b, params_stride);
     c.pp.set_scale(vs.s);
     if constexpr (W::MLP) {      // per-trajectory weights (launched with one wavefront per workgroup): loaded per trajectory

@@ -92,6 +92,7 @@ struct myr_handle_s {
   std::map<std::tuple<const void*, int, size_t>, int> occ;   // kernel_slots(): workgroups per CU of (kernel, block size, dynamic LDS)
   size_t eval_attr_lds[6] = {0, 0, 0, 0, 0, 0};   // dynamic-LDS attribute already set for the eval kernel variants (W = 1 / 4 / 8, nt)
   int fused_waves = 0;        // MYRIAD_FUSED_WAVES: wavefronts per trajectory (0 = by batch size)
+  unsigned long long poison = 0;   // MYRIAD_POISON: bit pattern written over a slot's LDS and scratch at every trajectory hand-over (tests)
   int cus = 0;                // compute units of the device (cached)
   // variable scaling of the solve path (myr_set_var_scale): the solver kernels see z/s, lb/s, ub/s
   VarScale vscale{{1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}};
@@ -465,7 +466,7 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   KTimer& kt = h->kt[MYR_K_SOLVE];
   HIPCHK(hipEventRecord(kt.a, h->stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
-                     params, pstride, cost, status, iters, kkt);
+                     params, pstride, cost, status, iters, kkt, h->poison);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -565,7 +566,7 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     KTimer& kt = h->kt[MYR_K_SOLVE];
     HIPCHK(hipEventRecord(kt.a, h->stream));
     hipLaunchKernelGGL(kern, dim3((unsigned)(slots / lwaves)), dim3(64 * wpb), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
-                       params, pstride, cost, status, iters, kkt, coop);
+                       params, pstride, cost, status, iters, kkt, coop, h->poison);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(kt.b, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -671,7 +672,7 @@ static int launch_shoot_solve(myr_handle h, int B, double* z, const double* lb, 
   KTimer& kt = h->kt[MYR_K_SOLVE];
   HIPCHK(hipEventRecord(kt.a, h->stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, params, pstride,
-                     cost, status, iters, kkt);
+                     cost, status, iters, kkt, h->poison);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -861,6 +862,11 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
   if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
   if (const char* e = getenv("MYRIAD_FUSED_WAVES")) h->fused_waves = atoi(e);     // developer knob: wavefronts per trajectory of the fused kernel
   if (const char* e = getenv("MYRIAD_SOLVE_SLOTS")) h->solve_slots = atoi(e);   // developer knob: resident wavefronts of the solve kernel
+  if (const char* e = getenv("MYRIAD_POISON")) {      // test knob: "nan" (signalling NaN), "big", or a 64-bit pattern in hex
+    if (strcmp(e, "nan") == 0) h->poison = 0x7ff4dead0000beefULL;
+    else if (strcmp(e, "big") == 0) h->poison = 0x4415af1d78b58c40ULL;      // 1e20
+    else h->poison = strtoull(e, nullptr, 16);
+  }
   *out = h;
   return MYR_OK;
 }

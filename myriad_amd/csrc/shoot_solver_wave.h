@@ -784,7 +784,7 @@ template <class Sys, int M = 1>
 __global__ __launch_bounds__(64, MYR_SHOOT_MIN_WAVES)
 void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                              const double* __restrict__ ub, double* __restrict__ lam, const double* __restrict__ params, int params_stride,
-                             double* cost, int32_t* status, int32_t* iters, double* kkt) {
+                             double* cost, int32_t* status, int32_t* iters, double* kkt, unsigned long long poison) {
   using W = ShootWave<Sys, M>;
   const typename W::Lds l = W::lds(o);
   const int n = W::nvars(o), m = o.N * W::NS;
@@ -793,6 +793,14 @@ void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, dou
     if (threadIdx.x == 0) t = atomicAdd(ticket, 1);
     const long b = __builtin_amdgcn_readfirstlane(t);
     if (b >= B) break;
+    if (poison) {      // MYRIAD_POISON (tests/test_gpu_poison.py): the whole LDS of the workgroup, which is all a trajectory inherits here
+      extern __shared__ __attribute__((aligned(16))) char smem_poison[];
+      const double pv = __longlong_as_double((long long)poison);
+      double* l0 = reinterpret_cast<double*>(smem_poison);
+      const int nl = (int)(W::lds_bytes(o.N, o.cpi) / 8);
+      for (int i = threadIdx.x; i < nl; i += 64) l0[i] = pv;
+      __syncthreads();
+    }
     for (int i = threadIdx.x; i < n; i += 64) { const double v = z[b * n + i]; l.z[i] = v; l.z0[i] = v; l.lb[i] = lb[b * n + i]; l.ub[i] = ub[b * n + i]; }
     if (threadIdx.x == 0) { l.ex[W::X_Z] = 0.0; l.ex[W::X_DN] = (double)o.N; l.ex[W::X_DCPI] = (double)o.cpi; l.ex[W::X_TA] = -1.0; }
     SysParams<Sys> pp;
@@ -825,7 +833,9 @@ void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, dou
       for (int i = threadIdx.x; i < n; i += 64) l.z[i] = l.z0[i];
       __syncthreads();
       HsSolveOpts o2 = o;
-      o2.mu_init = o.mu_init * ((attempt & 1) == 0 ? 3.0 : 1.0 / 3.0);
+      // a different initial barrier parameter per attempt: x 3, / 3, x 9, / 9 (a repeated factor would repeat the failed solve)
+      const double fac = (attempt >> 1) == 0 ? 3.0 : 9.0;
+      o2.mu_init = o.mu_init * ((attempt & 1) == 0 ? fac : 1.0 / fac);
       HsSolveResult r2;
       IpLoop<W>::run(w, o2, pp.get(), r2);
       __syncthreads();
