@@ -5,7 +5,8 @@ CARTPOLE Hermite-Simpson collocation, 100 intervals, B = 4096 random x0 per GPU 
 One "step" = one pass of the hot path over one batch:
    z0 -> [myr_solve: batched SQP on device] -> z*, lambda*, cost, status
       -> [myr_eval : hs_eval kernel on z*]   -> c(z*), J blocks, grad f   (independent convergence verification)
-      -> (N > 1) RCCL gather of z*, cost, status to rank 0 (the path's only collective).
+      -> (N > 1) RCCL gather of z*, cost, status to rank 0 (the path's only collective)
+      -> download of z*, cost, status into pinned host buffers on rank 0 (side stream; SURVEY.md 8(d): "gathered on host rank 0").
 Inputs are resident in HBM before the timed region.  Multi-GPU: independent instances are sharded across ranks, one
 process per GPU.  `--scaling weak` (default): --batch instances PER GPU; `--scaling strong`: --batch instances in
 total, split by myriad_amd.batched.shard_range (4096 -> 512 per GPU at 8 GPUs).
@@ -100,27 +101,39 @@ def cpu_baseline(N, budget_s):
   dt, nit, done, _ = timed_solve(N, budget_s)
   its_per_s = nit / dt
   full_its, measured = 110, None
-  for rnd in ("r03",):                       # a whole solve measured on a GPU-box host by `bench.py --cpu-full` (committed)
+  for rnd in ("r04", "r03"):                 # a whole solve measured on a GPU-box host by `bench.py --cpu-full` (committed)
     fp = os.path.join(ROOT, "profiles", rnd, "cpu_baseline_full.json")
     if N == 100 and os.path.exists(fp):
       try:
         m = json.load(open(fp))["slsqp_full_solve"]
         full_its = int(m["iterations"])
         measured = {"file": os.path.relpath(fp, ROOT), "seconds": m["seconds"], "iterations": m["iterations"], "value": m["value"],
+                    "host_cores": json.load(open(fp)).get("host_cores"),
                     "trust_constr": json.load(open(fp)).get("trust_constr_subsample", {}).get("value")}
+        break
       except Exception:
         pass
-  value = (1.0 / dt) if done else its_per_s / full_its
+  # value: a WHOLE measured solve -- this run's own when the sample ran to convergence, else the committed whole solve of the same
+  # problem on a host of this pool (`measured_full_solve.file`); the bounded sample of this run is the cross-check beside it
+  # (`sample_its_per_s`, `sample_value_extrapolated`: the first iterations of SLSQP are its slowest, so the extrapolation reads low)
+  if done:
+    value, src = 1.0 / dt, "this run"
+  elif measured:
+    value, src = float(measured["value"]), measured["file"]
+  else:
+    value, src = its_per_s / full_its, "extrapolated from this run's sample"
   return {"value": value, "unit": "solves/s", "cores": 1, "torch_threads": int(torch.get_num_threads()),
-          "host_cores": os.cpu_count() or 1, "kind": "port", "extrapolated": (not done), "measured_full_solve": measured,
+          "host_cores": os.cpu_count() or 1, "kind": "port", "extrapolated": (not done and not measured), "value_from": src,
+          "sample_its_per_s": its_per_s, "sample_value_extrapolated": its_per_s / full_its, "measured_full_solve": measured,
           "full_solve": {"workload": "CARTPOLE HS N=25, default x0, SLSQP to its default tolerance", "seconds": dt25,
                          "iterations": it25, "converged": bool(ok25), "cost": cost25, "value": 1.0 / dt25, "unit": "solves/s"},
           "sample": f"oracle SciPy-SLSQP path (serial Fortran SLSQP + torch-autodiff callbacks), CARTPOLE HS N={N} instance 0 "
                     f"(default x0): {nit} SLSQP iterations in {dt:.1f} s ({its_per_s:.3f} it/s)" +
                     ("; ran to convergence" if done else
                      f"; a converged solve needs {full_its} iterations at the reference's default tolerance (" +
-                     (f"measured: {measured['file']}, {measured['seconds']:.0f} s on a GPU-box host" if measured else "BASELINE.md: 546 s measured for the reference") +
-                     f"), so value = this run's it/s / {full_its}; whole measured solves: `measured_full_solve` (N=100) and `full_solve` (N=25)")}
+                     (f"measured: {measured['file']}, {measured['seconds']:.0f} s = {measured['value']:.5f} solves/s on a {measured['host_cores']}-core GPU-box host: that is `value`; "
+                      f"this run's sample extrapolates to {its_per_s / full_its:.5f}" if measured else "BASELINE.md: 546 s measured for the reference; value = this run's it/s / 110") +
+                     "); whole measured solves: `measured_full_solve` (N=100) and `full_solve` (N=25)")}
 
 
 def cpu_full(N, out_path, trust_budget_s=600.0):
@@ -275,9 +288,22 @@ def run(a, rank, world, dev, make_engine):
   f64 = dict(dtype=torch.float64, device=dev)
   z0 = torch.from_numpy(np.ascontiguousarray(z0h)).to(dev); lb = torch.from_numpy(np.ascontiguousarray(lbh)).to(dev)
   ub = torch.from_numpy(np.ascontiguousarray(ubh)).to(dev)
-  z = torch.empty_like(z0)
-  lam = torch.empty(B, eng.m, **f64); cost = torch.empty(B, **f64); kkt = torch.empty(B, 3, **f64)
-  status = torch.empty(B, dtype=torch.int32, device=dev); iters = torch.empty(B, dtype=torch.int32, device=dev)
+  # two sets of result buffers: the download of step k's solutions (side stream) overlaps step k + 1's solve
+  zs = [torch.empty_like(z0) for _ in range(2)]
+  costs = [torch.empty(B, **f64) for _ in range(2)]
+  stats = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(2)]
+  lam = torch.empty(B, eng.m, **f64); kkt = torch.empty(B, 3, **f64)
+  iters = torch.empty(B, dtype=torch.int32, device=dev)
+  # the metric ends with "all z* / status gathered on HOST rank 0" -- pinned host buffers on rank 0, filled inside the step
+  host, d2h_done, copy_stream = None, [None, None], None
+  if rank == 0:
+    def _pin(t):
+      return t.pin_memory() if cuda else t
+    host = [{"z": _pin(torch.empty(total, z0.shape[1], dtype=torch.float64)), "cost": _pin(torch.empty(total, dtype=torch.float64)),
+             "status": _pin(torch.empty(total, dtype=torch.int32))} for _ in range(2)]
+    if cuda:
+      copy_stream = torch.cuda.Stream(device=dev)
+  d2h_bytes = total * (z0.shape[1] * 8 + 8 + 4)
   fv = torch.empty(B, **f64); gv = torch.empty(B, eng.ngrad, **f64); cv = torch.empty(B, eng.m, **f64)
   jv = torch.empty(B, eng.jblk, **f64)
 
@@ -285,7 +311,13 @@ def run(a, rank, world, dev, make_engine):
     if cuda:
       torch.cuda.synchronize()
 
-  def step():
+  nstep = [0]
+
+  def step(download=True):
+    cur = nstep[0] & 1; nstep[0] += 1
+    z, cost, status = zs[cur], costs[cur], stats[cur]
+    if cuda and d2h_done[cur] is not None:
+      torch.cuda.current_stream().wait_event(d2h_done[cur])   # this set's previous download (two steps ago) has left the device
     z.copy_(z0)
     if cuda:
       torch.cuda.current_stream().synchronize()            # library runs on its own stream
@@ -293,10 +325,23 @@ def run(a, rank, world, dev, make_engine):
     eng.eval(B, z, fv, gv, cv, jv)                           # verification pass (also the roofline kernel)
     feas = cv.abs().amax(dim=1)
     ok = (status == 0) & (feas <= 1e-8)
+    res = {"z": z, "cost": cost, "status": status}
     if world > 1:   # the path's only collective: final gather of the solutions to rank 0 over RCCL/xGMI
-      gathered = gather_solutions({"z": z, "cost": cost, "status": status}, counts, dst=0)
+      res = gather_solutions(res, counts, dst=0)
       if rank == 0:
-        assert gathered["z"].shape[0] == total
+        assert res["z"].shape[0] == total
+    if rank == 0 and download:      # ... and down to the host: pinned buffers, on a side stream
+      if cuda:
+        ready = torch.cuda.Event(); ready.record()
+        with torch.cuda.stream(copy_stream):
+          copy_stream.wait_event(ready)
+          for k, t in res.items():
+            host[cur][k].copy_(t, non_blocking=True)
+            t.record_stream(copy_stream)
+          d2h_done[cur] = torch.cuda.Event(); d2h_done[cur].record(copy_stream)
+      else:
+        for k, t in res.items():
+          host[cur][k].copy_(t)
     return ok
 
   def fence():
@@ -321,14 +366,26 @@ def run(a, rank, world, dev, make_engine):
     print("per-step ms:", " ".join("%.1f" % (1e3 * t) for t in trace), file=sys.stderr)
   fence()
   dt = time.perf_counter() - t0
-  tt = torch.tensor([dt, float(nconv)], **f64)
+  # cross-check of the download: the last step's solutions are on the host (status of every instance, z* finite)
+  if rank == 0:
+    last = host[(nstep[0] - 1) & 1]
+    assert bool(torch.isfinite(last["z"]).all()) and int((last["status"] == 0).sum()) >= int(ok.sum().item())
+  # the same K steps once more WITHOUT the download (informative: what the download costs; not `value`)
+  fence()
+  t1 = time.perf_counter()
+  for _ in range(a.steps):
+    int(step(download=False).sum().item())
+  fence()
+  dt_nodl = time.perf_counter() - t1
+  tt = torch.tensor([dt, float(nconv), dt_nodl], **f64)
   if world > 1:
     tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-    dt = float(tmax[0]); nconv_all = float(tsum[1])
+    dt = float(tmax[0]); nconv_all = float(tsum[1]); dt_nodl = float(tmax[2])
   else:
     nconv_all = float(nconv)
   (ev_ms, ev_n), (sv_ms, sv_n) = eng.timers()
+  ev_n //= 2; sv_n //= 2        # (the timers ran over both loops; averages are per launch)
   if rank != 0:
     return None
   itc = iters.cpu().numpy()
@@ -372,6 +429,9 @@ def run(a, rank, world, dev, make_engine):
                               (f"; {dist.get_backend()} group of {dist.get_world_size()} ranks, gather of z*, cost, status to rank 0"
                                if world > 1 else "")},
     "converged_fraction": nconv_all / (a.steps * total),
+    "download": {"what": "z*, cost, status of all instances -> pinned host buffers on rank 0, inside every timed step (side stream, double-buffered: "
+                         "overlaps the next step's solve); SURVEY.md 8(d): the metric ends on host rank 0",
+                 "bytes_per_step": d2h_bytes, "value_without_download": nconv_all / dt_nodl, "ms_per_step_without_download": 1e3 * dt_nodl / a.steps},
     "iterations": {"median": float(np.median(itc)), "p99": float(np.percentile(itc, 99)), "max": int(itc.max())},
     "roofline": {"kernel": "hs_eval_kernel<CARTPOLE> (HS defect + Jacobian blocks + grad f)", "bound": "hbm",
                  "achieved": alg / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

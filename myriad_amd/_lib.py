@@ -226,17 +226,33 @@ class Engine:
       raise ValueError(f"scale must have ns+nu = {self.ns + self.nu} entries")
     _chk(self.lib.myr_set_var_scale(self._h, _addr(s)), "myr_set_var_scale")
 
+  # Result arrays of solve / solve_x0: fresh numpy arrays per call by default.  A caller that solves batch after batch sets
+  # `result_buffers` to a dict of its own arrays ("z" [B,n], "lam" [B,m], "cost" [B], "status" int32 [B], "iters" int32 [B],
+  # "kkt" [B,3] -- e.g. views of pinned memory); a call whose batch size matches writes its results there (no allocation, no
+  # page faults) and returns views of them, valid until the next call.
+  result_buffers = None
+
+  def _results(self, B, z=None):
+    rb = self.result_buffers
+    if rb is not None and rb["cost"].shape[0] == B:
+      if z is not None:
+        rb["z"][...] = z
+      return rb["z"], rb["lam"], rb["cost"], rb["status"], rb["iters"], rb["kkt"]
+    return (np.empty((B, self.n)) if z is None else z, np.empty((B, self.m)), np.empty(B), np.empty(B, dtype=np.int32),
+            np.empty(B, dtype=np.int32), np.empty((B, 3)))
+
   def solve(self, z0, lb, ub, params=None, opts: Optional[SolveOpts] = None):
-    z = _f64(z0).copy()
+    z = _f64(z0)
     if z.ndim == 1:
       z = z[None]
     B = z.shape[0]
+    if not (self.result_buffers is not None and self.result_buffers["cost"].shape[0] == B):
+      z = z.copy()
     lb = np.ascontiguousarray(np.broadcast_to(_f64(lb), z.shape))
     ub = np.ascontiguousarray(np.broadcast_to(_f64(ub), z.shape))
     p, ps = self._params(params, B)
     o = opts or self.default_opts()
-    lam = np.empty((B, self.m)); cost = np.empty(B)
-    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); kkt = np.empty((B, 3))
+    z, lam, cost, status, iters, kkt = self._results(B, z)
     _chk(self.lib.myr_solve(self._h, B, _addr(z), _addr(lb), _addr(ub), _addr(p), ps, C.byref(o), _addr(lam),
                             _addr(cost), _addr(status), _addr(iters), _addr(kkt), MEM_HOST), "myr_solve")
     return {"z": z, "lam": lam, "cost": cost, "status": status, "iters": iters, "kkt": kkt}
@@ -255,8 +271,7 @@ class Engine:
       raise ValueError(f"g0, g1, lb, ub must have {self.n} entries")
     p, ps = self._params(params, B)
     o = opts or self.default_opts()
-    z = np.empty((B, self.n)); lam = np.empty((B, self.m)); cost = np.empty(B)
-    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); kkt = np.empty((B, 3))
+    z, lam, cost, status, iters, kkt = self._results(B)
     _chk(self.lib.myr_solve_x0(self._h, B, _addr(x0s), _addr(tpl[0]), _addr(tpl[1]), _addr(tpl[2]), _addr(tpl[3]), _addr(p), ps,
                                C.byref(o), _addr(z), _addr(lam), _addr(cost), _addr(status), _addr(iters), _addr(kkt), MEM_HOST), "myr_solve_x0")
     return {"z": z, "lam": lam, "cost": cost, "status": status, "iters": iters, "kkt": kkt}

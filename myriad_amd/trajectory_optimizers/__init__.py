@@ -94,16 +94,19 @@ class TrajectoryOptimizer(object):
     return eng
 
   def _device_list(self):
-    """Device ordinals of the fan-out: `self.devices`, else MYRIAD_DEVICES ("all" | "0,1,.."), else every visible device --
-    but only this rank's device under a one-process-per-GPU launch (bench.py, torchrun)."""
-    if self.devices is not None:
+    """Device ordinals of the fan-out.  OPT-IN: `self.devices` (a list of ordinals, or "all") or MYRIAD_DEVICES ("all" | "0,1,..");
+    without either a batch runs on ONE device -- this rank's under a one-process-per-GPU launch (LOCAL_RANK), else device 0 --
+    so that an existing caller never finds handles created on GPUs it did not ask for."""
+    if self.devices is not None and self.devices != "all":
       return [int(d) for d in self.devices]
     env = os.environ.get("MYRIAD_DEVICES")
-    if env and env != "all":
+    if self.devices == "all" or env == "all":
+      return list(range(max(1, _lib.device_count())))
+    if env:
       return [int(d) for d in env.replace(",", " ").split()]
-    if env is None and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
       return [int(os.environ.get("LOCAL_RANK", "0"))]
-    return list(range(max(1, _lib.device_count())))
+    return [0]
 
   def engines_for(self, B: int):
     """Handles a batch of B instances is sharded over: one per device of `_device_list()`, as many as leave every shard at
@@ -349,6 +352,20 @@ class TrajectoryOptimizer(object):
     res["restored"] = np.zeros(B, dtype=np.int32)
     if fail.size == 0 or not (second_starts and (cycles or self._twin_engine() is not None)):
       return res
+    # (caller-provided result buffers, Engine.result_buffers, belong to the first attempt: the retries below run through the same
+    # handles with batches of their own and must not write into -- or alias -- the arrays they are merged into)
+    held = [(e, e.result_buffers) for e in self._engines.values() if getattr(e, "result_buffers", None) is not None]
+    if held:
+      res = {k: np.array(v) for k, v in res.items()}
+      for e, _ in held:
+        e.result_buffers = None
+    try:
+      return self._device_solve_tail(res, fail, z0, lb, ub, p, params, opts, cycles, x0_form, B)
+    finally:
+      for e, rb in held:
+        e.result_buffers = rb
+
+  def _device_solve_tail(self, res, fail, z0, lb, ub, p, params, opts, cycles, x0_form, B):
     if x0_form is not None:
       z0, lb, ub = self._expand_x0(x0_form[0][fail], x0_form[1])
       if p is not None and p.ndim == 2:
