@@ -1568,12 +1568,12 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
       // MYRIAD_POISON (tests/test_gpu_poison.py): everything a trajectory inherits from its predecessor in this slot -- the solver's
       // LDS and the slot's global scratch -- is overwritten with one bit pattern (a signalling NaN, or plain garbage).  A solve
       // whose result depends on the pattern reads something before it writes it.
-      const double pv = __longlong_as_double((long long)poison);
       __syncthreads();           // (every wavefront has read the ticket from sMisc)
       double* l0 = reinterpret_cast<double*>(smem_fused);
       const int nl = W::lds_solver_doubles(c.N) + (W::MLP ? c.K * W::NS : 0);
-      for (int i = c.tid; i < nl; i += W::NT) l0[i] = pv;
-      for (long i = c.tid; i < scratch_stride; i += W::NT) s[i] = pv;
+      const unsigned long long salt = (unsigned long long)b * 1315423911ULL + blockIdx.x;
+      for (int i = c.tid; i < nl; i += W::NT) l0[i] = poison_value(poison, (unsigned long long)i, salt);
+      for (long i = c.tid; i < scratch_stride; i += W::NT) s[i] = poison_value(poison, (unsigned long long)i + (1ULL << 32), salt);
       __syncthreads();
     }
 #ifdef MYR_TRACE

@@ -2028,11 +2028,11 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
     c.z = z + b * (long)c.n; c.lb = lb + b * (long)c.n; c.ub = ub + b * (long)c.n;
     c.lam = lam ? lam + b * (long)(W::MLAM * c.N * W::NS) : lam_own;
     if (poison) {      // MYRIAD_POISON (tests/test_gpu_poison.py): what this wavefront inherits from its previous trajectory -- its LDS, its scratch slot
-      const double pv = __longlong_as_double((long long)poison);
+      const unsigned long long salt = (unsigned long long)b * 1315423911ULL + blockIdx.x * 8 + wave;
       double* l0 = reinterpret_cast<double*>(smem_wave) + (long)wave * W::lds_solver_doubles(c.N);
-      for (int i = c.lane; i < W::lds_solver_doubles(c.N); i += 64) l0[i] = pv;
+      for (int i = c.lane; i < W::lds_solver_doubles(c.N); i += 64) l0[i] = poison_value(poison, (unsigned long long)i, salt);
       double* s0 = scratch + ((long)blockIdx.x * waves + wave) * scratch_stride;
-      for (long i = c.lane; i < scratch_stride; i += 64) s0[i] = pv;
+      for (long i = c.lane; i < scratch_stride; i += 64) s0[i] = poison_value(poison, (unsigned long long)i + (1ULL << 32), salt);
       W::wsync();
     }
     c.pp.load(params, b, params_stride);

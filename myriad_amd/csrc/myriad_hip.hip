@@ -862,9 +862,10 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
   if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
   if (const char* e = getenv("MYRIAD_FUSED_WAVES")) h->fused_waves = atoi(e);     // developer knob: wavefronts per trajectory of the fused kernel
   if (const char* e = getenv("MYRIAD_SOLVE_SLOTS")) h->solve_slots = atoi(e);   // developer knob: resident wavefronts of the solve kernel
-  if (const char* e = getenv("MYRIAD_POISON")) {      // test knob: "nan" (signalling NaN), "big", or a 64-bit pattern in hex
+  if (const char* e = getenv("MYRIAD_POISON")) {      // test knob: "nan" (signalling NaN), "big", "random", or a 64-bit pattern in hex
     if (strcmp(e, "nan") == 0) h->poison = 0x7ff4dead0000beefULL;
     else if (strcmp(e, "big") == 0) h->poison = 0x4415af1d78b58c40ULL;      // 1e20
+    else if (strcmp(e, "random") == 0) h->poison = MYR_POISON_RANDOM;       // finite values of order one, different in every word
     else h->poison = strtoull(e, nullptr, 16);
   }
   *out = h;

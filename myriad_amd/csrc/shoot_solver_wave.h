@@ -795,10 +795,9 @@ void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, dou
     if (b >= B) break;
     if (poison) {      // MYRIAD_POISON (tests/test_gpu_poison.py): the whole LDS of the workgroup, which is all a trajectory inherits here
       extern __shared__ __attribute__((aligned(16))) char smem_poison[];
-      const double pv = __longlong_as_double((long long)poison);
       double* l0 = reinterpret_cast<double*>(smem_poison);
       const int nl = (int)(W::lds_bytes(o.N, o.cpi) / 8);
-      for (int i = threadIdx.x; i < nl; i += 64) l0[i] = pv;
+      for (int i = threadIdx.x; i < nl; i += 64) l0[i] = poison_value(poison, (unsigned long long)i, (unsigned long long)b * 1315423911ULL + blockIdx.x);
       __syncthreads();
     }
     for (int i = threadIdx.x; i < n; i += 64) { const double v = z[b * n + i]; l.z[i] = v; l.z0[i] = v; l.lb[i] = lb[b * n + i]; l.ub[i] = ub[b * n + i]; }

@@ -31,6 +31,13 @@ def main():
       for k in keys:
         os.environ.pop(k, None)
       os.environ.update(cfg)
+      fill = os.environ.get("WPROBE_FILL")       # leave a bit pattern in every CU's LDS and in freed device memory before each solve
+      if fill:
+        import ctypes
+        lf = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "variants", "libldsfill.so"))
+        lf.lds_fill.argtypes = [ctypes.c_ulonglong]; lf.mem_fill.argtypes = [ctypes.c_ulonglong, ctypes.c_size_t]
+        pat = {"nan": 0x7ff4dead0000beef, "big": 0x4415af1d78b58c40, "zero": 0, "one": 0x3ff0000000000000}[fill]
+        assert lf.mem_fill(pat, 1 << 30) == 0 and lf.lds_fill(pat) == 0
       try:
         hp = HParams(system=SystemType[s], optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule["HERMITE_SIMPSON" if r == "HS" else "TRAPEZOIDAL"],
                      intervals=N, nlpsolver=NLPSolverType.SQP)
