@@ -120,6 +120,22 @@ typedef struct {
   double  tol_stat;     /* converged: scaled ||grad f + J^T lam - zL + zU||_inf <= tol_stat (1e-6) */
   double  tol_compl;    /* converged: complementarity <= tol_compl        (default 1e-7)  */
   double  mu_init;      /* initial barrier parameter                      (default 0.1)   */
+  int32_t restoration;  /* what stands in for IPOPT's feasibility-restoration phase (the reference gets it from inside the one
+                           minimize_ipopt call, nlp_solvers/__init__.py:57-58), applied INSIDE myr_solve / myr_solve_x0 to the
+                           instances the first attempt leaves without a KKT point -- a bit mask:
+                             1  elastic phase: the instance is solved on the system's ELASTIC TWIN (x' = f(x,u) + s, cost
+                                g + rho/2 |s|^2; systems listed above as *_ELASTIC, collocation transcriptions) for rho = 1,
+                                1e2, 1e4, each from the previous solution, and the twin's trajectory starts the problem itself;
+                                a twin that converges with a slack that neither vanishes (> 1e-3) nor shrinks (> 1/10 of its
+                                value at the previous rho) marks the instance MYR_STATUS_INFEASIBLE;
+                             2  second starts: excitation guesses -- controls u(t) = centre + 0.95 amp sin(2 pi c t / T) over
+                                the control bounds, states by a rollout of the true dynamics -- for c = 2, 3, 5 cycles, first
+                                success wins;
+                           0 = one attempt from the caller's point and nothing else (the reference's call, minus IPOPT's own
+                           restoration); -1 = the library's default (3; the environment variables MYRIAD_ELASTIC=0 /
+                           MYRIAD_SECOND_STARTS=0 clear the bits, MYRIAD_SECOND_STARTS="2,7" sets other cycle counts).
+                           `iters` then sums the attempts of an instance; myr_solve_info reports which start produced it. */
+  int32_t reserved;
 } myr_solve_opts;
 
 int myr_create(const myr_problem_desc* desc, myr_handle* out);
@@ -165,12 +181,22 @@ int myr_eval(myr_handle h, int32_t B, const double* z, const double* params, int
  *                  and restarts a solve that ended without a KKT point from the caller's point with another initial barrier
  *                  parameter (x3, then /3, each with the full max_iter): `iters` sums the attempts and may exceed max_iter.
  *   kkt    [B][3]  out (may be NULL): final {max|c|, stationarity, complementarity}
- * There is no feasibility-restoration phase: a binding that wants IPOPT's robustness against a poor starting point re-solves
- * the instances with status != MYR_STATUS_CONVERGED from another guess ("What replaces IPOPT's restoration phase").
+ * Restoration (myr_solve_opts.restoration, on by default): instances the first attempt leaves without a KKT point go through the
+ * elastic phase and the second starts described at the field, inside this call; a converged instance is never touched.
  */
 int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, const double* ub,
               const double* params, int32_t params_stride, const myr_solve_opts* opts,
               double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt, int32_t mem);
+
+/*
+ * Per-instance account of the LAST myr_solve / myr_solve_x0 call on this handle (HOST arrays of B int32 each, any may be NULL):
+ *   start    0 = the caller's point produced the returned result, c > 0 = the excitation guess with c cycles
+ *   attempts device solves the instance went through (1 = the first attempt only; the elastic phase counts 4: three twin solves
+ *            and the solve of the problem itself)
+ *   restored 1 = the returned result comes out of the elastic phase
+ * B must be the batch size of that call.
+ */
+int myr_solve_info(myr_handle h, int32_t B, int32_t* start, int32_t* attempts, int32_t* restored);
 
 /*
  * myr_solve for B instances that differ in their START STATE only (EXTENSION; the reference builds guess and bounds of an

@@ -30,7 +30,7 @@ STATUS_INFEASIBLE = 4   # assigned by the host's elastic phase (TrajectoryOptimi
 
 EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve", "myr_solve_x0",
            "myr_set_var_scale", "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_fbsm", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",
-           "myr_version", "myr_device_count"]
+           "myr_version", "myr_device_count", "myr_solve_info"]
 
 
 class ProblemDesc(C.Structure):
@@ -47,7 +47,8 @@ class Dims(C.Structure):
 
 class SolveOpts(C.Structure):
   _fields_ = [("max_iter", C.c_int32), ("restarts", C.c_int32), ("tol_feas", C.c_double),
-              ("tol_stat", C.c_double), ("tol_compl", C.c_double), ("mu_init", C.c_double)]
+              ("tol_stat", C.c_double), ("tol_compl", C.c_double), ("mu_init", C.c_double),
+              ("restoration", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MyriadHipError(RuntimeError):
@@ -91,6 +92,8 @@ def load() -> C.CDLL:
   lib.myr_solve.restype = C.c_int
   lib.myr_solve_x0.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_int32, C.POINTER(SolveOpts), dp, dp, dp, ip, ip, dp, C.c_int32]
   lib.myr_solve_x0.restype = C.c_int
+  lib.myr_solve_info.argtypes = [vp, C.c_int32, ip, ip, ip]
+  lib.myr_solve_info.restype = C.c_int
   lib.myr_rollout.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, dp, dp, C.c_int32]
   lib.myr_rollout.restype = C.c_int
   lib.myr_set_var_scale.argtypes = [vp, dp]
@@ -255,7 +258,14 @@ class Engine:
     z, lam, cost, status, iters, kkt = self._results(B, z)
     _chk(self.lib.myr_solve(self._h, B, _addr(z), _addr(lb), _addr(ub), _addr(p), ps, C.byref(o), _addr(lam),
                             _addr(cost), _addr(status), _addr(iters), _addr(kkt), MEM_HOST), "myr_solve")
-    return {"z": z, "lam": lam, "cost": cost, "status": status, "iters": iters, "kkt": kkt}
+    return self._with_info({"z": z, "lam": lam, "cost": cost, "status": status, "iters": iters, "kkt": kkt}, B)
+
+  def _with_info(self, res, B):
+    """myr_solve_info: which start produced each instance (restoration inside the library, include/myriad_hip.h)"""
+    start = np.empty(B, dtype=np.int32); attempts = np.empty(B, dtype=np.int32); restored = np.empty(B, dtype=np.int32)
+    _chk(self.lib.myr_solve_info(self._h, B, _addr(start), _addr(attempts), _addr(restored)), "myr_solve_info")
+    res["start"] = start; res["attempts"] = attempts; res["restored"] = restored
+    return res
 
   def solve_x0(self, x0s, g0, g1, lb, ub, params=None, opts: Optional[SolveOpts] = None):
     """myr_solve_x0: the instances differ in their start state only; guess and bounds are expanded on the device
@@ -274,7 +284,7 @@ class Engine:
     z, lam, cost, status, iters, kkt = self._results(B)
     _chk(self.lib.myr_solve_x0(self._h, B, _addr(x0s), _addr(tpl[0]), _addr(tpl[1]), _addr(tpl[2]), _addr(tpl[3]), _addr(p), ps,
                                C.byref(o), _addr(z), _addr(lam), _addr(cost), _addr(status), _addr(iters), _addr(kkt), MEM_HOST), "myr_solve_x0")
-    return {"z": z, "lam": lam, "cost": cost, "status": status, "iters": iters, "kkt": kkt}
+    return self._with_info({"z": z, "lam": lam, "cost": cost, "status": status, "iters": iters, "kkt": kkt}, B)
 
   def solve_device(self, B, z, lb, ub, params, params_stride, opts, lam, cost, status, iters, kkt=None):
     _chk(self.lib.myr_solve(self._h, int(B), _addr(z), _addr(lb), _addr(ub), _addr(params), int(params_stride),

@@ -39,7 +39,7 @@ struct VarScale { double s[16]; };
 // from slot to slot: "plausible leftovers", the kind a previous trajectory leaves behind (a constant can hide a read-before-write
 // behind a comparison that happens to come out right).
 constexpr unsigned long long MYR_POISON_RANDOM = 0x52414e444f4d5f5fULL;
-__host__ __device__ inline double poison_value(unsigned long long pattern, unsigned long long i, unsigned long long salt) {
+MYR_HD inline double poison_value(unsigned long long pattern, unsigned long long i, unsigned long long salt) {
   if (pattern != MYR_POISON_RANDOM) { union { unsigned long long u; double d; } c; c.u = pattern; return c.d; }
   unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ULL ^ (salt + 0x632BE59BD9B4E019ULL) * 0xD1B54A32D192ED03ULL;
   x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;

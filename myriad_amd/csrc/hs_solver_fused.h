@@ -115,7 +115,12 @@ struct HsFused {
   __device__ static inline void use_set(Ctx& c, double* kg, double* x) {
     c.kg = kg; c.sP = x; c.sPc = x + NW * NW; c.sTnu = c.sPc + NW * NC; c.sKu = c.sTnu + NS * NC;
   }
-  __device__ static inline void wsync() { __syncthreads(); }
+  __device__ static inline void wsync() {
+#ifdef MYR_WG_STRONG      // experiment: agent-scope fences around the workgroup barrier (s_waitcnt vmcnt(0) + L1 invalidate) when wavefronts share a trajectory
+    if constexpr (W > 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); return; }
+#endif
+    __syncthreads();
+  }
   // partial results of the W wavefronts -> the workgroup's (op: 0 sum, 1 max, 2 min); every wavefront ends with the same values
   template <int NV>
   __device__ static inline void wg_combine(Ctx& c, double* v, const int (&op)[NV]) {
@@ -984,18 +989,36 @@ struct HsFused {
     if constexpr (TRAP) return riccati_mfma_trap(c, o, a.delta, a.abort != 0);
     else return riccati_mfma(c, o, a.delta, a.abort != 0);
   }
+  __device__ __attribute__((always_inline)) static int sweep_inl(SwArgs a) {
+    Ctx c;
+    c.N = a.N; c.lane = a.lane; c.hr = (double*)a.hr; c.st = (double*)a.st; c.zr = (double*)a.zr;
+    use_set(c, (double*)a.kg, (double*)a.xs);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) c.term_pinned[q] = ((a.pinned >> q) & 1) != 0;
+    HsSolveOpts o;
+    o.reg_floor = a.reg_floor; o.rho_term = a.rho_term;
+    if constexpr (TRAP) return riccati_mfma_trap(c, o, a.delta, a.abort != 0);
+    else return riccati_mfma(c, o, a.delta, a.abort != 0);
+  }
   __device__ static inline int sweep(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
 #ifndef MYR_SWEEP_INLINE
-    // (W > 1 keeps the sweep inline: called as a function from wavefront 0 alone -- the others wait at the barrier -- the kernel
-    // faulted on BIOREACTOR (N = 20, first iteration) and left VANDERPOL's trapezoidal solve infeasible, while the same call made
-    // by ALL wavefronts, or the inlined sweep, are fine.  Not understood; tools/dev/crash_probe2.py with -DMYR_SWEEP_CALL_W.)
-#ifndef MYR_SWEEP_CALL_W
-    if constexpr (W > 1) {
+    // W = 1 calls the sweep as a function of its own (SwArgs: address-space-qualified pointers, a frame of its own).  W > 1 -- where only
+    // wavefront 0 sweeps -- inlines riccati_mfma on the context: with the wavefront index wave-uniform BY CONSTRUCTION (readfirstlane in
+    // the kernel) the branch around it is a scalar one.  Round 3 had the index as a per-lane value: the sweep then sat inside an
+    // EXEC-masked region, and that build returned results that differed from launch to launch on fresh handles (DESIGN.md section 8;
+    // tests/test_gpu_poison.py).  Two other forms were tried in round 4 and are kept behind flags because they FAULT in some
+    // instantiations (-DMYR_SWEEP_CALL_W: a call made by one wavefront; -DMYR_W2_QUALIFIED: the inlined body on SwArgs).
+#if defined(MYR_SWEEP_CALL_W)
+    constexpr bool CALL = true, QUAL = false;
+#elif defined(MYR_W2_QUALIFIED)
+    constexpr bool CALL = W == 1, QUAL = true;
+#else
+    constexpr bool CALL = W == 1, QUAL = false;
+#endif
+    if constexpr (!CALL && !QUAL) {
       if constexpr (TRAP) return riccati_mfma_trap(c, o, delta, abort_on_reg);
       else return riccati_mfma(c, o, delta, abort_on_reg);
-    } else
-#endif
-    {
+    }
     SwArgs a;
     a.hr = (nd_glb*)c.hr; a.st = (nd_glb*)c.st; a.zr = (nd_glb*)c.zr; a.kg = (nd_glb*)c.kg; a.xs = (nd_lds*)c.sP;
     a.N = c.N; a.lane = c.lane; a.abort = abort_on_reg ? 1 : 0;
@@ -1003,8 +1026,8 @@ struct HsFused {
 #pragma unroll
     for (int q = 0; q < NS; ++q) a.pinned |= c.term_pinned[q] ? (1 << q) : 0;
     a.reg_floor = o.reg_floor; a.rho_term = o.rho_term; a.delta = delta;
-    return sweep_call(a);
-    }
+    if constexpr (CALL) return sweep_call(a);
+    else return sweep_inl(a);
 #else
     if constexpr (TRAP) return riccati_mfma_trap(c, o, delta, abort_on_reg);
     else return riccati_mfma(c, o, delta, abort_on_reg);
@@ -1524,7 +1547,12 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   using W = HsFused<Sys, NWAVES, SCHEME>;
   extern __shared__ __attribute__((aligned(16))) char smem_fused[];
   typename W::Ctx c;
-  c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x & 63; c.tid = threadIdx.x; c.wave = threadIdx.x >> 6;
+  c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x & 63; c.tid = threadIdx.x;
+#ifdef MYR_WAVE_DIVERGENT       // (round 3's form: the compiler cannot see that the wavefront index is the same in every lane)
+  c.wave = threadIdx.x >> 6;
+#else
+  c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform BY CONSTRUCTION: `if (c.wave == 0)` is a scalar branch
+#endif
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
   double* s = scratch + (long)blockIdx.x * scratch_stride;
   c.zr = s; c.hr = s + W::off_hr(c.N); c.st = s + W::off_st(c.N); c.kg = s + W::off_kg(c.N);

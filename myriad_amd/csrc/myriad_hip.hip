@@ -92,6 +92,12 @@ struct myr_handle_s {
   std::map<std::tuple<const void*, int, size_t>, int> occ;   // kernel_slots(): workgroups per CU of (kernel, block size, dynamic LDS)
   size_t eval_attr_lds[6] = {0, 0, 0, 0, 0, 0};   // dynamic-LDS attribute already set for the eval kernel variants (W = 1 / 4 / 8, nt)
   int fused_waves = 0;        // MYRIAD_FUSED_WAVES: wavefronts per trajectory (0 = by batch size)
+  // restoration inside myr_solve (myr_solve_opts.restoration): the twin handle, device scratch, and the account of the last call
+  myr_handle_s* twin = nullptr;
+  bool twin_unavailable = false;
+  void* rbuf = nullptr; size_t rbuf_bytes = 0;      // copy of the caller's guess + status / iters when the caller passed none
+  void* fbuf = nullptr; size_t fbuf_bytes = 0;      // working set of the failed instances
+  std::vector<int32_t> info_start, info_attempts, info_restored;
   unsigned long long poison = 0;   // MYRIAD_POISON: bit pattern written over a slot's LDS and scratch at every trajectory hand-over (tests)
   int cus = 0;                // compute units of the device (cached)
   // variable scaling of the solve path (myr_set_var_scale): the solver kernels see z/s, lb/s, ub/s
@@ -465,6 +471,9 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   HsSolveOpts o = make_opts(h, so);
   KTimer& kt = h->kt[MYR_K_SOLVE];
   HIPCHK(hipEventRecord(kt.a, h->stream));
+  if (getenv("MYRIAD_DEBUG_PTRS"))
+    fprintf(stderr, "[myriad] fused W=%d N=%d B=%d slots=%d lds=%zu stride=%ld doubles: scratch [%p, %p) z %p lb %p ub %p lam %p ticket %p\n", NWAVES, N, B, slots, lds, stride,
+            h->sbuf, (char*)h->sbuf + need, (void*)z, (const void*)lb, (const void*)ub, (void*)lam, (void*)h->ticket);
   hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
                      params, pstride, cost, status, iters, kkt, h->poison);
   HIPCHK(hipGetLastError());
@@ -483,12 +492,11 @@ static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, con
   if constexpr (NodeTraits<Sys>::mlp) {     // network dynamics: four wavefronts share a trajectory and the 40 KB of weights in LDS
     return launch_hs_fused_w<Sys, 4, 0>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   } else {
-    // W = 2 (two wavefronts per trajectory for batches of at most two trajectories per CU: +15 % at B = 512) is OFF by default since
-    // the end of round 3: tools/dev/w2_probe.py found it disagreeing with W = 1 in 8 of 288 single- / three-instance solves
-    // (MOULDFUNGICIDE N = 6 / 100: NaN / stalled at another point; CANCERTREATMENT N = 100: the first instance stalled) -- a defect in
-    // its cross-wavefront exchange that the test suite did not reach.  MYRIAD_FUSED_WAVES=2 selects it for development.
-    int waves = 1;
-    (void)B;
+    // W = 2: two wavefronts per trajectory for batches of at most two trajectories per CU (a launch then lasts as long as one solve,
+    // and the parallel passes of an iteration take half the time: +15 % at B = 512).  Round 3 switched it off -- its build returned
+    // results that differed from launch to launch; round 4 found the form of the sweep that does it
+    // (hs_solver_fused.h: sweep) and gates every build with tests/test_gpu_poison.py.  MYRIAD_FUSED_WAVES=1|2 overrides the choice.
+    int waves = (B <= 2 * device_cus(h)) ? 2 : 1;
     if (h->fused_waves > 0) waves = h->fused_waves;
     if (waves == 2 && HsFused<Sys, 2, SCHEME>::lds_bytes(h->d.intervals) <= 160 * 1024)
       return launch_hs_fused_w<Sys, 2, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
@@ -798,6 +806,8 @@ extern "C" void myr_default_solve_opts(myr_solve_opts* o) {
   o->tol_stat = 1e-6;
   o->tol_compl = 1e-7;
   o->mu_init = 0.1;
+  o->restoration = -1;  // library default: elastic phase + second starts, see the header
+  o->reserved = 0;
 }
 
 extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
@@ -879,6 +889,9 @@ extern "C" int myr_destroy(myr_handle h) {
   if (h->sbuf) (void)hipFree(h->sbuf);
   if (h->ticket) (void)hipFree(h->ticket);
   if (h->vbuf) (void)hipFree(h->vbuf);
+  if (h->rbuf) (void)hipFree(h->rbuf);
+  if (h->fbuf) (void)hipFree(h->fbuf);
+  if (h->twin) { (void)myr_destroy(h->twin); h->twin = nullptr; }
   for (int i = 0; i < MYR_K_COUNT; ++i) {
     if (h->kt[i].a) (void)hipEventDestroy(h->kt[i].a);
     if (h->kt[i].b) (void)hipEventDestroy(h->kt[i].b);
@@ -1124,11 +1137,360 @@ static int dispatch_solve_scaled(myr_handle h, int B, double* z, const double* l
   return MYR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Restoration inside the solve call (myr_solve_opts.restoration): what the reference gets from inside its one minimize_ipopt call
+// (/root/reference/myriad/nlp_solvers/__init__.py:57-58 -- IPOPT falls back to a feasibility-restoration phase when its line search
+// fails) happens here for the instances the first attempt leaves without a KKT point, for EVERY binding of the C-ABI:
+//   1. elastic phase  -- the system's elastic twin (x' = f(x,u) + s, cost g + rho/2 |s|^2) solved for rho = 1, 1e2, 1e4, each from the
+//                        previous solution; its trajectory starts the problem itself;
+//   2. second starts  -- excitation guesses (oscillating controls, states by a rollout of the true dynamics), c = 2, 3, 5 cycles.
+// Host logic over device arrays: the failed rows are gathered into a working set, solved, and scattered back where they converged.
+// (Rounds 2-3 had this in the Python host only: myriad_amd/trajectory_optimizers/__init__.py, removed in round 4.)
+// ------------------------------------------------------------------------------------------------------------------------------
+static int dispatch_rollout(myr_handle h, int B, int num_steps, int u_rows, const double* x0, const double* us,
+                            const double* params, int pstride, double* xs, double* cost);
+extern "C" int myr_set_var_scale(myr_handle h, const double* scale);
+
+__global__ void gather_rows_kernel(long total, int w, const int32_t* __restrict__ idx, const double* __restrict__ src, double* __restrict__ dst) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long r = t / w; const int c = (int)(t - r * w);
+    dst[t] = src[(long)idx[r] * w + c];
+  }
+}
+__global__ void scatter_rows_kernel(long total, int w, const int32_t* __restrict__ idx, const int32_t* __restrict__ take, const double* __restrict__ src,
+                                    double* __restrict__ dst) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long r = t / w; const int c = (int)(t - r * w);
+    if (take[r]) dst[(long)idx[r] * w + c] = src[t];
+  }
+}
+// z of the problem -> z of its twin: the state rows as they are, every control row widened by ns slack controls (= fill)
+__global__ void twin_widen_kernel(long total, int nx, int nu, int ns, double fill, const double* __restrict__ src, double* __restrict__ dst, int n, int nt) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long b = t / nt; const int i = (int)(t - b * nt);
+    double v;
+    if (i < nx) v = src[b * n + i];
+    else { const int row = (i - nx) / (nu + ns), c = (i - nx) % (nu + ns); v = c < nu ? src[b * n + nx + row * nu + c] : fill; }
+    dst[t] = v;
+  }
+}
+// the twin's states and controls -> a start of the problem itself; zt is first clipped into its bounds (non-finite entries -> 0 / +-1e6),
+// as a start must be; slack[b] = max |s| of the clipped twin solution
+__global__ void twin_clip_kernel(long total, const double* __restrict__ lb, const double* __restrict__ ub, double* __restrict__ z) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    double v = z[t];
+    if (v != v) v = 0.0; else if (v > 1e300) v = 1e6; else if (v < -1e300) v = -1e6;
+    v = v < lb[t] ? lb[t] : v; v = v > ub[t] ? ub[t] : v;
+    z[t] = v;
+  }
+}
+__global__ __launch_bounds__(256) void twin_slack_kernel(int nx, int rows_u, int nu, int ns, int nt, const double* __restrict__ zt, double* __restrict__ slack) {
+  __shared__ double red[256];
+  const long b = blockIdx.x;
+  double m = 0.0;
+  for (int i = threadIdx.x; i < rows_u * ns; i += blockDim.x) {
+    const int row = i / ns, c = i % ns;
+    const double v = fabs(zt[b * nt + nx + row * (nu + ns) + nu + c]);
+    m = v > m ? v : m;
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + o] ? red[threadIdx.x] : red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) slack[b] = red[0];
+}
+__global__ void twin_narrow_kernel(long total, int nx, int nu, int ns, const double* __restrict__ zt, double* __restrict__ z, int n, int nt) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long b = t / n; const int i = (int)(t - b * n);
+    z[t] = i < nx ? zt[b * nt + i] : zt[b * nt + nx + ((i - nx) / nu) * (nu + ns) + (i - nx) % nu];
+  }
+}
+__global__ void twin_params_kernel(int B, int np, const double* __restrict__ params, int pstride, const double* __restrict__ defaults, double rho, double* __restrict__ out) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)B * (np + 1); t += (long)gridDim.x * blockDim.x) {
+    const long b = t / (np + 1); const int i = (int)(t - b * (np + 1));
+    out[t] = i == np ? rho : (params ? params[b * (long)pstride + i] : defaults[i]);
+  }
+}
+// excitation guess, controls: us[b][j][a] = centre_a + 0.95 amp_a sin(2 pi c t_j / T), t_j = T j / (rr - 1); centre / amplitude from the bounds of
+// the instance's first control row (the reference's control bounds are the same on every row); x0[b] = the pinned start state, else the guess's
+__global__ void excitation_controls_kernel(int B, int rr, int nu, int ns, int nx, int n, double cycles, const double* __restrict__ lb, const double* __restrict__ ub,
+                                           const double* __restrict__ z0, double* __restrict__ us, double* __restrict__ x0) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)B * rr * nu; t += (long)gridDim.x * blockDim.x) {
+    const long b = t / ((long)rr * nu); const int j = (int)((t / nu) % rr), a = (int)(t % nu);
+    const double lo = lb[b * n + nx + a], hi = ub[b * n + nx + a];
+    const bool fin = lo > -1e300 && hi < 1e300;
+    const double centre = fin ? 0.5 * (lo + hi) : 0.0, amp = fin ? 0.5 * (hi - lo) : 1.0;
+    us[t] = centre + 0.95 * amp * sin(2.0 * 3.14159265358979323846 * cycles * ((double)j / (double)(rr - 1)));
+    if (j == 0 && a == 0) {
+      for (int q = 0; q < ns; ++q) { const double l = lb[b * n + q], u = ub[b * n + q]; x0[b * ns + q] = (l == u) ? l : z0[b * n + q]; }
+    }
+  }
+}
+// ... and the guess itself: states = every `xstride`-th state of the rollout, controls = every `ustride`-th row, clipped into the bounds
+__global__ void excitation_pack_kernel(long total, int n, int nx, int ns, int nu, int steps, int xstride, int rr, int ustride, const double* __restrict__ xs,
+                                       const double* __restrict__ us, const double* __restrict__ lb, const double* __restrict__ ub, double* __restrict__ z) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long b = t / n; const int i = (int)(t - b * n);
+    double v;
+    if (i < nx) { const int row = i / ns, c = i % ns; v = xs[(b * (steps + 1) + (long)row * xstride) * ns + c]; }
+    else { const int row = (i - nx) / nu, c = (i - nx) % nu; v = us[(b * rr + (long)row * ustride) * nu + c]; }
+    if (v != v) v = 0.0; else if (v > 1e300) v = 1e6; else if (v < -1e300) v = -1e6;
+    v = v < lb[t] ? lb[t] : v; v = v > ub[t] ? ub[t] : v;
+    z[t] = v;
+  }
+}
+
+static bool twin_defaults(int twin_id, double* buf) {
+  switch (twin_id) {
+#define X(N) case MYR_SYS_##N: Sys##N::default_params(buf); return true;
+    MYR_CLOSED_FORM_SYSTEMS(X)
+#undef X
+  }
+  return false;
+}
+
+static unsigned grid_for(long total) { long b = (total + 255) / 256; if (b > 16384) b = 16384; if (b < 1) b = 1; return (unsigned)b; }
+
+static int ensure_buf(void** buf, size_t* have, size_t need) {
+  if (need <= *have) return MYR_OK;
+  if (*buf) HIPCHK(hipFree(*buf));
+  *buf = nullptr; *have = 0;
+  HIPCHK(hipMalloc(buf, need));
+  *have = need;
+  return MYR_OK;
+}
+
+struct RestoreCfg { bool elastic, starts; std::vector<int> cycles; };
+static RestoreCfg restore_cfg(const myr_solve_opts& so) {
+  RestoreCfg c;
+  int mode = so.restoration < 0 ? 3 : so.restoration;
+  c.elastic = (mode & 1) != 0; c.starts = (mode & 2) != 0;
+  c.cycles = {2, 3, 5};
+  if (so.restoration < 0) {      // the library default listens to the environment (the explicit values do not)
+    if (const char* e = getenv("MYRIAD_ELASTIC")) { if (atoi(e) == 0) c.elastic = false; }
+    if (const char* e = getenv("MYRIAD_SECOND_STARTS")) {
+      c.cycles.clear();
+      for (const char* q = e; *q;) { char* end = nullptr; long v = strtol(q, &end, 10); if (end == q) { ++q; continue; } if (v > 0) c.cycles.push_back((int)v); q = end; }
+      if (c.cycles.empty()) c.starts = false;
+    }
+  }
+  return c;
+}
+
+// the twin handle of a collocation problem whose system has one (lazily; nullptr when there is none or its solver is not built)
+static myr_handle twin_of(myr_handle h) {
+  if (h->twin || h->twin_unavailable) return h->twin;
+  SysInfo si;
+  if (h->d.transcription == MYR_TR_SHOOTING || h->d.system_id >= 100 || !sys_info(h->d.system_id + 100, &si)) { h->twin_unavailable = true; return nullptr; }
+  myr_problem_desc d = h->d;
+  d.system_id += 100;
+  myr_handle t = nullptr;
+  if (myr_create(&d, &t) != MYR_OK) { h->twin_unavailable = true; return nullptr; }
+  if (h->vscale_on) {          // a slack is a rate of its state: it takes the state's scale
+    double sc[16];
+    const int nw = h->dims.ns + h->dims.nu;
+    for (int i = 0; i < nw; ++i) sc[i] = h->vscale.s[i];
+    for (int i = 0; i < h->dims.ns && nw + i < 16; ++i) sc[nw + i] = h->vscale.s[i];
+    if (myr_set_var_scale(t, sc) != MYR_OK) { (void)myr_destroy(t); h->twin_unavailable = true; return nullptr; }
+  }
+  t->solve_mode = h->solve_mode; t->solve_fused = h->solve_fused;
+  h->twin = t;
+  return t;
+}
+
+static int solve_restored(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params, int pstride,
+                          const myr_solve_opts& so, double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt) {
+  h->info_start.assign(B, 0); h->info_attempts.assign(B, 1); h->info_restored.assign(B, 0);
+  const RestoreCfg cfg = restore_cfg(so);
+  if (!cfg.elastic && !cfg.starts) return dispatch_solve_scaled(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  const myr_dims& dm = h->dims;
+  const int n = dm.n, m = dm.m, ns = dm.ns, nu = dm.nu, np = dm.np;
+  auto al = [](size_t v) { return (v + 1) & ~(size_t)1; };
+  // the caller's guess is overwritten by the first attempt: keep it
+  if (int rc = ensure_buf(&h->rbuf, &h->rbuf_bytes, (al((size_t)B * n) + 2 * al((size_t)B)) * 8)) return rc;
+  double* z0c = (double*)h->rbuf;
+  int32_t* dstat = status ? status : (int32_t*)(z0c + al((size_t)B * n));
+  int32_t* dit = iters ? iters : (int32_t*)(z0c + al((size_t)B * n) + al((size_t)B));
+  HIPCHK(hipMemcpyAsync(z0c, z, (size_t)B * n * 8, hipMemcpyDeviceToDevice, h->stream));
+  if (int rc = dispatch_solve_scaled(h, B, z, lb, ub, params, pstride, so, lam, cost, dstat, dit, kkt)) return rc;
+  std::vector<int32_t> hstat(B), hit(B);
+  HIPCHK(hipMemcpyAsync(hstat.data(), dstat, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<int32_t> fail_;
+  for (int b = 0; b < B; ++b) if (hstat[b] != MYR_STATUS_CONVERGED) fail_.push_back(b);
+  if (fail_.empty()) return MYR_OK;
+  myr_handle twin = cfg.elastic ? twin_of(h) : nullptr;
+  if (!twin && !cfg.starts) return MYR_OK;
+  HIPCHK(hipMemcpyAsync(hit.data(), dit, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+
+  // working set of the failed rows (device): idx | take | z0f zf lbf ubf | pf | lamf costf kktf statf itf | twin: zt lbt ubt pt slack | excitation: us x0 xs
+  const int nf0 = (int)fail_.size();
+  const int nt = twin ? twin->dims.n : 0;
+  const int mc = (h->d.transcription == MYR_TR_SHOOTING && h->d.integration_method == MYR_INT_RK4) ? 2 : 1;
+  const int steps = (dm.u_rows - 1) / mc;
+  const int rr = (h->d.integration_method == MYR_INT_RK4) ? 2 * steps + 1 : steps + 1;
+  size_t words = 2 * al((size_t)nf0) + 4 * al((size_t)nf0 * n) + al((size_t)nf0 * (np > 0 ? np : 1)) + al((size_t)nf0 * m) + al((size_t)nf0) + al((size_t)nf0 * 3) + 2 * al((size_t)nf0);
+  if (twin) words += 3 * al((size_t)nf0 * nt) + al((size_t)nf0 * (np + 1)) + al((size_t)nf0) + al(64);
+  if (cfg.starts) words += al((size_t)nf0 * rr * nu) + al((size_t)nf0 * ns) + al((size_t)nf0 * (steps + 1) * ns);
+  if (int rc = ensure_buf(&h->fbuf, &h->fbuf_bytes, words * 8)) return rc;
+  double* q = (double*)h->fbuf;
+  int32_t* didx = (int32_t*)q; q += al((size_t)nf0);
+  int32_t* dtake = (int32_t*)q; q += al((size_t)nf0);
+  double* z0f = q; q += al((size_t)nf0 * n);
+  double* zf = q; q += al((size_t)nf0 * n);
+  double* lbf = q; q += al((size_t)nf0 * n);
+  double* ubf = q; q += al((size_t)nf0 * n);
+  double* pf = q; q += al((size_t)nf0 * (np > 0 ? np : 1));
+  double* lamf = q; q += al((size_t)nf0 * m);
+  double* costf = q; q += al((size_t)nf0);
+  double* kktf = q; q += al((size_t)nf0 * 3);
+  int32_t* statf = (int32_t*)q; q += al((size_t)nf0);
+  int32_t* itf = (int32_t*)q; q += al((size_t)nf0);
+  double *zt = nullptr, *lbt = nullptr, *ubt = nullptr, *pt = nullptr, *dslack = nullptr, *ddef = nullptr;
+  if (twin) { zt = q; q += al((size_t)nf0 * nt); lbt = q; q += al((size_t)nf0 * nt); ubt = q; q += al((size_t)nf0 * nt); pt = q; q += al((size_t)nf0 * (np + 1));
+              dslack = q; q += al((size_t)nf0); ddef = q; q += al(64); }
+  double *dus = nullptr, *dx0 = nullptr, *dxs = nullptr;
+  if (cfg.starts) { dus = q; q += al((size_t)nf0 * rr * nu); dx0 = q; q += al((size_t)nf0 * ns); dxs = q; q += al((size_t)nf0 * (steps + 1) * ns); }
+  const bool per_row_params = params && pstride != 0;
+  const int nx = dm.x_rows * ns;
+
+  // rows `rows` (indices into the batch) -> the working set
+  auto gather = [&](const std::vector<int32_t>& rows) -> int {
+    const int nf = (int)rows.size();
+    HIPCHK(hipMemcpyAsync(didx, rows.data(), (size_t)nf * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)nf * n)), dim3(256), 0, h->stream, (long)nf * n, n, didx, z0c, z0f);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)nf * n)), dim3(256), 0, h->stream, (long)nf * n, n, didx, lb, lbf);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)nf * n)), dim3(256), 0, h->stream, (long)nf * n, n, didx, ub, ubf);
+    if (per_row_params) hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)nf * np)), dim3(256), 0, h->stream, (long)nf * np, np, didx, params, pf);
+    HIPCHK(hipGetLastError());
+    return MYR_OK;
+  };
+  const double* pfp = per_row_params ? pf : params;
+  // rows of the working set with take[r] != 0 -> the caller's arrays
+  auto scatter = [&](const std::vector<int32_t>& take, int nf) -> int {
+    HIPCHK(hipMemcpyAsync(dtake, take.data(), (size_t)nf * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((long)nf * n)), dim3(256), 0, h->stream, (long)nf * n, n, didx, dtake, zf, z);
+    if (lam) hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((long)nf * m)), dim3(256), 0, h->stream, (long)nf * m, m, didx, dtake, lamf, lam);
+    if (cost) hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((long)nf)), dim3(256), 0, h->stream, (long)nf, 1, didx, dtake, costf, cost);
+    if (kkt) hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((long)nf * 3)), dim3(256), 0, h->stream, (long)nf * 3, 3, didx, dtake, kktf, kkt);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));     // (`take` is a host vector of the caller's frame)
+    return MYR_OK;
+  };
+  std::vector<int32_t> st2, it2;
+  auto read_back = [&](int nf) -> int {
+    st2.resize(nf); it2.resize(nf);
+    HIPCHK(hipMemcpyAsync(st2.data(), statf, (size_t)nf * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(it2.data(), itf, (size_t)nf * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MYR_OK;
+  };
+  myr_solve_opts plain = so;
+  plain.restoration = 0;
+
+  if (twin) {      // ---- elastic phase -----------------------------------------------------------------------------------------
+    const int nf = (int)fail_.size();
+    if (int rc = gather(fail_)) return rc;
+    double defs[64];
+    for (int i = 0; i < 64; ++i) defs[i] = 0.0;
+    if (!twin_defaults(twin->d.system_id - 100, defs)) return fail(MYR_E_ARG, "restoration: no default parameters for the system");
+    HIPCHK(hipMemcpyAsync(ddef, defs, 64 * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(twin_widen_kernel, dim3(grid_for((long)nf * nt)), dim3(256), 0, h->stream, (long)nf * nt, nx, nu, ns, 0.0, z0f, zt, n, nt);
+    hipLaunchKernelGGL(twin_widen_kernel, dim3(grid_for((long)nf * nt)), dim3(256), 0, h->stream, (long)nf * nt, nx, nu, ns, -INFINITY, lbf, lbt, n, nt);
+    hipLaunchKernelGGL(twin_widen_kernel, dim3(grid_for((long)nf * nt)), dim3(256), 0, h->stream, (long)nf * nt, nx, nu, ns, INFINITY, ubf, ubt, n, nt);
+    HIPCHK(hipGetLastError());
+    myr_solve_opts topt = plain;
+    if (topt.max_iter > 500) topt.max_iter = 500;      // per twin solve (the ones that help take 30-300 iterations)
+    const double rhos[3] = {1.0, 1e2, 1e4};
+    std::vector<double> slack_prev(nf, 0.0), slack_last(nf, 0.0);
+    std::vector<int64_t> it_acc(nf, 0);
+    std::vector<int32_t> twin_stat(nf, 1);
+    bool twin_ok = true;
+    for (int k = 0; k < 3 && twin_ok; ++k) {
+      hipLaunchKernelGGL(twin_params_kernel, dim3(grid_for((long)nf * (np + 1))), dim3(256), 0, h->stream, nf, np, pfp, per_row_params ? np : 0, ddef, rhos[k], pt);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(h->stream));      // the twin runs on a stream of its own
+      const int rc = dispatch_solve_scaled(twin, nf, zt, lbt, ubt, pt, np + 1, topt, nullptr, nullptr, statf, itf, nullptr);
+      if (rc == MYR_E_UNSUPPORTED) { twin_ok = false; h->twin_unavailable = true; break; }     // (ROCKETLANDING's twin under the trapezoidal scheme: not built)
+      if (rc) return rc;
+      hipLaunchKernelGGL(twin_clip_kernel, dim3(grid_for((long)nf * nt)), dim3(256), 0, h->stream, (long)nf * nt, lbt, ubt, zt);
+      hipLaunchKernelGGL(twin_slack_kernel, dim3((unsigned)nf), dim3(256), 0, h->stream, nx, dm.u_rows, nu, ns, nt, zt, dslack);
+      HIPCHK(hipGetLastError());
+      if (int rc2 = read_back(nf)) return rc2;
+      slack_prev = slack_last;
+      HIPCHK(hipMemcpy(slack_last.data(), dslack, (size_t)nf * 8, hipMemcpyDeviceToHost));
+      for (int r = 0; r < nf; ++r) { it_acc[r] += it2[r]; twin_stat[r] = st2[r]; }
+    }
+    if (twin_ok) {
+      hipLaunchKernelGGL(twin_narrow_kernel, dim3(grid_for((long)nf * n)), dim3(256), 0, h->stream, (long)nf * n, nx, nu, ns, zt, zf, n, nt);
+      HIPCHK(hipGetLastError());
+      if (int rc = dispatch_solve_scaled(h, nf, zf, lbf, ubf, pfp, per_row_params ? np : pstride, plain, lamf, costf, statf, itf, kktf)) return rc;
+      if (int rc = read_back(nf)) return rc;
+      std::vector<int32_t> take(nf, 0), left;
+      for (int r = 0; r < nf; ++r) {
+        const int b = fail_[r];
+        const bool ok = st2[r] == MYR_STATUS_CONVERGED;
+        take[r] = ok ? 1 : 0;
+        hit[b] += (int32_t)(it2[r] + it_acc[r]);
+        h->info_attempts[b] += 4;
+        if (ok) { hstat[b] = MYR_STATUS_CONVERGED; h->info_restored[b] = 1; }
+        else {
+          // stationary point of the infeasibility: the twin converged for the largest rho and its slack neither vanished nor shrank
+          if (twin_stat[r] == MYR_STATUS_CONVERGED && slack_last[r] > 1e-3 && slack_last[r] > 0.1 * slack_prev[r]) hstat[b] = MYR_STATUS_INFEASIBLE;
+          left.push_back(b);
+        }
+      }
+      if (int rc = scatter(take, nf)) return rc;
+      fail_.swap(left);
+    }
+  }
+  if (cfg.starts) {      // ---- second starts: excitation guesses --------------------------------------------------------------
+    const int xstride = steps / (dm.x_rows - 1 > 0 ? dm.x_rows - 1 : 1), ustride = (rr - 1) / (dm.u_rows - 1 > 0 ? dm.u_rows - 1 : 1);
+    for (size_t ci = 0; ci < cfg.cycles.size() && !fail_.empty(); ++ci) {
+      const int nf = (int)fail_.size(), c = cfg.cycles[ci];
+      if (int rc = gather(fail_)) return rc;
+      hipLaunchKernelGGL(excitation_controls_kernel, dim3(grid_for((long)nf * rr * nu)), dim3(256), 0, h->stream, nf, rr, nu, ns, nx, n, (double)c, lbf, ubf, z0f, dus, dx0);
+      HIPCHK(hipGetLastError());
+      if (int rc = dispatch_rollout(h, nf, steps, rr, dx0, dus, pfp, per_row_params ? np : pstride, dxs, nullptr)) return rc;
+      hipLaunchKernelGGL(excitation_pack_kernel, dim3(grid_for((long)nf * n)), dim3(256), 0, h->stream, (long)nf * n, n, nx, ns, nu, steps, xstride, rr, ustride, dxs, dus, lbf, ubf, zf);
+      HIPCHK(hipGetLastError());
+      if (int rc = dispatch_solve_scaled(h, nf, zf, lbf, ubf, pfp, per_row_params ? np : pstride, plain, lamf, costf, statf, itf, kktf)) return rc;
+      if (int rc = read_back(nf)) return rc;
+      std::vector<int32_t> take(nf, 0), left;
+      for (int r = 0; r < nf; ++r) {
+        const int b = fail_[r];
+        const bool ok = st2[r] == MYR_STATUS_CONVERGED;
+        take[r] = ok ? 1 : 0;
+        hit[b] += it2[r];
+        h->info_attempts[b] += 1;
+        if (ok) { hstat[b] = MYR_STATUS_CONVERGED; h->info_restored[b] = 0; h->info_start[b] = c; }
+        else left.push_back(b);
+      }
+      if (int rc = scatter(take, nf)) return rc;
+      fail_.swap(left);
+    }
+  }
+  HIPCHK(hipMemcpyAsync(dstat, hstat.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dit, hit.data(), (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MYR_OK;
+}
+
+extern "C" int myr_solve_info(myr_handle h, int32_t B, int32_t* start, int32_t* attempts, int32_t* restored) {
+  if (!h) return fail(MYR_E_ARG, "myr_solve_info: null handle");
+  if (B != (int32_t)h->info_start.size()) return fail(MYR_E_ARG, "myr_solve_info: B is not the batch size of the last solve on this handle");
+  if (start) memcpy(start, h->info_start.data(), (size_t)B * 4);
+  if (attempts) memcpy(attempts, h->info_attempts.data(), (size_t)B * 4);
+  if (restored) memcpy(restored, h->info_restored.data(), (size_t)B * 4);
+  return MYR_OK;
+}
+
 extern "C" int myr_set_var_scale(myr_handle h, const double* scale) {
   if (!h) return fail(MYR_E_ARG, "myr_set_var_scale: null handle");
   if (h->d.system_id == MYR_SYS_NODE_CARTPOLE && scale) return fail(MYR_E_UNSUPPORTED, "myr_set_var_scale: not available for NODE systems");
   const int nw = h->dims.ns + h->dims.nu;
   if (nw > 16) return fail(MYR_E_CAPACITY, "myr_set_var_scale: more than 16 variables per point");
+  if (h->twin) { (void)myr_destroy(h->twin); h->twin = nullptr; }      // (the twin of the restoration phase takes its scales from here: made again on demand)
   bool on = false;
   for (int i = 0; i < 16; ++i) h->vscale.s[i] = 1.0;
   if (scale) {
@@ -1159,7 +1521,7 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
   HIPCHK(hipSetDevice(h->d.device));
   const myr_dims& dm = h->dims;
   if (mem == MYR_MEM_DEVICE)
-    return dispatch_solve_scaled(h, B, z, lb, ub, params, params_stride, so, lam, cost, status, iters, kkt);
+    return solve_restored(h, B, z, lb, ub, params, params_stride, so, lam, cost, status, iters, kkt);
   if (mem != MYR_MEM_HOST) return fail(MYR_E_ARG, "myr_solve: bad mem kind");
   const size_t nz = (size_t)B * dm.n, nl = lam ? (size_t)B * dm.m : 0;
   const size_t npar = params ? (params_stride ? (size_t)B * dm.np : (size_t)dm.np) : 0;
@@ -1180,7 +1542,7 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
   HIPCHK(hipMemcpyAsync(dlb, lb, nz * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(dub, ub, nz * 8, hipMemcpyHostToDevice, h->stream));
   if (npar) HIPCHK(hipMemcpyAsync(dp, params, npar * 8, hipMemcpyHostToDevice, h->stream));
-  rc = dispatch_solve_scaled(h, B, dz, dlb, dub, npar ? dp : nullptr, params_stride, so, nl ? dlam : nullptr, dcost, dstat, dit, dkkt);
+  rc = solve_restored(h, B, dz, dlb, dub, npar ? dp : nullptr, params_stride, so, nl ? dlam : nullptr, dcost, dstat, dit, dkkt);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(z, dz, nz * 8, hipMemcpyDeviceToHost, h->stream));
   if (nl) HIPCHK(hipMemcpyAsync(lam, dlam, nl * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1271,7 +1633,7 @@ extern "C" int myr_solve_x0(myr_handle h, int32_t B, const double* x0s, const do
     hipLaunchKernelGGL(pack_x0_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, tz, dm.n, dm.ns, dm.x_rows * dm.ns, dx0, dg0, dg1, dlt, dut, dz, dlb, dub);
     HIPCHK(hipGetLastError());
   }
-  rc = dispatch_solve_scaled(h, B, dz, dlb, dub, dpar, params_stride, so, dlam, dcost, dstat, dit, dkkt);
+  rc = solve_restored(h, B, dz, dlb, dub, dpar, params_stride, so, dlam, dcost, dstat, dit, dkkt);
   if (rc) return rc;
   if (host) {
     HIPCHK(hipMemcpyAsync(z, dz, nz * 8, hipMemcpyDeviceToHost, h->stream));

@@ -201,98 +201,13 @@ class TrajectoryOptimizer(object):
     z, lam = self.engine.exgd(variables, lmbdas, self.bounds[:, 0], self.bounds[:, 1], eta_x, eta_v, nsteps, params=p)
     return z[0], lam[0]
 
-  # ---- second starts (extension: the substitute for IPOPT's restoration phase) ---------------------------------
-  # The batched SQP has no feasibility-restoration phase.  From the reference's straight-line guess a problem like the
-  # torque-limited PENDULUM swing-up (torque below gravity: the pendulum has to be pumped up) jams against its bounds
-  # at an infeasible stationary point of the merit function.  An instance that ends without a KKT point is therefore
-  # started again from an EXCITATION guess: controls that oscillate over the horizon, u(t) = centre + 0.95 amp
-  # sin(2 pi c t / T), with the states of their true-dynamics rollout (rollout kernel) -- c = 2, 3, 5 cycles, first
-  # success wins.  PENDULUM converges from every such guess (c = 1 .. 13, N = 20 / 50 / 100) to one optimum; instances
-  # that converge from the reference guess are untouched.  MYRIAD_SECOND_STARTS="" (or "0") switches it off.
-  second_start_cycles = (2, 3, 5)
-
-  def excitation_guess(self, x0s, lb, ub, params, cycles):
-    x0s = np.asarray(x0s, dtype=np.float64)
-    B = x0s.shape[0]
-    (rows_x, ns), (rows_u, nu) = self._x_shape, self._u_shape
-    mc = getattr(self, "_mc", 1)
-    steps = (rows_u - 1) // mc                                   # integration steps behind the control rows
-    rk4 = self.hp.integration_method == IntegrationMethod.RK4
-    rr = 2 * steps + 1 if rk4 else steps + 1                      # control rows the rollout reads (RK4: half steps too)
-    t = np.linspace(0.0, float(self.system.T), rr)
-    b = np.asarray(self.system.bounds, dtype=np.float64)
-    lo, hi = b[ns:, 0], b[ns:, 1]
-    fin = np.isfinite(lo) & np.isfinite(hi)
-    centre = np.where(fin, 0.5 * (lo + hi), 0.0)
-    amp = np.where(fin, 0.5 * (hi - lo), 1.0)
-    u_t = centre[None, :] + 0.95 * amp[None, :] * np.sin(2.0 * np.pi * cycles * t / float(self.system.T))[:, None]
-    us = np.broadcast_to(u_t, (B, rr, nu)).copy()
-    xs_all, _ = self.engine.rollout(x0s, us, steps, params=params)
-    xs = np.nan_to_num(xs_all[:, ::steps // (rows_x - 1)], nan=0.0, posinf=1e6, neginf=-1e6)
-    z = np.concatenate([xs.reshape(B, -1), us[:, ::(rr - 1) // (rows_u - 1)].reshape(B, -1)], axis=1)
-    return np.clip(z, lb, ub)
-
-  # ---- elastic mode: what stands in for a feasibility-restoration phase -----------------------------------------------
-  # An instance the solver leaves without a KKT point is handed to the system's ELASTIC TWIN (include/myriad_hip.h: the
-  # dynamics x' = f(x,u) + s with free slack controls s and the running cost g + rho/2 |s|^2): every state trajectory is
-  # feasible for the twin, so the iterate cannot jam against an infeasible stationary point of the merit function.  The twin
-  # is solved from the reference's guess for rho = elastic_rhos (each from the previous solution), and its last state / control
-  # trajectory starts the problem itself.  A twin that ends at a KKT point whose slack does not shrink as rho grows is a
-  # stationary point of the infeasibility: the instance is reported INFEASIBLE (status 4) unless a later start solves it.
-  # Twins exist for the systems listed in _lib.SYS_IDS as <NAME>_ELASTIC, under the collocation transcriptions.
-  elastic_rhos = (1.0, 1e2, 1e4)
-  elastic_slack_tol = 1e-3
-  elastic_max_iter = 500      # per twin solve (the ones that help take 30-300 iterations; a twin on the lane kernel costs 16 ms an iteration)
-
-  def _twin_engine(self) -> Optional[_lib.Engine]:
-    name = self.system.name + "_ELASTIC"
-    if name not in _lib.SYS_IDS or self.transcription == "SHOOTING" or os.environ.get("MYRIAD_ELASTIC", "1") == "0":
-      return None
-    if getattr(self, "_twin_unsupported", False):      # the library does not build this twin's solver for this transcription
-      return None
-    if getattr(self, "_twin", None) is None:
-      self._twin = _lib.Engine(name, self.transcription, self.hp.intervals, self.system.T, device=self._primary_device())
-      scale = getattr(self.system, "var_scale", None)
-      if scale is not None and os.environ.get("MYRIAD_VAR_SCALE", "1") != "0":
-        s = scale()
-        if s is not None and np.any(s != 1.0):
-          self._twin.set_var_scale(np.concatenate([s, s[:self._x_shape[1]]]))     # a slack is a rate of its state
-    return self._twin
-
-  def elastic_restoration(self, z0, lb, ub, params, opts):
-    """The elastic phase for the instances (z0, lb, ub, params) [B,..]: returns the result of the final solve of the problem
-    itself from the twin's trajectory, with `iters` summed over the phase, `attempts` = device solves, `slack` [B, len(rhos)]
-    = max |s| of the twin's solution per rho and `twin_status` [B] of the last twin solve."""
-    twin = self._twin_engine()
-    B = z0.shape[0]
-    (rows_x, ns), (rows_u, nu) = self._x_shape, self._u_shape
-    nx = rows_x * ns
-
-    def widen(a, fill):
-      U = a[:, nx:].reshape(B, rows_u, nu)
-      return np.concatenate([a[:, :nx], np.concatenate([U, np.full((B, rows_u, ns), fill)], axis=2).reshape(B, -1)], axis=1)
-
-    zt, lbt, ubt = widen(z0, 0.0), widen(lb, -np.inf), widen(ub, np.inf)
-    pb = self.system.device_params() if params is None else np.asarray(params, dtype=np.float64)
-    pb = np.broadcast_to(pb, (B, pb.shape[-1]))
-    iters = np.zeros(B, dtype=np.int64)
-    slack = np.zeros((B, len(self.elastic_rhos)))
-    topts = opts
-    if opts is not None and opts.max_iter > self.elastic_max_iter:
-      topts = type(opts).from_buffer_copy(opts)
-      topts.max_iter = self.elastic_max_iter
-    for k, rho in enumerate(self.elastic_rhos):
-      r = twin.solve(zt, lbt, ubt, params=np.concatenate([pb, np.full((B, 1), float(rho))], axis=1), opts=topts)
-      zt = np.clip(np.nan_to_num(r["z"], nan=0.0, posinf=1e6, neginf=-1e6), lbt, ubt)
-      iters += r["iters"]
-      slack[:, k] = np.abs(zt[:, nx:].reshape(B, rows_u, nu + ns)[:, :, nu:]).max(axis=(1, 2))
-    z1 = np.concatenate([zt[:, :nx], zt[:, nx:].reshape(B, rows_u, nu + ns)[:, :, :nu].reshape(B, -1)], axis=1)
-    res = self._solve_sharded(z1, lb, ub, params, opts)
-    res["iters"] = (res["iters"] + iters).astype(res["iters"].dtype)
-    res["slack"] = slack
-    res["twin_status"] = r["status"].copy()
-    res["attempts"] = np.full(B, len(self.elastic_rhos) + 1, dtype=np.int32)
-    return res
+  # ---- what stands in for IPOPT's restoration phase ---------------------------------------------------------------------
+  # The batched SQP has no feasibility-restoration phase of its own.  An instance that ends without a KKT point goes through
+  # an ELASTIC PHASE (the system's elastic twin, where the library carries one) and then through SECOND STARTS from excitation
+  # guesses -- inside the library's solve call (include/myriad_hip.h: myr_solve_opts.restoration, csrc/myriad_hip.hip:
+  # solve_restored), so that every binding of the C-ABI gets it; rounds 2-3 had this logic here, in the Python host.
+  # MYRIAD_ELASTIC=0 / MYRIAD_SECOND_STARTS=0 switch the two halves off; `start`, `attempts`, `restored` of a result say which
+  # start produced each instance (myr_solve_info).
 
   def _solve_sharded(self, z0, lb, ub, params, opts):
     """One device call per handle of `engines_for(B)`, concurrently (myriad_amd.batched.fan_out_solve)."""
@@ -332,94 +247,20 @@ class TrajectoryOptimizer(object):
     return z0, lb, ub
 
   def device_solve(self, z0, lb, ub, params, opts, second_starts=True, x0_form=None):
-    """The device solve (fanned out over `engines_for(B)`) + second starts for the instances that did not reach a KKT point.
-    The result says which start produced each instance: `start` = 0 for the caller's point, c for the excitation guess with c
-    cycles; `attempts` = device solves the instance went through (its `iters` are summed over them).  `second_starts=False`
-    (what solve_with_params / solve_batch pass when the caller gave an explicit guess) returns the first attempt as it is."""
-    if x0_form is not None:       # (x0s, rule): the arrays exist on the device only; expanded here for failed instances alone
-      res = self._solve_sharded_x0(x0_form[0], x0_form[1], params, opts)
-    else:
-      res = self._solve_sharded(z0, lb, ub, params, opts)
-    B = res["status"].shape[0]
-    res["start"] = np.zeros(B, dtype=np.int32)
-    res["attempts"] = np.ones(B, dtype=np.int32)
-    env = os.environ.get("MYRIAD_SECOND_STARTS")
-    cycles = self.second_start_cycles if env is None else tuple(int(c) for c in env.replace(",", " ").split() if int(c) > 0)
+    """The device solve, fanned out over `engines_for(B)`.  `second_starts=False` (what solve_with_params / solve_batch pass when the
+    caller gave an explicit guess) asks the library for ONE attempt from that guess (restoration = 0); otherwise its default applies:
+    elastic phase + second starts for the instances the first attempt leaves without a KKT point.  The result says which start
+    produced each instance: `start` = 0 for the caller's point, c for the excitation guess with c cycles; `attempts` = device solves
+    the instance went through (its `iters` are summed over them); `restored` = 1 when it comes out of the elastic phase."""
+    if opts is None:
+      opts = self.engine.default_opts()
+    import copy
+    o = type(opts).from_buffer_copy(opts) if hasattr(type(opts), "from_buffer_copy") else copy.copy(opts)
     if not second_starts:
-      cycles = ()
-    fail = np.nonzero(res["status"] != 0)[0]
-    p = None if params is None else np.asarray(params, dtype=np.float64)
-    res["restored"] = np.zeros(B, dtype=np.int32)
-    if fail.size == 0 or not (second_starts and (cycles or self._twin_engine() is not None)):
-      return res
-    # (caller-provided result buffers, Engine.result_buffers, belong to the first attempt: the retries below run through the same
-    # handles with batches of their own and must not write into -- or alias -- the arrays they are merged into)
-    held = [(e, e.result_buffers) for e in self._engines.values() if getattr(e, "result_buffers", None) is not None]
-    if held:
-      res = {k: np.array(v) for k, v in res.items()}
-      for e, _ in held:
-        e.result_buffers = None
-    try:
-      return self._device_solve_tail(res, fail, z0, lb, ub, p, params, opts, cycles, x0_form, B)
-    finally:
-      for e, rb in held:
-        e.result_buffers = rb
-
-  def _device_solve_tail(self, res, fail, z0, lb, ub, p, params, opts, cycles, x0_form, B):
-    if x0_form is not None:
-      z0, lb, ub = self._expand_x0(x0_form[0][fail], x0_form[1])
-      if p is not None and p.ndim == 2:
-        p = p[fail]
-      return self.device_solve_retries(res, fail, z0, lb, ub, p, opts, cycles)
-    z0 = np.asarray(z0, dtype=np.float64).reshape(B, -1)
-    lb = np.broadcast_to(np.asarray(lb, dtype=np.float64), z0.shape)
-    ub = np.broadcast_to(np.asarray(ub, dtype=np.float64), z0.shape)
-    pf = p if (p is None or p.ndim == 1) else p[fail]
-    return self.device_solve_retries(res, fail, z0[fail], lb[fail], ub[fail], pf, opts, cycles)
-
-  def device_solve_retries(self, res, fail, z0, lb, ub, p, opts, cycles):
-    """The elastic phase and the second starts for the instances `fail` of `res` (rows of z0, lb, ub, p = those instances)."""
-    sel = np.arange(fail.size)          # rows of z0 / lb / ub / p still unsolved (fail[i] is the instance of row sel[i])
-    rows_p = lambda idx: p if (p is None or p.ndim == 1) else p[idx]
-    r2 = None
-    if self._twin_engine() is not None:        # elastic mode first, other guesses after it
-      try:
-        r2 = self.elastic_restoration(z0, lb, ub, rows_p(sel), opts)
-      except NotImplementedError as e:          # MYR_E_UNSUPPORTED (myriad_amd/_lib.py: _chk)
-        if "not built" not in str(e):
-          raise
-        self._twin_unsupported = True          # (ROCKETLANDING's twin under the trapezoidal scheme: include/myriad_hip.h)
-        r2 = None
-    if r2 is not None:
-      ok = r2["status"] == 0
-      for k in ("z", "lam", "cost", "status", "kkt"):
-        res[k][fail[ok]] = r2[k][ok]
-      res["iters"][fail] += r2["iters"]
-      res["attempts"][fail] += r2["attempts"]
-      res["restored"][fail[ok]] = 1
-      # stationary point of the infeasibility: the twin converged for the largest rho and its slack neither vanished nor shrank
-      s = r2["slack"]
-      stuck = (~ok) & (r2["twin_status"] == 0) & (s[:, -1] > self.elastic_slack_tol) & (s[:, -1] > 0.1 * s[:, -2])
-      res["status"][fail[stuck]] = _lib.STATUS_INFEASIBLE
-      fail, sel = fail[~ok], sel[~ok]
-    for c in cycles:
-      if fail.size == 0:
-        break
-      lbf, ubf = lb[sel], ub[sel]
-      ns = self._x_shape[1]
-      x0f = np.where(lbf[:, :ns] == ubf[:, :ns], lbf[:, :ns], z0[sel][:, :ns])
-      pf = rows_p(sel)
-      r2 = self._solve_sharded(self.excitation_guess(x0f, lbf, ubf, pf, c), lbf, ubf, pf, opts)
-      r2["iters"] = r2["iters"] + res["iters"][fail]
-      ok = r2["status"] == 0
-      for k in r2:
-        res[k][fail[ok]] = r2[k][ok]
-      res["restored"][fail[ok]] = 0
-      res["start"][fail[ok]] = c
-      res["attempts"][fail] += 1
-      res["iters"][fail[~ok]] = r2["iters"][~ok]
-      fail, sel = fail[~ok], sel[~ok]
-    return res
+      o.restoration = 0
+    if x0_form is not None:       # (x0s, rule): guess and bounds are expanded on the device
+      return self._solve_sharded_x0(x0_form[0], x0_form[1], params, o)
+    return self._solve_sharded(z0, lb, ub, params, o)
 
   # ---- solve ---------------------------------------------------------------------------------------
   def _opt_inputs(self, params=None, guess=None) -> Dict:
@@ -472,9 +313,10 @@ class TrajectoryOptimizer(object):
         z0 = np.broadcast_to(np.asarray(guess, dtype=np.float64), z0.shape).copy()
       res = self.device_solve(z0, lb, ub, p, o, second_starts=ss)
     x, u = self.unravel(res["z"])
+    B = res["status"].shape[0]
+    info = {k: res[k] if k in res else (np.ones(B, np.int32) if k == "attempts" else np.zeros(B, np.int32)) for k in ("start", "attempts", "restored")}
     return {'x': x, 'u': u, 'xs_and_us': res["z"], 'cost': res["cost"], 'lambda': res["lam"],
-            'status': res["status"], 'iters': res["iters"], 'kkt': res["kkt"], 'start': res["start"], 'attempts': res["attempts"],
-            'restored': res["restored"]}
+            'status': res["status"], 'iters': res["iters"], 'kkt': res["kkt"], **info}
 
   def _batch_bounds(self, x0s):
     B, ns = x0s.shape

@@ -248,114 +248,37 @@ class _SecondStartEngine:
             "iters": np.full(B, 10, np.int32), "kkt": np.zeros((B, 3))}
 
 
-def test_second_starts_resolve_only_failed_instances_from_an_excitation_guess(monkeypatch):
-  """device_solve: instances with status != 0 are solved again from oscillating controls + the states of their rollout
-  (clipped into the bounds, pinned rows untouched); converged instances are left alone; iters accumulates;
-  MYRIAD_SECOND_STARTS=0 switches it off."""
+def test_restoration_is_the_librarys_business(monkeypatch):
+  """Rounds 2-3 ran the elastic phase and the second starts in this Python host; round 4 moved them behind the C-ABI
+  (myr_solve_opts.restoration, csrc/myriad_hip.hip: solve_restored; GPU tests: tests/test_gpu_elastic.py,
+  tests/test_integration_stub.py).  What is left here: device_solve makes ONE engine call, and asks for a single attempt
+  (restoration = 0) when the caller brought an explicit guess."""
   from myriad_amd.config import Config, HParams, IntegrationMethod, OptimizerType, QuadratureRule
   from myriad_amd.systems import SystemType
   from myriad_amd.trajectory_optimizers import get_optimizer
   hp = HParams(system=SystemType.PENDULUM, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
                integration_method=IntegrationMethod.HEUN, intervals=6)
   opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
-  eng = _SecondStartEngine(); eng.rows_u = opt._u_shape[0]
+  seen = []
+
+  class Opts:
+    max_iter = 7; restoration = -1
+
+  class Eng(_SecondStartEngine):
+    def solve(self, z0, lb, ub, params=None, opts=None):
+      seen.append(opts.restoration)
+      return super().solve(z0, lb, ub, params=params, opts=opts)
+
+    def default_opts(self):
+      return Opts()
+
+  eng = Eng(); eng.rows_u = opt._u_shape[0]
   opt._engine = eng
-  monkeypatch.setenv("MYRIAD_ELASTIC", "0")       # the elastic phase (next test) comes before the second starts
-  B = 3
-  x0s = np.tile(opt.system.x_0, (B, 1))
-  z0, lb, ub = opt.batch_inputs(x0s, None)
-  z0[1, -1] = 0.1                          # instance 1 has a non-zero control guess: "converges" at the first attempt
-  res = opt.device_solve(z0, lb, ub, None, None)
-  assert (res["status"] == 0).all() and list(res["iters"]) == [20, 10, 20] and list(res["cost"]) == [1.0, 1.0, 1.0]
-  assert len(eng.calls) == 2 and eng.calls[1].shape[0] == 2            # one second start, for the two failed instances only
-  assert list(res["start"]) == [2, 0, 2] and list(res["attempts"]) == [2, 1, 2]   # which start produced each instance
-  eng.calls.clear()
-  r1 = opt.device_solve(z0, lb, ub, None, None, second_starts=False)   # an explicit guess: the first attempt is returned as it is
-  assert list(r1["status"]) == [1, 0, 1] and len(eng.calls) == 1 and list(r1["attempts"]) == [1, 1, 1]
-  eng.calls.clear()
-  res = opt.device_solve(z0, lb, ub, None, None)
-  g = eng.calls[1]
-  assert (g >= lb[[0, 2]]).all() and (g <= ub[[0, 2]]).all()           # clipped (the rollout left the box at row 3)
-  nx = z0.shape[1] - eng.rows_u
-  assert np.array_equal(g[:, :2], x0s[[0, 2]])                          # pinned first state
-  u = g[0, nx:]
-  umax = opt.system.bounds[2][1]
-  assert abs(u[0]) < 1e-12 and 0.7 * umax < np.abs(u).max() <= 0.95 * umax + 1e-12 and (np.diff(np.sign(u[1:-1])) != 0).sum() >= 3
-  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0")
-  eng.calls.clear()
-  res = opt.device_solve(z0, lb, ub, None, None)
-  assert list(res["status"]) == [1, 0, 1] and len(eng.calls) == 1
-
-
-class _TwinEngine:
-  """CPU stand-in for the handle of an elastic twin (PENDULUM_ELASTIC: 2 states, 1 control + 2 slacks): returns the point it was
-  given with controls 0.5 and slacks `slack[k]` at the k-th call of a phase, status 0."""
-
-  def __init__(self, slack):
-    self.slack, self.calls = slack, []
-
-  def solve(self, z0, lb, ub, params=None, opts=None):
-    z = np.array(z0, copy=True); B = z.shape[0]
-    k = len(self.calls) % len(self.slack)
-    self.calls.append((z0.copy(), np.array(lb, copy=True), np.array(ub, copy=True), np.array(params, copy=True)))
-    U = z[:, self.nx:].reshape(B, -1, 3)
-    U[:, :, 0] = 0.5 * self.u_value
-    U[:, :, 1:] = self.slack[k]
-    return {"z": z, "lam": np.zeros((B, 1)), "cost": np.ones(B), "status": np.zeros(B, np.int32), "iters": np.full(B, 7, np.int32),
-            "kkt": np.zeros((B, 3))}
-
-
-def test_elastic_phase_restores_failed_instances_and_reports_infeasibility(monkeypatch):
-  """device_solve: an instance without a KKT point goes through its system's elastic twin (slack controls, rho = 1, 1e2, 1e4, each
-  from the previous solution) and is solved again from the twin's states and controls -- before any second start; a twin whose
-  slack does not shrink marks the instance INFEASIBLE (status 4) when the final solve fails as well."""
-  from myriad_amd import _lib
-  from myriad_amd.config import Config, HParams, IntegrationMethod, OptimizerType, QuadratureRule
-  from myriad_amd.systems import SystemType
-  from myriad_amd.trajectory_optimizers import get_optimizer
-  hp = HParams(system=SystemType.PENDULUM, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
-               integration_method=IntegrationMethod.HEUN, intervals=6)
-  opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
-  eng = _SecondStartEngine(); eng.rows_u = opt._u_shape[0]
-  opt._engine = eng
-  rows_u = opt._u_shape[0]; nx = opt._x_shape[0] * 2
-  twin = _TwinEngine(slack=[1.0, 1e-2, 1e-4]); twin.nx = nx; twin.u_value = 1.0
-  opt._twin = twin
-  B = 3
-  z0, lb, ub = opt.batch_inputs(np.tile(opt.system.x_0, (B, 1)), None)
-  z0[1, -1] = 0.1                                            # instance 1 converges at the first attempt
-  res = opt.device_solve(z0, lb, ub, None, None)
-  assert (res["status"] == 0).all() and list(res["restored"]) == [1, 0, 1] and list(res["start"]) == [0, 0, 0]
-  assert list(res["attempts"]) == [5, 1, 5] and list(res["iters"]) == [10 + 3 * 7 + 10, 10, 10 + 3 * 7 + 10]
-  assert len(twin.calls) == 3 and len(eng.calls) == 2          # three twin solves, one final solve: no second start was needed
-  zt, lbt, ubt, pt = twin.calls[0]
-  assert zt.shape == (2, nx + rows_u * 3) and np.array_equal(zt[:, :nx], z0[[0, 2], :nx])      # the failed instances, from THEIR guess
-  Ut = zt[:, nx:].reshape(2, rows_u, 3)
-  assert (Ut[:, :, 1:] == 0).all() and np.array_equal(Ut[:, :, 0], z0[[0, 2], nx:])
-  assert np.isneginf(lbt[:, nx:].reshape(2, rows_u, 3)[:, :, 1:]).all() and np.isposinf(ubt[:, nx:].reshape(2, rows_u, 3)[:, :, 1:]).all()
-  assert np.array_equal(lbt[:, nx:].reshape(2, rows_u, 3)[:, :, 0], lb[[0, 2], nx:])
-  assert [c[3][0, -1] for c in twin.calls] == [1.0, 1e2, 1e4] and np.array_equal(twin.calls[0][3][0, :-1], opt.system.device_params())
-  assert np.array_equal(twin.calls[1][0], np.clip(twin.calls[1][0], lbt, ubt)) and (twin.calls[1][0][:, nx:].reshape(2, rows_u, 3)[:, :, 1:] == 1.0).all()
-  final = eng.calls[1]
-  assert final.shape == (2, nx + rows_u) and (final[:, nx:] == 0.5).all()                  # the twin's controls without the slacks
-  # a twin whose slack stays: the final solve fails (controls zero), second starts are off -> INFEASIBLE
-  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0")
-  twin2 = _TwinEngine(slack=[1.0, 0.9, 0.8]); twin2.nx = nx; twin2.u_value = 0.0
-  opt._twin = twin2
-  res = opt.device_solve(z0, lb, ub, None, None)
-  assert list(res["status"]) == [_lib.STATUS_INFEASIBLE, 0, _lib.STATUS_INFEASIBLE] and list(res["restored"]) == [0, 0, 0]
-  assert _lib.STATUS_NAMES[_lib.STATUS_INFEASIBLE] == "INFEASIBLE"
-  # a twin whose slack vanishes while the final solve still fails: no certificate, the solver's own status stays
-  twin3 = _TwinEngine(slack=[1.0, 1e-2, 1e-4]); twin3.nx = nx; twin3.u_value = 0.0
-  opt._twin = twin3
-  res = opt.device_solve(z0, lb, ub, None, None)
-  assert list(res["status"]) == [1, 0, 1]
-  # an explicit guess (second_starts=False) or MYRIAD_ELASTIC=0: the first attempt is returned as it is
-  n = len(twin3.calls)
-  opt.device_solve(z0, lb, ub, None, None, second_starts=False)
-  monkeypatch.setenv("MYRIAD_ELASTIC", "0")
-  opt.device_solve(z0, lb, ub, None, None)
-  assert len(twin3.calls) == n
+  z0, lb, ub = opt.batch_inputs(np.tile(opt.system.x_0, (3, 1)), None)
+  r = opt.device_solve(z0, lb, ub, None, None)
+  assert len(eng.calls) == 1 and seen == [-1] and list(r["status"]) == [1, 1, 1]      # the stub's statuses, untouched
+  opt.device_solve(z0, lb, ub, None, Opts(), second_starts=False)
+  assert seen == [-1, 0] and Opts.restoration == -1                                    # (the caller's options are not modified)
 
 
 class _ShardEngine:
@@ -437,29 +360,33 @@ def test_solve_batch_fans_out_beneath_the_unchanged_api(monkeypatch):
   assert len(e0.calls) == 1 and e0.calls[0][0].shape[0] == B and not e1.calls
 
 
-def test_x0_form_takes_the_device_expansion_and_expands_only_failed_instances_on_the_host(monkeypatch):
+def test_x0_form_takes_the_device_expansion(monkeypatch):
   """solve_batch without an explicit guess hands start states + the guess rule to the engine (myr_solve_x0: no [B][n] arrays on
-  the host); the instances that fail are expanded on the host -- bit for bit batch_inputs' arrays -- for the second starts.
-  MYRIAD_SOLVE_X0=0 and an explicit guess keep the array path."""
+  the host); the rule reproduces batch_inputs' arrays bit for bit.  MYRIAD_SOLVE_X0=0 and an explicit guess keep the array path."""
   from myriad_amd.config import Config, HParams, IntegrationMethod, OptimizerType, QuadratureRule
   from myriad_amd.systems import SystemType
   from myriad_amd.trajectory_optimizers import get_optimizer
   hp = HParams(system=SystemType.PENDULUM, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON,
                integration_method=IntegrationMethod.HEUN, intervals=6)
   opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
-  monkeypatch.setenv("MYRIAD_ELASTIC", "0")
   x0_calls = []
 
   class Eng(_SecondStartEngine):
     def solve_x0(self, x0s, g0, g1, lb, ub, params=None, opts=None):
       x0_calls.append((np.array(x0s), np.array(g0), np.array(g1), np.array(lb), np.array(ub)))
       B = x0s.shape[0]
-      st = np.zeros(B, np.int32); st[1] = 1                       # instance 1 fails the first attempt
-      return {"z": np.zeros((B, g0.size)), "lam": np.zeros((B, 1)), "cost": np.ones(B), "status": st,
-              "iters": np.full(B, 10, np.int32), "kkt": np.zeros((B, 3))}
+      return {"z": np.zeros((B, g0.size)), "lam": np.zeros((B, 1)), "cost": np.ones(B), "status": np.zeros(B, np.int32),
+              "iters": np.full(B, 10, np.int32), "kkt": np.zeros((B, 3)), "start": np.zeros(B, np.int32), "attempts": np.ones(B, np.int32),
+              "restored": np.zeros(B, np.int32)}
+
+    def solve(self, z0, lb, ub, params=None, opts=None):
+      r = super().solve(z0, lb, ub, params=params, opts=opts)
+      B = r["status"].shape[0]
+      r.update(start=np.zeros(B, np.int32), attempts=np.ones(B, np.int32), restored=np.zeros(B, np.int32))
+      return r
 
     def default_opts(self):
-      class O: max_iter = 0
+      class O: max_iter = 0; restoration = -1
       return O()
 
   eng = Eng(); eng.rows_u = opt._u_shape[0]
@@ -467,21 +394,17 @@ def test_x0_form_takes_the_device_expansion_and_expands_only_failed_instances_on
   rng = np.random.default_rng(0)
   x0s = opt.system.x_0[None] + 0.1 * rng.standard_normal((3, 2))
   res = opt.solve_batch(x0s=x0s)
-  assert len(x0_calls) == 1 and np.array_equal(x0_calls[0][0], x0s)
+  assert len(x0_calls) == 1 and np.array_equal(x0_calls[0][0], x0s) and not eng.calls
   z0, lb, ub = opt.batch_inputs(x0s, None)
   g0, g1 = x0_calls[0][1], x0_calls[0][2]
   rows, ns = opt._x_shape
   ze = np.tile(g0, (3, 1)); ze[:, :rows * ns] += np.tile(x0s, (1, rows)) * g1[None, :rows * ns]
   assert np.array_equal(ze, z0)                                    # the rule reproduces the reference guess bit for bit
   assert np.array_equal(x0_calls[0][3], opt.bounds[:, 0]) and np.array_equal(x0_calls[0][4], opt.bounds[:, 1])
-  assert len(eng.calls) == 1 and eng.calls[0].shape[0] == 1        # one second start, for the failed instance only
-  assert np.array_equal(eng.calls[0][:, :ns], x0s[[1]])            # ... expanded from ITS start state
-  assert list(res["status"]) == [0, 0, 0] and list(res["start"]) == [0, 2, 0] and list(res["attempts"]) == [1, 2, 1]
+  assert list(res["status"]) == [0, 0, 0] and list(res["attempts"]) == [1, 1, 1]
   monkeypatch.setenv("MYRIAD_SOLVE_X0", "0")
-  x0_calls.clear(); eng.calls.clear()
   opt.solve_batch(x0s=x0s)
-  assert len(x0_calls) == 0 and np.array_equal(eng.calls[0], z0)   # the array path, same inputs
+  assert len(x0_calls) == 1 and len(eng.calls) == 1 and np.array_equal(eng.calls[0], z0)
   monkeypatch.delenv("MYRIAD_SOLVE_X0")
-  eng.calls.clear()
   opt.solve_batch(x0s=x0s, guess=z0[0])
-  assert len(x0_calls) == 0 and len(eng.calls) == 1                # an explicit guess: arrays, no second start
+  assert len(x0_calls) == 1 and len(eng.calls) == 2

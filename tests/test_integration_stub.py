@@ -111,6 +111,27 @@ def test_hip_sqp_stub_solves_like_the_package(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_hip_sqp_stub_solves_pendulum_from_the_reference_guess_with_no_host_logic(monkeypatch):
+  """the stand-in for IPOPT's restoration phase travels with the C-ABI.  The torque-limited PENDULUM swing-up jams
+  at an infeasible stationary point from the reference's straight-line guess (what the reference leaves to IPOPT's restoration phase,
+  nlp_solvers/__init__.py:57-58); the ctypes stub of INTEGRATION.md -- myr_create, myr_solve, myr_destroy, nothing else -- returns
+  the optimum, because myr_solve itself runs the elastic phase / the second starts (myr_solve_opts.restoration, default on)."""
+  from myriad_amd.config import Config, HParams, IntegrationMethod, NLPSolverType, OptimizerType, QuadratureRule
+  from myriad_amd.systems import SystemType
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  ns = _namespace(monkeypatch)
+  for k in ("MYRIAD_ELASTIC", "MYRIAD_SECOND_STARTS"):
+    monkeypatch.delenv(k, raising=False)
+  for rule, N, cost in ((QuadratureRule.HERMITE_SIMPSON, 20, 25.539), (QuadratureRule.TRAPEZOIDAL, 40, 25.43)):
+    hp = HParams(system=SystemType.PENDULUM, optimizer=OptimizerType.COLLOCATION, quadrature_rule=rule, integration_method=IntegrationMethod.RK4,
+                 intervals=N, nlpsolver=NLPSolverType.SQP)
+    opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+    sol = ns["hip_sqp"](hp, opt._opt_inputs())
+    assert sol["success"], (rule, sol["nit"])
+    assert sol["fun"] == pytest.approx(cost, rel=2e-3)
+
+
+@pytest.mark.gpu
 def test_hip_fbsm_stub_matches_the_mirror(monkeypatch):
   from myriad_amd.config import Config, HParams, OptimizerType
   from myriad_amd.systems import SystemType
