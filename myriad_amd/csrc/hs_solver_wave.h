@@ -1984,7 +1984,9 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
   typename W::Ctx c;
   // coop (network systems, small batches): the workgroup's wavefronts share ONE trajectory -- wavefront 0 solves, the others
   // help with the network passes (node_pass); otherwise every wavefront of the workgroup is an independent solve
-  const int wave = coop ? 0 : (int)(threadIdx.x >> 6), waves = coop ? 1 : (int)(blockDim.x >> 6);
+  // (wavefront index wave-uniform by construction: branches on it are scalar branches, not EXEC-masked regions -- hs_solver_fused.h, sweep())
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = coop ? 0 : wv, waves = coop ? 1 : (int)(blockDim.x >> 6);
   c.N = o.N; c.K = W::npoints(o.N); c.n = c.K * W::NW; c.lane = threadIdx.x & 63;
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
   double* s = scratch + ((long)blockIdx.x * waves + wave) * scratch_stride + W::PADF;
@@ -2012,11 +2014,11 @@ void hs_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double
     if (params_stride == 0) {
       SysParams<Sys> pw;
       pw.load(params, 0, 0);
-      if ((threadIdx.x >> 6) == 0) NodeMfma64::load_weights(pw.get(), c.wl, c.lane);
+      if (wv == 0) NodeMfma64::load_weights(pw.get(), c.wl, c.lane);
       __syncthreads();
     }
-    if (coop && (threadIdx.x >> 6) != 0) {       // helper wavefronts of the cooperative mode
-      W::coop_helper(c.wl, c.cmd, (int)(threadIdx.x >> 6), c.lane);
+    if (coop && wv != 0) {       // helper wavefronts of the cooperative mode
+      W::coop_helper(c.wl, c.cmd, wv, c.lane);
       return;
     }
   }

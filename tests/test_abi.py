@@ -31,13 +31,13 @@ def test_exports_match_header(lib):
 def test_struct_layouts_match_header():
   assert C.sizeof(_lib.ProblemDesc) == 8 * 4 + 8
   assert C.sizeof(_lib.Dims) == 10 * 4
-  assert C.sizeof(_lib.SolveOpts) == 2 * 4 + 4 * 8
+  assert C.sizeof(_lib.SolveOpts) == 2 * 4 + 4 * 8 + 2 * 4          # (round 4: + restoration, reserved)
 
 
 def test_default_opts(lib):
   o = _lib.SolveOpts()
   lib.myr_default_solve_opts(C.byref(o))
-  assert o.max_iter == 1000 and o.tol_feas == 1e-8 and o.tol_stat == 1e-6
+  assert o.max_iter == 1000 and o.tol_feas == 1e-8 and o.tol_stat == 1e-6 and o.restoration == -1
 
 
 def test_create_rejects_bad_arguments(lib):
