@@ -29,7 +29,10 @@ def gather_solutions(local: Dict[str, "torch.Tensor"], counts: Sequence[int], gr
   out = {}
   equal = all(c == mx for c in counts)
   fused = dst is None and equal and dist.get_backend(group) == "nccl"      # RCCL: one flat all-gather straight into the result
+  stage = dist.get_backend(group) == "gloo"       # gloo moves host memory: device tensors are staged through it (results stay on the host)
   for k, t in local.items():
+    if stage and t.is_cuda:
+      t = t.cpu()
     if fused:
       res = t.new_empty((world * mx,) + tuple(t.shape[1:]))
       dist.all_gather_into_tensor(res, t.contiguous(), group=group)

@@ -97,6 +97,7 @@ struct myr_handle_s {
   bool twin_unavailable = false;
   void* rbuf = nullptr; size_t rbuf_bytes = 0;      // copy of the caller's guess + status / iters when the caller passed none
   void* fbuf = nullptr; size_t fbuf_bytes = 0;      // working set of the failed instances
+  int32_t* nfail_host = nullptr;                    // pinned, device-visible: instances the first attempt left without a KKT point
   std::vector<int32_t> info_start, info_attempts, info_restored;
   unsigned long long poison = 0;   // MYRIAD_POISON: bit pattern written over a slot's LDS and scratch at every trajectory hand-over (tests)
   int cus = 0;                // compute units of the device (cached)
@@ -891,6 +892,7 @@ extern "C" int myr_destroy(myr_handle h) {
   if (h->vbuf) (void)hipFree(h->vbuf);
   if (h->rbuf) (void)hipFree(h->rbuf);
   if (h->fbuf) (void)hipFree(h->fbuf);
+  if (h->nfail_host) (void)hipHostFree(h->nfail_host);
   if (h->twin) { (void)myr_destroy(h->twin); h->twin = nullptr; }
   for (int i = 0; i < MYR_K_COUNT; ++i) {
     if (h->kt[i].a) (void)hipEventDestroy(h->kt[i].a);
@@ -1239,6 +1241,14 @@ __global__ void excitation_pack_kernel(long total, int n, int nx, int ns, int nu
   }
 }
 
+// how many instances ended without a KKT point -> a pinned host word (the common answer, none, costs no status download)
+__global__ void count_failed_kernel(int B, const int32_t* __restrict__ status, int32_t* __restrict__ out) {
+  int n = 0;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) n += status[b] != MYR_STATUS_CONVERGED ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
+}
+
 static bool twin_defaults(int twin_id, double* buf) {
   switch (twin_id) {
 #define X(N) case MYR_SYS_##N: Sys##N::default_params(buf); return true;
@@ -1312,6 +1322,12 @@ static int solve_restored(myr_handle h, int B, double* z, const double* lb, cons
   int32_t* dit = iters ? iters : (int32_t*)(z0c + al((size_t)B * n) + al((size_t)B));
   HIPCHK(hipMemcpyAsync(z0c, z, (size_t)B * n * 8, hipMemcpyDeviceToDevice, h->stream));
   if (int rc = dispatch_solve_scaled(h, B, z, lb, ub, params, pstride, so, lam, cost, dstat, dit, kkt)) return rc;
+  if (!h->nfail_host) HIPCHK(hipHostMalloc((void**)&h->nfail_host, 64, hipHostMallocMapped));
+  *h->nfail_host = 0;
+  hipLaunchKernelGGL(count_failed_kernel, dim3((unsigned)((B + 255) / 256 > 64 ? 64 : (B + 255) / 256)), dim3(256), 0, h->stream, B, dstat, h->nfail_host);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (*h->nfail_host == 0) return MYR_OK;
   std::vector<int32_t> hstat(B), hit(B);
   HIPCHK(hipMemcpyAsync(hstat.data(), dstat, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1510,7 +1526,7 @@ extern "C" int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, c
   if (!h || !z || !lb || !ub) return fail(MYR_E_ARG, "myr_solve: null handle, z, lb or ub");
   if (h->d.system_id == MYR_SYS_INVASIVEPLANT) return no_such_path(h, "myr_solve");
   if (B < 0) return fail(MYR_E_ARG, "myr_solve: negative batch");
-  if (B == 0) return MYR_OK;
+  if (B == 0) { h->info_start.clear(); h->info_attempts.clear(); h->info_restored.clear(); return MYR_OK; }
   if (params && params_stride != 0 && params_stride != h->dims.np)
     return fail(MYR_E_ARG, "myr_solve: params_stride must be 0 (shared) or np");
   if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, "myr_solve: a NODE system needs its weights in `params`");
@@ -1585,7 +1601,7 @@ extern "C" int myr_solve_x0(myr_handle h, int32_t B, const double* x0s, const do
   if (!h || !x0s || !g0 || !g1 || !lb || !ub || !z) return fail(MYR_E_ARG, "myr_solve_x0: null handle, x0s, g0, g1, lb, ub or z");
   if (h->d.system_id == MYR_SYS_INVASIVEPLANT) return no_such_path(h, "myr_solve_x0");
   if (B < 0) return fail(MYR_E_ARG, "myr_solve_x0: negative batch");
-  if (B == 0) return MYR_OK;
+  if (B == 0) { h->info_start.clear(); h->info_attempts.clear(); h->info_restored.clear(); return MYR_OK; }
   if (params && params_stride != 0 && params_stride != h->dims.np)
     return fail(MYR_E_ARG, "myr_solve_x0: params_stride must be 0 (shared) or np");
   if (!params && h->d.system_id == MYR_SYS_NODE_CARTPOLE) return fail(MYR_E_ARG, "myr_solve_x0: a NODE system needs its weights in `params`");
