@@ -1006,8 +1006,8 @@ struct HsFused {
     // wavefront 0 sweeps -- inlines riccati_mfma on the context: with the wavefront index wave-uniform BY CONSTRUCTION (readfirstlane in
     // the kernel) the branch around it is a scalar one.  Round 3 had the index as a per-lane value: the sweep then sat inside an
     // EXEC-masked region, and that build returned results that differed from launch to launch on fresh handles (DESIGN.md section 8;
-    // tests/test_gpu_poison.py).  Two other forms were tried in round 4 and are kept behind flags because they FAULT in some
-    // instantiations (-DMYR_SWEEP_CALL_W: a call made by one wavefront; -DMYR_W2_QUALIFIED: the inlined body on SwArgs).
+    // tests/test_gpu_poison.py).  Two other forms are kept behind flags because they FAULT in some instantiations
+    // (-DMYR_SWEEP_CALL_W: a call made by one wavefront, round 3; -DMYR_W2_QUALIFIED: the inlined body on SwArgs, round 4 exp9).
 #if defined(MYR_SWEEP_CALL_W)
     constexpr bool CALL = true, QUAL = false;
 #elif defined(MYR_W2_QUALIFIED)

@@ -6,7 +6,8 @@
     the same bits under all of them;
   * fresh handles: the same problem on three handles created one after the other (new scratch, whatever the previous kernel left in
     LDS) -- the way the two-wavefront kernel of round 3 showed its defect (three processes, three answers).
-What replaces: tools/dev/w2_probe.py, node_coop_probe.py, rocket_probe.py (kept as thin command-line front ends of tools/dev/wprobe.py).
+What it replaces: tools/dev/w2_probe.py, node_coop_probe.py, rocket_probe.py of round 3 (removed; tools/dev/wprobe.py and fresh_stats.py are the
+command-line forms of the same comparisons).
 Reference behaviour held: /root/reference/tests/test_smoke.py:29-61 (every system returns, from the reference's guess)."""
 import hashlib
 import os

@@ -174,7 +174,10 @@ def test_fused_kernel_wavefront_forms_and_round2_kernel_agree(monkeypatch):
     a, b = out["w1"], out[tag]
     assert (a["status"] == 0).all() and (b["status"] == 0).all()
     np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-9)
-    assert (a["iters"] == b["iters"]).mean() >= 0.9, (tag, np.bincount(np.abs(a["iters"] - b["iters"])))
+    if tag == "w2":     # W = 1 and W = 2 take bit-identical steps; only the merit sums differ in their last bits: the same iterations
+      assert np.array_equal(a["iters"], b["iters"]), (tag, np.bincount(np.abs(a["iters"] - b["iters"])))
+    else:
+      assert (a["iters"] == b["iters"]).mean() >= 0.9, (tag, np.bincount(np.abs(a["iters"] - b["iters"])))
     same = a["iters"] == b["iters"]
     assert np.abs(a["z"][same] - b["z"][same]).max() < 1e-6
     assert np.abs(a["lam"][same] - b["lam"][same]).max() < 1e-4 * max(1.0, np.abs(a["lam"]).max())
