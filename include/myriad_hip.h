@@ -113,7 +113,7 @@ typedef struct {
                            shooting wavefront kernel, 0 for every other kernel), 0 = a single attempt of at most max_iter
                            iterations -- `iters` <= max_iter then holds --, k > 0 = up to k more (at most 4).  With restarts
                            the first attempt is cut at max(100, max_iter / 8) iterations, a restart takes the caller's point
-                           again with another initial barrier parameter (mu_init x 3, then / 3) and the full max_iter, and
+                           again with another initial barrier parameter (mu_init x 3, / 3, x 9, / 9: a different one per attempt) and the full max_iter, and
                            `iters` reports the sum over the attempts.  Only the shooting wavefront kernel restarts; the lane
                            kernels (MYRIAD_SOLVE_MODE=lane, iterates too large for LDS) ignore the field. */
   double  tol_feas;     /* converged: max|c| <= tol_feas                  (default 1e-8)  */
