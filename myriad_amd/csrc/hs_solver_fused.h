@@ -27,6 +27,20 @@
 
 namespace myriad {
 
+// A condition that is the same in every lane by the algorithm but not by the compiler's analysis, as a wave-uniform value: the branch on
+// it is a scalar branch (s_cbranch_scc), not an EXEC-masked region.  Used by the sweeps of the W > 1 kernels (inlined into a kernel whose
+// wavefronts take different paths; measured there: B = 256 / 512 kernel 2.95 / 3.10 ms against 3.01 / 3.15 ms); the sweep W = 1 calls as a
+// function keeps the per-lane form (all-or-none masks in uniform control flow, gated by the same tests: the scalar form costs it 1.6 %,
+// 14.55 against 14.33 ms -- profiles/r04/README.md).  -DMYR_SWEEP_UNIFORM=0 / 1 forces one form everywhere.
+#ifndef MYR_SWEEP_UNIFORM
+#define MYR_SWEEP_UNIFORM -1
+#endif
+template <bool ON>
+__device__ inline bool uniform_if(bool c) {
+  if constexpr (ON) return __builtin_amdgcn_readfirstlane((int)c) != 0;
+  else return c;
+}
+
 // lane l <- lane l - 1 (lane 0: unspecified, the callers overwrite it)
 __device__ inline double lane_up1(double v) { return __shfl_up(v, 1, 64); }
 
@@ -781,6 +795,7 @@ struct HsFused {
     double reg_floor = o.reg_floor;
     asm volatile("" : "+v"(reg_floor));
     int nreg = 0;
+    const bool abort_u = uniform_if<(MYR_SWEEP_UNIFORM < 0 ? (W > 1) : (MYR_SWEEP_UNIFORM != 0))>(abort_on_reg);
     double in[PF][6];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -838,7 +853,11 @@ struct HsFused {
         const double b0 = D2[3], b1 = D2[2];
         double kk0 = fma(q11, b0, -(q10 * b1)) * rdet;
         double kk1 = fma(q00, b1, -(q10 * b0)) * rdet;
-        if (!(q00 > reg_floor) || !(det > reg_floor * q00)) {          // wave-uniform, rare
+        // (the pivot test is wave-uniform -- the pivots come from v_readlane -- but the compiler sees per-lane values: decided in the
+        //  vector unit and, in the W > 1 kernels, made a SCALAR branch through readfirstlane, so that no matrix instruction of their sweep
+        //  sits inside an EXEC-masked region: v_mfma does not honour EXEC on this part, tools/dev/litmus/mfma_exec.hip)
+        const bool rare_ = !(q00 > reg_floor) || !(det > reg_floor * q00);
+        if (uniform_if<(MYR_SWEEP_UNIFORM < 0 ? (W > 1) : (MYR_SWEEP_UNIFORM != 0))>(rare_)) {                                       // rare
           const double u00 = q00, u10 = q10, u11 = q11;
           double d0 = u00;
           if (!(d0 > reg_floor)) { d0 = dmax(fabs(d0), reg_floor); ++nreg; }
@@ -846,7 +865,7 @@ struct HsFused {
           const double l10 = u10 * i0;
           double d1 = u11 - l10 * l10 * d0;
           if (!(d1 > reg_floor)) { d1 = dmax(fabs(d1), reg_floor); ++nreg; }
-          if (nreg > 0 && abort_on_reg) return nreg;
+          if (uniform_if<(MYR_SWEEP_UNIFORM < 0 ? (W > 1) : (MYR_SWEEP_UNIFORM != 0))>(nreg > 0) && abort_u) return nreg;
           const double i1 = fast_rcp(d1);
           kk0 = b0; kk1 = b1;
           kk1 -= l10 * kk0;
@@ -917,6 +936,7 @@ struct HsFused {
     double reg_floor = o.reg_floor;
     asm volatile("" : "+v"(reg_floor));
     int nreg = 0;
+    const bool abort_u = uniform_if<(MYR_SWEEP_UNIFORM < 0 ? (W > 1) : (MYR_SWEEP_UNIFORM != 0))>(abort_on_reg);
     double in[PF][3];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -944,9 +964,10 @@ struct HsFused {
         const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
         const double q11 = W0::rdlane(D2[2], 8);
         double d = q11;
-        if (!(d > reg_floor)) {                                        // wave-uniform, rare (same pivot rule as chol_reg)
+        const bool rare_ = !(d > reg_floor);
+        if (uniform_if<(MYR_SWEEP_UNIFORM < 0 ? (W > 1) : (MYR_SWEEP_UNIFORM != 0))>(rare_)) {                                       // rare (same pivot rule as chol_reg); a scalar branch, see riccati_mfma
           d = dmax(fabs(d), reg_floor); ++nreg;
-          if (abort_on_reg) return nreg;
+          if (abort_u) return nreg;
         }
         const double kk = D2[2] * fast_rcp(d);
         k_ptr[0] = kk;
