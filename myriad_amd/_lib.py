@@ -20,7 +20,7 @@ SYS_IDS = {"CARTPOLE": 0, "VANDERPOL": 1, "CANCERTREATMENT": 2, "SIMPLECASE": 3,
            "BEARPOPULATIONS": 12, "PENDULUM": 13, "MOUNTAINCAR": 14, "ROCKETLANDING": 15,
            "BACTERIA": 16, "TUMOUR": 17, "HARVEST": 18, "TIMBERHARVEST": 19, "PREDATORPREY": 20,
            "INVASIVEPLANT": 21,   # INVASIVEPLANT: discrete-time, myr_fbsm only
-           "PENDULUM_ELASTIC": 113, "ROCKETLANDING_ELASTIC": 115}   # elastic twins (slack controls on the dynamics), see include/myriad_hip.h
+           "PENDULUM_ELASTIC": 113, "ROCKETLANDING_ELASTIC": 115, "CARTPOLE_ELASTIC": 100, "VANDERPOL_ELASTIC": 101, "MOUNTAINCAR_ELASTIC": 114}   # elastic twins (slack controls on the dynamics), see include/myriad_hip.h
 TR_IDS = {"HERMITE_SIMPSON": 0, "TRAPEZOIDAL": 1, "SHOOTING": 2}
 INT_IDS = {"EULER": 0, "HEUN": 1, "MIDPOINT": 2, "RK4": 3}
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -28,7 +28,7 @@
   X(CARTPOLE) X(VANDERPOL) X(CANCERTREATMENT) X(SIMPLECASE) X(BIOREACTOR) X(GLUCOSE) X(MOULDFUNGICIDE)           \
   X(SIMPLECASEWITHBOUNDS) X(HIVTREATMENT) X(EPIDEMICSEIRN) X(SEIR) X(BEARPOPULATIONS) X(PENDULUM) X(MOUNTAINCAR)     \
   X(ROCKETLANDING) X(BACTERIA) X(TUMOUR) X(HARVEST) X(TIMBERHARVEST) X(PREDATORPREY)                               \
-  X(PENDULUM_ELASTIC) X(ROCKETLANDING_ELASTIC)
+  X(PENDULUM_ELASTIC) X(ROCKETLANDING_ELASTIC) X(CARTPOLE_ELASTIC) X(VANDERPOL_ELASTIC) X(MOUNTAINCAR_ELASTIC)
 
 
 using namespace myriad;
@@ -711,9 +711,8 @@ int solve_for_system(myr_handle h, int B, double* z, const double* lb, const dou
     case MYR_TR_HERMITE_SIMPSON:
       return launch_hs_solve<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     case MYR_TR_TRAPEZOIDAL:     // wavefront form (falls back to the lane form for MYRIAD_SOLVE_MODE=lane / very large N)
-      // (an elastic twin with more than 8 variables per point -- ROCKETLANDING's has 14 -- would run on the lane kernel at 16 ms an
-      // iteration, too slow to deliver a verdict, and costs a minute of build time: not built)
-      if constexpr (Sys::ID >= 100 && Sys::NW > 8) return fail(MYR_E_UNSUPPORTED, "myr_solve: the trapezoidal solver of this elastic twin is not built");
+      // (the twin of ROCKETLANDING -- 14 variables per point -- costs minutes of build time per solver: its trapezoidal one is not built)
+      if constexpr (Sys::ID >= 100 && Sys::NW > 9) return fail(MYR_E_UNSUPPORTED, "myr_solve: the trapezoidal solver of this elastic twin is not built");
       else return launch_hs_solve<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     case MYR_TR_SHOOTING:
       // elastic twins (id >= 100) exist for the collocation solvers, whose restoration device they are; their shooting solver is not built

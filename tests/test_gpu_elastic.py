@@ -14,7 +14,7 @@ from myriad_amd.trajectory_optimizers import get_optimizer, hs_dense_from_blocks
 CFG = Config(verbose=False, plot=False)
 
 
-@pytest.mark.parametrize("base", ["PENDULUM", "ROCKETLANDING"])
+@pytest.mark.parametrize("base", ["PENDULUM", "ROCKETLANDING", "CARTPOLE", "VANDERPOL", "MOUNTAINCAR"])
 @pytest.mark.parametrize("tr_name,N", [("HERMITE_SIMPSON", 5), ("TRAPEZOIDAL", 9)])
 def test_twin_callbacks_match_the_oracle(base, tr_name, N):
   """objective, constraints, gradient and Jacobian of the twin (ns + nu + ns variables per point) against autodiff of oracle.Elastic"""
@@ -38,6 +38,25 @@ def test_twin_callbacks_match_the_oracle(base, tr_name, N):
   ref = g_ref + J_ref.T @ lam
   np.testing.assert_allclose(eng.vjp(z[None], lam[None], params=s.params(), add_gradf=True)[0], ref, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(ref).max()))
   np.testing.assert_allclose(eng.vjp(z[None], 0 * lam[None], params=s.params(), add_gradf=True)[0], g_ref, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(g_ref).max()))
+
+
+@pytest.mark.parametrize("base", ["CARTPOLE", "VANDERPOL", "MOUNTAINCAR"])
+def test_new_twins_solve_the_first_problem_of_the_phase(base):
+  """the twins added in round 4 (one per system with pinned terminal states): the FIRST problem of the elastic phase -- rho = 1, from the
+  reference's guess widened by s = 0, Hermite-Simpson -- converges, and its solution is feasible for the oracle's restatement of the twin.
+  (Not a requirement of the phase: a twin solve that stops at its iteration cap still hands its trajectory on -- PENDULUM's first twin
+  solve and the trapezoidal twins at these sizes do -- but a convergent one says the twin's device code solves what the oracle states.)"""
+  from oracle import myriad_oracle as O
+  N = 20
+  s = O.Elastic(O.SYSTEMS[base](), 1.0)
+  tr = O.hermite_simpson(s, N)
+  cb = O.Callbacks(tr)
+  eng = _lib.Engine(base + "_ELASTIC", "HERMITE_SIMPSON", N, s.T)
+  o = eng.default_opts(); o.restoration = 0
+  r = eng.solve(tr.guess[None], tr.bounds[None, :, 0], tr.bounds[None, :, 1], params=s.params(), opts=o)
+  assert r["status"][0] == 0, (r["status"], r["iters"], r["kkt"])
+  assert np.abs(cb.cons(r["z"][0])).max() <= 1e-7
+  assert r["cost"][0] == pytest.approx(cb.fun(r["z"][0]), rel=1e-9)
 
 
 def _opt(name, rule="HERMITE_SIMPSON", N=20, **kw):

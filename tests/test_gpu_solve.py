@@ -97,7 +97,7 @@ def test_solve_nonconvergence_is_reported_not_raised():
   o = eng.default_opts(); o.max_iter = 2; o.restoration = 0          # ONE attempt from the caller's point (the reference's call)
   res = eng.solve(tr.guess[None], tr.bounds[None, :, 0], tr.bounds[None, :, 1], opts=o)
   assert res["status"][0] == 1 and res["iters"][0] == 2 and res["attempts"][0] == 1
-  o.restoration = -1                                                  # the library's default: three second starts follow (no twin for CARTPOLE)
+  o.restoration = 2                                                   # second starts only (bit 2): three excitation guesses follow
   res = eng.solve(tr.guess[None], tr.bounds[None, :, 0], tr.bounds[None, :, 1], opts=o)
   assert res["status"][0] == 1 and res["iters"][0] == 8 and res["attempts"][0] == 4 and res["restored"][0] == 0
   assert eng.solve(np.zeros((0, eng.n)), np.zeros((0, eng.n)), np.zeros((0, eng.n)))["z"].shape == (0, eng.n)

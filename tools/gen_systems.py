@@ -243,7 +243,9 @@ def systems():
   # twin, and its optima approach those of the system as rho grows (quadratic penalty on the dynamics residual).  ids: 100 + id.
   # Under the solver's variable scaling the penalty is rho/2 |s / sc|^2 (sc: the scale of the slack = that of its state).
   base = {S["name"]: S for S in out}
-  for nm in ("PENDULUM", "ROCKETLANDING"):
+  # (round 4: every system with pinned terminal states -- the ones a solve can jam on -- has its twin; PREDATORPREY pins one state and is
+  #  refused by the collocation transcriptions, the reference's behaviour)
+  for nm in ("PENDULUM", "ROCKETLANDING", "CARTPOLE", "VANDERPOL", "MOUNTAINCAR"):
     out.append(elastic(base[nm]))
   return out
 
