@@ -187,3 +187,28 @@ def test_shooting_wavefront_kernel_under_poison(monkeypatch, cfg):
     res[pat] = hashlib.sha1(b"".join(np.ascontiguousarray(o[k]).tobytes() for k in ("xs_and_us", "lambda", "cost", "status", "iters"))).hexdigest()
     opt.engine.close()
   assert len(set(res.values())) == 1, res
+
+
+def test_headline_batch_is_bit_reproducible(monkeypatch):
+  """BASELINE config 2 at full size (CARTPOLE Hermite-Simpson N = 100, B = 4096 random x0, the persistent kernel's four resident rounds: every slot
+  hands its LDS and scratch from trajectory to trajectory): three fresh handles and the three poison patterns give bit-identical z*, lambda*,
+  cost, status and iteration counts -- whatever order the ticket counter deals the trajectories in."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  from bench import build_workload
+  from myriad_amd import _lib
+  N, B = 100, 4096
+  x0, z0, lb, ub, T = build_workload(B, N, 2019)
+  ref = None
+  for env in ({}, {}, {"MYRIAD_POISON": "nan"}, {"MYRIAD_POISON": "big"}, {"MYRIAD_POISON": "random"}):
+    for k in KNOBS:
+      monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    eng = _lib.Engine("CARTPOLE", "HERMITE_SIMPSON", N, T, max_batch=B)
+    r = eng.solve(z0, lb, ub)
+    eng.close()
+    assert (r["status"] == 0).all()
+    bits = hashlib.sha1(b"".join(np.ascontiguousarray(r[k]).tobytes() for k in ("z", "lam", "cost", "kkt", "status", "iters"))).hexdigest()
+    ref = ref or bits
+    assert bits == ref, env
