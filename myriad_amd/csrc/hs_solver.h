@@ -366,6 +366,15 @@ struct HsSolver {
       lin_point(Vm, p, Pm);
       set_time<Sys>(p, 0.5 * h * js);
       lin_point(Vs, p, Ps);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MYR_LANE_ONE_SCHED_REGION)
+      // The body of this loop is ONE basic block of tens of thousands of instructions once everything below is unrolled; for six states
+      // and two controls (ROCKETLANDING) the compiler's pre-RA machine scheduler, given that block whole, produces a kernel in which the
+      // loop-carried Pe.g reads as 0 in every iteration (the objective loses its knot terms: 1.802207 for 2.637376; round 3's "refused
+      // lane instantiation").  Splitting the scheduling region here -- or anywhere in the first two thirds of the body -- gives the right
+      // code, as do -O1, -fno-unroll-loops, -mllvm -enable-misched=0, -misched-fusion=false or -join-liveintervals=false, and an asm
+      // marker on the value: tools/dev/repro/lane_rocket_misched/.  No instruction is added; the scheduler just sees two regions.
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       const double we = wsimp(K, 2 * k + 2, h), wm = wsimp(K, jm, h);
       so.f += we * Pe.g + wm * Pm.g;
 

@@ -591,19 +591,6 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   if constexpr (SCHEME == 1)
     return launch_lane_solve<TrapCore<Sys>, Sys>(h, B, TrapCore<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   else {
-    // ROCKETLANDING (six states, two controls) under Hermite-Simpson: the LANE kernel this compiler produces walks another path than
-    // the wavefront kernel and than the host build of the same source (first iterate: objective 1.802207 instead of 2.637376 = 41/60
-    // of it, no progress afterwards; the host twin under ASan / UBSan with poisoned scratch agrees with the wavefront kernel to the
-    // last digit, and a build of this kernel with a printf in the sweep gives the right value: a code-generation problem, not found
-    // -- tools/dev/rocket_probe.py, rocket_probe2.py).  A wrong answer is worse than none: the lane form of this one instantiation is
-    // refused (it is only reached with MYRIAD_SOLVE_MODE=lane or when N exceeds the wavefront kernel's LDS);
-    // MYRIAD_LANE_UNVERIFIED=1 runs it anyway.
-    if constexpr (Sys::ID == MYR_SYS_ROCKETLANDING) {
-      const char* e = getenv("MYRIAD_LANE_UNVERIFIED");
-      if (!(e && atoi(e) != 0))
-        return fail(MYR_E_UNSUPPORTED, "myr_solve: the lane-per-trajectory Hermite-Simpson kernel of ROCKETLANDING is not verified (miscompiled: DESIGN.md section 8); "
-                                       "use the wavefront kernel (default; N within its LDS limit)");
-    }
     return launch_lane_solve<HsSolver<Sys>, Sys>(h, B, HsSol<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
 }

@@ -109,11 +109,10 @@ def test_wavefront_forms_take_the_same_iterations(monkeypatch, system, rule):
 @pytest.mark.parametrize("system", _systems())
 def test_lane_kernel_agrees_with_the_wavefront_kernel(monkeypatch, system, rule):
   """tools/dev/rocket_probe.py over every system: the lane-per-trajectory kernel against the default (wavefront) path, iteration limits
-  0, 2, 8 and a whole solve at N = 6 and 20 -- the check that found the miscompiled lane instantiation of ROCKETLANDING (refused since)."""
+  0, 2, 8 and a whole solve at N = 6 and 20 -- the check that found the miscompiled lane instantiation of ROCKETLANDING (round 3: refused; round 4:
+  the scheduling region of its backward loop is split, hs_solver.h, and it agrees like the others)."""
   if not _collocation_ok(system):
     pytest.skip("collocation is refused for a partially pinned terminal state (reference behaviour)")
-  if system == "ROCKETLANDING" and rule == "HERMITE_SIMPSON":
-    pytest.xfail("lane_solve_kernel<HsSolver<SysROCKETLANDING>> is miscompiled (DESIGN.md, known limits) and refused with MYR_E_UNSUPPORTED")
   for N in (6, 20):
     for lim in (0, 2, 8, 300):
       w = _solve(monkeypatch, {}, system, rule, N, 3, max_iter=lim)
