@@ -14,6 +14,7 @@ pids=""
 for TU in ${TUS//,/ }; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -c -DMYR_TU_SYSTEM=$TU "$@" $SRC/myriad_hip.hip -o /tmp/variant_obj/$OUT.$TU.o &
   pids="$pids $!"
+  while [ $(jobs -r | wc -l) -ge ${MYR_VARIANT_JOBS:-8} ]; do wait -n; done
   OBJS=$(echo "$OBJS" | grep -v "/$TU.o")
   NEW="$NEW /tmp/variant_obj/$OUT.$TU.o"
 done
