@@ -1444,7 +1444,7 @@ static int solve_restored(myr_handle h, int B, double* z, const double* lb, cons
         else {
           // stationary point of the infeasibility: the twin converged for the largest rho and its slack neither vanished nor shrank.
           // (A twin that ran on the lane kernel gives no verdict: its instantiations with many variables per point are not covered by the
-          // wave / lane agreement tests -- ROCKETLANDING's own lane kernel is known to be miscompiled)
+          // wave / lane agreement tests -- and ROCKETLANDING's own lane kernel was once miscompiled)
           if (twin->last_solve_form == 1 && twin_stat[r] == MYR_STATUS_CONVERGED && slack_last[r] > 1e-3 && slack_last[r] > 0.1 * slack_prev[r])
             hstat[b] = MYR_STATUS_INFEASIBLE;
           left.push_back(b);
