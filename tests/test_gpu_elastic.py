@@ -59,6 +59,39 @@ def test_new_twins_solve_the_first_problem_of_the_phase(base):
   assert r["cost"][0] == pytest.approx(cb.fun(r["z"][0]), rel=1e-9)
 
 
+@pytest.mark.parametrize("rule", ["HERMITE_SIMPSON", "TRAPEZOIDAL"])
+@pytest.mark.parametrize("base", ["PENDULUM", "ROCKETLANDING", "CARTPOLE", "VANDERPOL", "MOUNTAINCAR"])
+def test_twin_lane_kernel_agrees_with_the_wavefront_kernel(monkeypatch, base, rule):
+  """The elastic twins have the most variables per point of all instantiations (ROCKETLANDING's: 14) -- the largest unrolled blocks the
+  compiler sees, which is where the one miscompiled lane kernel came from.  Their lane kernels against their
+  wavefront kernels: the same first iterates (iteration limits 0, 2, 5) from the reference's guess widened by s = 0, rho = 1.  (Not further:
+  ROCKETLANDING's twin -- states of 1e3 beside slacks of 1, stationarity residual 1e4 -- follows one path to 3e-9 for six iterations at
+  N = 6 and ten at N = 20 and then takes another branch within ONE iteration in the two kernels, a decision on a near-tie, not a drift:
+  tools/dev/exp/exp29.sh.)"""
+  from oracle import myriad_oracle as O
+  s = O.Elastic(O.SYSTEMS[base](), 1.0)
+  for N in ((6, 20) if rule == "HERMITE_SIMPSON" else (9, 20)):      # (trapezoidal.py:71's pinned row needs N + 1 > nu)
+    tr = O.hermite_simpson(s, N) if rule == "HERMITE_SIMPSON" else O.trapezoidal(s, N)
+    for lim in (0, 2, 5):
+      res = {}
+      for mode in ("wave", "lane"):
+        monkeypatch.setenv("MYRIAD_SOLVE_MODE", mode)
+        eng = _lib.Engine(base + "_ELASTIC", rule, N, s.T)
+        o = eng.default_opts(); o.restoration = 0; o.max_iter = lim
+        try:
+          res[mode] = eng.solve(tr.guess[None], tr.bounds[None, :, 0], tr.bounds[None, :, 1], params=s.params(), opts=o)
+        except NotImplementedError:
+          pytest.skip(f"no {rule} solver is built for the twin of {base} ({mode})")
+        finally:
+          eng.close()
+      w, l = res["wave"], res["lane"]
+      assert w["cost"][0] == pytest.approx(l["cost"][0], rel=1e-9, abs=1e-12), (base, rule, N, lim, w["cost"], l["cost"])
+      fin = np.isfinite(w["z"]) & np.isfinite(l["z"])
+      assert np.array_equal(np.isfinite(w["z"]), np.isfinite(l["z"]))
+      d = np.abs(w["z"] - l["z"])[fin] / np.maximum(1.0, np.abs(l["z"])[fin])
+      assert d.max(initial=0.0) <= 1e-7, (base, rule, N, lim, d.max())
+
+
 def _opt(name, rule="HERMITE_SIMPSON", N=20, **kw):
   hp = HParams(system=SystemType[name], optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule[rule],
                integration_method=IntegrationMethod.HEUN, intervals=N, nlpsolver=NLPSolverType.SQP, **kw)
