@@ -313,7 +313,8 @@ def run(a, rank, world, dev, make_engine):
     host = [{"z": _pin(torch.empty(total, z0.shape[1], dtype=torch.float64)), "cost": _pin(torch.empty(total, dtype=torch.float64)),
              "status": _pin(torch.empty(total, dtype=torch.int32))} for _ in range(2)]
   if cuda:
-    copy_stream = torch.cuda.Stream(device=dev)
+    copy_streams = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get('MYRIAD_BENCH_COPY_STREAMS', '1')))]
+    copy_stream = copy_streams[0]
   d2h_bytes = total * (z0.shape[1] * 8 + 8 + 4)
   fv = torch.empty(B, **f64); gv = torch.empty(B, eng.ngrad, **f64); cv = torch.empty(B, eng.m, **f64)
   jv = torch.empty(B, eng.jblk, **f64)
@@ -323,20 +324,27 @@ def run(a, rank, world, dev, make_engine):
       torch.cuda.synchronize()
 
   nstep = [0]
+  tracing = bool(os.environ.get("MYRIAD_BENCH_TRACE")) and rank == 0
+  segs = []
 
   def step(download=True):
     cur = nstep[0] & 1; nstep[0] += 1
     z, cost, status = zs[cur], costs[cur], stats[cur]
     if cuda and d2h_done[cur] is not None:
       torch.cuda.current_stream().wait_event(d2h_done[cur])   # this set's previous download (two steps ago) has left the device
+    seg = [time.perf_counter()] if tracing else None
     z.copy_(z0)
     if cuda:
       torch.cuda.current_stream().synchronize()            # library runs on its own stream
+    if tracing: seg.append(time.perf_counter())
     eng.solve(B, z, lb, ub, lam, cost, status, iters, kkt)
+    if tracing: seg.append(time.perf_counter())
     eng.eval(B, z, fv, gv, cv, jv)                           # verification pass (also the roofline kernel)
+    if tracing: seg.append(time.perf_counter())
     feas = cv.abs().amax(dim=1)
     ok = (status == 0) & (feas <= 1e-8)
     res = {"z": z, "cost": cost, "status": status}
+    if tracing: seg.append(time.perf_counter()); segs.append(seg)
 
     def ship(res):
       if world > 1:   # the path's only collective: final gather of the solutions to rank 0 over RCCL/xGMI
@@ -344,20 +352,28 @@ def run(a, rank, world, dev, make_engine):
         if rank == 0:
           assert res["z"].shape[0] == total
       if rank == 0 and download:      # ... and down to the host: pinned buffers
-        for k, t in res.items():
+        # (the small ones first: the runtime serves a small device-to-host copy on the calling thread, behind whatever the stream still
+        #  has in flight -- queued after the 33 MB of z* it sometimes held the host for 6 ms; profiles/r04/README.md)
+        for k in sorted(res, key=lambda k_: res[k_].numel()):
+          t = res[k]
+          t0_ = time.perf_counter()
           host[cur][k].copy_(t, non_blocking=cuda)
+          if tracing and time.perf_counter() - t0_ > 1e-3:
+            print("slow enqueue of the download of %s: %.2f ms (step %d)" % (k, 1e3 * (time.perf_counter() - t0_), nstep[0]), file=sys.stderr)
 
     if cuda:
       # gather and download run on a SIDE stream of every rank, behind the step that produced the solutions: they overlap the next
       # step's solve (which writes the other buffer set), so neither the 231 MB that rank 0 receives at N = 8 nor its download sits
       # on the critical path of a step; the fence at the end of the timed region waits for all of it.
       ready = torch.cuda.Event(); ready.record()
+      copy_stream = copy_streams[cur % len(copy_streams)]
       with torch.cuda.stream(copy_stream):
         copy_stream.wait_event(ready)
         ship(res)
         d2h_done[cur] = torch.cuda.Event(); d2h_done[cur].record(copy_stream)
     else:
       ship(res)
+    if tracing: seg.append(time.perf_counter())
     return ok
 
   def fence():
@@ -378,8 +394,14 @@ def run(a, rank, world, dev, make_engine):
     ok = step()
     nconv += int(ok.sum().item())
     trace.append(time.perf_counter() - ts)
-  if os.environ.get("MYRIAD_BENCH_TRACE") and rank == 0:
+  if tracing:
     print("per-step ms:", " ".join("%.1f" % (1e3 * t) for t in trace), file=sys.stderr)
+    k = int(np.argmax(trace)); sg = segs[a.warmup + k]       # host-side segments of the slowest step: wait + copy z0, solve, eval (the rest: count, ship)
+    print("slowest step %d: copy %.2f solve %.2f eval %.2f check %.2f ship %.2f count %.2f ms" % (k, 1e3 * (sg[1] - sg[0]), 1e3 * (sg[2] - sg[1]), 1e3 * (sg[3] - sg[2]),
+          1e3 * (sg[4] - sg[3]), 1e3 * (sg[5] - sg[4]), 1e3 * (trace[k] - (sg[5] - sg[0]))), file=sys.stderr)
+    med = int(np.argsort(trace)[len(trace) // 2]); sg = segs[a.warmup + med]
+    print("median step %d: copy %.2f solve %.2f eval %.2f check %.2f ship %.2f count %.2f ms" % (med, 1e3 * (sg[1] - sg[0]), 1e3 * (sg[2] - sg[1]), 1e3 * (sg[3] - sg[2]),
+          1e3 * (sg[4] - sg[3]), 1e3 * (sg[5] - sg[4]), 1e3 * (trace[med] - (sg[5] - sg[0]))), file=sys.stderr)
   fence()
   dt = time.perf_counter() - t0
   (ev_ms, ev_n), (sv_ms, sv_n) = eng.timers()      # kernel timers of the measured loop only
@@ -441,6 +463,8 @@ def run(a, rank, world, dev, make_engine):
     tp = os.path.join(ROOT, "profiles", rnd, "hs_eval_traffic.json")
     if "eval" not in prof and os.path.exists(tp) and B == 4096 and N == 100:
       prof["eval"] = (json.load(open(tp)).get("traffic_bytes_per_launch"), os.path.relpath(tp, ROOT))
+  # the library's two-phase launch: at least two whole solves per resident wavefront (four per CU), unless switched off
+  two_phase = fused and cuda and os.environ.get("MYRIAD_PARK_ITER", "-1") != "0" and B >= 2 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count
   traffic, traffic_src = prof.get("eval", (None, None))
   sol_bytes, sol_src = prof.get("solver", (None, None))
   out = {
@@ -477,7 +501,9 @@ def run(a, rank, world, dev, make_engine):
                  "achieved": alg / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": alg / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from_profile": traffic_src,
                  "alg_bytes_per_launch": alg, "avg_ms": ev_ms, "launches": ev_n},
-    "solver_kernel": {"kernel": ("hs_solve_fused_kernel<CARTPOLE> (persistent, one trajectory per wavefront, iterate in LDS, fused backward / forward phases, Riccati sweep on fp64 MFMA, whole SQP in one launch)"
+    "solver_kernel": {"kernel": ("hs_solve_fused_kernel<CARTPOLE> (persistent, one trajectory per wavefront, iterate in LDS, fused backward / forward phases, Riccati sweep on fp64 MFMA, whole SQP on the device" +
+                                  (": TWO launches per solve -- 12 iterations for every trajectory, the unfinished ones parked and resumed longest-first (myr_solve_opts.park_iter); avg_ms is the sum of both)"
+                                   if two_phase else " in one launch)")
                                  if fused else
                                  ("hs_solve_wave_kernel<CARTPOLE> (round-2 kernel: persistent, one trajectory per wavefront, thirteen phases through global records)"
                                   if os.environ.get("MYRIAD_SOLVE_MODE") == "wave1" else

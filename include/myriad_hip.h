@@ -136,7 +136,14 @@ typedef struct {
                            restoration); -1 = the library's default (3; the environment variables MYRIAD_ELASTIC=0 /
                            MYRIAD_SECOND_STARTS=0 clear the bits, MYRIAD_SECOND_STARTS="2,7" sets other cycle counts).
                            `iters` then sums the attempts of an instance; myr_solve_info reports which start produced it. */
-  int32_t reserved;
+  int32_t park_iter;    /* two-phase launch of the one-wavefront collocation kernel (a scheduling matter: the iterates of an instance
+                           are the same, bit for bit).  A batch much larger than the number of resident wavefronts runs as several
+                           whole solves per wavefront and ends with the wavefronts that drew the long solves last; instead every
+                           instance first gets `park_iter` iterations, the unfinished ones are parked (40 KB each) and resumed
+                           longest-first by their residuals at that point.  0 = the library decides (12 iterations when B is at
+                           least twice the resident wavefronts, whole solves otherwise; MYRIAD_PARK_ITER overrides), -1 = whole
+                           solves, k > 0 = k iterations.  Needs the per-instance `status` and `kkt` outputs; ignored by the other
+                           kernels. */
 } myr_solve_opts;
 
 int myr_create(const myr_problem_desc* desc, myr_handle* out);

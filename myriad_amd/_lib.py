@@ -48,7 +48,7 @@ class Dims(C.Structure):
 class SolveOpts(C.Structure):
   _fields_ = [("max_iter", C.c_int32), ("restarts", C.c_int32), ("tol_feas", C.c_double),
               ("tol_stat", C.c_double), ("tol_compl", C.c_double), ("mu_init", C.c_double),
-              ("restoration", C.c_int32), ("reserved", C.c_int32)]
+              ("restoration", C.c_int32), ("park_iter", C.c_int32)]
 
 
 class MyriadHipError(RuntimeError):

@@ -50,6 +50,21 @@ __device__ inline double lane_up1(double v) { return __shfl_up(v, 1, 64); }
 // SCHEME 0: Hermite-Simpson (K = 2N+1 points, stage unknowns y = (dx_s, du_s, du_m, du_e), two eliminated controls);
 // SCHEME 1: trapezoidal collocation (/root/reference/myriad/trajectory_optimizers/collocation/trapezoidal.py:80-163; K = N+1 points,
 // y = (dx_s, du_s, du_e), one eliminated control, no midpoint) -- the same passes, the algorithm of TrapCore (os_solver.h).
+// Two-phase launch of the one-wavefront kernel (myriad_hip.hip: launch_hs_fused_w).  A batch of B > (resident wavefronts) trajectories runs as whole
+// solves, several per slot, and the launch ends with the slots that drew the long solves last: 98 iterations' worth of time for the headline batch where
+// a divisible load would take 77.5.  Phase 1 gives EVERY trajectory its first k1 iterations (equal work per slot) and parks the unfinished ones -- the
+// solver's LDS and the loop's scalars, 40 KB -- in global memory; the residuals at that point predict what is left (rank correlation 0.95), so phase 2
+// resumes them longest-first (`perm`) and the ragged end shrinks to a few iterations.  The arithmetic of a trajectory is the same, bit for bit.
+struct ParkArgs {
+  int mode;              // 0: whole solves; 1: stop at the top of iteration k1 and park; 2: ticket t resumes trajectory perm[t]
+  int k1;
+  const int* perm;       // mode 2: trajectories in resume order; count[0] of them
+  const int* count;
+  double* state;         // [B][stride]: the scalars of the loop, then the solver's LDS
+  long stride;
+};
+constexpr int MYR_STATUS_PARKED_ = 5;     // internal: never leaves myr_solve
+
 template <class Sys, int W = 1, int SCHEME = 0>
 struct HsFused {
   static constexpr int NT = 64 * W;
@@ -104,6 +119,8 @@ struct HsFused {
   __host__ __device__ static int lds_solver_doubles(int N) { return 4 * npoints(N) * NW + MLAM * N * NS + 6 * NW + XCH + (W > 1 ? 2 : 1) * EXCH + 8; }
   __host__ __device__ static int lds_doubles(int N) { return lds_solver_doubles(N) + (MLP ? npoints(N) * NS + NodeTraits<Sys>::lds_doubles : 0); }
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
+  static constexpr int NSCAL = 48;      // scalars of the solve loop in a parked trajectory's record
+  __host__ __device__ static long park_doubles(int N) { return NSCAL + lds_solver_doubles(N); }
 
   struct Ctx {
     int N, K, n, lane, wave, tid;
@@ -1372,25 +1389,65 @@ struct HsFused {
   }
 
   // ---- the solve (control flow identical to HsWave::solve / HsSolver::solve) -----------------------------------------------------
-  __device__ static void solve(Ctx& c, const HsSolveOpts& o, const double* zg, HsSolveResult& res) {
+  __device__ static void solve(Ctx& c, const HsSolveOpts& o, const double* zg, HsSolveResult& res, int park_mode = 0, int park_k1 = 0,
+                               double* sv = nullptr) {
     using namespace detail;
-    init(c, zg);
-    wsync();
-#pragma unroll
-    for (int q = 0; q < NS; ++q) c.term_pinned[q] = !(c.sB[2 * NW + q] < c.sB[3 * NW + q]);
+    constexpr int NMMAX = 8;
+    static_assert(17 + NS + NMMAX + 5 <= NSCAL, "record of a parked trajectory");
     double mu = o.mu_init, pen = 1.0;
     int pen_over = 0, pen_cuts = 0;
     double nuT[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) nuT[i] = 0.0;
-    const double mu_min = dmin(o.tol_compl, o.tol_stat) * 0.1;
-    res.status = 1; res.iters = o.max_iter;
     int stall = 0, small_steps = 0;
     double delta_last = 0.0, lm = 0.0;
-    constexpr int NMMAX = 8;
     double hist[NMMAX]; int nhist = 0, hpos = 0; double hist_mu = -1.0, hist_pen = -1.0;
+#pragma unroll
+    for (int i = 0; i < NMMAX; ++i) hist[i] = 0.0;
     Step pending{false, 0.0, 0.0, 0.0, o.kappa_sigma};
-    for (int it = 0; it <= o.max_iter; ++it) {
+    int it0 = 0;
+    res.cost = 0.0; res.feas = 0.0; res.stat = 0.0; res.compl_ = 0.0;
+    if (park_mode == 2) {
+      // resume a parked trajectory: the solver's LDS as it was at the top of iteration k1, the scalars of the loop, the slot's block of zeros
+      const int nl = lds_solver_doubles(c.N);
+      for (int i = c.tid; i < nl; i += NT) c.z[i] = __builtin_nontemporal_load(&sv[NSCAL + i]);     // (read once: keep it out of the caches the next kernels use)
+      if (c.tid < ZR) c.zr[c.tid] = 0.0;
+      mu = sv[0]; pen = sv[1]; pen_over = (int)sv[2]; pen_cuts = (int)sv[3]; stall = (int)sv[4]; small_steps = (int)sv[5];
+      delta_last = sv[6]; lm = sv[7]; nhist = (int)sv[8]; hpos = (int)sv[9]; hist_mu = sv[10]; hist_pen = sv[11];
+      pending.on = sv[12] != 0.0; pending.ap = sv[13]; pending.ad = sv[14]; pending.mu = sv[15]; pending.ksig = sv[16];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) nuT[i] = sv[17 + i];
+#pragma unroll
+      for (int i = 0; i < NMMAX; ++i) hist[i] = sv[17 + NS + i];
+      c.uni = sv[17 + NS + NMMAX] != 0.0;
+      res.cost = sv[18 + NS + NMMAX]; res.feas = sv[19 + NS + NMMAX]; res.stat = sv[20 + NS + NMMAX]; res.compl_ = sv[21 + NS + NMMAX];
+      it0 = park_k1;
+    } else
+      init(c, zg);
+    wsync();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) c.term_pinned[q] = !(c.sB[2 * NW + q] < c.sB[3 * NW + q]);
+    const double mu_min = dmin(o.tol_compl, o.tol_stat) * 0.1;
+    res.status = 1; res.iters = o.max_iter;
+    for (int it = it0; it <= o.max_iter; ++it) {
+      if (park_mode == 1 && it == park_k1) {
+        // park: everything the rest of the solve needs (the previous iteration ended with a workgroup barrier)
+        const int nl = lds_solver_doubles(c.N);
+        for (int i = c.tid; i < nl; i += NT) __builtin_nontemporal_store(c.z[i], &sv[NSCAL + i]);
+        if (c.tid == 0) {
+          sv[0] = mu; sv[1] = pen; sv[2] = (double)pen_over; sv[3] = (double)pen_cuts; sv[4] = (double)stall; sv[5] = (double)small_steps;
+          sv[6] = delta_last; sv[7] = lm; sv[8] = (double)nhist; sv[9] = (double)hpos; sv[10] = hist_mu; sv[11] = hist_pen;
+          sv[12] = pending.on ? 1.0 : 0.0; sv[13] = pending.ap; sv[14] = pending.ad; sv[15] = pending.mu; sv[16] = pending.ksig;
+#pragma unroll
+          for (int i = 0; i < NS; ++i) sv[17 + i] = nuT[i];
+#pragma unroll
+          for (int i = 0; i < NMMAX; ++i) sv[17 + NS + i] = hist[i];
+          sv[17 + NS + NMMAX] = c.uni ? 1.0 : 0.0;
+          sv[18 + NS + NMMAX] = res.cost; sv[19 + NS + NMMAX] = res.feas; sv[20 + NS + NMMAX] = res.stat; sv[21 + NS + NMMAX] = res.compl_;
+        }
+        res.status = MYR_STATUS_PARKED_; res.iters = it;
+        return;
+      }
       BOut p1;
       { NuT nu_; for (int q = 0; q < NS; ++q) nu_.v[q] = nuT[q]; p1 = backward_pass(c, pending, nu_); }
       pending.on = false;
@@ -1564,7 +1621,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1)
 void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                            const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                            const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
-                           int32_t* iters, double* kkt, unsigned long long poison) {
+                           int32_t* iters, double* kkt, unsigned long long poison, ParkArgs pk) {
   using W = HsFused<Sys, NWAVES, SCHEME>;
   extern __shared__ __attribute__((aligned(16))) char smem_fused[];
   typename W::Ctx c;
@@ -1608,8 +1665,11 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
       __syncthreads();
       t = reinterpret_cast<int*>(c.sMisc)[0];
     }
-    const long b = __builtin_amdgcn_readfirstlane(t);
-    if (b >= B) break;
+    long b = __builtin_amdgcn_readfirstlane(t);
+    if (pk.mode == 2) {          // resume order: ticket t takes the t-th longest parked trajectory
+      if (b >= pk.count[0]) break;
+      b = pk.perm[b];
+    } else if (b >= B) break;
     double* zg = z + b * (long)c.n;
     c.lb = lb + b * (long)c.n; c.ub = ub + b * (long)c.n;
     double* lamg = lam ? lam + b * (long)(W::MLAM * c.N * W::NS) : lam_own;
@@ -1641,9 +1701,12 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     for (int i = 0; i < 16; ++i) c.tph[i] = 0;
     c.t0 = clock64();
 #endif
-    W::solve(c, o, zg, r);
-    for (int i = c.tid; i < c.n; i += W::NT) zg[i] = c.z[i];
-    for (int i = c.tid; i < W::MLAM * c.N * W::NS; i += W::NT) lamg[i] = c.sLam[i];
+    if constexpr (NWAVES == 1 && !W::MLP) W::solve(c, o, zg, r, pk.mode, pk.k1, pk.state + b * pk.stride);
+    else W::solve(c, o, zg, r);
+    if (r.status != MYR_STATUS_PARKED_) {
+      for (int i = c.tid; i < c.n; i += W::NT) zg[i] = c.z[i];
+      for (int i = c.tid; i < W::MLAM * c.N * W::NS; i += W::NT) lamg[i] = c.sLam[i];
+    }
 #ifdef MYR_PHASE_TIMING
     if (c.lane == 0 && b < 4) {
       printf("traj %ld it %d: backward %lld hess %lld ricc %lld nu %lld forward %lld ls %lld\n",

@@ -92,6 +92,10 @@ struct myr_handle_s {
   std::map<std::tuple<const void*, int, size_t>, int> occ;   // kernel_slots(): workgroups per CU of (kernel, block size, dynamic LDS)
   size_t eval_attr_lds[6] = {0, 0, 0, 0, 0, 0};   // dynamic-LDS attribute already set for the eval kernel variants (W = 1 / 4 / 8, nt)
   int fused_waves = 0;        // MYRIAD_FUSED_WAVES: wavefronts per trajectory (0 = by batch size)
+  // two-phase launch of the one-wavefront fused kernel (hs_solver_fused.h: ParkArgs): records of the parked trajectories, resume order
+  void* park_state = nullptr; size_t park_bytes = 0;
+  int* park_perm = nullptr; size_t park_n = 0;      // [park_n] resume order, then PARK_BUCKETS + 1 counters
+  int park_iter = -1;         // MYRIAD_PARK_ITER: iterations of phase 1 (-1 = by batch size, 0 = whole solves only)
   // restoration inside myr_solve (myr_solve_opts.restoration): the twin handle, device scratch, and the account of the last call
   myr_handle_s* twin = nullptr;
   bool twin_unavailable = false;
@@ -444,6 +448,33 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
                              int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                              int32_t* iters, double* kkt);
 
+// Resume order of a two-phase launch: parked trajectories by DESCENDING key (the geometric mean of the stationarity and the complementarity
+// residual at the parking point: rank correlation 0.9 with the iterations still to go), bucketed by half powers of two.  Three small launches.
+constexpr int PARK_BUCKETS = 256;
+static __device__ inline int park_bucket(const double* kkt, int b) {
+  const double st = kkt[3 * b + 1], cp = kkt[3 * b + 2];
+  const double key = (cp > 0.0 && st > 0.0) ? sqrt(st * cp) : (st > cp ? st : cp);
+  if (!(key > 0.0)) return 0;
+  if (!(key < 1e300)) return PARK_BUCKETS - 1;
+  int v = (int)floor(2.0 * log2(key)) + PARK_BUCKETS / 2 + 32;       // key 1 -> bucket 160; 1e-24 .. 1e14 spans the table
+  return v < 0 ? 0 : (v > PARK_BUCKETS - 1 ? PARK_BUCKETS - 1 : v);
+}
+static __global__ void park_hist_kernel(int B, const int32_t* __restrict__ status, const double* __restrict__ kkt, int* __restrict__ cnt) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B && status[b] == myriad::MYR_STATUS_PARKED_) atomicAdd(&cnt[park_bucket(kkt, b)], 1);
+}
+static __global__ void park_scan_kernel(int* __restrict__ cnt) {        // one thread: 256 counters -> start offsets, largest bucket first
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int run = 0;
+    for (int k = PARK_BUCKETS - 1; k >= 0; --k) { const int c = cnt[k]; cnt[k] = run; run += c; }
+    cnt[PARK_BUCKETS] = run;
+  }
+}
+static __global__ void park_scatter_kernel(int B, const int32_t* __restrict__ status, const double* __restrict__ kkt, int* __restrict__ cnt, int* __restrict__ perm) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B && status[b] == myriad::MYR_STATUS_PARKED_) perm[atomicAdd(&cnt[park_bucket(kkt, b)], 1)] = b;
+}
+
 // fused-phase wavefront kernel (hs_solver_fused.h): Hermite-Simpson, closed-form systems with one control and <= 4 states.
 // NWAVES wavefronts per trajectory: 1 for throughput (four trajectories per CU), 2 when the batch leaves CUs idle otherwise
 // (B <= 2 trajectories per CU: the parallel phases of an iteration take half the time, the launch lasts as long as one solve).
@@ -458,6 +489,7 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   int per_cu = 0;       // (attributes and occupancy once per handle and configuration, not per call)
   if (int rc = kernel_blocks_per_cu(h, reinterpret_cast<const void*>(kern), 64 * NWAVES, lds, &per_cu)) return rc;
   int slots = h->solve_slots > 0 ? h->solve_slots : (per_cu > 0 ? per_cu : 4 / NWAVES) * device_cus(h);
+  const int slots_full = slots;
   if (slots > B) slots = B;
   long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
   if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate slots over HBM channels
@@ -477,8 +509,46 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   if (getenv("MYRIAD_DEBUG_PTRS"))
     fprintf(stderr, "[myriad] fused W=%d N=%d B=%d slots=%d lds=%zu stride=%ld doubles: scratch [%p, %p) z %p lb %p ub %p lam %p ticket %p\n", NWAVES, N, B, slots, lds, stride,
             h->sbuf, (char*)h->sbuf + need, (void*)z, (const void*)lb, (const void*)ub, (void*)lam, (void*)h->ticket);
+  // Two phases when a slot would take at least two whole solves (B >= 2 x resident wavefronts): k1 iterations for every trajectory, the
+  // unfinished ones parked, then resumed longest-first (hs_solver_fused.h: ParkArgs).  Needs the per-instance status and residuals.
+  int k1 = 0;
+  if constexpr (NWAVES == 1 && !W::MLP) {
+    k1 = so.park_iter != 0 ? so.park_iter : h->park_iter;
+    if (k1 < 0 && so.park_iter < 0) k1 = 0;                     // opts.park_iter = -1: whole solves
+    else if (k1 < 0) k1 = (B >= 2 * slots_full) ? 12 : 0;       // a little more than half of a typical interior-point solve (20-25 iterations)
+    if (k1 >= o.max_iter || !status || !kkt) k1 = 0;
+  }
+  myriad::ParkArgs pk{0, 0, nullptr, nullptr, nullptr, 0};
+  if (k1 > 0) {
+    const long pstr = (W::park_doubles(N) + 31) / 32 * 32;
+    const size_t pneed = (size_t)B * (size_t)pstr * 8;
+    if (pneed > h->park_bytes) {
+      if (h->park_state) HIPCHK(hipFree(h->park_state));
+      h->park_state = nullptr; h->park_bytes = 0;
+      HIPCHK(hipMalloc(&h->park_state, pneed));
+      h->park_bytes = pneed;
+    }
+    if ((size_t)B > h->park_n) {
+      if (h->park_perm) HIPCHK(hipFree(h->park_perm));
+      h->park_perm = nullptr; h->park_n = 0;
+      HIPCHK(hipMalloc(&h->park_perm, ((size_t)B + PARK_BUCKETS + 1) * sizeof(int)));
+      h->park_n = (size_t)B;
+    }
+    int* cnt = h->park_perm + h->park_n;
+    pk = myriad::ParkArgs{1, k1, h->park_perm, cnt + PARK_BUCKETS, (double*)h->park_state, pstr};
+    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
+                       params, pstride, cost, status, iters, kkt, h->poison, pk);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(cnt, 0, (PARK_BUCKETS + 1) * sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int), h->stream));
+    const unsigned gb = (unsigned)((B + 255) / 256);
+    hipLaunchKernelGGL(park_hist_kernel, dim3(gb), dim3(256), 0, h->stream, B, status, kkt, cnt);
+    hipLaunchKernelGGL(park_scan_kernel, dim3(1), dim3(64), 0, h->stream, cnt);
+    hipLaunchKernelGGL(park_scatter_kernel, dim3(gb), dim3(256), 0, h->stream, B, status, kkt, cnt, h->park_perm);
+    pk.mode = 2;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
-                     params, pstride, cost, status, iters, kkt, h->poison);
+                     params, pstride, cost, status, iters, kkt, h->poison, pk);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -799,7 +869,7 @@ extern "C" void myr_default_solve_opts(myr_solve_opts* o) {
   o->tol_compl = 1e-7;
   o->mu_init = 0.1;
   o->restoration = -1;  // library default: elastic phase + second starts, see the header
-  o->reserved = 0;
+  o->park_iter = 0;     // the library decides, see the header
 }
 
 extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
@@ -862,6 +932,7 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
   if (md) { h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1; h->solve_fused = (strcmp(md, "wave1") == 0) ? 0 : 1; }
   const char* l = getenv("MYRIAD_SOLVE_LPW");
   if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
+  if (const char* e = getenv("MYRIAD_PARK_ITER")) h->park_iter = atoi(e);         // developer knob: iterations of phase 1 of the two-phase launch (0 = off)
   if (const char* e = getenv("MYRIAD_FUSED_WAVES")) h->fused_waves = atoi(e);     // developer knob: wavefronts per trajectory of the fused kernel
   if (const char* e = getenv("MYRIAD_SOLVE_SLOTS")) h->solve_slots = atoi(e);   // developer knob: resident wavefronts of the solve kernel
   if (const char* e = getenv("MYRIAD_POISON")) {      // test knob: "nan" (signalling NaN), "big", "random", or a 64-bit pattern in hex
@@ -880,6 +951,8 @@ extern "C" int myr_destroy(myr_handle h) {
   if (h->dbuf) (void)hipFree(h->dbuf);
   if (h->sbuf) (void)hipFree(h->sbuf);
   if (h->ticket) (void)hipFree(h->ticket);
+  if (h->park_state) (void)hipFree(h->park_state);
+  if (h->park_perm) (void)hipFree(h->park_perm);
   if (h->vbuf) (void)hipFree(h->vbuf);
   if (h->rbuf) (void)hipFree(h->rbuf);
   if (h->fbuf) (void)hipFree(h->fbuf);

@@ -31,7 +31,7 @@ def test_exports_match_header(lib):
 def test_struct_layouts_match_header():
   assert C.sizeof(_lib.ProblemDesc) == 8 * 4 + 8
   assert C.sizeof(_lib.Dims) == 10 * 4
-  assert C.sizeof(_lib.SolveOpts) == 2 * 4 + 4 * 8 + 2 * 4          # (round 4: + restoration, reserved)
+  assert C.sizeof(_lib.SolveOpts) == 2 * 4 + 4 * 8 + 2 * 4          # (round 4: + restoration, park_iter)
 
 
 def test_default_opts(lib):

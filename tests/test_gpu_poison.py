@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 NS_ = (6, 20, 50, 100)
 BS_ = (1, 3)
-KNOBS = ("MYRIAD_FUSED_WAVES", "MYRIAD_SOLVE_MODE", "MYRIAD_POISON", "MYRIAD_LANE_UNVERIFIED", "MYRIAD_NODE_COOP", "MYRIAD_NODE_WPB")
+KNOBS = ("MYRIAD_FUSED_WAVES", "MYRIAD_SOLVE_MODE", "MYRIAD_POISON", "MYRIAD_LANE_UNVERIFIED", "MYRIAD_NODE_COOP", "MYRIAD_NODE_WPB", "MYRIAD_PARK_ITER")
 
 
 def _systems():
@@ -128,6 +128,22 @@ def test_lane_kernel_agrees_with_the_wavefront_kernel(monkeypatch, system, rule)
         np.testing.assert_allclose(w["cost"][short], l["cost"][short], rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("rule", ["HERMITE_SIMPSON", "TRAPEZOIDAL"])
+@pytest.mark.parametrize("system", _systems())
+def test_two_phase_launch_returns_the_bits_of_whole_solves(monkeypatch, system, rule):
+  """The two-phase launch of the one-wavefront kernel (hs_solver_fused.h: ParkArgs) is a scheduling matter: parked after k iterations -- LDS and
+  loop scalars to global memory -- and resumed in another slot, in another order, under poison, a trajectory returns the bits of a whole solve.
+  k = 1 (parked before anything settled), 4 and 9, and every solve that ends before k is simply finished in phase 1."""
+  if not _collocation_ok(system):
+    pytest.skip("collocation is refused for a partially pinned terminal state (reference behaviour)")
+  N, B = 20, 5
+  ref = _solve(monkeypatch, {"MYRIAD_FUSED_WAVES": "1", "MYRIAD_PARK_ITER": "0"}, system, rule, N, B)
+  for env in ({"MYRIAD_PARK_ITER": "1"}, {"MYRIAD_PARK_ITER": "4", "MYRIAD_POISON": "nan"}, {"MYRIAD_PARK_ITER": "9", "MYRIAD_POISON": "random"}):
+    r = _solve(monkeypatch, dict(env, MYRIAD_FUSED_WAVES="1"), system, rule, N, B)
+    assert np.array_equal(r["status"], ref["status"]) and np.array_equal(r["iters"], ref["iters"]), (system, rule, env, r["status"], ref["status"], r["iters"], ref["iters"])
+    assert r["bits"] == ref["bits"], (system, rule, env)
+
+
 def _node_solve(monkeypatch, env, N, B, seed):
   from myriad_amd.config import Config, HParams, IntegrationMethod, NLPSolverType, OptimizerType, QuadratureRule
   from myriad_amd.systems import SystemType
@@ -199,7 +215,9 @@ def test_headline_batch_is_bit_reproducible(monkeypatch):
   N, B = 100, 4096
   x0, z0, lb, ub, T = build_workload(B, N, 2019)
   ref = None
-  for env in ({}, {}, {"MYRIAD_POISON": "nan"}, {"MYRIAD_POISON": "big"}, {"MYRIAD_POISON": "random"}):
+  # ({}: the library's choice for this batch -- the two-phase launch, ten iterations for everybody, then longest-first; MYRIAD_PARK_ITER=0: whole solves)
+  for env in ({}, {}, {"MYRIAD_POISON": "nan"}, {"MYRIAD_POISON": "big"}, {"MYRIAD_POISON": "random"}, {"MYRIAD_PARK_ITER": "0"},
+              {"MYRIAD_PARK_ITER": "0", "MYRIAD_POISON": "nan"}, {"MYRIAD_PARK_ITER": "14", "MYRIAD_POISON": "random"}):
     for k in KNOBS:
       monkeypatch.delenv(k, raising=False)
     for k, v in env.items():

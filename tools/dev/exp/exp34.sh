@@ -1,0 +1,7 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+run() { echo "== $*"; env "$@" python bench.py --cpu-budget 0 --no-other-configs 2>gpurun_out/exp34_err.txt | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],3), 'kernel', round(d['solver_kernel']['avg_ms'],3), 'eval', round(d['roofline']['avg_ms'],4), 'no-download', round(d['download']['value_without_download']), round(d['download']['ms_per_step_without_download'],3))"; grep "per-step" gpurun_out/exp34_err.txt | cut -c1-200; }
+run MYRIAD_PARK_ITER=12 MYRIAD_BENCH_TRACE=1
+run MYRIAD_PARK_ITER=0 MYRIAD_BENCH_TRACE=1
+run MYRIAD_PARK_ITER=12 HSA_ENABLE_SDMA=0
+run MYRIAD_PARK_ITER=0 HSA_ENABLE_SDMA=0
