@@ -352,8 +352,8 @@ def run(a, rank, world, dev, make_engine):
         if rank == 0:
           assert res["z"].shape[0] == total
       if rank == 0 and download:      # ... and down to the host: pinned buffers
-        # (the small ones first: the runtime serves a small device-to-host copy on the calling thread, behind whatever the stream still
-        #  has in flight -- queued after the 33 MB of z* it sometimes held the host for 6 ms; profiles/r04/README.md)
+        # (ONE of these enqueues per process, at a random step, holds the host for ~6 ms -- a one-time event inside the runtime's copy
+        #  path that neither the order, nor a second copy stream, nor its pool / queue settings move: profiles/r04/README.md)
         for k in sorted(res, key=lambda k_: res[k_].numel()):
           t = res[k]
           t0_ = time.perf_counter()
