@@ -465,6 +465,7 @@ def run(a, rank, world, dev, make_engine):
       prof["eval"] = (json.load(open(tp)).get("traffic_bytes_per_launch"), os.path.relpath(tp, ROOT))
   # the library's two-phase launch: at least two whole solves per resident wavefront (four per CU), unless switched off
   two_phase = fused and cuda and os.environ.get("MYRIAD_PARK_ITER", "-1") != "0" and B >= 2 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+  lps = 2 if two_phase else 1
   traffic, traffic_src = prof.get("eval", (None, None))
   sol_bytes, sol_src = prof.get("solver", (None, None))
   out = {
@@ -510,9 +511,10 @@ def run(a, rank, world, dev, make_engine):
                                   "hs_solve_kernel<CARTPOLE> (one trajectory per lane, whole SQP in one launch)")),
                       "avg_ms": sv_ms, "launches": sv_n, "bound": "dependent-instruction latency of one wavefront per SIMD (the Riccati sweep is 45 % of an iteration; see DESIGN.md section 4)",
                       "alg_io_bytes_per_launch": B * 8 * (3 * (2 * N + 1) * 5 + (2 * N + 1) * 5 + 2 * N * 4),
-                      "hbm_bytes_per_launch_from_profile": sol_bytes, "hbm_profile": sol_src,
-                      "hbm_GBps": (sol_bytes / (sv_ms * 1e-3) / 1e9) if (sol_bytes and sv_ms) else None,
-                      "hbm_over_alg": (sol_bytes / (B * 8 * (3 * (2 * N + 1) * 5 + (2 * N + 1) * 5 + 2 * N * 4))) if sol_bytes else None},
+                      "launches_per_solve": lps,
+                      "hbm_bytes_per_launch_from_profile": sol_bytes, "hbm_profile": sol_src,       # (per KERNEL launch: the profile averages over both phases)
+                      "hbm_GBps": (lps * sol_bytes / (sv_ms * 1e-3) / 1e9) if (sol_bytes and sv_ms) else None,
+                      "hbm_over_alg": (lps * sol_bytes / (B * 8 * (3 * (2 * N + 1) * 5 + (2 * N + 1) * 5 + 2 * N * 4))) if sol_bytes else None},
   }
   if world == 1 and a.cpu_budget > 0 and cuda:
     try:
