@@ -515,7 +515,8 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   if constexpr (NWAVES == 1 && !W::MLP) {
     k1 = so.park_iter != 0 ? so.park_iter : h->park_iter;
     if (k1 < 0 && so.park_iter < 0) k1 = 0;                     // opts.park_iter = -1: whole solves
-    else if (k1 < 0) k1 = (B >= 2 * slots_full) ? 12 : 0;       // a little more than half of a typical interior-point solve (20-25 iterations)
+    else if (k1 < 0) k1 = (SCHEME == 0 && B >= 2 * slots_full) ? 12 : 0;       // a little more than half of a typical interior-point solve (20-25 iterations);
+                                                                               // (trapezoidal solves are shorter and closer together: two phases cost them 2.5 %)
     if (k1 >= o.max_iter || !status || !kkt) k1 = 0;
   }
   myriad::ParkArgs pk{0, 0, nullptr, nullptr, nullptr, 0};
