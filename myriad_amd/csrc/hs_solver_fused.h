@@ -1701,7 +1701,7 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     for (int i = 0; i < 16; ++i) c.tph[i] = 0;
     c.t0 = clock64();
 #endif
-    if constexpr (NWAVES == 1 && !W::MLP) W::solve(c, o, zg, r, pk.mode, pk.k1, pk.state + b * pk.stride);
+    if constexpr (NWAVES == 1 || W::MLP) W::solve(c, o, zg, r, pk.mode, pk.k1, pk.state + b * pk.stride);      // (W = 2 serves batches of one round only)
     else W::solve(c, o, zg, r);
     if (r.status != MYR_STATUS_PARKED_) {
       for (int i = c.tid; i < c.n; i += W::NT) zg[i] = c.z[i];

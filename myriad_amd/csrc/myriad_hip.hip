@@ -512,11 +512,13 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   // Two phases when a slot would take at least two whole solves (B >= 2 x resident wavefronts): k1 iterations for every trajectory, the
   // unfinished ones parked, then resumed longest-first (hs_solver_fused.h: ParkArgs).  Needs the per-instance status and residuals.
   int k1 = 0;
-  if constexpr (NWAVES == 1 && !W::MLP) {
+  if constexpr (NWAVES == 1 || W::MLP) {        // the one-wavefront kernels and the network kernel (four wavefronts, one trajectory per CU: B = 1024 is four rounds)
     k1 = so.park_iter != 0 ? so.park_iter : h->park_iter;
     if (k1 < 0 && so.park_iter < 0) k1 = 0;                     // opts.park_iter = -1: whole solves
-    else if (k1 < 0) k1 = (SCHEME == 0 && B >= 2 * slots_full) ? 12 : 0;       // a little more than half of a typical interior-point solve (20-25 iterations);
-                                                                               // (trapezoidal solves are shorter and closer together: two phases cost them 2.5 %)
+    else if (k1 < 0) k1 = (SCHEME == 0 && !W::MLP && B >= 2 * slots_full) ? 12 : 0;       // a little more than half of a typical interior-point solve (20-25 iterations);
+                                                                               // (trapezoidal solves are shorter and closer together: two phases cost them 2.5 %;
+                                                                               //  the network system's longest solves -- 75 iterations against a median of 24 -- have SMALL
+                                                                               //  residuals at the parking point and would come last: 41 -> 52 ms at B = 1024, exp42 / exp43)
     if (k1 >= o.max_iter || !status || !kkt) k1 = 0;
   }
   myriad::ParkArgs pk{0, 0, nullptr, nullptr, nullptr, 0};

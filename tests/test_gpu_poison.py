@@ -165,6 +165,17 @@ def _node_solve(monkeypatch, env, N, B, seed):
   return out
 
 
+@pytest.mark.parametrize("N,B", [(20, 3), (100, 12)])
+def test_network_kernel_two_phase_launch_returns_the_bits_of_whole_solves(monkeypatch, N, B):
+  """the two-phase launch under the four-wavefront network kernel (config 5 at B = 1024 is four rounds of one trajectory per CU): parked after 2, 7 or 12
+  iterations, under poison, a trajectory returns the bits of a whole solve"""
+  ref = _node_solve(monkeypatch, {"MYRIAD_PARK_ITER": "0"}, N, B, N * 1000 + B)
+  for env in ({"MYRIAD_PARK_ITER": "2"}, {"MYRIAD_PARK_ITER": "7", "MYRIAD_POISON": "nan"}, {"MYRIAD_PARK_ITER": "12", "MYRIAD_POISON": "random"}):
+    r = _node_solve(monkeypatch, env, N, B, N * 1000 + B)
+    assert np.array_equal(r["status"], ref["status"]) and np.array_equal(r["iters"], ref["iters"]), (N, B, env, r["iters"], ref["iters"])
+    assert r["bits"] == ref["bits"], (N, B, env)
+
+
 @pytest.mark.parametrize("N,B", [(10, 1), (10, 12), (20, 3), (50, 12), (100, 3), (100, 128), (100, 300)])
 def test_network_dynamics_four_wavefront_kernel(monkeypatch, N, B):
   """tools/dev/node_coop_probe.py: the default kernel of config 5 (four wavefronts share a trajectory: the same cross-wavefront
