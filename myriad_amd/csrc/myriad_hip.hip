@@ -528,9 +528,12 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
     if (pneed > h->park_bytes) {
       if (h->park_state) HIPCHK(hipFree(h->park_state));
       h->park_state = nullptr; h->park_bytes = 0;
-      HIPCHK(hipMalloc(&h->park_state, pneed));
-      h->park_bytes = pneed;
+      if (hipMalloc(&h->park_state, pneed) == hipSuccess) h->park_bytes = pneed;
+      else { (void)hipGetLastError(); h->park_state = nullptr; k1 = 0; }      // no room for the records (41 KB per instance): whole solves
     }
+  }
+  if (k1 > 0) {
+    const long pstr = (W::park_doubles(N) + 31) / 32 * 32;
     if ((size_t)B > h->park_n) {
       if (h->park_perm) HIPCHK(hipFree(h->park_perm));
       h->park_perm = nullptr; h->park_n = 0;
