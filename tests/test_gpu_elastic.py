@@ -92,6 +92,26 @@ def test_twin_lane_kernel_agrees_with_the_wavefront_kernel(monkeypatch, base, ru
       assert d.max(initial=0.0) <= 1e-7, (base, rule, N, lim, d.max())
 
 
+def test_two_phase_first_attempt_and_restoration_give_the_bits_of_whole_solves(monkeypatch):
+  """A batch large enough for the two-phase launch (B >= 2 x resident wavefronts) whose instances almost all need the elastic phase: the first
+  attempt parks and resumes, the failed instances go through the restoration inside myr_solve -- same statuses, iterations and bits as with
+  whole solves (MYRIAD_PARK_ITER=0)."""
+  import hashlib
+  hp = HParams(system=SystemType.PENDULUM, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON, intervals=20, nlpsolver=NLPSolverType.SQP)
+  B = 2500
+  out = {}
+  for k in ("0", None):
+    if k is None: monkeypatch.delenv("MYRIAD_PARK_ITER", raising=False)
+    else: monkeypatch.setenv("MYRIAD_PARK_ITER", k)
+    opt = get_optimizer(hp, CFG, hp.system())
+    x0 = np.tile(opt.system.x_0, (B, 1)) + 0.05 * np.random.default_rng(3).standard_normal((B, opt.system.x_0.size))
+    o = opt.solve_batch(x0s=x0, max_iter=300)
+    out[k] = (np.bincount(o["status"]).tolist(), int(np.sum(o["restored"])), hashlib.sha1(b"".join(np.ascontiguousarray(o[q]).tobytes() for q in ("xs_and_us", "cost", "status", "iters"))).hexdigest())
+    opt.engine.close()
+  assert out["0"] == out[None], out
+  assert out[None][0][0] >= 0.95 * B and out[None][1] > 0.9 * B        # nearly all converge, nearly all through the elastic phase
+
+
 def _opt(name, rule="HERMITE_SIMPSON", N=20, **kw):
   hp = HParams(system=SystemType[name], optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule[rule],
                integration_method=IntegrationMethod.HEUN, intervals=N, nlpsolver=NLPSolverType.SQP, **kw)
