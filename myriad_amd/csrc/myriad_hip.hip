@@ -558,6 +558,13 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (k1 > 0) {
+    if (const char* path = getenv("MYRIAD_PARK_DUMP")) {      // developer knob: the loop scalars of every record as parked ([B][NSCAL] doubles), for the study of resume orders
+      std::vector<double> sc((size_t)B * W::NSCAL);
+      HIPCHK(hipMemcpy2D(sc.data(), W::NSCAL * sizeof(double), h->park_state, (size_t)pk.stride * sizeof(double), W::NSCAL * sizeof(double), (size_t)B, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(path, "wb")) { fwrite(sc.data(), sizeof(double), sc.size(), f); fclose(f); }
+    }
+  }
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, kt.a, kt.b));
   kt.sum_ms += ms;
