@@ -467,7 +467,7 @@ def run(a, rank, world, dev, make_engine):
     if "eval" not in prof and os.path.exists(tp) and B == 4096 and N == 100:
       prof["eval"] = (json.load(open(tp)).get("traffic_bytes_per_launch"), os.path.relpath(tp, ROOT))
   # the library's two-phase launch: at least two whole solves per resident wavefront (four per CU), unless switched off
-  two_phase = fused and cuda and os.environ.get("MYRIAD_PARK_ITER", "-1") != "0" and B >= 2 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+  two_phase = fused and cuda and os.environ.get("MYRIAD_PARK_ITER", "-1") != "0" and B >= 1.5 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count
   lps = 2 if two_phase else 1
   traffic, traffic_src = prof.get("eval", (None, None))
   sol_bytes, sol_src = prof.get("solver", (None, None))
@@ -506,7 +506,7 @@ def run(a, rank, world, dev, make_engine):
                  "frac": alg / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from_profile": traffic_src,
                  "alg_bytes_per_launch": alg, "avg_ms": ev_ms, "launches": ev_n},
     "solver_kernel": {"kernel": ("hs_solve_fused_kernel<CARTPOLE> (persistent, one trajectory per wavefront, iterate in LDS, fused backward / forward phases, Riccati sweep on fp64 MFMA, whole SQP on the device" +
-                                  (": TWO launches per solve -- 12 iterations for every trajectory, the unfinished ones parked and resumed longest-first (myr_solve_opts.park_iter); avg_ms is the sum of both)"
+                                  (": TWO launches per solve -- the first 8 to 12 iterations for every trajectory (12 at this batch size), the unfinished ones parked and resumed longest-first (myr_solve_opts.park_iter); avg_ms is the sum of both)"
                                    if two_phase else " in one launch)")
                                  if fused else
                                  ("hs_solve_wave_kernel<CARTPOLE> (round-2 kernel: persistent, one trajectory per wavefront, thirteen phases through global records)"

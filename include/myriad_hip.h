@@ -140,8 +140,8 @@ typedef struct {
                            are the same, bit for bit).  A batch much larger than the number of resident wavefronts runs as several
                            whole solves per wavefront and ends with the wavefronts that drew the long solves last; instead every
                            instance first gets `park_iter` iterations, the unfinished ones are parked (40 KB each) and resumed
-                           longest-first by their residuals at that point.  0 = the library decides (Hermite-Simpson: 12 iterations when B
-                           is at least twice the resident wavefronts; whole solves otherwise; MYRIAD_PARK_ITER overrides), -1 = whole
+                           longest-first by their residuals at that point.  0 = the library decides (Hermite-Simpson, closed-form systems: 8 / 10 /
+                           12 iterations from 1.5 / 2 / 3 solves per resident wavefront on; whole solves otherwise; MYRIAD_PARK_ITER overrides), -1 = whole
                            solves, k > 0 = k iterations.  Needs the per-instance `status` and `kkt` outputs; ignored by the other
                            kernels. */
 } myr_solve_opts;

@@ -515,7 +515,12 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   if constexpr (NWAVES == 1 || W::MLP) {        // the one-wavefront kernels and the network kernel (four wavefronts, one trajectory per CU: B = 1024 is four rounds)
     k1 = so.park_iter != 0 ? so.park_iter : h->park_iter;
     if (k1 < 0 && so.park_iter < 0) k1 = 0;                     // opts.park_iter = -1: whole solves
-    else if (k1 < 0) k1 = (SCHEME == 0 && !W::MLP && B >= 2 * slots_full) ? 12 : 0;       // a little more than half of a typical interior-point solve (20-25 iterations);
+    else if (k1 < 0) {
+      // by the number of solves a resident wavefront gets (measured on the headline workload, tools/dev/exp/exp47.sh: B = 1536 +4 %, 2048 +7 %,
+      // 3072 +16 %, 4096 +9 %, 8192 +7 %; below one and a half solves per wavefront whole solves are faster)
+      const double per_slot = (double)B / (double)slots_full;
+      k1 = (SCHEME != 0 || W::MLP) ? 0 : (per_slot >= 3.0 ? 12 : (per_slot >= 2.0 ? 10 : (per_slot >= 1.5 ? 8 : 0)));
+    }       // a little more than half of a typical interior-point solve (20-25 iterations);
                                                                                // (trapezoidal solves are shorter and closer together: two phases cost them 2.5 %;
                                                                                //  the network system's longest solves -- 75 iterations against a median of 24 -- have SMALL
                                                                                //  residuals at the parking point and would come last: 41 -> 52 ms at B = 1024, exp42 / exp43)
