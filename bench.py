@@ -469,6 +469,11 @@ def run(a, rank, world, dev, make_engine):
   # the library's two-phase launch: at least two whole solves per resident wavefront (four per CU), unless switched off
   two_phase = fused and cuda and os.environ.get("MYRIAD_PARK_ITER", "-1") != "0" and B >= 1.5 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count
   lps = 2 if two_phase else 1
+  park_k1 = 0
+  if two_phase:        # the library's rule (myriad_hip.hip: launch_hs_fused_w), restated for the description of the line
+    per_slot = B / (4.0 * torch.cuda.get_device_properties(dev).multi_processor_count)
+    park_k1 = int(os.environ.get("MYRIAD_PARK_ITER", "-1"))
+    if park_k1 < 0: park_k1 = 12 if per_slot >= 3 else (10 if per_slot >= 2 else 8)
   traffic, traffic_src = prof.get("eval", (None, None))
   sol_bytes, sol_src = prof.get("solver", (None, None))
   out = {
@@ -506,7 +511,7 @@ def run(a, rank, world, dev, make_engine):
                  "frac": alg / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from_profile": traffic_src,
                  "alg_bytes_per_launch": alg, "avg_ms": ev_ms, "launches": ev_n},
     "solver_kernel": {"kernel": ("hs_solve_fused_kernel<CARTPOLE> (persistent, one trajectory per wavefront, iterate in LDS, fused backward / forward phases, Riccati sweep on fp64 MFMA, whole SQP on the device" +
-                                  (": TWO launches per solve -- the first 8 to 12 iterations for every trajectory (12 at this batch size), the unfinished ones parked and resumed longest-first (myr_solve_opts.park_iter); avg_ms is the sum of both)"
+                                  (": TWO launches per solve -- the first %d iterations for every trajectory, the unfinished ones parked and resumed longest-first (myr_solve_opts.park_iter); avg_ms is the sum of both)" % park_k1
                                    if two_phase else " in one launch)")
                                  if fused else
                                  ("hs_solve_wave_kernel<CARTPOLE> (round-2 kernel: persistent, one trajectory per wavefront, thirteen phases through global records)"
