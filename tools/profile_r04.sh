@@ -15,7 +15,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 done
 python tools/pmc_summary.py $OUT $OUT/pmc_bench_n1.json
 # batch sweep (W = 2 up to two trajectories per CU)
-for B in 256 512 1024 2048 8192; do python bench.py --batch $B --cpu-budget 0 --no-other-configs 2>/dev/null | tail -1 >> $OUT/batch_sweep.jsonl; done
+for B in 256 512 1024 1536 2048 3072 8192; do python bench.py --batch $B --cpu-budget 0 --no-other-configs 2>/dev/null | tail -1 >> $OUT/batch_sweep.jsonl; done
 for B in 256 512; do MYRIAD_FUSED_WAVES=1 python bench.py --batch $B --cpu-budget 0 --no-other-configs 2>/dev/null | tail -1 >> $OUT/batch_sweep_w1.jsonl; done
 # configs 3 and 5: kernel trace of the round-4 build
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt3 -o kt -- python tools/dev/cfg3.py 8192 > $OUT/config3.log 2>&1
