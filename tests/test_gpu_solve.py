@@ -87,6 +87,29 @@ def test_solve_random_batch_properties():
   np.testing.assert_allclose(res2["cost"], res["cost"], rtol=1e-7)
 
 
+def test_park_iter_option_of_the_abi_changes_the_schedule_not_the_result(monkeypatch):
+  """myr_solve_opts.park_iter through the C-ABI (not the environment): a batch too small for the library to choose the two-phase launch, forced into
+  it with park_iter = 3 and 9, against whole solves (park_iter = -1): the same bits, and a zero-initialised field (the library decides) as well."""
+  from oracle import myriad_oracle as O
+  monkeypatch.setenv("MYRIAD_FUSED_WAVES", "1"); monkeypatch.delenv("MYRIAD_PARK_ITER", raising=False)
+  N, B = 25, 77
+  s = O.CartPole()
+  x0 = O.random_x0(s, B, seed=11)
+  tr = O.hermite_simpson(s, N)
+  K = 2 * N + 1
+  z0 = np.stack([np.concatenate([np.linspace(x0[b], s.x_T, K).ravel(), np.zeros(K)]) for b in range(B)])
+  lb = np.tile(tr.bounds[:, 0], (B, 1)); ub = np.tile(tr.bounds[:, 1], (B, 1))
+  lb[:, :4] = x0; ub[:, :4] = x0
+  eng = _engine(N, B)
+  out = {}
+  for k in (-1, 0, 3, 9):
+    o = eng.default_opts(); o.restoration = 0; o.park_iter = k
+    r = eng.solve(z0, lb, ub, opts=o)
+    assert (r["status"] == 0).all()
+    out[k] = b"".join(np.ascontiguousarray(r[q]).tobytes() for q in ("z", "lam", "cost", "kkt", "status", "iters"))
+  assert out[0] == out[-1] and out[3] == out[-1] and out[9] == out[-1]
+
+
 def test_solve_nonconvergence_is_reported_not_raised():
   """max_iter too small: status = MAXITER per instance, no exception (reference: solution['success'] is only printed,
   nlp_solvers/__init__.py:64)."""
