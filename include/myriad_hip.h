@@ -142,8 +142,9 @@ typedef struct {
                            instance first gets `park_iter` iterations, the unfinished ones are parked (40 KB each) and resumed
                            longest-first by their residuals at that point.  0 = the library decides (Hermite-Simpson, closed-form systems: 8 / 10 /
                            12 iterations from 1.5 / 2 / 3 solves per resident wavefront on; whole solves otherwise; MYRIAD_PARK_ITER overrides), -1 = whole
-                           solves, k > 0 = k iterations.  Needs the per-instance `status` and `kkt` outputs; ignored by the other
-                           kernels. */
+                           solves, k > 0 = k iterations (an explicit k > 0 also selects the one-wavefront form for small batches, which the
+                           library would otherwise give two wavefronts per trajectory: the two-wavefront form has no parking).  Needs the
+                           per-instance `status` and `kkt` outputs; ignored by the other kernels. */
 } myr_solve_opts;
 
 int myr_create(const myr_problem_desc* desc, myr_handle* out);
@@ -293,6 +294,13 @@ int myr_device_count(void);
 
 const char* myr_last_error(void);
 const char* myr_version(void);
+
+/* ABI guard (round 5): the bytes this build of the library reads and writes through a `myr_solve_opts*`, a `myr_problem_desc*` and a
+ * `myr_dims*`.  The structs carry no size field and `myr_solve_opts` has grown before (round 4: restoration, park_iter: 40 -> 48 bytes);
+ * a binding compares these numbers with the sizes of its OWN declarations once, at load time, and refuses a library that disagrees
+ * (myriad_amd/_lib.py: load()) instead of letting the library read past a shorter struct.  `which`: 0 = myr_solve_opts,
+ * 1 = myr_problem_desc, 2 = myr_dims; anything else returns -1. */
+int32_t myr_abi_sizeof(int32_t which);
 
 #ifdef __cplusplus
 }

@@ -26,11 +26,11 @@ INT_IDS = {"EULER": 0, "HEUN": 1, "MIDPOINT": 2, "RK4": 3}
 MEM_HOST, MEM_DEVICE = 0, 1
 K_EVAL, K_SOLVE, K_ROLLOUT, K_RESID, K_PROD, K_FBSM = 0, 1, 2, 3, 4, 5
 STATUS_NAMES = {0: "CONVERGED", 1: "MAXITER", 2: "NAN", 3: "STALLED", 4: "INFEASIBLE"}
-STATUS_INFEASIBLE = 4   # assigned by the host's elastic phase (TrajectoryOptimizer.device_solve), never by a kernel
+STATUS_INFEASIBLE = 4   # assigned by the library's restoration phase inside myr_solve (csrc/myriad_hip.hip: solve_restored), never by a kernel
 
 EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve", "myr_solve_x0",
            "myr_set_var_scale", "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_fbsm", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",
-           "myr_version", "myr_device_count", "myr_solve_info"]
+           "myr_version", "myr_device_count", "myr_solve_info", "myr_abi_sizeof"]
 
 
 class ProblemDesc(C.Structure):
@@ -113,6 +113,15 @@ def load() -> C.CDLL:
   lib.myr_kernel_time_reset.restype = C.c_int
   lib.myr_last_error.restype = C.c_char_p
   lib.myr_version.restype = C.c_char_p
+  # ABI guard: the structs have no size field; a library built from another header would read past (or short of) ours
+  if not hasattr(lib, "myr_abi_sizeof"):
+    raise MyriadHipError(f"{LIB_PATH} ({lib.myr_version().decode()}) predates myr_abi_sizeof: rebuild it (python __graft_entry__.py build)")
+  lib.myr_abi_sizeof.argtypes = [C.c_int32]
+  lib.myr_abi_sizeof.restype = C.c_int32
+  for which, st in ((0, SolveOpts), (1, ProblemDesc), (2, Dims)):
+    if lib.myr_abi_sizeof(which) != C.sizeof(st):
+      raise MyriadHipError(f"{LIB_PATH} ({lib.myr_version().decode()}): {st.__name__} is {lib.myr_abi_sizeof(which)} bytes in the library, "
+                           f"{C.sizeof(st)} in this binding -- library and binding come from different headers")
   _lib = lib
   return lib
 

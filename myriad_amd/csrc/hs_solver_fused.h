@@ -65,6 +65,10 @@ struct ParkArgs {
 };
 constexpr int MYR_STATUS_PARKED_ = 5;     // internal: never leaves myr_solve
 
+#ifdef MYR_PHASE_TIMING
+__device__ long long node_tph_[8];      // cycles of workgroup 0's network passes (MODE 0 / 1 / 2), wavefront 0
+#endif
+
 template <class Sys, int W = 1, int SCHEME = 0>
 struct HsFused {
   static constexpr int NT = 64 * W;
@@ -109,7 +113,11 @@ struct HsFused {
   __host__ __device__ static long off_lam(int N) { return off_kg(N) + (long)N * KST; }
   __host__ __device__ static long off_kg2(int N) { return off_lam(N) + (long)MLAM * N * NS; }      // W = 2: gains of the speculative second sweep
   __host__ __device__ static long off_pt(int N) { return off_kg2(N) + (W > 1 ? (long)N * KST : 0); }     // network systems: point records (SoA)
-  __host__ __device__ static long scratch_doubles(int N) { return off_pt(N) + (MLP ? (long)PT_N * npoints(N) : 0); }
+  // network systems (round 5): hidden activations of the last evaluated point and the tangents of the linearisation, per tile of 16 points
+  // and lane (node_mfma.h: MODE 0 / 3 write, MODE 3 / 4 read -- always the lane that wrote them)
+  __host__ __device__ static long off_hb(int N) { return off_pt(N) + (MLP ? (long)PT_N * npoints(N) : 0); }
+  __host__ __device__ static long off_mb(int N) { return off_hb(N) + (MLP ? (long)NodeMfma64::ntiles(npoints(N)) * NodeMfma64::HB_TILE : 0); }
+  __host__ __device__ static long scratch_doubles(int N) { return off_mb(N) + (MLP ? (long)NodeMfma64::ntiles(npoints(N)) * NodeMfma64::MB_TILE : 0); }
   // LDS (doubles): z | zL | zU | dz | multipliers | bound table | neighbour stash | first-point exchange
   static constexpr int NREC = NS + NS + NS * NS + NS * NU + NS;   // x, f, A, B, own: what an interval takes from its end knot
   static constexpr int EXCH = NW * NW + NW * NC + NS * NC + NU * NC;
@@ -129,6 +137,8 @@ struct HsFused {
     double *hr, *st, *kg, *zr;            // global scratch of this wavefront
     double *kgA, *kgB, *xA, *xB;          // W = 2: the two sets of sweep outputs (gains in global scratch, first-point exchange in LDS)
     double *pt, *sF, *wl;                 // network systems: point records (global), trial values and weights (LDS)
+    double *hb, *mb;                      //   stored activations / tangents (global, per tile and lane)
+    bool h_valid;                         //   hb holds the activations of the iterate (the last trial point was accepted)
     const double *lb, *ub;                // the caller's bounds (global)
     bool uni;                             // interior points share one bound per component: served from sB
     SysParams<Sys> pp;
@@ -179,13 +189,20 @@ struct HsFused {
   template <int MODE>
   __device__ static inline void node_pass(Ctx& c, double alpha) {
     if constexpr (MLP) {
+#ifdef MYR_PHASE_TIMING
+      const long long tn0_ = clock64();
+#endif
       NodeMfma64::ArgsT<nd_lds> a;
       a.z = (const nd_lds*)c.z; a.dz = (const nd_lds*)c.dz; a.lam = (const nd_lds*)c.sLam; a.pt = (nd_glb*)c.pt;
       a.sF = (nd_lds*)c.sF;
       a.alpha = alpha; a.h6 = c.h6; a.h8 = c.h8; a.K = c.K; a.N = c.N;
       a.pf_f = PT_F; a.pf_a = PT_A; a.pf_b = PT_B; a.pf_d2 = PT_D2;
       a.t0 = c.wave; a.ts = W;
+      a.hb = (nd_glb*)c.hb; a.mb = (nd_glb*)c.mb; a.h_valid = c.h_valid ? 1 : 0;
       NodeMfma64::pass<MODE, nd_lds>((const nd_lds*)c.wl, a, c.lane);
+#ifdef MYR_PHASE_TIMING
+      if (blockIdx.x == 0 && c.tid == 0) node_tph_[MODE] += clock64() - tn0_;
+#endif
     } else { (void)c; (void)alpha; }
   }
 
@@ -324,7 +341,7 @@ struct HsFused {
         wsync();
         stp_.on = false;
       }
-      node_pass<1>(c, 0.0);
+      node_pass<3>(c, 0.0);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       wsync();
     }
@@ -641,7 +658,7 @@ struct HsFused {
     const double h6 = c.h6, h8 = c.h8;
     double st_ = 0;
     if constexpr (MLP) {          // the network's multiplier-contracted second derivatives of all points (reads the multipliers in LDS)
-      node_pass<2>(c, 0.0);
+      node_pass<4>(c, 0.0);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       wsync();
     }
@@ -1407,6 +1424,7 @@ struct HsFused {
     Step pending{false, 0.0, 0.0, 0.0, o.kappa_sigma};
     int it0 = 0;
     res.cost = 0.0; res.feas = 0.0; res.stat = 0.0; res.compl_ = 0.0;
+    c.h_valid = false;                      // a new or resumed trajectory: the activation store belongs to the slot's previous one
     if (park_mode == 2) {
       // resume a parked trajectory: the solver's LDS as it was at the top of iteration k1, the scalars of the loop, the slot's block of zeros
       const int nl = lds_solver_doubles(c.N);
@@ -1451,6 +1469,7 @@ struct HsFused {
       BOut p1;
       { NuT nu_; for (int q = 0; q < NS; ++q) nu_.v[q] = nuT[q]; p1 = backward_pass(c, pending, nu_); }
       pending.on = false;
+      c.h_valid = false;                    // (from here on the store holds the activations of THIS iterate, whichever pass wrote them; the flag is for the next linearisation)
       wsync();
       MYR_PH(0)
       double stat_raw;
@@ -1591,6 +1610,7 @@ struct HsFused {
       if (!ok) {
         if (++stall > 5) { res.status = 3; res.iters = it; return; }
       } else stall = 0;
+      c.h_valid = ok;                       // network systems: the accepted trial point is the next iterate, its activations are in the store
       MYR_PH(11)
 #ifdef MYR_TRACE
       if (c.lane == 0 && c.traj < MYR_TRACE)
@@ -1635,6 +1655,7 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   double* s = scratch + (long)blockIdx.x * scratch_stride;
   c.zr = s; c.hr = s + W::off_hr(c.N); c.st = s + W::off_st(c.N); c.kg = s + W::off_kg(c.N);
   c.kgA = c.kg; c.kgB = s + W::off_kg2(c.N); c.pt = s + W::off_pt(c.N);
+  c.hb = s + W::off_hb(c.N); c.mb = s + W::off_mb(c.N); c.h_valid = false;
   double* const lam_own = s + W::off_lam(c.N);
   double* l = reinterpret_cast<double*>(smem_fused);
   c.z = l; l += c.n; c.zL = l; l += c.n; c.zU = l; l += c.n; c.dz = l; l += c.n;
@@ -1711,6 +1732,10 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     if (c.lane == 0 && b < 4) {
       printf("traj %ld it %d: backward %lld hess %lld ricc %lld nu %lld forward %lld ls %lld\n",
              b, r.iters, c.tph[0], c.tph[4], c.tph[6], c.tph[7], c.tph[8], c.tph[11]);
+    }
+    if (W::MLP && c.tid == 0 && blockIdx.x == 0) {
+      printf("  workgroup 0, traj %ld it %d: network passes of wavefront 0 (cycles): MODE0 %lld MODE3 %lld MODE4 %lld\n", b, r.iters, node_tph_[0], node_tph_[3], node_tph_[4]);
+      node_tph_[0] = node_tph_[3] = node_tph_[4] = 0;
     }
 #endif
     if (c.tid == 0) {

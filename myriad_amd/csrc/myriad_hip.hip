@@ -101,7 +101,8 @@ struct myr_handle_s {
   bool twin_unavailable = false;
   void* rbuf = nullptr; size_t rbuf_bytes = 0;      // copy of the caller's guess + status / iters when the caller passed none
   void* fbuf = nullptr; size_t fbuf_bytes = 0;      // working set of the failed instances
-  int32_t* nfail_host = nullptr;                    // pinned, device-visible: instances the first attempt left without a KKT point
+  int32_t* nfail_host = nullptr;                    // pinned: instances the first attempt left without a KKT point (copied from nfail_dev)
+  int32_t* nfail_dev = nullptr;                     // the device word the count kernel adds to (device-scope atomics on device memory: no PCIe atomics needed)
   std::vector<int32_t> info_start, info_attempts, info_restored;
   int last_solve_form = 1;         // kernel form of the last solve launch on this handle: 1 = a wavefront kernel, 0 = the lane kernel
   unsigned long long poison = 0;   // MYRIAD_POISON: bit pattern written over a slot's LDS and scratch at every trajectory hand-over (tests)
@@ -588,6 +589,7 @@ static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, con
     // results that differed from launch to launch; round 4 found the form of the sweep that does it
     // (hs_solver_fused.h: sweep) and gates every build with tests/test_gpu_poison.py.  MYRIAD_FUSED_WAVES=1|2 overrides the choice.
     int waves = (B <= 2 * device_cus(h)) ? 2 : 1;
+    if (so.park_iter > 0) waves = 1;                  // an explicit two-phase launch: only the one-wavefront form parks (include/myriad_hip.h: park_iter)
     if (h->fused_waves > 0) waves = h->fused_waves;
     if (waves == 2 && HsFused<Sys, 2, SCHEME>::lds_bytes(h->d.intervals) <= 160 * 1024)
       return launch_hs_fused_w<Sys, 2, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
@@ -653,6 +655,8 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     long stride = (W::scratch_doubles(N) + 31) / 32 * 32;
     if (((stride / 32) & 1) == 0) stride += 32;          // odd multiple of 256 B: rotate slots over HBM channels
     const size_t need = (size_t)slots * (size_t)stride * 8;
+    if (getenv("MYRIAD_DEBUG_PTRS"))
+      fprintf(stderr, "[myriad] wave kernel N=%d B=%d slots=%d wpb=%d coop=%d per_cu=%d lds=%zu stride=%ld doubles need=%zu\n", N, B, slots, wpb, coop, per_cu, lds, stride, need);
     if (need > h->sbuf_bytes) {
       if (h->sbuf) HIPCHK(hipFree(h->sbuf));
       h->sbuf = nullptr; h->sbuf_bytes = 0;
@@ -871,7 +875,15 @@ MYR_SYSTEM_ENTRY_POINTS(extern, SysNODE_CARTPOLE)
 
 #if !defined(MYR_TU_SYSTEM)   // ===== C-ABI and dispatch: the main object only ============================================
 extern "C" const char* myr_last_error(void) { return g_err.c_str(); }
-extern "C" const char* myr_version(void) { return "myriad_hip 0.1 (gfx950)"; }
+extern "C" const char* myr_version(void) { return "myriad_hip 0.2 (gfx950)"; }
+extern "C" int32_t myr_abi_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return (int32_t)sizeof(myr_solve_opts);
+    case 1: return (int32_t)sizeof(myr_problem_desc);
+    case 2: return (int32_t)sizeof(myr_dims);
+  }
+  return -1;
+}
 extern "C" int myr_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -975,6 +987,7 @@ extern "C" int myr_destroy(myr_handle h) {
   if (h->rbuf) (void)hipFree(h->rbuf);
   if (h->fbuf) (void)hipFree(h->fbuf);
   if (h->nfail_host) (void)hipHostFree(h->nfail_host);
+  if (h->nfail_dev) (void)hipFree(h->nfail_dev);
   if (h->twin) { (void)myr_destroy(h->twin); h->twin = nullptr; }
   for (int i = 0; i < MYR_K_COUNT; ++i) {
     if (h->kt[i].a) (void)hipEventDestroy(h->kt[i].a);
@@ -1294,13 +1307,16 @@ __global__ void twin_params_kernel(int B, int np, const double* __restrict__ par
     out[t] = i == np ? rho : (params ? params[b * (long)pstride + i] : defaults[i]);
   }
 }
-// excitation guess, controls: us[b][j][a] = centre_a + 0.95 amp_a sin(2 pi c t_j / T), t_j = T j / (rr - 1); centre / amplitude from the bounds of
-// the instance's first control row (the reference's control bounds are the same on every row); x0[b] = the pinned start state, else the guess's
-__global__ void excitation_controls_kernel(int B, int rr, int nu, int ns, int nx, int n, double cycles, const double* __restrict__ lb, const double* __restrict__ ub,
+// excitation guess, controls: us[b][j][a] = centre_a + 0.95 amp_a sin(2 pi c t_j / T), t_j = T j / (rr - 1); centre / amplitude from control a's own
+// bounds.  The reference writes control bounds control-major (quirk Q1: hermite_simpson.py:71-74, trapezoidal.py:58-61, shooting.py:264-267 -- flat
+// entries [a rr, (a + 1) rr) of the control part hold control a's bounds) while the variables are time-major, so control a's bounds are read at flat
+// index a * u_rows (u_rows = control rows of the decision vector), NOT at the variable's own entry (for nu > 1 the first row holds control 0's bounds in every component).  x0[b] = the pinned start
+// state, else the guess's
+__global__ void excitation_controls_kernel(int B, int rr, int u_rows, int nu, int ns, int nx, int n, double cycles, const double* __restrict__ lb, const double* __restrict__ ub,
                                            const double* __restrict__ z0, double* __restrict__ us, double* __restrict__ x0) {
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)B * rr * nu; t += (long)gridDim.x * blockDim.x) {
     const long b = t / ((long)rr * nu); const int j = (int)((t / nu) % rr), a = (int)(t % nu);
-    const double lo = lb[b * n + nx + a], hi = ub[b * n + nx + a];
+    const double lo = lb[b * n + nx + (long)a * u_rows], hi = ub[b * n + nx + (long)a * u_rows];
     const bool fin = lo > -1e300 && hi < 1e300;
     const double centre = fin ? 0.5 * (lo + hi) : 0.0, amp = fin ? 0.5 * (hi - lo) : 1.0;
     us[t] = centre + 0.95 * amp * sin(2.0 * 3.14159265358979323846 * cycles * ((double)j / (double)(rr - 1)));
@@ -1323,7 +1339,7 @@ __global__ void excitation_pack_kernel(long total, int n, int nx, int ns, int nu
   }
 }
 
-// how many instances ended without a KKT point -> a pinned host word (the common answer, none, costs no status download)
+// how many instances ended without a KKT point -> a device word, copied to a pinned host word (the common answer, none, costs no status download)
 __global__ void count_failed_kernel(int B, const int32_t* __restrict__ status, int32_t* __restrict__ out) {
   int n = 0;
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) n += status[b] != MYR_STATUS_CONVERGED ? 1 : 0;
@@ -1370,7 +1386,8 @@ static RestoreCfg restore_cfg(const myr_solve_opts& so) {
 
 // the twin handle of a collocation problem whose system has one (lazily; nullptr when there is none or its solver is not built)
 static myr_handle twin_of(myr_handle h) {
-  if (h->twin || h->twin_unavailable) return h->twin;
+  if (h->twin_unavailable) return nullptr;
+  if (h->twin) return h->twin;
   SysInfo si;
   if (h->d.transcription == MYR_TR_SHOOTING || h->d.system_id >= 100 || !sys_info(h->d.system_id + 100, &si)) { h->twin_unavailable = true; return nullptr; }
   myr_problem_desc d = h->d;
@@ -1404,11 +1421,15 @@ static int solve_restored(myr_handle h, int B, double* z, const double* lb, cons
   int32_t* dit = iters ? iters : (int32_t*)(z0c + al((size_t)B * n) + al((size_t)B));
   HIPCHK(hipMemcpyAsync(z0c, z, (size_t)B * n * 8, hipMemcpyDeviceToDevice, h->stream));
   if (int rc = dispatch_solve_scaled(h, B, z, lb, ub, params, pstride, so, lam, cost, dstat, dit, kkt)) return rc;
-  if (!h->nfail_host) HIPCHK(hipHostMalloc((void**)&h->nfail_host, 64, hipHostMallocMapped));
-  *h->nfail_host = 0;
-  hipLaunchKernelGGL(count_failed_kernel, dim3((unsigned)((B + 255) / 256 > 64 ? 64 : (B + 255) / 256)), dim3(256), 0, h->stream, B, dstat, h->nfail_host);
+  if (!h->nfail_host) HIPCHK(hipHostMalloc((void**)&h->nfail_host, 64, hipHostMallocDefault));
+  if (!h->nfail_dev) HIPCHK(hipMalloc((void**)&h->nfail_dev, 64));
+  *h->nfail_host = -1;
+  HIPCHK(hipMemsetAsync(h->nfail_dev, 0, 4, h->stream));
+  hipLaunchKernelGGL(count_failed_kernel, dim3((unsigned)((B + 255) / 256 > 64 ? 64 : (B + 255) / 256)), dim3(256), 0, h->stream, B, dstat, h->nfail_dev);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h->nfail_host, h->nfail_dev, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (*h->nfail_host < 0) return fail(MYR_E_HIP, "restoration: the count of failed instances did not arrive");
   if (*h->nfail_host == 0) return MYR_OK;
   std::vector<int32_t> hstat(B), hit(B);
   HIPCHK(hipMemcpyAsync(hstat.data(), dstat, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1509,7 +1530,13 @@ static int solve_restored(myr_handle h, int B, double* z, const double* lb, cons
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(h->stream));      // the twin runs on a stream of its own
       const int rc = dispatch_solve_scaled(twin, nf, zt, lbt, ubt, pt, np + 1, topt, nullptr, nullptr, statf, itf, nullptr);
-      if (rc == MYR_E_UNSUPPORTED) { twin_ok = false; h->twin_unavailable = true; break; }     // (ROCKETLANDING's twin under the trapezoidal scheme: not built)
+      if (rc == MYR_E_UNSUPPORTED) {      // (a twin whose solver is not built for this scheme): drop the handle -- its stream and buffers -- for good, and do not
+        twin_ok = false;                  // leave "... not built" behind as the last error of a myr_solve that returns MYR_OK
+        h->twin_unavailable = true;
+        (void)myr_destroy(h->twin); h->twin = nullptr; twin = nullptr;
+        g_err.clear();
+        break;
+      }
       if (rc) return rc;
       hipLaunchKernelGGL(twin_clip_kernel, dim3(grid_for((long)nf * nt)), dim3(256), 0, h->stream, (long)nf * nt, lbt, ubt, zt);
       hipLaunchKernelGGL(twin_slack_kernel, dim3((unsigned)nf), dim3(256), 0, h->stream, nx, dm.u_rows, nu, ns, nt, zt, dslack);
@@ -1550,7 +1577,7 @@ static int solve_restored(myr_handle h, int B, double* z, const double* lb, cons
     for (size_t ci = 0; ci < cfg.cycles.size() && !fail_.empty(); ++ci) {
       const int nf = (int)fail_.size(), c = cfg.cycles[ci];
       if (int rc = gather(fail_)) return rc;
-      hipLaunchKernelGGL(excitation_controls_kernel, dim3(grid_for((long)nf * rr * nu)), dim3(256), 0, h->stream, nf, rr, nu, ns, nx, n, (double)c, lbf, ubf, z0f, dus, dx0);
+      hipLaunchKernelGGL(excitation_controls_kernel, dim3(grid_for((long)nf * rr * nu)), dim3(256), 0, h->stream, nf, rr, dm.u_rows, nu, ns, nx, n, (double)c, lbf, ubf, z0f, dus, dx0);
       HIPCHK(hipGetLastError());
       if (int rc = dispatch_rollout(h, nf, steps, rr, dx0, dus, pfp, per_row_params ? np : pstride, dxs, nullptr)) return rc;
       hipLaunchKernelGGL(excitation_pack_kernel, dim3(grid_for((long)nf * n)), dim3(256), 0, h->stream, (long)nf * n, n, nx, ns, nu, steps, xstride, rr, ustride, dxs, dus, lbf, ubf, zf);

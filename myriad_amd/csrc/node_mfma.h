@@ -17,6 +17,11 @@
 //   MODE 0  F                                   (merit-function trials)               88 MFMA per 16 points
 //   MODE 1  F, dF/dx, dF/du  (forward tangents) (linearisation)                       488
 //   MODE 2  sum_r a_r d2 F_r / d(x,u)2          (Lagrangian Hessian, 15 entries)      476
+// Round 5: the fused solver's passes share what they compute instead of recomputing it (hb / tb of the arguments):
+//   MODE 0  + stores the hidden activations h1, h2 of the trial point (the accepted trial point IS the next iterate)
+//   MODE 3  MODE 1 from the stored activations (no layer 1 / 2 products, no sigmoids when they are valid); the tangents
+//           m_c = W2^T (s'(A1) * W1[c, :]) are stored for MODE 4; the last layer on the vector pipe                320
+//   MODE 4  MODE 2 from the stored activations and tangents: g1 = W2 e2 is the one 64 x 64 product left            68
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -45,6 +50,13 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
     if (t < NS) wl[L_B3 + t] = p[O_B3 + t];
   }
 
+  // the activation / tangent stores are streams (written once, read once or twice by the same lane, ~0.9 MB per trajectory and iteration):
+  // non-temporal, so that they do not evict the solver's records from the L2 (-DMYR_NODE_NT=0: plain accesses)
+#ifndef MYR_NODE_NT
+#define MYR_NODE_NT 1
+#endif
+  __device__ static inline double ntl(const nd_glb* p) { return MYR_NODE_NT ? __builtin_nontemporal_load(p) : *p; }
+  __device__ static inline void nts(double v, nd_glb* p) { if (MYR_NODE_NT) __builtin_nontemporal_store(v, p); else *p = v; }
   __device__ static inline nd4 mm(double a, double b, nd4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
   // 1 / (1 + exp(-a)) with the reciprocal from v_rcp_f64 + two Newton steps (5 instructions instead of the ~35 of the IEEE
   // division sequence: a tile of 16 points takes 32 sigmoids per lane); <= 1 ulp
@@ -118,6 +130,24 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
     return (acc[0][0] + acc[1][0]) + (acc[2][0] + acc[3][0]);
   }
 
+  // The same on the vector pipe (round 5): the last layer has four output rows -- a quarter of the matrix instruction's sixteen -- so
+  // 64 multiply-adds per lane and one scattered sum over the lane groups (9 instructions) cost a third of the sixteen matrix
+  // instructions (on this part the fp64 matrix rate IS the fp64 vector rate).  Output r of point i in lane 16 r + i.
+  __device__ static inline double layer3_valu(const nd_lds* wl, int g, const nd4* in) {
+    double f[NS];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) f[r] = 0.0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const nd_lds* w = wl + L_W3 + (16 * mt + 4 * s + g) * NS;
+#pragma unroll
+        for (int r = 0; r < NS; ++r) f[r] = fma(w[r], in[mt][s], f[r]);
+      }
+    return group_scatter_sum(f[0], f[1], f[2], f[3]) + wl[L_B3 + g];
+  }
+
   // ZT: address space of the iterate, the step and the multipliers (global in HsWave, LDS in the fused kernel)
   template <class ZT>
   struct ArgsT {
@@ -130,7 +160,29 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
     nd_lds* rec = nullptr;                                  // MODE 1, evaluation kernel: F / A / B go to the LDS record of point j
     int use_rec = 0;                                        //   (an explicit flag: the record may sit at LDS offset 0)
     int rec_stride = 0, rec_f = 0, rec_a = 0, rec_b = 0;    //   rec[j * rec_stride + rec_f + r], + rec_a + r * NS + c, + rec_b + r * NU
+    nd_glb* hb = nullptr;                                   // hidden activations of tile t: hb[(t * 32 + f) * 64 + lane], f = 4 mt + s (h1), 16 + 4 mt + s (h2)
+    nd_glb* mb = nullptr;                                   // MODE 3 -> MODE 4: tangents m_c of tile t: mb[(t * 80 + c * 16 + 4 mt + s) * 64 + lane]
+    int h_valid = 0;                                        // MODE 3: hb holds the activations of this iterate (the last trial was accepted)
   };
+  static constexpr int HB_TILE = 32 * 64, MB_TILE = NW * 16 * 64;
+  __host__ __device__ static constexpr int ntiles(int K) { return (K + 15) / 16; }
+
+  // sums over the four lane groups (lanes 16 g + i, g = 0..3), scattered: lane group g ends with the total of v[g].
+  // v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-wavefronts / odd and even rows between two registers: 9 vector
+  // instructions for four values where the shuffle form takes 8 LDS-crossbar moves and 8 additions.
+  __device__ static inline double swap32_sum(double a, double b) {      // lanes < 32: a + a(lane ^ 32); lanes >= 32: b + b(lane ^ 32)
+    auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+  }
+  __device__ static inline double swap16_sum(double a, double b) {      // even rows: a + a(lane ^ 16); odd rows: b + b(lane ^ 16)
+    auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+  }
+  __device__ static inline double group_scatter_sum(double v0, double v1, double v2, double v3) {
+    return swap16_sum(swap32_sum(v0, v2), swap32_sum(v1, v3));
+  }
   using Args = ArgsT<nd_glb>;
 
   template <int MODE, class ZT = nd_glb>
@@ -147,32 +199,150 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
       }
       // (s'(A) = h (1 - h) and s''(A) = s'(A) (1 - 2 h) are formed where they are used: keeping them as arrays next to h1, h2
       // cost MODE 2 64 more live registers than it had)
-      nd4 h1[4];
-      {
-        nd4 a1[4];
+      nd4 h1[4], h2[4];
+      nd_glb* const hbt = (MODE == 0 || MODE >= 3) && a.hb ? a.hb + (long)(j0 >> 4) * HB_TILE + lane : nullptr;
+      const bool stored = (MODE == 4) || (MODE == 3 && a.h_valid);      // (wave-uniform)
+      if (stored) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) a1[mt][s] = wl[L_B1 + 16 * mt + 4 * s + g];
+          for (int s = 0; s < 4; ++s) { h1[mt][s] = ntl(&hbt[(4 * mt + s) * 64]); h2[mt][s] = ntl(&hbt[(16 + 4 * mt + s) * 64]); }
+      } else {
+        {
+          nd4 a1[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a1[mt] = mm(wl[L_W1 + g * H + 16 * mt + i], xg, a1[mt]);
+          for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a1[mt] = mm(wl[L_W1 + (4 + g) * H + 16 * mt + i], ug, a1[mt]);
+            for (int s = 0; s < 4; ++s) a1[mt][s] = wl[L_B1 + 16 * mt + 4 * s + g];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) a1[mt] = mm(wl[L_W1 + g * H + 16 * mt + i], xg, a1[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) a1[mt] = mm(wl[L_W1 + (4 + g) * H + 16 * mt + i], ug, a1[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) h1[mt][s] = sigm(a1[mt][s]);
+        }
+        gemm_t<true>(wl, g, i, h1, h2);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) h1[mt][s] = sigm(a1[mt][s]);
+          for (int s = 0; s < 4; ++s) h2[mt][s] = sigm(h2[mt][s]);
+        if (hbt) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { nts(h1[mt][s], &hbt[(4 * mt + s) * 64]); nts(h2[mt][s], &hbt[(16 + 4 * mt + s) * 64]); }
+        }
       }
-      nd4 h2[4];
-      gemm_t<true>(wl, g, i, h1, h2);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) h2[mt][s] = sigm(h2[mt][s]);
-      if (MODE == 0 || MODE == 1) {
-        const double F = layer3<true>(wl, g, i, h2);
+      if (MODE == 0 || MODE == 1 || MODE == 3) {
+        const double F = (MODE == 1) ? layer3<true>(wl, g, i, h2) : layer3_valu(wl, g, h2);
         if (MODE == 0) { if (valid) a.sF[j * NS + g] = F; }
         else if (valid) { if (a.use_rec) a.rec[j * a.rec_stride + a.rec_f + g] = F; else a.pt[(long)(a.pf_f + g) * K + j] = F; }
+      }
+      if (MODE == 3) {
+        // All five forward tangents through W2 in ONE k-loop: a k-step's weight reads feed ten independent matrix instructions
+        // (5 tangents x 2 output tiles; the output tiles in two halves), the seeds s'(A1) W1[c, :] are formed on the fly.  The tangents
+        // m_c = W2^T (s'(A1) * W1[c, :]) go to `mb` for MODE 4; the last layer -- four output rows, a quarter of a matrix instruction
+        // -- runs on the vector pipe: J[r][c] = sum_n W3[n][r] s'(A2_n) m_c[n], 16 units per lane, then over the lane groups.
+        double J[NS][NW];
+#pragma unroll
+        for (int r = 0; r < NS; ++r)
+#pragma unroll
+          for (int c = 0; c < NW; ++c) J[r][c] = 0.0;
+        nd_glb* const mbt = a.mb + (long)(j0 >> 4) * MB_TILE + lane;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          nd4 m[NW][2];
+#pragma unroll
+          for (int c = 0; c < NW; ++c) { m[c][0] = nd4{0.0, 0.0, 0.0, 0.0}; m[c][1] = nd4{0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int k = 16 * t + 4 * s + g;
+              const nd_lds* row = wl + L_W2 + k * LD2 + 32 * half + i;
+              const double w0 = row[0], w1 = row[16];
+              const double sp = h1[t][s] * (1.0 - h1[t][s]);
+#pragma unroll
+              for (int c = 0; c < NW; ++c) {
+                const double d = sp * wl[L_W1 + c * H + k];
+                m[c][0] = mm(w0, d, m[c][0]);
+                m[c][1] = mm(w1, d, m[c][1]);
+              }
+            }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int mt = 2 * half + q;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int n = 16 * mt + 4 * s + g;
+              const double hv = h2[mt][s], sp2 = hv * (1.0 - hv);
+#pragma unroll
+              for (int c = 0; c < NW; ++c) nts(m[c][q][s], &mbt[(c * 16 + 4 * mt + s) * 64]);
+#pragma unroll
+              for (int r = 0; r < NS; ++r) {
+                const double qr = wl[L_W3 + n * NS + r] * sp2;
+#pragma unroll
+                for (int c = 0; c < NW; ++c) J[r][c] = fma(qr, m[c][q][s], J[r][c]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+          const double dF = group_scatter_sum(J[0][c], J[1][c], J[2][c], J[3][c]);      // d F_g / d w_c at point i
+          if (valid) {
+            if (a.use_rec) a.rec[j * a.rec_stride + (c < NS ? a.rec_a + g * NS + c : a.rec_b + g * NU)] = dF;
+            else a.pt[(long)(c < NS ? a.pf_a + g * NS + c : a.pf_b + g * NU) * K + j] = dF;
+          }
+        }
+      }
+      if (MODE == 4) {
+        double ar;
+        if (j & 1) ar = -4.0 * a.h6 * a.lam[(long)((j - 1) >> 1) * NS + g];
+        else {
+          const int kL = (j >> 1) - 1, kR = j >> 1;
+          ar = 0.0;
+          if (kL >= 0) ar += -a.h6 * a.lam[(long)kL * NS + g] + a.h8 * a.lam[(long)a.N * NS + (long)kL * NS + g];
+          if (kR < a.N) ar += -a.h6 * a.lam[(long)kR * NS + g] - a.h8 * a.lam[(long)a.N * NS + (long)kR * NS + g];
+        }
+        const nd_glb* const mbt = a.mb + (long)(j0 >> 4) * MB_TILE + lane;
+        // e2 = (W3 a) s'(A2); c2 = e2 (1 - 2 h2); g1 = W2 e2; c1 = g1 s''(A1)
+        nd4 e2[4], c1[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) e2[nt] = mm(wl[L_W3 + (16 * nt + i) * NS + g], ar, nd4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) e2[nt][s] *= h2[nt][s] * (1.0 - h2[nt][s]);
+        gemm_n(wl, g, i, e2, c1);
+        double acc[NPAIR];
+#pragma unroll
+        for (int e = 0; e < NPAIR; ++e) acc[e] = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double cv1 = c1[mt][s] * (h1[mt][s] * (1.0 - h1[mt][s]) * (1.0 - 2.0 * h1[mt][s]));
+            const double cv2 = e2[mt][s] * (1.0 - 2.0 * h2[mt][s]);
+            double w1v[NW], mv[NW];
+#pragma unroll
+            for (int c = 0; c < NW; ++c) { w1v[c] = wl[L_W1 + c * H + 16 * mt + 4 * s + g]; mv[c] = ntl(&mbt[(c * 16 + 4 * mt + s) * 64]); }
+            int e = 0;
+#pragma unroll
+            for (int pa = 0; pa < NW; ++pa) {
+              const double wa = cv1 * w1v[pa], ma = cv2 * mv[pa];
+#pragma unroll
+              for (int pb = pa; pb < NW; ++pb, ++e) acc[e] = fma(ma, mv[pb], fma(wa, w1v[pb], acc[e]));
+            }
+          }
+#pragma unroll
+        for (int e0 = 0; e0 < NPAIR; e0 += 4) {
+          const double v = group_scatter_sum(acc[e0], e0 + 1 < NPAIR ? acc[e0 + 1] : 0.0, e0 + 2 < NPAIR ? acc[e0 + 2] : 0.0,
+                                             e0 + 3 < NPAIR ? acc[e0 + 3] : 0.0);
+          if (valid && e0 + g < NPAIR) a.pt[(long)(a.pf_d2 + e0 + g) * K + j] = v;
+        }
       }
       if (MODE == 1) {
         // forward tangents: d A1 / d w_c = W1[c, :] (constant), so d H1 = s'(A1) * W1[c, :], then the two upper layers
