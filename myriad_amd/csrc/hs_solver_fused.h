@@ -65,6 +65,38 @@ struct ParkArgs {
 };
 constexpr int MYR_STATUS_PARKED_ = 5;     // internal: never leaves myr_solve
 
+// Helper workgroups for the network passes (round 5; config 5's share of an 8-GPU node is 128 trajectories: one per CU leaves half of the device idle,
+// and two thirds of an iteration are matrix-core passes over 13 independent tiles of 16 points).  With B <= #CU / 2 the launch adds nh = #CU / B - 1 (at
+// most 3) workgroups per trajectory that do nothing but take their share of the tiles of every pass: the owner posts the pass (mode, sequence number)
+// and the few KB a helper needs (the evaluation point, or the multipliers) in global memory, all 4 (nh + 1) wavefronts deal the tiles round robin, the
+// helpers write their results into the OWNER's records and raise a counter, the owner waits for it.  Same instructions on the same inputs whoever runs
+// a tile: the results are those of the launch without helpers, bit for bit (tests/test_gpu_node.py).  Workgroup ids: owners 0..B-1 (trajectory =
+// workgroup, no ticket), helper h of owner s is workgroup h B + s -- the same XCD when B is a multiple of 8.  All workgroups of the launch are resident
+// (one per CU, grid <= #CU), so the waits cannot deadlock; every wait is bounded all the same and raises `abort` instead of hanging the device.
+struct NodeBoard {
+  unsigned long long cmd;       // (sequence number << 32) | (activations valid << 8) | mode; mode 15: the owner's solve is over
+  unsigned int done;            // passes finished by helpers, cumulative over the solve: the owner waits for seq * nh
+  unsigned int xcc;             // 1 + the owner's XCD
+  unsigned int pad_[28];        // 128 B apart
+};
+struct CoopArgs {
+  NodeBoard* boards;            // [owners]
+  double* pub;                  // [owners][pub_stride]: x (n = K NW) | multipliers (MLAM N NS) | f of the trial point (K NS)
+  long pub_stride;
+  int nh;                       // helpers per owner (0: none; the kernel then is the round-4 one)
+  int* abort;                   // set when a wait ran into its bound
+};
+constexpr int MYR_COOP_EXIT = 15;
+// Visibility between an owner and its helpers WITHOUT agent-scope fences: those write the whole L2 back (buffer_wbl2) -- measured with 256 workgroups on
+// the device, B = 128 with one helper each: 14.0 ms against 9.4 ms without helpers (tools/dev/exp/exp54.sh).  Owner and helpers sit on the SAME XCD (the
+// dispatcher deals workgroup ids round robin over the 8 XCDs and B is a multiple of 8; checked at run time through HW_REG_XCC_ID, a mismatch aborts),
+// i.e. behind the same L2: the producer only has to wait until its stores have left the CU (the vector L1 is write-through: s_waitcnt vmcnt(0)), the
+// consumer only has to drop its L1 (buffer_inv sc1: no write-back); the flag words are relaxed atomics, executed at the L2.
+__device__ inline void coop_release() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+__device__ inline void coop_acquire() { asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ inline unsigned int coop_xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u; }      // hwreg(HW_REG_XCC_ID)
+constexpr unsigned MYR_COOP_SPIN_MAX = 1u << 23;
+
 #ifdef MYR_PHASE_TIMING
 __device__ long long node_tph_[8];      // cycles of workgroup 0's network passes (MODE 0 / 1 / 2), wavefront 0
 #endif
@@ -138,6 +170,9 @@ struct HsFused {
     double *kgA, *kgB, *xA, *xB;          // W = 2: the two sets of sweep outputs (gains in global scratch, first-point exchange in LDS)
     double *pt, *sF, *wl;                 // network systems: point records (global), trial values and weights (LDS)
     double *hb, *mb;                      //   stored activations / tangents (global, per tile and lane)
+    int nh, hidx;                         //   helper workgroups of this trajectory, this workgroup's index among them (0: the owner)
+    NodeBoard* board; int* coop_abort;    //   the owner's board
+    double *pubx, *publam, *pubf;         //   what the owner publishes for a pass / the helpers' trial values (global)
     bool h_valid;                         //   hb holds the activations of the iterate (the last trial point was accepted)
     const double *lb, *ub;                // the caller's bounds (global)
     bool uni;                             // interior points share one bound per component: served from sB
@@ -185,6 +220,110 @@ struct HsFused {
     } else { (void)c; (void)v; (void)op; }
   }
 
+  // ---- helper workgroups (see NodeBoard) ------------------------------------------------------------------------------------------------------
+  __device__ static inline unsigned int& coop_seq(Ctx& c) { return reinterpret_cast<unsigned int*>(c.sMisc)[6]; }      // (sMisc[3]: free)
+  // owner: publish what pass MODE reads, then the command
+  template <int MODE>
+  __device__ static inline void coop_post(Ctx& c, double alpha) {
+    if constexpr (MLP) {
+      if (MODE == 0) { for (int i = c.tid; i < c.n; i += NT) c.pubx[i] = fma(alpha, c.dz[i], c.z[i]); }
+      if (MODE == 3 && !c.h_valid) { for (int i = c.tid; i < c.n; i += NT) c.pubx[i] = c.z[i]; }
+      if (MODE == 4) { for (int i = c.tid; i < MLAM * c.N * NS; i += NT) c.publam[i] = c.sLam[i]; }
+      coop_release();
+      __syncthreads();
+      if (c.tid == 0) {
+        const unsigned int seq = ++coop_seq(c);
+        __hip_atomic_store(&c.board->cmd, ((unsigned long long)seq << 32) | (c.h_valid ? 256ull : 0ull) | (unsigned long long)MODE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else { (void)c; (void)alpha; }
+  }
+  // owner: wait for the helpers' share of the pass (their records are in this slot's global scratch; trial values arrive through pubf)
+  template <int MODE>
+  __device__ static inline void coop_wait(Ctx& c) {
+    if constexpr (MLP) {
+      if (c.tid == 0) {
+        const unsigned int target = coop_seq(c) * (unsigned int)c.nh;
+        unsigned int spins = 0;
+        while (__hip_atomic_load(&c.board->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > MYR_COOP_SPIN_MAX || __hip_atomic_load(c.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            __hip_atomic_store(c.coop_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      coop_acquire();
+      if (MODE == 0) {
+        const int ts = W * (c.nh + 1);
+        for (int j = c.tid; j < c.K; j += NT)
+          if (((j >> 4) % ts) >= W) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) c.sF[j * NS + q] = c.pubf[j * NS + q];
+          }
+      }
+    } else (void)c;
+  }
+  // helper: serve the owner's passes until its solve is over
+  __device__ static void coop_serve(Ctx& c) {
+    if constexpr (MLP) {
+      unsigned int expect = 1;
+      unsigned long long* lcmd = reinterpret_cast<unsigned long long*>(c.sMisc) + 2;      // (sMisc[2]: the helpers run no sweeps)
+      for (;;) {
+        if (c.tid == 0) {
+          unsigned long long v; unsigned int spins = 0;
+          for (;;) {
+            v = __hip_atomic_load(&c.board->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned int)(v >> 32) >= expect) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > MYR_COOP_SPIN_MAX || __hip_atomic_load(c.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+              __hip_atomic_store(c.coop_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              v = ((unsigned long long)expect << 32) | MYR_COOP_EXIT;
+              break;
+            }
+          }
+          if (expect == 1) {      // (the owner wrote its XCD before its first command) another XCD means another L2: the cheap visibility rules do not hold
+            const unsigned int ox = __hip_atomic_load(&c.board->xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ox != 1u + coop_xcc_id()) { __hip_atomic_store(c.coop_abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = ((unsigned long long)expect << 32) | MYR_COOP_EXIT; }
+          }
+          *lcmd = v;
+        }
+        __syncthreads();
+        const unsigned long long v = *lcmd;
+        coop_acquire();
+        const int mode = __builtin_amdgcn_readfirstlane((int)(v & 255)), hv = __builtin_amdgcn_readfirstlane((int)((v >> 8) & 1));
+        if (mode == MYR_COOP_EXIT) break;
+        if (mode == 0 || (mode == 3 && !hv)) { for (int i = c.tid; i < c.n; i += NT) c.z[i] = c.pubx[i]; }
+        if (mode == 4) { for (int i = c.tid; i < MLAM * c.N * NS; i += NT) c.sLam[i] = c.publam[i]; }
+        __syncthreads();
+        NodeMfma64::ArgsT<nd_lds> a;
+        a.z = (const nd_lds*)c.z; a.dz = (const nd_lds*)c.z; a.lam = (const nd_lds*)c.sLam; a.pt = (nd_glb*)c.pt;
+        a.sF = (nd_lds*)c.sF;
+        a.alpha = 0.0; a.h6 = c.h6; a.h8 = c.h8; a.K = c.K; a.N = c.N;
+        a.pf_f = PT_F; a.pf_a = PT_A; a.pf_b = PT_B; a.pf_d2 = PT_D2;
+        a.t0 = W * c.hidx + c.wave; a.ts = W * (c.nh + 1);
+        a.hb = (nd_glb*)c.hb; a.mb = (nd_glb*)c.mb; a.h_valid = hv;
+        if (mode == 0) NodeMfma64::pass<0, nd_lds>((const nd_lds*)c.wl, a, c.lane);
+        else if (mode == 3) NodeMfma64::pass<3, nd_lds>((const nd_lds*)c.wl, a, c.lane);
+        else NodeMfma64::pass<4, nd_lds>((const nd_lds*)c.wl, a, c.lane);
+        if (mode == 0) {
+          __syncthreads();
+          for (int j = c.tid; j < c.K; j += NT) {
+            const int own = ((j >> 4) % a.ts) - W * c.hidx;
+            if (own >= 0 && own < W) {
+#pragma unroll
+              for (int q = 0; q < NS; ++q) c.pubf[j * NS + q] = c.sF[j * NS + q];
+            }
+          }
+        }
+        coop_release();
+        __syncthreads();
+        if (c.tid == 0) __hip_atomic_fetch_add(&c.board->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++expect;
+      }
+    } else (void)c;
+  }
+
   // network systems: one matrix-core pass over all points, tiles of 16 points dealt over the W wavefronts
   template <int MODE>
   __device__ static inline void node_pass(Ctx& c, double alpha) {
@@ -197,9 +336,11 @@ struct HsFused {
       a.sF = (nd_lds*)c.sF;
       a.alpha = alpha; a.h6 = c.h6; a.h8 = c.h8; a.K = c.K; a.N = c.N;
       a.pf_f = PT_F; a.pf_a = PT_A; a.pf_b = PT_B; a.pf_d2 = PT_D2;
-      a.t0 = c.wave; a.ts = W;
+      a.t0 = c.wave; a.ts = W * (c.nh + 1);
       a.hb = (nd_glb*)c.hb; a.mb = (nd_glb*)c.mb; a.h_valid = c.h_valid ? 1 : 0;
+      if (c.nh > 0) coop_post<MODE>(c, alpha);
       NodeMfma64::pass<MODE, nd_lds>((const nd_lds*)c.wl, a, c.lane);
+      if (c.nh > 0) coop_wait<MODE>(c);
 #ifdef MYR_PHASE_TIMING
       if (blockIdx.x == 0 && c.tid == 0) node_tph_[MODE] += clock64() - tn0_;
 #endif
@@ -1641,7 +1782,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1)
 void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                            const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                            const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
-                           int32_t* iters, double* kkt, unsigned long long poison, ParkArgs pk) {
+                           int32_t* iters, double* kkt, unsigned long long poison, ParkArgs pk, CoopArgs co) {
   using W = HsFused<Sys, NWAVES, SCHEME>;
   extern __shared__ __attribute__((aligned(16))) char smem_fused[];
   typename W::Ctx c;
@@ -1652,7 +1793,14 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform BY CONSTRUCTION: `if (c.wave == 0)` is a scalar branch
 #endif
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
-  double* s = scratch + (long)blockIdx.x * scratch_stride;
+  // helper workgroups of the network kernel (NodeBoard): owners are workgroups 0..B-1, helper h of owner w is workgroup h B + w
+  const bool coop = W::MLP && co.nh > 0;
+  const int owner = coop ? (int)(blockIdx.x % (unsigned)B) : (int)blockIdx.x;
+  c.nh = coop ? co.nh : 0; c.hidx = coop ? (int)(blockIdx.x / (unsigned)B) : 0;
+  c.board = coop ? co.boards + owner : nullptr; c.coop_abort = co.abort;
+  c.pubx = coop ? co.pub + (long)owner * co.pub_stride : nullptr;
+  c.publam = coop ? c.pubx + c.n : nullptr; c.pubf = coop ? c.publam + W::MLAM * c.N * W::NS : nullptr;
+  double* s = scratch + (long)owner * scratch_stride;
   c.zr = s; c.hr = s + W::off_hr(c.N); c.st = s + W::off_st(c.N); c.kg = s + W::off_kg(c.N);
   c.kgA = c.kg; c.kgB = s + W::off_kg2(c.N); c.pt = s + W::off_pt(c.N);
   c.hb = s + W::off_hb(c.N); c.mb = s + W::off_mb(c.N); c.h_valid = false;
@@ -1678,9 +1826,19 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
       __syncthreads();
     }
   }
+  if constexpr (W::MLP) {
+    if (coop) {
+      if (c.tid == 0) {
+        W::coop_seq(c) = 0;
+        if (c.hidx == 0) __hip_atomic_store(&c.board->xcc, 1u + coop_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (c.hidx > 0) { W::coop_serve(c); return; }
+    }
+  }
   for (;;) {
     int t = 0;
-    if (c.tid == 0) t = atomicAdd(ticket, 1);
+    if (c.tid == 0) t = coop ? (int)blockIdx.x + (int)(W::coop_seq(c) != 0 ? B : 0) : atomicAdd(ticket, 1);      // (an owner with helpers: its own trajectory, once)
     if constexpr (NWAVES > 1) {
       if (c.tid == 0) reinterpret_cast<int*>(c.sMisc)[0] = t;
       __syncthreads();
@@ -1704,6 +1862,7 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
       const unsigned long long salt = (unsigned long long)b * 1315423911ULL + blockIdx.x;
       for (int i = c.tid; i < nl; i += W::NT) l0[i] = poison_value(poison, (unsigned long long)i, salt);
       for (long i = c.tid; i < scratch_stride; i += W::NT) s[i] = poison_value(poison, (unsigned long long)i + (1ULL << 32), salt);
+      if (coop && c.tid == 0) W::coop_seq(c) = 0;      // (the pass counter of an owner with helper workgroups lives in the poisoned LDS)
       __syncthreads();
     }
 #ifdef MYR_TRACE
@@ -1745,6 +1904,16 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
       if (kkt) { kkt[3 * b] = r.feas; kkt[3 * b + 1] = r.stat; kkt[3 * b + 2] = r.compl_; }
     }
     W::wsync();      // the slot's scratch and LDS are handed to the next trajectory
+    if constexpr (W::MLP) {
+      if (coop) {        // release the helpers
+        if (c.tid == 0) {
+          const unsigned int seq = W::coop_seq(c) + 1;
+          W::coop_seq(c) = seq | 0x40000000u;        // (non-zero whatever happened: the ticket above ends the loop)
+          __hip_atomic_store(&c.board->cmd, ((unsigned long long)seq << 32) | (unsigned long long)MYR_COOP_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+      }
+    }
   }
 }
 

@@ -112,6 +112,9 @@ struct myr_handle_s {
   bool vscale_on = false;
   void* vbuf = nullptr;       // scaled copies of lb, ub
   size_t vbuf_bytes = 0;
+  // helper workgroups of the network kernel (hs_solver_fused.h: NodeBoard): boards | abort word | published vectors
+  void* coop_buf = nullptr; size_t coop_bytes = 0;
+  int node_helpers = -1;      // MYRIAD_NODE_HELPERS: helper workgroups per trajectory (-1 = by batch size)
 };
 
 static int device_cus(myr_handle h) {
@@ -137,6 +140,15 @@ static int kernel_blocks_per_cu(myr_handle h, const void* kern, int threads, siz
     it = h->occ.emplace(key, per_cu).first;
   }
   *out = it->second;
+  return MYR_OK;
+}
+
+static int ensure_buf(void** buf, size_t* have, size_t need) {
+  if (need <= *have) return MYR_OK;
+  if (*buf) HIPCHK(hipFree(*buf));
+  *buf = nullptr; *have = 0;
+  HIPCHK(hipMalloc(buf, need));
+  *have = need;
   return MYR_OK;
 }
 
@@ -527,6 +539,29 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
                                                                                //  residuals at the parking point and would come last: 41 -> 52 ms at B = 1024, exp42 / exp43)
     if (k1 >= o.max_iter || !status || !kkt) k1 = 0;
   }
+  // Helper workgroups for the network passes (hs_solver_fused.h: NodeBoard): a batch of at most half the CUs (config 5's share of an 8-GPU node is 128
+  // trajectories) gets nh = #CU / B - 1 <= 3 more workgroups per trajectory; whole solves with one shared weight set only.
+  myriad::CoopArgs co{nullptr, nullptr, 0, 0, nullptr};
+  unsigned grid = (unsigned)slots;
+  if constexpr (W::MLP) {
+    const int cus = device_cus(h);
+    int nh = (B <= cus / 2) ? cus / B - 1 : 0;
+    if (h->node_helpers >= 0) nh = h->node_helpers;
+    if (nh > 3) nh = 3;
+    if ((long)B * (nh + 1) > (long)cus) nh = cus / B - 1;     // every workgroup of the launch must be resident: the owners wait for their helpers
+    if (pstride != 0 || k1 > 0 || per_cu < 1 || h->solve_slots > 0 || (B % 8) != 0) nh = 0;      // (B % 8: owner and helpers on one XCD, hs_solver_fused.h: coop_release)
+    if (nh > 0) {
+      const long pub = ((long)h->dims.n + (long)W::MLAM * N * W::NS + (long)W::npoints(N) * W::NS + 15) / 16 * 16;
+      const size_t head = ((size_t)B * sizeof(myriad::NodeBoard) + 128 + 127) / 128 * 128;
+      if (int rc = ensure_buf(&h->coop_buf, &h->coop_bytes, head + (size_t)B * (size_t)pub * 8)) return rc;
+      HIPCHK(hipMemsetAsync(h->coop_buf, 0, head, h->stream));
+      co.boards = (myriad::NodeBoard*)h->coop_buf;
+      co.abort = (int*)((char*)h->coop_buf + (size_t)B * sizeof(myriad::NodeBoard));
+      co.pub = (double*)((char*)h->coop_buf + head);
+      co.pub_stride = pub; co.nh = nh;
+      grid = (unsigned)(B * (nh + 1));
+    }
+  }
   myriad::ParkArgs pk{0, 0, nullptr, nullptr, nullptr, 0};
   if (k1 > 0) {
     const long pstr = (W::park_doubles(N) + 31) / 32 * 32;
@@ -549,7 +584,7 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
     int* cnt = h->park_perm + h->park_n;
     pk = myriad::ParkArgs{1, k1, h->park_perm, cnt + PARK_BUCKETS, (double*)h->park_state, pstr};
     hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
-                       params, pstride, cost, status, iters, kkt, h->poison, pk);
+                       params, pstride, cost, status, iters, kkt, h->poison, pk, co);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(cnt, 0, (PARK_BUCKETS + 1) * sizeof(int), h->stream));
     HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int), h->stream));
@@ -559,11 +594,17 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
     hipLaunchKernelGGL(park_scatter_kernel, dim3(gb), dim3(256), 0, h->stream, B, status, kkt, cnt, h->park_perm);
     pk.mode = 2;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
-                     params, pstride, cost, status, iters, kkt, h->poison, pk);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
+                     params, pstride, cost, status, iters, kkt, h->poison, pk, co);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (co.nh > 0) {
+    int ab = 0;
+    HIPCHK(hipMemcpy(&ab, co.abort, sizeof(int), hipMemcpyDeviceToHost));
+    if (ab) return fail(MYR_E_HIP, ab == 2 ? "network kernel: a helper workgroup runs on another XCD than its owner (MYRIAD_NODE_HELPERS=0 runs without helper workgroups)"
+                                           : "network kernel: a wait between a trajectory's workgroups ran into its bound (MYRIAD_NODE_HELPERS=0 runs without helper workgroups)");
+  }
   if (k1 > 0) {
     if (const char* path = getenv("MYRIAD_PARK_DUMP")) {      // developer knob: the loop scalars of every record as parked ([B][NSCAL] doubles), for the study of resume orders
       std::vector<double> sc((size_t)B * W::NSCAL);
@@ -962,6 +1003,7 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
   if (md) { h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1; h->solve_fused = (strcmp(md, "wave1") == 0) ? 0 : 1; }
   const char* l = getenv("MYRIAD_SOLVE_LPW");
   if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
+  if (const char* e = getenv("MYRIAD_NODE_HELPERS")) h->node_helpers = atoi(e);   // developer knob: helper workgroups per trajectory of the network kernel (0 = none)
   if (const char* e = getenv("MYRIAD_PARK_ITER")) h->park_iter = atoi(e);         // developer knob: iterations of phase 1 of the two-phase launch (0 = off)
   if (const char* e = getenv("MYRIAD_FUSED_WAVES")) h->fused_waves = atoi(e);     // developer knob: wavefronts per trajectory of the fused kernel
   if (const char* e = getenv("MYRIAD_SOLVE_SLOTS")) h->solve_slots = atoi(e);   // developer knob: resident wavefronts of the solve kernel
@@ -988,6 +1030,7 @@ extern "C" int myr_destroy(myr_handle h) {
   if (h->fbuf) (void)hipFree(h->fbuf);
   if (h->nfail_host) (void)hipHostFree(h->nfail_host);
   if (h->nfail_dev) (void)hipFree(h->nfail_dev);
+  if (h->coop_buf) (void)hipFree(h->coop_buf);
   if (h->twin) { (void)myr_destroy(h->twin); h->twin = nullptr; }
   for (int i = 0; i < MYR_K_COUNT; ++i) {
     if (h->kt[i].a) (void)hipEventDestroy(h->kt[i].a);
@@ -1358,14 +1401,6 @@ static bool twin_defaults(int twin_id, double* buf) {
 
 static unsigned grid_for(long total) { long b = (total + 255) / 256; if (b > 16384) b = 16384; if (b < 1) b = 1; return (unsigned)b; }
 
-static int ensure_buf(void** buf, size_t* have, size_t need) {
-  if (need <= *have) return MYR_OK;
-  if (*buf) HIPCHK(hipFree(*buf));
-  *buf = nullptr; *have = 0;
-  HIPCHK(hipMalloc(buf, need));
-  *have = need;
-  return MYR_OK;
-}
 
 struct RestoreCfg { bool elastic, starts; std::vector<int> cycles; };
 static RestoreCfg restore_cfg(const myr_solve_opts& so) {

@@ -194,8 +194,8 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
       // inputs in B-operand layout: state component g of point i, and the control in lane group 0 of the second k-step
       double xg = a.z[(long)j * NS + g], ug = g == 0 ? a.z[(long)K * NS + j] : 0.0;
       if (MODE == 0) {
-        xg += a.alpha * a.dz[(long)j * NS + g];
-        if (g == 0) ug += a.alpha * a.dz[(long)K * NS + j];
+        xg = fma(a.alpha, a.dz[(long)j * NS + g], xg);       // (explicitly fused: a helper workgroup gets fma(alpha, dz, z) from the owner and passes alpha = 0 -- same bits)
+        if (g == 0) ug = fma(a.alpha, a.dz[(long)K * NS + j], ug);
       }
       // (s'(A) = h (1 - h) and s''(A) = s'(A) (1 - 2 h) are formed where they are used: keeping them as arrays next to h1, h2
       // cost MODE 2 64 more live registers than it had)

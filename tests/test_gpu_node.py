@@ -140,3 +140,29 @@ def test_node_cooperative_mode_with_per_trajectory_weights(monkeypatch):
   assert (f1["status"] == 0).all() and (f1["iters"] == f0["iters"]).all()
   np.testing.assert_allclose(f1["cost"], f0["cost"], rtol=1e-12)
   np.testing.assert_allclose(f1["cost"], a["cost"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("N,B", [(20, 8), (100, 64), (100, 128)])
+def test_node_helper_workgroups_return_the_bits_of_the_launch_without(monkeypatch, N, B):
+  """Round 5 (hs_solver_fused.h: NodeBoard): a batch of at most half the CUs gets helper workgroups that take a share of the tiles of every
+  network pass -- other CUs of the owner's XCD, synchronised through global memory.  A tile is the same instruction sequence on the same inputs
+  whoever runs it: status, iterations and every bit of z*, lambda*, cost are those of the launch without helpers, also under poison."""
+  x0 = np.clip(0.1 * np.random.default_rng(100 * N + B).standard_normal((B, 4)), -2, 2)
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  out = {}
+  for nh, poison in (("0", None), ("1", None), ("3", None), (None, "random")):
+    for k in ("MYRIAD_NODE_HELPERS", "MYRIAD_POISON"):
+      monkeypatch.delenv(k, raising=False)
+    if nh is not None:
+      monkeypatch.setenv("MYRIAD_NODE_HELPERS", nh)
+    if poison:
+      monkeypatch.setenv("MYRIAD_POISON", poison)
+    hp, node, opt = _setup(N)
+    r = opt.solve_batch(x0s=x0, params=opt.system.device_params())
+    out[(nh, poison)] = {k: np.array(r[k]) for k in ("status", "iters", "cost", "xs_and_us", "lambda")}
+    opt.engine.close()
+  ref = out[("0", None)]
+  assert (ref["status"] == 0).all()
+  for key, r in out.items():
+    for k in ref:
+      assert np.array_equal(r[k], ref[k]), (key, k)
