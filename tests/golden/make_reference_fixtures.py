@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: fixtures computed by THE REFERENCE'S OWN LINES (round 5).
+
+Runs in the build container only (reads /root/reference in place, copies none of it, writes no bytecode): installs the name-forwarding stand-in
+for the small JAX surface of the hot-path files (tests/golden/refshim), imports the reference's `myriad.trajectory_optimizers.get_optimizer`
+and `myriad.utils`, and records, for every system x {Hermite-Simpson, trapezoidal, shooting x Euler / Heun / midpoint / RK4}:
+
+  guess, bounds                                the reference's initial point and box (hermite_simpson.py:37-81, trapezoidal.py:33-77, shooting.py:47-77,247-275)
+  z = guess + seeded noise (clipped away from nothing: objective / constraints are evaluated wherever z is)
+  objective(z), constraints(z)                 the callbacks nlp_solvers/__init__.py:32-40 hands to the NLP code
+  get_state_trajectory_and_cost(...)           utils.py:258-298 on the controls of z (RK4, and the transcription's own rule)
+  integrate(...) on tests/tests.py:19-43's setting is already carried in tests/test_oracle.py
+
+-> tests/golden/reference_callbacks.npz.  tests/test_reference_fixtures.py (CPU suite) holds the ORACLE to these numbers at 1e-13.
+The fixtures are data (inputs and outputs); nothing of the reference's text is stored.
+
+What this is not: "the reference run here" in the sense of the parity rules (jax itself is absent; a stand-in for a library the image lacks does
+not count), so DESIGN.md keeps "parity unpinned at the JAX / IPOPT boundary".  It replaces "read by eye" with "computed by the reference's lines".
+  usage: PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_reference_fixtures.py"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+
+refshim.install()
+sys.path.insert(0, "/root/reference")
+import numpy as np  # noqa: E402
+
+from myriad.config import Config, HParams, IntegrationMethod, OptimizerType, QuadratureRule  # noqa: E402
+from myriad.systems import SystemType  # noqa: E402
+from myriad.trajectory_optimizers import get_optimizer  # noqa: E402
+from myriad.utils import get_state_trajectory_and_cost  # noqa: E402
+
+CFG = Config(verbose=False, plot=False, jit=False)
+SKIP = {"INVASIVEPLANT"}      # discrete time: the reference's direct optimisers refuse it (base.py:66-67)
+CASES = [("HERMITE_SIMPSON", None, 6, 1), ("TRAPEZOIDAL", None, 7, 1),
+         ("SHOOTING", "EULER", 3, 4), ("SHOOTING", "HEUN", 3, 4), ("SHOOTING", "MIDPOINT", 2, 5), ("SHOOTING", "RK4", 2, 3),
+         ("SHOOTING", "HEUN", 1, 6)]
+
+
+def main():
+  out = {}
+  log = []
+  rng = np.random.default_rng(5)
+  for st in SystemType:
+    if st.name in SKIP:
+      continue
+    for tr, method, N, cpi in CASES:
+      key = f"{st.name}/{tr}/{method or '-'}/{N}x{cpi}"
+      try:
+        kw = dict(system=st, intervals=N, controls_per_interval=cpi)
+        if tr == "SHOOTING":
+          kw.update(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod[method])
+        else:
+          kw.update(optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule[tr])
+        hp = HParams(**kw)
+        system = st.value() if callable(st.value) else hp.system()
+        opt = get_optimizer(hp, CFG, hp.system())
+      except Exception as e:          # the reference itself refuses some combinations (PREDATORPREY under collocation: x_T with None)
+        log.append(f"{key}: {type(e).__name__} at construction: {str(e)[:80]}")
+        out[key + "/error"] = np.array(type(e).__name__)
+        continue
+      guess = np.asarray(opt.guess, dtype=np.float64)
+      bounds = np.asarray(opt.bounds, dtype=np.float64)
+      z = guess + 0.01 * (1.0 + np.abs(guess)) * rng.standard_normal(guess.shape)
+      try:
+        f = float(np.asarray(opt.objective(z)))
+        c = np.asarray(opt.constraints(z), dtype=np.float64).ravel()
+      except Exception as e:
+        log.append(f"{key}: {type(e).__name__} in the callbacks: {str(e)[:80]}")
+        out[key + "/error"] = np.array(type(e).__name__)
+        continue
+      out[key + "/guess"] = guess; out[key + "/bounds"] = bounds; out[key + "/z"] = z
+      out[key + "/objective"] = np.array(f); out[key + "/constraints"] = c
+      xs, us = opt.unravel(z)
+      out[key + "/x_rows"] = np.array(np.asarray(xs).shape[0]); out[key + "/u_rows"] = np.array(np.asarray(us).shape[0])
+      # post-solve rollout of the controls of z (utils.py:258-298): the rule the metric config uses (RK4) where the control rows allow it
+      sysobj = hp.system()
+      try:
+        hp_r = HParams(**{**kw, "integration_method": IntegrationMethod.RK4})
+        us_arr = np.asarray(us, dtype=np.float64)
+        if us_arr.shape[0] >= 2 * hp_r.num_steps + 1:
+          xs_r, cost_r = get_state_trajectory_and_cost(hp_r, sysobj, sysobj.x_0, us_arr)
+          out[key + "/rollout_rk4_xs"] = np.asarray(xs_r, dtype=np.float64); out[key + "/rollout_rk4_cost"] = np.array(float(np.asarray(cost_r)))
+      except Exception as e:
+        log.append(f"{key}: {type(e).__name__} in the RK4 rollout: {str(e)[:80]}")
+      log.append(f"{key}: n={guess.size} m={c.size} f={f:.12g} |c|max={np.abs(c).max():.6g}")
+  path = os.path.join(HERE, "reference_callbacks.npz")
+  np.savez_compressed(path, **out)
+  open(os.path.join(HERE, "reference_callbacks.log"), "w").write("\n".join(log) + "\n")
+  print("\n".join(log[-12:]))
+  print(f"{len([k for k in out if k.endswith('/objective')])} cases -> {path} ({os.path.getsize(path)} bytes)")
+
+
+if __name__ == "__main__":
+  main()
