@@ -65,27 +65,33 @@ struct ParkArgs {
 };
 constexpr int MYR_STATUS_PARKED_ = 5;     // internal: never leaves myr_solve
 
-// Helper workgroups for the network passes (round 5; config 5's share of an 8-GPU node is 128 trajectories: one per CU leaves half of the device idle,
-// and two thirds of an iteration are matrix-core passes over 13 independent tiles of 16 points).  With B <= #CU / 2 the launch adds nh = #CU / B - 1 (at
-// most 3) workgroups per trajectory that do nothing but take their share of the tiles of every pass: the owner posts the pass (mode, sequence number)
-// and the few KB a helper needs (the evaluation point, or the multipliers) in global memory, all 4 (nh + 1) wavefronts deal the tiles round robin, the
-// helpers write their results into the OWNER's records and raise a counter, the owner waits for it.  Same instructions on the same inputs whoever runs
-// a tile: the results are those of the launch without helpers, bit for bit (tests/test_gpu_node.py).  Workgroup ids: owners 0..B-1 (trajectory =
-// workgroup, no ticket), helper h of owner s is workgroup h B + s -- the same XCD when B is a multiple of 8.  All workgroups of the launch are resident
-// (one per CU, grid <= #CU), so the waits cannot deadlock; every wait is bounded all the same and raises `abort` instead of hanging the device.
+// Helper workgroups for the network passes (round 5).  Two thirds of an iteration of the network kernel are matrix-core passes over 13 independent tiles of
+// 16 points, and a workgroup owns a CU: a batch smaller than the device (config 5's share of an 8-GPU node is 128 trajectories) leaves CUs idle for the
+// whole launch, and every larger batch leaves them idle at its end, while the last -- longest -- solves run alone (one solve in a thousand takes 75
+// iterations against a median of 24).  A workgroup without a trajectory therefore ATTACHES itself to a running one (an "owner") on its own XCD, at most
+// `maxh` per owner, fewest-helpers-first.  The owner looks at its helper count once per iteration; for every pass it posts a command (sequence number,
+// mode, helper count) and the few KB a helper needs (the evaluation point, or the multipliers) in global memory, all 4 (nh + 1) wavefronts deal the
+// tiles round robin, the helpers write their results into the OWNER's records and raise a counter, the owner waits for it.  A tile is the same
+// instructions on the same inputs whoever runs it, and a change of the helper count only makes the next linearisation recompute the stored
+// activations (bit-identical to the stored ones): results do not depend on who helped when (tests/test_gpu_node.py).  Small batches (B <= grid) give
+// trajectory b to workgroup b, so that owners and helpers spread evenly over the XCDs; larger ones draw tickets as before and help once the tickets
+// are gone.  All workgroups of the launch are resident (one per CU, grid <= #CU), so the waits cannot deadlock; every wait is bounded all the same and
+// raises `abort` instead of hanging the device.
 struct NodeBoard {
-  unsigned long long cmd;       // (sequence number << 32) | (activations valid << 8) | mode; mode 15: the owner's solve is over
-  unsigned int done;            // passes finished by helpers, cumulative over the solve: the owner waits for seq * nh
+  unsigned long long cmd;       // (sequence number << 32) | (helpers taking part << 12) | (activations valid << 8) | mode; mode 15: the solve is over
+  unsigned int done;            // passes finished by helpers, cumulative: the owner waits for the sum of the helper counts it posted
   unsigned int xcc;             // 1 + the owner's XCD
-  unsigned int pad_[28];        // 128 B apart
+  unsigned int att;             // bit 31: a solve is running here; low bits: helpers attached to it
+  unsigned int pad_[27];        // 128 B apart
 };
 struct CoopArgs {
-  NodeBoard* boards;            // [owners]
-  double* pub;                  // [owners][pub_stride]: x (n = K NW) | multipliers (MLAM N NS) | f of the trial point (K NS)
+  NodeBoard* boards;            // [workgroups that can own a trajectory]
+  double* pub;                  // [same][pub_stride]: x (n = K NW) | multipliers (MLAM N NS) | f of the trial point (K NS)
   long pub_stride;
-  int nh;                       // helpers per owner (0: none; the kernel then is the round-4 one)
-  int* abort;                   // set when a wait ran into its bound
+  int maxh;                     // helpers per owner at most (0: none; the kernel then is the round-4 one)
+  int* abort;                   // set when a wait ran into its bound; abort[1]: trajectories finished
 };
+constexpr unsigned int MYR_COOP_RUNNING = 0x80000000u;
 constexpr int MYR_COOP_EXIT = 15;
 // Visibility between an owner and its helpers WITHOUT agent-scope fences: those write the whole L2 back (buffer_wbl2) -- measured with 256 workgroups on
 // the device, B = 128 with one helper each: 14.0 ms against 9.4 ms without helpers (tools/dev/exp/exp54.sh).  Owner and helpers sit on the SAME XCD (the
@@ -94,6 +100,17 @@ constexpr int MYR_COOP_EXIT = 15;
 // consumer only has to drop its L1 (buffer_inv sc1: no write-back); the flag words are relaxed atomics, executed at the L2.
 __device__ inline void coop_release() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 __device__ inline void coop_acquire() { asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); }
+#ifdef MYR_COOP_DEBUG
+#define COOP_DBG(bit, ...) do { if ((MYR_COOP_DEBUG) & (bit)) printf(__VA_ARGS__); } while (0)
+#else
+#define COOP_DBG(bit, ...)
+#endif
+#ifdef MYR_COOP_TRACE      // developer aid: state words in pinned host memory, dumped by a host thread when a launch takes too long (myriad_hip.hip)
+__device__ int* g_coop_trace;
+#define COOP_TR(slot, val) do { if (g_coop_trace) __hip_atomic_store(g_coop_trace + blockIdx.x * 16 + (slot), (int)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#else
+#define COOP_TR(slot, val)
+#endif
 __device__ inline unsigned int coop_xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u; }      // hwreg(HW_REG_XCC_ID)
 constexpr unsigned MYR_COOP_SPIN_MAX = 1u << 23;
 
@@ -155,7 +172,7 @@ struct HsFused {
   static constexpr int EXCH = NW * NW + NW * NC + NS * NC + NU * NC;
   // exchange between blocks / wavefronts (double-buffered by round): neighbour record, block total of a scan, trial knot; partial sums
   static constexpr int NTOT = NW * NW + NW, NRED = 12;
-  static constexpr int XCH = 2 * W * NREC + 2 * W * NTOT + 2 * W * 2 * NS + W * NRED + 4;
+  static constexpr int XCH = 2 * W * NREC + 2 * W * NTOT + 2 * W * 2 * NS + W * NRED + 8;
   __host__ __device__ static int lds_solver_doubles(int N) { return 4 * npoints(N) * NW + MLAM * N * NS + 6 * NW + XCH + (W > 1 ? 2 : 1) * EXCH + 8; }
   __host__ __device__ static int lds_doubles(int N) { return lds_solver_doubles(N) + (MLP ? npoints(N) * NS + NodeTraits<Sys>::lds_doubles : 0); }
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
@@ -221,7 +238,26 @@ struct HsFused {
   }
 
   // ---- helper workgroups (see NodeBoard) ------------------------------------------------------------------------------------------------------
-  __device__ static inline unsigned int& coop_seq(Ctx& c) { return reinterpret_cast<unsigned int*>(c.sMisc)[6]; }      // (sMisc[3]: free)
+  __device__ static inline unsigned int& coop_seq(Ctx& c) { return reinterpret_cast<unsigned int*>(c.sMisc)[6]; }         // owner: commands posted (sMisc[3])
+  __device__ static inline unsigned int& coop_target(Ctx& c) { return reinterpret_cast<unsigned int*>(c.sMisc)[7]; }      // owner: helper passes to wait for, cumulative
+  __device__ static inline bool coop_bounded(Ctx& c, unsigned int& spins) {      // a wait has run into its bound (or somebody else's has)
+    if (++spins > MYR_COOP_SPIN_MAX || __hip_atomic_load(c.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      if (spins > MYR_COOP_SPIN_MAX) __hip_atomic_store(c.coop_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return true;
+    }
+    return false;
+  }
+  // owner, once per iteration: how many helpers are attached now?  (A change moves the tiles between wavefronts: the stored activations are recomputed.)
+  __device__ static inline void coop_refresh(Ctx& c) {
+    if constexpr (MLP) {
+      unsigned int* w = reinterpret_cast<unsigned int*>(c.sMisc) + 8;
+      if (c.tid == 0) *w = __hip_atomic_load(&c.board->att, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
+      __syncthreads();
+      const int a = __builtin_amdgcn_readfirstlane((int)*w);
+      if (c.tid == 0) { COOP_TR(0, 100 + a); } if (c.tid == 64) { COOP_TR(11, 100 + a); } if (c.tid == 128) { COOP_TR(12, 100 + a); } if (c.tid == 192) { COOP_TR(13, 100 + a); }
+      if (a != c.nh) { if (c.tid == 0) COOP_DBG(1, "[wg %d] owner: helpers %d -> %d\n", (int)blockIdx.x, c.nh, a); c.nh = a; c.h_valid = false; }
+    } else (void)c;
+  }
   // owner: publish what pass MODE reads, then the command
   template <int MODE>
   __device__ static inline void coop_post(Ctx& c, double alpha) {
@@ -229,11 +265,16 @@ struct HsFused {
       if (MODE == 0) { for (int i = c.tid; i < c.n; i += NT) c.pubx[i] = fma(alpha, c.dz[i], c.z[i]); }
       if (MODE == 3 && !c.h_valid) { for (int i = c.tid; i < c.n; i += NT) c.pubx[i] = c.z[i]; }
       if (MODE == 4) { for (int i = c.tid; i < MLAM * c.N * NS; i += NT) c.publam[i] = c.sLam[i]; }
+      if (c.tid == 0) COOP_TR(9, 1);
       coop_release();
       __syncthreads();
       if (c.tid == 0) {
         const unsigned int seq = ++coop_seq(c);
-        __hip_atomic_store(&c.board->cmd, ((unsigned long long)seq << 32) | (c.h_valid ? 256ull : 0ull) | (unsigned long long)MODE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        COOP_TR(1, seq); COOP_TR(9, 2); COOP_TR(3, MODE);
+        coop_target(c) += (unsigned int)c.nh;
+        if (seq < 6) COOP_DBG(2, "[wg %d] owner: post seq %u mode %d nh %d target %u\n", (int)blockIdx.x, seq, MODE, c.nh, coop_target(c));
+        __hip_atomic_store(&c.board->cmd, ((unsigned long long)seq << 32) | ((unsigned long long)c.nh << 12) | (c.h_valid ? 256ull : 0ull) | (unsigned long long)MODE,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else { (void)c; (void)alpha; }
   }
@@ -242,17 +283,18 @@ struct HsFused {
   __device__ static inline void coop_wait(Ctx& c) {
     if constexpr (MLP) {
       if (c.tid == 0) {
-        const unsigned int target = coop_seq(c) * (unsigned int)c.nh;
+        const unsigned int target = coop_target(c);
         unsigned int spins = 0;
-        while (__hip_atomic_load(&c.board->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        COOP_TR(2, target); COOP_TR(9, 3);
+        while ((int)(__hip_atomic_load(&c.board->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
           __builtin_amdgcn_s_sleep(4);
-          if (++spins > MYR_COOP_SPIN_MAX || __hip_atomic_load(c.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            __hip_atomic_store(c.coop_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
+          if (coop_bounded(c, spins)) { COOP_DBG(4, "[wg %d] owner: wait for %u ran into its bound (done %u)\n", (int)blockIdx.x, target, c.board->done); break; }
         }
+        if (coop_seq(c) < 6) COOP_DBG(4, "[wg %d] owner: seq %u done\n", (int)blockIdx.x, coop_seq(c));
       }
+      if (c.tid == 0) { COOP_TR(9, 4); COOP_TR(14, __hip_atomic_load(&c.board->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); COOP_TR(15, __hip_atomic_load(c.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
       __syncthreads();
+      if (c.tid == 0) COOP_TR(9, 5);
       coop_acquire();
       if (MODE == 0) {
         const int ts = W * (c.nh + 1);
@@ -264,35 +306,41 @@ struct HsFused {
       }
     } else (void)c;
   }
-  // helper: serve the owner's passes until its solve is over
-  __device__ static void coop_serve(Ctx& c) {
+  // helper number c.hidx of the owner at c.board: serve its passes until its solve is over (commands after `seen`).
+  // EVERY lane polls the command word (a broadcast load) and the loop has no lane-0-only block next to its back edge: with `if (tid == 0) add` at the
+  // bottom and `if (tid == 0) poll` at the top the compiler threaded the two into one divergent region across the back edge, the structurizer turned
+  // lane 0's path into a loop EXIT, and lane 0 -- parked until the other lanes leave a loop they never leave -- never raised the counter: every owner
+  // waited into its bound (tools/dev/exp/exp56.sh; builds with a printf in the region came out right).
+  __device__ static void coop_serve(Ctx& c, unsigned int seen) {
     if constexpr (MLP) {
-      unsigned int expect = 1;
-      unsigned long long* lcmd = reinterpret_cast<unsigned long long*>(c.sMisc) + 2;      // (sMisc[2]: the helpers run no sweeps)
+      unsigned int expect = seen + 1;
+      bool finished_pass = false;
       for (;;) {
-        if (c.tid == 0) {
-          unsigned long long v; unsigned int spins = 0;
-          for (;;) {
-            v = __hip_atomic_load(&c.board->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned int)(v >> 32) >= expect) break;
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > MYR_COOP_SPIN_MAX || __hip_atomic_load(c.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-              __hip_atomic_store(c.coop_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              v = ((unsigned long long)expect << 32) | MYR_COOP_EXIT;
-              break;
-            }
-          }
-          if (expect == 1) {      // (the owner wrote its XCD before its first command) another XCD means another L2: the cheap visibility rules do not hold
-            const unsigned int ox = __hip_atomic_load(&c.board->xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ox != 1u + coop_xcc_id()) { __hip_atomic_store(c.coop_abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = ((unsigned long long)expect << 32) | MYR_COOP_EXIT; }
-          }
-          *lcmd = v;
+        __syncthreads();                   // (the previous pass: every wavefront's results have left the CU)
+        if (finished_pass && c.tid == 0) { (void)__hip_atomic_fetch_add(&c.board->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); COOP_TR(8, 3); }
+        unsigned long long v; unsigned int spins = 0;
+        COOP_TR(4, expect);
+        for (;;) {
+          v = __hip_atomic_load(&c.board->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(v >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+          if ((int)((unsigned int)(v >> 32) - expect) >= 0) break;
+          __builtin_amdgcn_s_sleep(8);
+          if (coop_bounded(c, spins)) { v = ((unsigned long long)expect << 32) | MYR_COOP_EXIT; break; }
         }
+        // (the wavefronts may have read different commands -- the owner posts on while this workgroup is not counted in: wavefront 0's is the workgroup's)
+        unsigned long long* lcmd = reinterpret_cast<unsigned long long*>(c.sMisc) + 5;
+        if (c.tid == 0) *lcmd = v;
         __syncthreads();
-        const unsigned long long v = *lcmd;
-        coop_acquire();
-        const int mode = __builtin_amdgcn_readfirstlane((int)(v & 255)), hv = __builtin_amdgcn_readfirstlane((int)((v >> 8) & 1));
+        v = *lcmd;
+        v = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(v >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+        const int mode = (int)(v & 255), hv = (int)((v >> 8) & 1), nh = (int)((v >> 12) & 15);
+        const unsigned int seq = (unsigned int)(v >> 32);
+        COOP_TR(7, seq);
+        finished_pass = false;
         if (mode == MYR_COOP_EXIT) break;
+        expect = seq + 1;
+        if (nh < c.hidx) continue;           // the owner has not counted this workgroup in yet (it looks once per iteration)
+        coop_acquire();
         if (mode == 0 || (mode == 3 && !hv)) { for (int i = c.tid; i < c.n; i += NT) c.z[i] = c.pubx[i]; }
         if (mode == 4) { for (int i = c.tid; i < MLAM * c.N * NS; i += NT) c.sLam[i] = c.publam[i]; }
         __syncthreads();
@@ -301,7 +349,7 @@ struct HsFused {
         a.sF = (nd_lds*)c.sF;
         a.alpha = 0.0; a.h6 = c.h6; a.h8 = c.h8; a.K = c.K; a.N = c.N;
         a.pf_f = PT_F; a.pf_a = PT_A; a.pf_b = PT_B; a.pf_d2 = PT_D2;
-        a.t0 = W * c.hidx + c.wave; a.ts = W * (c.nh + 1);
+        a.t0 = W * c.hidx + c.wave; a.ts = W * (nh + 1);
         a.hb = (nd_glb*)c.hb; a.mb = (nd_glb*)c.mb; a.h_valid = hv;
         if (mode == 0) NodeMfma64::pass<0, nd_lds>((const nd_lds*)c.wl, a, c.lane);
         else if (mode == 3) NodeMfma64::pass<3, nd_lds>((const nd_lds*)c.wl, a, c.lane);
@@ -317,11 +365,70 @@ struct HsFused {
           }
         }
         coop_release();
-        __syncthreads();
-        if (c.tid == 0) __hip_atomic_fetch_add(&c.board->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ++expect;
+        finished_pass = true;
       }
-    } else (void)c;
+    } else { (void)c; (void)seen; }
+  }
+  // a workgroup without a trajectory: attach to the running solve of this XCD with the fewest helpers, serve it to its end, look again -- until every
+  // trajectory of the batch is finished
+  // (A function of its own with everything it needs BY VALUE: the kernel's context must not escape to memory, and two nested endless loops inlined behind
+  // the solver came out of the compiler's structurizer with the helpers' counter update in a guard block they never reached -- tools/dev/exp/exp56.sh.)
+  struct HelpArgs {
+    int N, K, n, lane, wave, tid; double h6, h8;
+    double *z, *sLam, *sF, *wl, *sMisc;
+    CoopArgs co; double* scratch; long scratch_stride; int B, nboards;
+  };
+  __device__ __attribute__((noinline)) static void coop_help(HelpArgs ha) {
+    if constexpr (MLP) {
+      Ctx c;
+      c.N = ha.N; c.K = ha.K; c.n = ha.n; c.lane = ha.lane; c.wave = ha.wave; c.tid = ha.tid; c.h6 = ha.h6; c.h8 = ha.h8;
+      c.z = ha.z; c.sLam = ha.sLam; c.sF = ha.sF; c.wl = ha.wl; c.sMisc = ha.sMisc; c.coop_abort = ha.co.abort;
+      c.nh = 0; c.hidx = 0; c.board = nullptr; c.h_valid = false;
+      const CoopArgs co = ha.co; double* const scratch = ha.scratch; const long scratch_stride = ha.scratch_stride; const int B = ha.B, nboards = ha.nboards;
+      int* info = reinterpret_cast<int*>(c.sMisc) + 12;      // sMisc[6], sMisc[7]: owner, helper index, commands seen, quit
+      for (;;) {
+        if (c.tid == 0) {
+          const unsigned int myx = 1u + coop_xcc_id();
+          int found = -1, hid = 0, quit = 0; unsigned int seen = 0, spins = 0;
+          COOP_TR(8, 0);
+          for (;;) {
+            int best = -1; unsigned int bestk = 0xffffu;
+            for (int sl = (int)(blockIdx.x & 7u); sl < nboards; sl += 8) {        // (workgroup ids are dealt round robin over the 8 XCDs; the board says where its owner really is)
+              if (sl == (int)blockIdx.x) continue;
+              const unsigned int a = __hip_atomic_load(&co.boards[sl].att, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const unsigned int k = a & 0xffffu;
+              if ((a & MYR_COOP_RUNNING) && k < (unsigned int)co.maxh && k < bestk &&
+                  __hip_atomic_load(&co.boards[sl].xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == myx) { best = sl; bestk = k; }
+            }
+            if (best >= 0) {
+              // (the commands seen BEFORE attaching: every command that counts this workgroup in is posted after the attach)
+              seen = (unsigned int)(__hip_atomic_load(&co.boards[best].cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+              unsigned int expected = MYR_COOP_RUNNING | bestk;
+              if (__hip_atomic_compare_exchange_strong(&co.boards[best].att, &expected, MYR_COOP_RUNNING | (bestk + 1u), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                found = best; hid = (int)bestk + 1; COOP_DBG(16, "[wg %d] attached to %d as helper %d (seen %u)\n", (int)blockIdx.x, best, hid, seen); break;
+              }
+              continue;
+            }
+            if (__hip_atomic_load(co.abort + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= B) { quit = 1; COOP_DBG(32, "[wg %d] all finished: quit\n", (int)blockIdx.x); break; }
+            __builtin_amdgcn_s_sleep(64);
+            if (coop_bounded(c, spins)) { quit = 1; break; }
+          }
+          info[0] = found; info[1] = hid; info[2] = (int)seen; info[3] = quit;
+          COOP_TR(5, found); COOP_TR(6, hid); COOP_TR(10, quit ? 999 : 0);
+        }
+        __syncthreads();
+        const int found = __builtin_amdgcn_readfirstlane(info[0]), hid = __builtin_amdgcn_readfirstlane(info[1]);
+        const unsigned int seen = (unsigned int)__builtin_amdgcn_readfirstlane(info[2]);
+        const int quit = __builtin_amdgcn_readfirstlane(info[3]);
+        __syncthreads();
+        if (quit) break;
+        double* so = scratch + (long)found * scratch_stride;
+        c.pt = so + off_pt(c.N); c.hb = so + off_hb(c.N); c.mb = so + off_mb(c.N);
+        c.board = co.boards + found; c.hidx = hid;
+        c.pubx = co.pub + (long)found * co.pub_stride; c.publam = c.pubx + c.n; c.pubf = c.publam + MLAM * c.N * NS;
+        coop_serve(c, seen);
+      }
+    } else (void)ha;
   }
 
   // network systems: one matrix-core pass over all points, tiles of 16 points dealt over the W wavefronts
@@ -1607,6 +1714,7 @@ struct HsFused {
         res.status = MYR_STATUS_PARKED_; res.iters = it;
         return;
       }
+      if constexpr (MLP) { if (c.board) coop_refresh(c); }      // helper workgroups attached since the last iteration?
       BOut p1;
       { NuT nu_; for (int q = 0; q < NS; ++q) nu_.v[q] = nuT[q]; p1 = backward_pass(c, pending, nu_); }
       pending.on = false;
@@ -1794,13 +1902,15 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
 #endif
   c.h = o.h; c.h6 = o.h / 6.0; c.h8 = o.h / 8.0;
   // helper workgroups of the network kernel (NodeBoard): owners are workgroups 0..B-1, helper h of owner w is workgroup h B + w
-  const bool coop = W::MLP && co.nh > 0;
-  const int owner = coop ? (int)(blockIdx.x % (unsigned)B) : (int)blockIdx.x;
-  c.nh = coop ? co.nh : 0; c.hidx = coop ? (int)(blockIdx.x / (unsigned)B) : 0;
-  c.board = coop ? co.boards + owner : nullptr; c.coop_abort = co.abort;
-  c.pubx = coop ? co.pub + (long)owner * co.pub_stride : nullptr;
-  c.publam = coop ? c.pubx + c.n : nullptr; c.pubf = coop ? c.publam + W::MLAM * c.N * W::NS : nullptr;
-  double* s = scratch + (long)owner * scratch_stride;
+  const bool coop = W::MLP && co.maxh > 0;
+  const bool fixed = coop && B <= (int)gridDim.x;        // a batch that leaves workgroups without a trajectory: trajectory b belongs to workgroup b
+  const int nboards = fixed ? B : (int)gridDim.x;        // workgroups that can own a trajectory (boards, published vectors and scratch slots exist for these)
+  const bool can_own = !fixed || (int)blockIdx.x < B;
+  c.nh = 0; c.hidx = 0;
+  c.board = (coop && can_own) ? co.boards + blockIdx.x : nullptr; c.coop_abort = co.abort;
+  c.pubx = (coop && can_own) ? co.pub + (long)blockIdx.x * co.pub_stride : nullptr;
+  c.publam = c.pubx ? c.pubx + c.n : nullptr; c.pubf = c.pubx ? c.publam + W::MLAM * c.N * W::NS : nullptr;
+  double* s = scratch + (long)(can_own ? blockIdx.x : 0u) * scratch_stride;
   c.zr = s; c.hr = s + W::off_hr(c.N); c.st = s + W::off_st(c.N); c.kg = s + W::off_kg(c.N);
   c.kgA = c.kg; c.kgB = s + W::off_kg2(c.N); c.pt = s + W::off_pt(c.N);
   c.hb = s + W::off_hb(c.N); c.mb = s + W::off_mb(c.N); c.h_valid = false;
@@ -1813,7 +1923,7 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   c.sTot = l; l += 2 * NWAVES * W::NTOT;
   c.sTr = l; l += 2 * NWAVES * 2 * W::NS;
   c.sRed = l; l += NWAVES * W::NRED;
-  c.sMisc = l; l += 4;
+  c.sMisc = l; l += 8;
   c.xA = l; c.xB = l + W::EXCH;
   W::use_set(c, c.kgA, c.xA);
   c.sF = reinterpret_cast<double*>(smem_fused) + W::lds_solver_doubles(c.N);
@@ -1829,16 +1939,17 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   if constexpr (W::MLP) {
     if (coop) {
       if (c.tid == 0) {
-        W::coop_seq(c) = 0;
-        if (c.hidx == 0) __hip_atomic_store(&c.board->xcc, 1u + coop_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        W::coop_seq(c) = 0; W::coop_target(c) = 0;
+        if (c.board) __hip_atomic_store(&c.board->xcc, 1u + coop_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
-      if (c.hidx > 0) { W::coop_serve(c); return; }
     }
   }
+  bool took = false;
   for (;;) {
     int t = 0;
-    if (c.tid == 0) t = coop ? (int)blockIdx.x + (int)(W::coop_seq(c) != 0 ? B : 0) : atomicAdd(ticket, 1);      // (an owner with helpers: its own trajectory, once)
+    if (c.tid == 0) t = fixed ? ((can_own && !took) ? (int)blockIdx.x : B) : atomicAdd(ticket, 1);
+    took = true;
     if constexpr (NWAVES > 1) {
       if (c.tid == 0) reinterpret_cast<int*>(c.sMisc)[0] = t;
       __syncthreads();
@@ -1857,12 +1968,15 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
       // LDS and the slot's global scratch -- is overwritten with one bit pattern (a signalling NaN, or plain garbage).  A solve
       // whose result depends on the pattern reads something before it writes it.
       __syncthreads();           // (every wavefront has read the ticket from sMisc)
+      const unsigned int keep_seq = W::coop_seq(c), keep_target = W::coop_target(c);      // (the owner's command counters live in the poisoned LDS)
+      __syncthreads();
       double* l0 = reinterpret_cast<double*>(smem_fused);
       const int nl = W::lds_solver_doubles(c.N) + (W::MLP ? c.K * W::NS : 0);
       const unsigned long long salt = (unsigned long long)b * 1315423911ULL + blockIdx.x;
       for (int i = c.tid; i < nl; i += W::NT) l0[i] = poison_value(poison, (unsigned long long)i, salt);
       for (long i = c.tid; i < scratch_stride; i += W::NT) s[i] = poison_value(poison, (unsigned long long)i + (1ULL << 32), salt);
-      if (coop && c.tid == 0) W::coop_seq(c) = 0;      // (the pass counter of an owner with helper workgroups lives in the poisoned LDS)
+      __syncthreads();
+      if (c.tid == 0) { W::coop_seq(c) = keep_seq; W::coop_target(c) = keep_target; }
       __syncthreads();
     }
 #ifdef MYR_TRACE
@@ -1881,6 +1995,10 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     for (int i = 0; i < 16; ++i) c.tph[i] = 0;
     c.t0 = clock64();
 #endif
+    if constexpr (W::MLP) {
+      c.nh = 0;
+      if (coop && c.tid == 0) __hip_atomic_store(&c.board->att, MYR_COOP_RUNNING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // helpers may attach from here on
+    }
     if constexpr (NWAVES == 1 || W::MLP) W::solve(c, o, zg, r, pk.mode, pk.k1, pk.state + b * pk.stride);      // (W = 2 serves batches of one round only)
     else W::solve(c, o, zg, r);
     if (r.status != MYR_STATUS_PARKED_) {
@@ -1905,14 +2023,25 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     }
     W::wsync();      // the slot's scratch and LDS are handed to the next trajectory
     if constexpr (W::MLP) {
-      if (coop) {        // release the helpers
+      if (coop) {        // no more attaching; release the helpers; one more trajectory finished
         if (c.tid == 0) {
-          const unsigned int seq = W::coop_seq(c) + 1;
-          W::coop_seq(c) = seq | 0x40000000u;        // (non-zero whatever happened: the ticket above ends the loop)
+          (void)__hip_atomic_exchange(&c.board->att, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned int seq = ++W::coop_seq(c);
           __hip_atomic_store(&c.board->cmd, ((unsigned long long)seq << 32) | (unsigned long long)MYR_COOP_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          (void)__hip_atomic_fetch_add(co.abort + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        c.nh = 0;
         __syncthreads();
       }
+    }
+  }
+  if constexpr (W::MLP) {
+    if (coop) {
+      typename W::HelpArgs ha;
+      ha.N = c.N; ha.K = c.K; ha.n = c.n; ha.lane = c.lane; ha.wave = c.wave; ha.tid = c.tid; ha.h6 = c.h6; ha.h8 = c.h8;
+      ha.z = c.z; ha.sLam = c.sLam; ha.sF = c.sF; ha.wl = c.wl; ha.sMisc = c.sMisc;
+      ha.co = co; ha.scratch = scratch; ha.scratch_stride = scratch_stride; ha.B = B; ha.nboards = nboards;
+      W::coop_help(ha);
     }
   }
 }

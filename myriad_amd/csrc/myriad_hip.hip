@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <map>
+#include <thread>
+#include <atomic>
+#include <chrono>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -545,21 +548,22 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   unsigned grid = (unsigned)slots;
   if constexpr (W::MLP) {
     const int cus = device_cus(h);
-    int nh = (B <= cus / 2) ? cus / B - 1 : 0;
-    if (h->node_helpers >= 0) nh = h->node_helpers;
-    if (nh > 3) nh = 3;
-    if ((long)B * (nh + 1) > (long)cus) nh = cus / B - 1;     // every workgroup of the launch must be resident: the owners wait for their helpers
-    if (pstride != 0 || k1 > 0 || per_cu < 1 || h->solve_slots > 0 || (B % 8) != 0) nh = 0;      // (B % 8: owner and helpers on one XCD, hs_solver_fused.h: coop_release)
-    if (nh > 0) {
+    int maxh = 3;
+    if (B <= cus / 2 && cus / B - 1 < maxh) maxh = cus / B - 1;      // a small batch: spread the idle CUs evenly
+    if (h->node_helpers >= 0 && h->node_helpers < maxh) maxh = h->node_helpers;
+    // whole solves with one shared weight set; every workgroup of the launch must be resident (one per CU): owners wait for their helpers
+    if (pstride != 0 || k1 > 0 || per_cu != 1 || h->solve_slots > 0) maxh = 0;
+    if (maxh > 0) {
+      grid = (unsigned)((long)B * (maxh + 1) < (long)cus ? B * (maxh + 1) : cus);
+      const int nboards = B <= (int)grid ? B : (int)grid;      // workgroups that can own a trajectory (hs_solve_fused_kernel: `fixed`)
       const long pub = ((long)h->dims.n + (long)W::MLAM * N * W::NS + (long)W::npoints(N) * W::NS + 15) / 16 * 16;
-      const size_t head = ((size_t)B * sizeof(myriad::NodeBoard) + 128 + 127) / 128 * 128;
-      if (int rc = ensure_buf(&h->coop_buf, &h->coop_bytes, head + (size_t)B * (size_t)pub * 8)) return rc;
+      const size_t head = ((size_t)nboards * sizeof(myriad::NodeBoard) + 128 + 127) / 128 * 128;
+      if (int rc = ensure_buf(&h->coop_buf, &h->coop_bytes, head + (size_t)nboards * (size_t)pub * 8)) return rc;
       HIPCHK(hipMemsetAsync(h->coop_buf, 0, head, h->stream));
       co.boards = (myriad::NodeBoard*)h->coop_buf;
-      co.abort = (int*)((char*)h->coop_buf + (size_t)B * sizeof(myriad::NodeBoard));
+      co.abort = (int*)((char*)h->coop_buf + (size_t)nboards * sizeof(myriad::NodeBoard));
       co.pub = (double*)((char*)h->coop_buf + head);
-      co.pub_stride = pub; co.nh = nh;
-      grid = (unsigned)(B * (nh + 1));
+      co.pub_stride = pub; co.maxh = maxh;
     }
   }
   myriad::ParkArgs pk{0, 0, nullptr, nullptr, nullptr, 0};
@@ -594,12 +598,30 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
     hipLaunchKernelGGL(park_scatter_kernel, dim3(gb), dim3(256), 0, h->stream, B, status, kkt, cnt, h->park_perm);
     pk.mode = 2;
   }
+#ifdef MYR_COOP_TRACE
+  static int* trace_host = nullptr;
+  if (!trace_host) { HIPCHK(hipHostMalloc((void**)&trace_host, 256 * 16 * sizeof(int), hipHostMallocMapped)); }
+  for (int i = 0; i < 256 * 16; ++i) trace_host[i] = 0;
+  if (co.maxh > 0) {
+    int* dev = nullptr; HIPCHK(hipHostGetDevicePointer((void**)&dev, trace_host, 0));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(myriad::g_coop_trace), &dev, sizeof(dev)));
+    static std::atomic<int> launch_no{0};
+    const int my = ++launch_no; const int ng = (int)grid;
+    std::thread([my, ng]() {
+      std::this_thread::sleep_for(std::chrono::seconds(8));
+      if (launch_no.load() != my) return;
+      fprintf(stderr, "[coop trace] launch %d still running after 8 s; per workgroup: t0 seq target mode expect to hid lastcmd hstate ostate quit w1 w2 w3\n", my);
+      for (int w = 0; w < ng; ++w) { fprintf(stderr, "  wg %3d:", w); for (int k = 0; k < 16; ++k) fprintf(stderr, " %d", trace_host[w * 16 + k]); fprintf(stderr, "\n"); }
+      fflush(stderr);
+    }).detach();
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
                      params, pstride, cost, status, iters, kkt, h->poison, pk, co);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (co.nh > 0) {
+  if (co.maxh > 0) {
     int ab = 0;
     HIPCHK(hipMemcpy(&ab, co.abort, sizeof(int), hipMemcpyDeviceToHost));
     if (ab) return fail(MYR_E_HIP, ab == 2 ? "network kernel: a helper workgroup runs on another XCD than its owner (MYRIAD_NODE_HELPERS=0 runs without helper workgroups)"

@@ -88,6 +88,23 @@ def main():
       except Exception as e:
         log.append(f"{key}: {type(e).__name__} in the RK4 rollout: {str(e)[:80]}")
       log.append(f"{key}: n={guess.size} m={c.size} f={f:.12g} |c|max={np.abs(c).max():.6g}")
+  # ---- the reference's solve() itself (nlp_solvers/__init__.py:18-98, SLSQP branch: the SciPy call with jax.grad / jax.jacrev callbacks, here
+  # complex-step derivatives of the reference's own objective / constraints) on problems small enough for Python loops
+  from myriad.config import NLPSolverType
+  SOLVES = [("CARTPOLE", dict(optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON, intervals=5)),
+            ("CARTPOLE", dict(optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.TRAPEZOIDAL, intervals=8)),
+            ("VANDERPOL", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=1, controls_per_interval=20)),
+            ("CANCERTREATMENT", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=1, controls_per_interval=20)),
+            ("SIMPLECASE", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=2, controls_per_interval=10))]
+  for name, kw in SOLVES:
+    hp = HParams(system=SystemType[name], nlpsolver=NLPSolverType.SLSQP, **kw)
+    opt = get_optimizer(hp, CFG, hp.system())
+    res = opt.solve()                                        # base.py:69-79 -> nlp_solvers.solve
+    key = "solve/%s/%s/%s/%dx%d" % (name, kw["optimizer"].name, (kw.get("quadrature_rule") or kw.get("integration_method")).name, hp.intervals, hp.controls_per_interval)
+    out[key + "/xs_and_us"] = np.real(np.asarray(res["xs_and_us"], dtype=np.float64)); out[key + "/cost"] = np.array(float(np.real(res["cost"])))
+    out[key + "/x"] = np.asarray(res["x"], dtype=np.float64); out[key + "/u"] = np.asarray(res["u"], dtype=np.float64)
+    c = np.asarray(opt.constraints(np.asarray(res["xs_and_us"])), dtype=np.float64)
+    log.append(f"{key}: cost={float(np.real(res['cost'])):.12g} |c|max={np.abs(c).max():.3g}")
   path = os.path.join(HERE, "reference_callbacks.npz")
   np.savez_compressed(path, **out)
   open(os.path.join(HERE, "reference_callbacks.log"), "w").write("\n".join(log) + "\n")

@@ -80,14 +80,29 @@ def _grad(f, argnums=0):
     for i in range(flat.size):
       xc = flat.astype(np.complex128)
       xc[i] += 1e-30j
-      a = list(args); a[argnums] = xc.reshape(x.shape)
+      a = list(args); a[argnums] = xc.reshape(x.shape).view(_Arr)
       out.reshape(-1)[i] = np.imag(np.asarray(f(*a)).reshape(-1)[0]) / 1e-30
     return out
   return df
 
 
+def _jacrev(f, argnums=0):
+  """Jacobian of a vector-valued analytic f by the complex-step derivative, one column per input entry (the reference calls jax.jacrev on
+  its constraints, nlp_solvers/__init__.py:37; rounding-exact for the smooth transcriptions, not usable through abs / clip / max)."""
+  def jac(*args):
+    x = np.asarray(args[argnums], dtype=np.float64).reshape(-1)
+    cols = []
+    for i in range(x.size):
+      xc = x.astype(np.complex128); xc[i] += 1e-30j
+      a = list(args); a[argnums] = xc.view(_Arr)
+      cols.append(np.imag(np.asarray(f(*a)).reshape(-1)) / 1e-30)
+    return np.stack(cols, axis=1)
+  return jac
+
+
 def _ravel_pytree(tree):
-  leaves = [np.asarray(x, dtype=np.float64) for x in tree]
+  leaves = [np.asarray(x) for x in tree]
+  leaves = [x if x.dtype.kind == "c" else x.astype(np.float64) for x in leaves]
   shapes = [x.shape for x in leaves]
   sizes = [x.size for x in leaves]
   flat = np.concatenate([x.reshape(-1) for x in leaves]) if leaves else np.zeros((0,))
@@ -177,8 +192,9 @@ def install():
   jax = types.ModuleType("jax"); jax.__refshim__ = True; jax.__path__ = []
   jax.numpy = jnp; jax.lax = lax; jax.flatten_util = flat; jax.random = rnd; jax.config = cfgm.config
   jax.jit = _jit; jax.vmap = _vmap; jax.grad = _grad
-  def _unsupported(*a, **k): raise NotImplementedError("refshim: reverse-mode Jacobians are not provided (the fixtures hold values, not derivatives)")
-  jax.jacrev = jax.jacfwd = jax.hessian = _unsupported
+  def _unsupported(*a, **k): raise NotImplementedError("refshim: second derivatives are not provided")
+  jax.jacrev = jax.jacfwd = _jacrev
+  jax.hessian = _unsupported
   sys.modules.update({"jax": jax, "jax.numpy": jnp, "jax.lax": lax, "jax.flatten_util": flat, "jax.random": rnd, "jax.config": cfgm})
 
   gin = types.ModuleType("gin")
