@@ -105,6 +105,6 @@ def test_oracle_solve_path_reproduces_the_reference_solve(key):
   # single-shooting run -- reference and oracle alike -- stops at cost 23.74 on the default tolerance, a restart from there walks on to 2.92:
   # the ill-conditioning of long-horizon single shooting that BASELINE config 3 is about.)
   again = O.solve(t, "SLSQP", max_iter=1000, guess=z_ref)
-  assert float(again["cost"]) <= float(FIX[key + "/cost"]) * (1 + 2e-6) + 1e-9, key
+  assert float(again["cost"]) <= float(FIX[key + "/cost"]) + 2e-6 * abs(float(FIX[key + "/cost"])) + 1e-9, key
   if "VANDERPOL" not in key:
     assert float(again["cost"]) == pytest.approx(float(FIX[key + "/cost"]), rel=2e-6, abs=1e-9), key
