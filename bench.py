@@ -269,6 +269,10 @@ class DeviceEngine:
   def timers(self):
     return self.eng.kernel_time(self._lib.K_EVAL), self.eng.kernel_time(self._lib.K_SOLVE)
 
+  def plan(self):
+    """myr_solve_plan: how the library launched the last solve (the one source of truth for the description of the line)"""
+    return self.eng.solve_plan()
+
 
 def run(a, rank, world, dev, make_engine):
   """The measured loop on one rank; returns the JSON dict on rank 0 (None elsewhere).  `dev` is a torch.device; the
@@ -466,14 +470,11 @@ def run(a, rank, world, dev, make_engine):
     tp = os.path.join(ROOT, "profiles", rnd, "hs_eval_traffic.json")
     if "eval" not in prof and os.path.exists(tp) and B == 4096 and N == 100:
       prof["eval"] = (json.load(open(tp)).get("traffic_bytes_per_launch"), os.path.relpath(tp, ROOT))
-  # the library's two-phase launch: at least two whole solves per resident wavefront (four per CU), unless switched off
-  two_phase = fused and cuda and os.environ.get("MYRIAD_PARK_ITER", "-1") != "0" and B >= 1.5 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count
-  lps = 2 if two_phase else 1
-  park_k1 = 0
-  if two_phase:        # the library's rule (myriad_hip.hip: launch_hs_fused_w), restated for the description of the line
-    per_slot = B / (4.0 * torch.cuda.get_device_properties(dev).multi_processor_count)
-    park_k1 = int(os.environ.get("MYRIAD_PARK_ITER", "-1"))
-    if park_k1 < 0: park_k1 = 12 if per_slot >= 3 else (10 if per_slot >= 2 else 8)
+  # how the library launched the solves of this line: asked of the library (myr_solve_plan), not restated here
+  plan = eng.plan() if hasattr(eng, "plan") else {"launches_per_solve": 1, "park_iter": 0, "waves_per_trajectory": 1}
+  two_phase = plan["park_iter"] > 0
+  lps = plan["launches_per_solve"]
+  park_k1 = plan["park_iter"]
   traffic, traffic_src = prof.get("eval", (None, None))
   sol_bytes, sol_src = prof.get("solver", (None, None))
   out = {
@@ -519,7 +520,7 @@ def run(a, rank, world, dev, make_engine):
                                   "hs_solve_kernel<CARTPOLE> (one trajectory per lane, whole SQP in one launch)")),
                       "avg_ms": sv_ms, "launches": sv_n, "bound": "dependent-instruction latency of one wavefront per SIMD (the Riccati sweep is 45 % of an iteration; see DESIGN.md section 4)",
                       "alg_io_bytes_per_launch": B * 8 * (3 * (2 * N + 1) * 5 + (2 * N + 1) * 5 + 2 * N * 4),
-                      "launches_per_solve": lps,
+                      "launches_per_solve": lps, "plan": plan,
                       "hbm_bytes_per_launch_from_profile": sol_bytes, "hbm_profile": sol_src,       # (per KERNEL launch: the profile averages over both phases)
                       "hbm_GBps": (lps * sol_bytes / (sv_ms * 1e-3) / 1e9) if (sol_bytes and sv_ms) else None,
                       "hbm_over_alg": (lps * sol_bytes / (B * 8 * (3 * (2 * N + 1) * 5 + (2 * N + 1) * 5 + 2 * N * 4))) if sol_bytes else None},
@@ -544,6 +545,34 @@ def run(a, rank, world, dev, make_engine):
   return out
 
 
+def both_scalings(a, rank, world, dev, make_engine):
+  """The line of `--scaling` (weak by default: --batch instances per GPU) and, for N > 1, the OTHER split of the same workload measured in the same run
+  right after it (`other_scaling`): SURVEY.md 8(e) partitions ONE batch over the GPUs (strong: 4096 -> 512 per GPU at N = 8, where a launch is one
+  solve long and the single-GPU rate at that size bounds the efficiency -- profiles/r05/projected_scaling.json holds the expectation), the contract's
+  default keeps the work per GPU fixed.  Whoever reads a SCALE file gets both numbers under one clock."""
+  import copy
+  out = run(a, rank, world, dev, make_engine)
+  if world > 1 and not getattr(a, "no_other_scaling", False):
+    b = copy.copy(a)
+    b.scaling = "strong" if a.scaling == "weak" else "weak"
+    if b.scaling == "weak":
+      b.batch = max(1, a.batch // world)            # the per-GPU share of the strong line, held fixed
+    b.cpu_budget = 0; b.no_other_configs = True; b.warmup = max(1, min(a.warmup, 2))
+    o2 = run(b, rank, world, dev, make_engine)
+    if rank == 0 and out is not None and o2 is not None:
+      out["other_scaling"] = {k: o2[k] for k in ("scaling", "value", "unit", "ms_per_step", "steps", "warmup", "converged_fraction") if k in o2}
+      out["other_scaling"]["global_batch"] = o2["config"]["global_batch"]; out["other_scaling"]["per_gpu_batch"] = o2["config"]["per_gpu_batch"]
+      out["other_scaling"]["solver_kernel_avg_ms"] = o2["solver_kernel"]["avg_ms"]
+  if rank == 0 and out is not None:
+    pj = os.path.join(ROOT, "profiles", "r05", "projected_scaling.json")
+    if os.path.exists(pj):
+      try:
+        out["projected_scaling"] = {"file": os.path.relpath(pj, ROOT), "config2": json.load(open(pj)).get("config2")}
+      except Exception:
+        pass
+  return out
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -556,6 +585,7 @@ def main():
                   help="initial barrier parameter of the solves in the timed region (0 = the library default 0.1, which is what the headline is "
                        "measured with; a non-zero value is named in the line and the same steps are timed at the default as well)")
   ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the N=100 cpu_baseline sample (0 = skip)")
+  ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: skip the second line (the other of weak / strong) measured after the first")
   ap.add_argument("--no-other-configs", action="store_true", help="skip the informative solves of BASELINE configs 3/4/5 after the timed region")
   ap.add_argument("--cpu-full", metavar="FILE", default=None,
                   help="measure the whole CPU baseline (one full N-interval SLSQP solve, ~9 min, + a trust-constr subsample) on this host, write FILE, exit")
@@ -598,7 +628,8 @@ def main():
   if world == 1:
     local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
-  out = run(a, rank, world, torch.device("cuda", local), lambda N, T, dev, B: DeviceEngine(N, T, dev.index, B))
+  mk = lambda N, T, dev, B: DeviceEngine(N, T, dev.index, B)
+  out = both_scalings(a, rank, world, torch.device("cuda", local), mk)
   if rank == 0:
     print(json.dumps(out), flush=True)
   if world > 1:

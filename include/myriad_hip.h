@@ -208,6 +208,16 @@ int myr_solve(myr_handle h, int32_t B, double* z, const double* lb, const double
 int myr_solve_info(myr_handle h, int32_t B, int32_t* start, int32_t* attempts, int32_t* restored);
 
 /*
+ * How the library ran the FIRST attempt of the last myr_solve / myr_solve_x0 call on this handle (a scheduling matter: no entry changes a result).
+ * One source of truth for what a measurement says about its own launch (bench.py used to restate the library's rules).  plan[8]:
+ *   [0] kernel form: 0 one trajectory per lane, 1 fused-phase wavefront kernel, 2 round-2 wavefront kernel, 3 shooting wavefront kernel
+ *   [1] wavefronts per trajectory            [2] iterations of phase 1 of the two-phase launch (0 = whole solves)
+ *   [3] solver-kernel launches per solve     [4] resident trajectory slots of the launch
+ *   [5] helper workgroups per trajectory at most (network kernel; 0 = none)     [6], [7] reserved (0)
+ */
+int myr_solve_plan(myr_handle h, int32_t* plan);
+
+/*
  * myr_solve for B instances that differ in their START STATE only (EXTENSION; the reference builds guess and bounds of an
  * instance from system.x_0 in the optimiser's constructor: collocation/hermite_simpson.py:37-48 (guess), :55-81 (bounds);
  * collocation/trapezoidal.py:36-50, 55-77; shooting.py:56-74, 247-275 -- this entry point applies that constructor to B start

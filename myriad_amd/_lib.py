@@ -30,7 +30,7 @@ STATUS_INFEASIBLE = 4   # assigned by the library's restoration phase inside myr
 
 EXPORTS = ["myr_create", "myr_destroy", "myr_get_dims", "myr_default_solve_opts", "myr_eval", "myr_solve", "myr_solve_x0",
            "myr_set_var_scale", "myr_rollout", "myr_vjp", "myr_jvp", "myr_exgd", "myr_fbsm", "myr_kernel_time", "myr_kernel_time_reset", "myr_last_error",
-           "myr_version", "myr_device_count", "myr_solve_info", "myr_abi_sizeof"]
+           "myr_version", "myr_device_count", "myr_solve_info", "myr_abi_sizeof", "myr_solve_plan"]
 
 
 class ProblemDesc(C.Structure):
@@ -94,6 +94,8 @@ def load() -> C.CDLL:
   lib.myr_solve_x0.restype = C.c_int
   lib.myr_solve_info.argtypes = [vp, C.c_int32, ip, ip, ip]
   lib.myr_solve_info.restype = C.c_int
+  lib.myr_solve_plan.argtypes = [vp, ip]
+  lib.myr_solve_plan.restype = C.c_int
   lib.myr_rollout.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, C.c_int32, dp, dp, C.c_int32]
   lib.myr_rollout.restype = C.c_int
   lib.myr_set_var_scale.argtypes = [vp, dp]
@@ -379,6 +381,13 @@ class Engine:
     _chk(self.lib.myr_fbsm(self._h, B, int(N), _addr(x0), _addr(aT), _addr(p), ps, _addr(lo), _addr(hi), float(bang), float(delta),
                            int(max_sweeps), _addr(xs), _addr(us), _addr(adjs), _addr(sw), MEM_HOST), "myr_fbsm")
     return {"x": xs, "u": us, "adj": adjs, "sweeps": sw}
+
+  def solve_plan(self) -> dict:
+    """myr_solve_plan: how the library launched the first attempt of the last solve on this handle (include/myriad_hip.h)"""
+    p = np.zeros(8, dtype=np.int32)
+    _chk(self.lib.myr_solve_plan(self._h, _addr(p)), "myr_solve_plan")
+    return {"form": ("lane", "fused", "wave", "shooting_wave")[int(p[0])], "waves_per_trajectory": int(p[1]), "park_iter": int(p[2]),
+            "launches_per_solve": int(p[3]), "slots": int(p[4]), "helpers_max": int(p[5])}
 
   def kernel_time(self, kernel_id: int):
     ms = C.c_double(); n = C.c_int32()

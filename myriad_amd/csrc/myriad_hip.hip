@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/myriad_hip.h"
+#include "dbg_regfill.h"
 #include "hs_eval.h"
 #include "colloc_products.h"
 #include "hs_solver.h"
@@ -67,6 +68,8 @@ static bool sys_info(int id, SysInfo* s) {
   return false;
 }
 
+struct myr_handle_s;
+static int device_cus_early(myr_handle_s* h);
 struct KTimer {
   hipEvent_t a = nullptr, b = nullptr;
   double sum_ms = 0.0;
@@ -118,7 +121,59 @@ struct myr_handle_s {
   // helper workgroups of the network kernel (hs_solver_fused.h: NodeBoard): boards | abort word | published vectors
   void* coop_buf = nullptr; size_t coop_bytes = 0;
   int node_helpers = -1;      // MYRIAD_NODE_HELPERS: helper workgroups per trajectory (-1 = by batch size)
+  int32_t plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // myr_solve_plan: how the last first-attempt solve was launched
+  int reg_fill = 0;                    // MYRIAD_REG_FILL (tests): pattern left in every VGPR / AGPR of every SIMD before every solver launch (1 nan, 2 finite, 3 big, 4 zero)
+  unsigned long long stack_fill = 0;   // MYRIAD_STACK_FILL (tests / experiments): bit pattern left in the queue's private-segment memory before every solver launch
 };
+
+// MYRIAD_STACK_FILL: what a kernel's spill slots and stack objects inherit.  The private segment ("scratch") of a queue is not cleared between
+// launches: a kernel that reads a stack slot before writing it gets what the previous kernel ON THIS QUEUE left there -- the same leftovers call after
+// call on one handle, something else on a fresh handle (new stream, new queue, new backing memory).  This kernel overwrites 4 KB of private memory per
+// lane of every resident wavefront slot with one pattern (MYRIAD_POISON does the same for the LDS and the solver's global scratch slots).
+template <int WORDS>
+static __global__ __launch_bounds__(64) void stack_fill_kernel(unsigned long long pat, int salt, unsigned long long* sink) {
+  volatile unsigned long long a[WORDS];
+  for (int i = 0; i < WORDS; ++i) a[i] = pat == 2 ? (0x3ff0000000000000ULL + ((unsigned long long)(i * 2654435761u + threadIdx.x * 40503u + salt) << 20)) : pat;
+  unsigned long long acc = 0;
+  for (int i = threadIdx.x & 7; i < WORDS; i += 61) acc ^= a[i];
+  if (acc == 0x1234567ULL) sink[0] = acc;
+}
+// ... and the form for locating ONE slot: exactly `BYTES` of private memory per lane (the solver kernel's own private-segment size, so that the wave
+// slots of the two kernels coincide), every dword the NaN pattern except dwords [z0, z1), which are zero
+template <int DWORDS>
+static __global__ __launch_bounds__(64) void stack_fill_window_kernel(int z0, int z1, unsigned* sink) {
+  volatile unsigned a[DWORDS];
+  for (int i = 0; i < DWORDS; ++i) a[i] = (i >= z0 && i < z1) ? 0u : ((i & 1) ? 0x7ff40000u : 0x00000001u);
+  unsigned acc = 0;
+  for (int i = threadIdx.x & 7; i < DWORDS; i += 61) acc ^= a[i];
+  if (acc == 0x1234567u) sink[0] = acc;
+}
+static int stack_fill(myr_handle h) {
+  if (const char* w = getenv("MYRIAD_STACK_FILL_WINDOW")) {      // "bytes:z0:z1"
+    int bytes = 0, z0 = 0, z1 = 0;
+    if (sscanf(w, "%d:%d:%d", &bytes, &z0, &z1) == 3) {
+      if (!h->ticket) HIPCHK(hipMalloc(&h->ticket, sizeof(int)));
+      for (int rep = 0; rep < 3; ++rep) {
+        if (bytes == 528) hipLaunchKernelGGL((stack_fill_window_kernel<132>), dim3((unsigned)(device_cus_early(h) * 16)), dim3(64), 0, h->stream, z0, z1, (unsigned*)h->ticket);
+        else hipLaunchKernelGGL((stack_fill_window_kernel<512>), dim3((unsigned)(device_cus_early(h) * 16)), dim3(64), 0, h->stream, z0, z1, (unsigned*)h->ticket);
+      }
+      HIPCHK(hipGetLastError());
+      return MYR_OK;
+    }
+  }
+  if (h->reg_fill) {      // MYRIAD_REG_FILL: what the registers inherit (dbg_regfill.h)
+    const unsigned rp = h->reg_fill == 1 ? 0x7ff40000u : (h->reg_fill == 3 ? 0x4415af1du : (h->reg_fill == 4 ? 0u : 0x3ff12345u));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(myriad::reg_fill_kernel, dim3((unsigned)(device_cus_early(h) * 16)), dim3(64), 0, h->stream, rp);
+    HIPCHK(hipGetLastError());
+  }
+  if (!h->stack_fill) return MYR_OK;
+  if (!h->ticket) HIPCHK(hipMalloc(&h->ticket, sizeof(int)));
+  const unsigned long long pat = h->stack_fill == 1 ? 0x7ff4000000000000ULL /* signalling NaN */ : (h->stack_fill == 3 ? 0x4415af1d78b58c40ULL /* 1e20 */ : (h->stack_fill == 4 ? 0ULL : 2ULL));
+  for (int rep = 0; rep < 3; ++rep)
+    hipLaunchKernelGGL((stack_fill_kernel<512>), dim3((unsigned)(device_cus_early(h) * 16)), dim3(64), 0, h->stream, pat, rep, (unsigned long long*)h->ticket);
+  HIPCHK(hipGetLastError());
+  return MYR_OK;
+}
 
 static int device_cus(myr_handle h) {
   if (h->cus <= 0) {
@@ -128,6 +183,8 @@ static int device_cus(myr_handle h) {
   }
   return h->cus;
 }
+
+static int device_cus_early(myr_handle_s* h) { return device_cus(h); }
 
 // Workgroups of `kern` a CU keeps resident at this block size and dynamic-LDS size; sets the kernel's dynamic-LDS limit on the
 // way.  Asked of the runtime once per handle and configuration, not on every solve call.
@@ -190,6 +247,7 @@ static int launch_hs_eval(myr_handle h, int B, const double* z, const double* pa
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
       h->eval_attr_lds[(W == 1 ? 0 : (W == 4 ? 1 : 2)) + (NTV ? 3 : 0)] = 1;                                     \
     }                                                                                                             \
+    if (int rc_fill = stack_fill(h)) return rc_fill;                                                              \
     HIPCHK(hipEventRecord(kt.a, h->stream));                                                                      \
     hipLaunchKernelGGL(kern, dim3(B), dim3(64 * W), lds, h->stream, N, hstep, z, params, pstride, f, g, c, j);    \
   }
@@ -222,6 +280,7 @@ static int launch_shoot_eval(myr_handle h, int B, const double* z, const double*
     h->sbuf_bytes = need;
   }
   KTimer& kt = h->kt[MYR_K_EVAL];
+  if (int rc_fill = stack_fill(h)) return rc_fill;
   HIPCHK(hipEventRecord(kt.a, h->stream));
   if (method == MYR_INT_RK4)
     hipLaunchKernelGGL((shoot_eval_kernel<Sys, 2>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, I, cpi, method, h->d.T,
@@ -272,6 +331,7 @@ static int launch_products(myr_handle h, const ProdArgs& a) {
   const double hstep = h->d.T / N;
   using P = CollocProducts<Sys, SCHEME>;
   KTimer& kt = h->kt[MYR_K_PROD];
+  if (int rc_fill = stack_fill(h)) return rc_fill;
   HIPCHK(hipEventRecord(kt.a, h->stream));
   if (a.op == PRODOP_EXGD) {
     const size_t lds = colloc_exgd_lds_bytes<Sys, SCHEME>(N);
@@ -318,6 +378,7 @@ static int launch_shoot_products_m(myr_handle h, const ProdArgs& a) {
   double* scr = (double*)h->sbuf;
   const dim3 grid((unsigned)((a.B + 63) / 64)), blk(64);
   KTimer& kt = h->kt[MYR_K_PROD];
+  if (int rc_fill = stack_fill(h)) return rc_fill;
   HIPCHK(hipEventRecord(kt.a, h->stream));
   if (a.op == PRODOP_VJP) {
     hipLaunchKernelGGL((shoot_eval_kernel<Sys, M>), grid, blk, 0, h->stream, a.B, I, cpi, method, h->d.T, a.z, a.params, a.pstride,
@@ -519,6 +580,7 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   if (!h->ticket) HIPCHK(hipMalloc(&h->ticket, sizeof(int)));
   HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int), h->stream));
   HsSolveOpts o = make_opts(h, so);
+  if (int rc = stack_fill(h)) return rc;
   KTimer& kt = h->kt[MYR_K_SOLVE];
   HIPCHK(hipEventRecord(kt.a, h->stream));
   h->last_solve_form = 1;
@@ -616,6 +678,7 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
     }).detach();
   }
 #endif
+  if (h->d.system_id < 100) { const int32_t pl[8] = {1, NWAVES, k1, k1 > 0 ? 2 : 1, slots, co.maxh, 0, 0}; memcpy(h->plan, pl, sizeof(pl)); }      // (twins: the restoration's solves are not "the" solve)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
                      params, pstride, cost, status, iters, kkt, h->poison, pk, co);
   HIPCHK(hipGetLastError());
@@ -730,8 +793,10 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int), h->stream));
     HsSolveOpts o = make_opts(h, so);
     KTimer& kt = h->kt[MYR_K_SOLVE];
+    if (int rc_fill = stack_fill(h)) return rc_fill;
     HIPCHK(hipEventRecord(kt.a, h->stream));
     h->last_solve_form = 1;
+    if (h->d.system_id < 100) { const int32_t pl[8] = {2, coop ? wpb : 1, 0, 1, slots, 0, 0, 0}; memcpy(h->plan, pl, sizeof(pl)); }
     hipLaunchKernelGGL(kern, dim3((unsigned)(slots / lwaves)), dim3(64 * wpb), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
                        params, pstride, cost, status, iters, kkt, coop, h->poison);
     HIPCHK(hipGetLastError());
@@ -784,9 +849,11 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, h->stream, ub, sub, B, (int)n, Bp);
   HsSolveOpts o = make_opts(h, so);
   KTimer& kt = h->kt[MYR_K_SOLVE];
+  if (int rc_fill = stack_fill(h)) return rc_fill;
   HIPCHK(hipEventRecord(kt.a, h->stream));
   const int lpw = h->solve_lpw;
   h->last_solve_form = 0;
+  if (h->d.system_id < 100) { const int32_t pl[8] = {0, 0, 0, 1, B, 0, 0, 0}; memcpy(h->plan, pl, sizeof(pl)); }
   hipLaunchKernelGGL((lane_solve_kernel<Core, Sys>), dim3((unsigned)((B + lpw - 1) / lpw)), dim3(64), 0, h->stream, B, Bp, lpw, o, h->vscale, sz, slb, sub, szL,
                      szU, slam, sdz, sst, params, pstride, cost, status, iters, kkt);
   HIPCHK(hipGetLastError());
@@ -825,8 +892,10 @@ static int launch_shoot_solve(myr_handle h, int B, double* z, const double* lb, 
   HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int), h->stream));
   HsSolveOpts o = make_opts(h, so);
   KTimer& kt = h->kt[MYR_K_SOLVE];
+  if (int rc_fill = stack_fill(h)) return rc_fill;
   HIPCHK(hipEventRecord(kt.a, h->stream));
   h->last_solve_form = 1;
+  if (h->d.system_id < 100) { const int32_t pl[8] = {3, 1, 0, 1, slots, 0, 0, 0}; memcpy(h->plan, pl, sizeof(pl)); }
   hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, params, pstride,
                      cost, status, iters, kkt, h->poison);
   HIPCHK(hipGetLastError());
@@ -896,6 +965,7 @@ int launch_fbsm(myr_handle h, int B, long Bp, int N, const double* x0, const dou
     return fail(MYR_E_UNSUPPORTED, "myr_fbsm: this system has no adjoint dynamics (not an IndirectFHCS on the path)");
   } else {
     KTimer& kt = h->kt[MYR_K_FBSM];
+    if (int rc_fill = stack_fill(h)) return rc_fill;
     HIPCHK(hipEventRecord(kt.a, h->stream));
     hipLaunchKernelGGL(fbsm_kernel<Sys>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, Bp, N, h->d.T, x0, adjT, params,
                        pstride, lo, hi, bang, delta, max_sweeps, X, U, A, sweeps);
@@ -1025,6 +1095,8 @@ extern "C" int myr_create(const myr_problem_desc* desc, myr_handle* out) {
   if (md) { h->solve_mode = (strcmp(md, "lane") == 0) ? 0 : 1; h->solve_fused = (strcmp(md, "wave1") == 0) ? 0 : 1; }
   const char* l = getenv("MYRIAD_SOLVE_LPW");
   if (l) { int v = atoi(l); if (v >= 1 && v <= 64) h->solve_lpw = v; }
+  if (const char* e = getenv("MYRIAD_REG_FILL")) h->reg_fill = !strcmp(e, "nan") ? 1 : (!strcmp(e, "random") ? 2 : (!strcmp(e, "big") ? 3 : (!strcmp(e, "zero") ? 4 : 0)));
+  if (const char* e = getenv("MYRIAD_STACK_FILL")) h->stack_fill = !strcmp(e, "nan") ? 1 : (!strcmp(e, "random") ? 2 : (!strcmp(e, "big") ? 3 : (!strcmp(e, "zero") ? 4 : 0)));
   if (const char* e = getenv("MYRIAD_NODE_HELPERS")) h->node_helpers = atoi(e);   // developer knob: helper workgroups per trajectory of the network kernel (0 = none)
   if (const char* e = getenv("MYRIAD_PARK_ITER")) h->park_iter = atoi(e);         // developer knob: iterations of phase 1 of the two-phase launch (0 = off)
   if (const char* e = getenv("MYRIAD_FUSED_WAVES")) h->fused_waves = atoi(e);     // developer knob: wavefronts per trajectory of the fused kernel
@@ -1670,6 +1742,12 @@ extern "C" int myr_solve_info(myr_handle h, int32_t B, int32_t* start, int32_t* 
   return MYR_OK;
 }
 
+extern "C" int myr_solve_plan(myr_handle h, int32_t* plan) {
+  if (!h || !plan) return fail(MYR_E_ARG, "myr_solve_plan: null argument");
+  memcpy(plan, h->plan, sizeof(h->plan));
+  return MYR_OK;
+}
+
 extern "C" int myr_set_var_scale(myr_handle h, const double* scale) {
   if (!h) return fail(MYR_E_ARG, "myr_set_var_scale: null handle");
   if (h->d.system_id == MYR_SYS_NODE_CARTPOLE && scale) return fail(MYR_E_UNSUPPORTED, "myr_set_var_scale: not available for NODE systems");
@@ -1835,6 +1913,7 @@ extern "C" int myr_solve_x0(myr_handle h, int32_t B, const double* x0s, const do
 static int dispatch_rollout(myr_handle h, int B, int num_steps, int u_rows, const double* x0, const double* us,
                             const double* params, int pstride, double* xs, double* cost) {
   KTimer& kt = h->kt[MYR_K_ROLLOUT];
+  if (int rc_fill = stack_fill(h)) return rc_fill;
   HIPCHK(hipEventRecord(kt.a, h->stream));
   int rc = MYR_E_ARG;
   switch (h->d.system_id) {
@@ -1932,6 +2011,7 @@ extern "C" int myr_fbsm(myr_handle h, int32_t B, int32_t N, const double* x0, co
 #undef X
     case MYR_SYS_INVASIVEPLANT: {
       KTimer& kt = h->kt[MYR_K_FBSM];
+      if (int rc_fill = stack_fill(h)) return rc_fill;
       HIPCHK(hipEventRecord(kt.a, h->stream));
       hipLaunchKernelGGL(fbsm_discrete_kernel<DiscINVASIVEPLANT>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, B, Bp, N, dx0,
                          adj_T ? dadj : nullptr, dp, params_stride, vlo, vhi, delta, max_sweeps, X, U, A, dsw);

@@ -194,6 +194,39 @@ def test_bench_run_world2_gloo_with_stub_engine(scaling, batch):
   assert "cpu_baseline" not in out          # rank 0 at N=1 only
 
 
+def _both_worker(rank, world, port, q):
+  import argparse
+  import torch
+  import torch.distributed as dist
+  import bench
+  os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  a = argparse.Namespace(gpus=world, steps=2, warmup=1, batch=8, scaling="weak", intervals=4, cpu_budget=0.0, no_other_configs=True)
+  _StubEngine.bad_x0 = float("nan")
+  out = bench.both_scalings(a, rank, world, torch.device("cpu"), lambda N, T, dev, B: _StubEngine(N, T, dev, B))
+  q.put((rank, out))
+  dist.destroy_process_group()
+
+
+def test_bench_prints_the_strong_split_beside_the_weak_line_world2_gloo():
+  """N > 1: the contract's line (weak: --batch per GPU) carries the other split of the same batch (strong: --batch in total, SURVEY.md 8(e)'s
+  partitioning) measured in the same run -- the driver's SCALE file then holds both under one clock."""
+  import torch.multiprocessing as mp
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = 35500 + (os.getpid() % 2000)
+  ps = [ctx.Process(target=_both_worker, args=(r, 2, port, q)) for r in range(2)]
+  [p.start() for p in ps]
+  res = dict(q.get(timeout=180) for _ in range(2))
+  [p.join(60) for p in ps]
+  assert res[1] is None
+  out = res[0]
+  assert out["scaling"] == "weak" and out["config"]["global_batch"] == 16 and out["config"]["per_gpu_batch"] == [8, 8]
+  o2 = out["other_scaling"]
+  assert o2["scaling"] == "strong" and o2["global_batch"] == 8 and o2["per_gpu_batch"] == [4, 4]
+  assert o2["unit"] == "solves/s" and o2["value"] > 0 and o2["steps"] == 2
+
+
 def test_gather_to_one_rank_gloo_world2():
   import torch.multiprocessing as mp
   ctx = mp.get_context("spawn")
