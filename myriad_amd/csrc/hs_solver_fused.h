@@ -219,10 +219,10 @@ struct HsFused {
   __device__ static inline void wg_combine(Ctx& c, double* v, const int (&op)[NV]) {
     static_assert(NV <= NRED, "partial-sum slots");
     if constexpr (W > 1) {
-      if (c.lane == 0) {
+      // (EVERY lane stores the wave-uniform partial result -- 64 stores of one value to one address -- instead of lane 0 alone: a lane-0 region here
+      // ended the passes in a join block, and a spill the compiler put in FRONT of that block's EXEC restore missed lanes 1..63)
 #pragma unroll
-        for (int i = 0; i < NV; ++i) c.sRed[c.wave * NRED + i] = v[i];
-      }
+      for (int i = 0; i < NV; ++i) c.sRed[c.wave * NRED + i] = v[i];
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -910,7 +910,11 @@ struct HsFused {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       wsync();
     }
-    for (int j = c.tid; j < K; j += NT) {
+    // Every lane runs every round (uniform trip count; `live` gates the stores and the stationarity maximum): a divergent loop here ended in a join block
+    // into whose prologue -- IN FRONT of the EXEC restore -- this compiler placed spills of values all lanes need afterwards
+    for (int j0 = 0; j0 < K; j0 += NT) {
+      const bool live = j0 + c.tid < K;
+      const int j = live ? j0 + c.tid : K - 1;
       double a[NS];
       if (TRAP) {           // a_j = h/2 (lam_{j-1} + lam_j): TrapCore's mue = mu_c + h/2 lam
 #pragma unroll
@@ -963,7 +967,7 @@ struct HsFused {
         double r = wj * P.gw[NS + u] + zlu[NS + u];
 #pragma unroll
         for (int t = 0; t < NS; ++t) r += P.B[t * NU + u] * a[t];
-        st_ = detail::dmax(st_, fabs(r));
+        st_ = live ? detail::dmax(st_, fabs(r)) : st_;
       }
       double Wh[NW * NW];
       if constexpr (MLP) {
@@ -975,6 +979,7 @@ struct HsFused {
         Sys::hessian(P.x, P.u, c.pp.get(), P.D2, a, wj, Wh);
       double* hr = c.hr + (long)j * HR_N;
       const bool last = (j == K - 1);
+      if (live) {
 #pragma unroll
       for (int r = 0; r < NW; ++r) {
         const bool zr = last && r < NS && c.term_pinned[r < NS ? r : 0];
@@ -985,6 +990,7 @@ struct HsFused {
         }
         hr[HR_G0 + r] = zr ? 0.0 : wj * P.gw[r];
         hr[HR_G1 + r] = zr ? 0.0 : g1v[r];
+      }
       }
     }
     double v[1] = {wv_max(st_)};
@@ -1305,14 +1311,14 @@ struct HsFused {
   }
   __device__ static inline int sweep(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
 #ifndef MYR_SWEEP_INLINE
-    // W = 1 calls the sweep as a function of its own (SwArgs: address-space-qualified pointers, a frame of its own).  W > 1 -- where only
-    // wavefront 0 sweeps -- inlines riccati_mfma on the context: with the wavefront index wave-uniform BY CONSTRUCTION (readfirstlane in
-    // the kernel) the branch around it is a scalar one.  Round 3 had the index as a per-lane value: the sweep then sat inside an
-    // EXEC-masked region, and that build returned results that differed from launch to launch on fresh handles (DESIGN.md section 8;
-    // tests/test_gpu_poison.py).  Two other forms are kept behind flags because they FAULT in some instantiations
-    // (-DMYR_SWEEP_CALL_W: a call made by one wavefront, round 3; -DMYR_W2_QUALIFIED: the inlined body on SwArgs, round 4 exp9).
-#if defined(MYR_SWEEP_CALL_W)
-    constexpr bool CALL = true, QUAL = false;
+    // The sweep is a function of its own in every form (SwArgs: address-space-qualified pointers, a frame of its own; W > 1: called by wavefront 0 -- and
+    // by wavefront 1 for the speculative rung -- under a branch on the wave-uniform wavefront index, a scalar branch).  History: round 3 had the index as a
+    // per-lane value, the inlined sweep then sat inside an EXEC-masked region and results differed from handle to handle; round 4 made the index uniform
+    // and kept W > 1 on the inlined form because call + speculative rung together still failed the fresh-handle gate; round 5 found why -- a spill in
+    // front of a join block's EXEC restore, nothing to do with the call -- and holds every build with a listing scan and the
+    // register-fill gate.  -DMYR_SWEEP_CALL_W=0: round 4's form; -DMYR_W2_QUALIFIED: the inlined body on SwArgs (faults in some instantiations, exp9).
+#if !defined(MYR_SWEEP_CALL_W) || MYR_SWEEP_CALL_W
+    constexpr bool CALL = true, QUAL = false;      // (the sweep is a call in every form since round 5; -DMYR_SWEEP_CALL_W=0: round 4's inlined sweep for W > 1)
 #elif defined(MYR_W2_QUALIFIED)
     constexpr bool CALL = W == 1, QUAL = true;
 #else
@@ -1735,8 +1741,8 @@ struct HsFused {
       // (Speculative second rung, -DMYR_FUSED_SPEC: measured +3.5 % at B=512, and bit-identical to the plain ladder on CARTPOLE -- but
       // TIMBERHARVEST N=6 takes another path in the build WITHOUT debug output and the right one with it, the outputs of the
       // speculative sweep being provably those of a repeated one; not understood, so it stays off.)
-#ifdef MYR_FUSED_SPEC
-      constexpr bool SPEC = W > 1;
+#if !defined(MYR_FUSED_SPEC) || MYR_FUSED_SPEC
+      constexpr bool SPEC = W > 1;          // (on since round 5: the build guard tools/dev/scan_exec_prologue.py and the register-fill gate hold it; -DMYR_FUSED_SPEC=0 switches it off)
 #else
       constexpr bool SPEC = false;
 #endif
@@ -1754,7 +1760,7 @@ struct HsFused {
             if (c.wave == 1) use_set(cw, c.kgB, c.xB);
             if (c.wave < 2) {
               const int nr = sweep(cw, o, c.wave == 0 ? delta : delta_b, c.wave == 0 ? abort_a : abort_b);
-              if (c.lane == 0) c.sMisc[1 + c.wave] = (double)nr;
+              c.sMisc[1 + c.wave] = (double)nr;        // (every lane: the count is wave-uniform; no lane-0 region in front of the barrier)
             }
           }
           wsync();
@@ -1778,7 +1784,7 @@ struct HsFused {
           if constexpr (W > 1) {
             if (c.wave == 0) {
               nreg = sweep(c, o, delta, abort_on_reg);
-              if (c.lane == 0) c.sMisc[1] = (double)nreg;
+              c.sMisc[1] = (double)nreg;
             }
             wsync();
             nreg = (int)c.sMisc[1];

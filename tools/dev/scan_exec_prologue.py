@@ -34,8 +34,11 @@ def scan(path, window=24):
         if l.strip().startswith(";") or not l.strip(): j += 1; continue
         n += 1
         if RESTORE.match(l):
-          spills = [(k, t) for k, t in pend if re.match(r"\s+(v_accvgpr_write_b32|scratch_store_)", t)]
-          if spills:
+          # the signature of the misplaced spill: NOTHING but spill stores (and constant / register moves) between the label and the restore --
+          # computation in front of a restore is ordinary code of an enclosing divergent region that an inner region's join interrupts
+          spills = [t for k, t in pend if re.match(r"\s+(v_accvgpr_write_b32|scratch_store_)", t)]
+          other = [t for k, t in pend if not re.match(r"\s+(v_accvgpr_write_b32|scratch_store_\w+|v_mov_b32_e32|v_mov_b64_e32)\s", t)]
+          if spills and not other:
             hits.append((fn, label, j + 1, [t.strip() for k, t in pend]))
           break
         if VEC.match(l): pend.append((j + 1, l))
