@@ -101,7 +101,7 @@ def cpu_baseline(N, budget_s):
   dt, nit, done, _ = timed_solve(N, budget_s)
   its_per_s = nit / dt
   full_its, measured = 110, None
-  for rnd in ("r04", "r03"):                 # a whole solve measured on a GPU-box host by `bench.py --cpu-full` (committed)
+  for rnd in ("r05", "r04", "r03"):          # a whole solve measured on a GPU-box host by `bench.py --cpu-full` (committed)
     fp = os.path.join(ROOT, "profiles", rnd, "cpu_baseline_full.json")
     if N == 100 and os.path.exists(fp):
       try:
@@ -109,6 +109,8 @@ def cpu_baseline(N, budget_s):
         full_its = int(m["iterations"])
         measured = {"file": os.path.relpath(fp, ROOT), "seconds": m["seconds"], "iterations": m["iterations"], "value": m["value"],
                     "host_cores": json.load(open(fp)).get("host_cores"),
+                    "value_host": {"round": rnd, "hostname": json.load(open(fp)).get("hostname"), "measured_utc": json.load(open(fp)).get("measured_utc"),
+                                   "note": "where and when the committed whole solve was measured: a stale file shows here"},
                     "trust_constr": json.load(open(fp)).get("trust_constr_subsample", {}).get("value")}
         break
       except Exception:
@@ -146,7 +148,9 @@ def cpu_full(N, out_path, trust_budget_s=600.0):
   for 60 s instead).  The default run cites the file this writes."""
   from oracle import myriad_oracle as O
   import torch
+  import datetime, socket
   res = {"host_cores": os.cpu_count() or 1, "torch_threads": int(torch.get_num_threads()), "kind": "port",
+         "hostname": socket.gethostname(), "measured_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ"),
          "what": "oracle SciPy path (serial SLSQP / trust-constr + torch-autodiff callbacks) = the reference's SciPy branches minus JAX"}
   s = O.CartPole()
   tr = O.hermite_simpson(s, N)
