@@ -166,14 +166,19 @@ struct HsFused {
   // and lane (node_mfma.h: MODE 0 / 3 write, MODE 3 / 4 read -- always the lane that wrote them)
   __host__ __device__ static long off_hb(int N) { return off_pt(N) + (MLP ? (long)PT_N * npoints(N) : 0); }
   __host__ __device__ static long off_mb(int N) { return off_hb(N) + (MLP ? (long)NodeMfma64::ntiles(npoints(N)) * NodeMfma64::HB_TILE : 0); }
-  __host__ __device__ static long scratch_doubles(int N) { return off_mb(N) + (MLP ? (long)NodeMfma64::ntiles(npoints(N)) * NodeMfma64::MB_TILE : 0); }
+  // The two-wavefront form of the network kernel (round 5: the THROUGHPUT form for batches beyond one trajectory per CU -- two trajectories per CU, each on
+  // two SIMDs, so that one trajectory's sequential sweep overlaps the other's matrix-core passes) keeps the bound multipliers zL, zU in its global
+  // scratch slot instead of LDS: two workgroups of 42.7 KB + 40.5 KB of weights do not fit a CU's 160 KB, two of 26.7 KB + 40.5 KB do.
+  static constexpr bool ZLU_GLOBAL = MLP && W == 2;
+  __host__ __device__ static long off_zlu(int N) { return off_mb(N) + (MLP ? (long)NodeMfma64::ntiles(npoints(N)) * NodeMfma64::MB_TILE : 0); }
+  __host__ __device__ static long scratch_doubles(int N) { return off_zlu(N) + (ZLU_GLOBAL ? 2L * npoints(N) * NW : 0); }
   // LDS (doubles): z | zL | zU | dz | multipliers | bound table | neighbour stash | first-point exchange
   static constexpr int NREC = NS + NS + NS * NS + NS * NU + NS;   // x, f, A, B, own: what an interval takes from its end knot
   static constexpr int EXCH = NW * NW + NW * NC + NS * NC + NU * NC;
   // exchange between blocks / wavefronts (double-buffered by round): neighbour record, block total of a scan, trial knot; partial sums
   static constexpr int NTOT = NW * NW + NW, NRED = 12;
   static constexpr int XCH = 2 * W * NREC + 2 * W * NTOT + 2 * W * 2 * NS + W * NRED + 8;
-  __host__ __device__ static int lds_solver_doubles(int N) { return 4 * npoints(N) * NW + MLAM * N * NS + 6 * NW + XCH + (W > 1 ? 2 : 1) * EXCH + 8; }
+  __host__ __device__ static int lds_solver_doubles(int N) { return (ZLU_GLOBAL ? 2 : 4) * npoints(N) * NW + MLAM * N * NS + 6 * NW + XCH + (W > 1 ? 2 : 1) * EXCH + 8; }
   __host__ __device__ static int lds_doubles(int N) { return lds_solver_doubles(N) + (MLP ? npoints(N) * NS + NodeTraits<Sys>::lds_doubles : 0); }
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
   static constexpr int NSCAL = 48;      // scalars of the solve loop in a parked trajectory's record
@@ -1922,7 +1927,10 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   c.hb = s + W::off_hb(c.N); c.mb = s + W::off_mb(c.N); c.h_valid = false;
   double* const lam_own = s + W::off_lam(c.N);
   double* l = reinterpret_cast<double*>(smem_fused);
-  c.z = l; l += c.n; c.zL = l; l += c.n; c.zU = l; l += c.n; c.dz = l; l += c.n;
+  c.z = l; l += c.n;
+  if constexpr (W::ZLU_GLOBAL) { c.zL = s + W::off_zlu(c.N); c.zU = c.zL + c.n; }
+  else { c.zL = l; l += c.n; c.zU = l; l += c.n; }
+  c.dz = l; l += c.n;
   c.sLam = l; l += W::MLAM * c.N * W::NS;
   c.sB = l; l += 6 * W::NW;
   c.sStash = l; l += 2 * NWAVES * W::NREC;

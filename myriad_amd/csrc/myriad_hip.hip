@@ -603,6 +603,7 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
                                                                                //  the network system's longest solves -- 75 iterations against a median of 24 -- have SMALL
                                                                                //  residuals at the parking point and would come last: 41 -> 52 ms at B = 1024, exp42 / exp43)
     if (k1 >= o.max_iter || !status || !kkt) k1 = 0;
+    if (W::ZLU_GLOBAL) k1 = 0;        // (the parked record is the solver's LDS: this form keeps part of the iterate in its scratch slot)
   }
   // Helper workgroups for the network passes (hs_solver_fused.h: NodeBoard): a batch of at most half the CUs (config 5's share of an 8-GPU node is 128
   // trajectories) gets nh = #CU / B - 1 <= 3 more workgroups per trajectory; whole solves with one shared weight set only.
@@ -610,13 +611,14 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   unsigned grid = (unsigned)slots;
   if constexpr (W::MLP) {
     const int cus = device_cus(h);
-    int maxh = 3;
-    if (B <= cus / 2 && cus / B - 1 < maxh) maxh = cus / B - 1;      // a small batch: spread the idle CUs evenly
+    const int resident = per_cu * cus;                               // workgroups the device holds: 1 per CU (four wavefronts), 2 per CU (two)
+    int maxh = NWAVES == 2 ? 5 : 3;                                  // 13 tiles over 4 (nh + 1) resp. 2 (nh + 1) wavefronts
+    if (B <= resident / 2 && resident / B - 1 < maxh) maxh = resident / B - 1;      // a small batch: spread the idle workgroups evenly
     if (h->node_helpers >= 0 && h->node_helpers < maxh) maxh = h->node_helpers;
-    // whole solves with one shared weight set; every workgroup of the launch must be resident (one per CU): owners wait for their helpers
-    if (pstride != 0 || k1 > 0 || per_cu != 1 || h->solve_slots > 0) maxh = 0;
+    // whole solves with one shared weight set; every workgroup of the launch must be resident: owners wait for their helpers
+    if (pstride != 0 || k1 > 0 || per_cu < 1 || per_cu != 4 / NWAVES || h->solve_slots > 0) maxh = 0;
     if (maxh > 0) {
-      grid = (unsigned)((long)B * (maxh + 1) < (long)cus ? B * (maxh + 1) : cus);
+      grid = (unsigned)((long)B * (maxh + 1) < (long)resident ? B * (maxh + 1) : resident);
       const int nboards = B <= (int)grid ? B : (int)grid;      // workgroups that can own a trajectory (hs_solve_fused_kernel: `fixed`)
       const long pub = ((long)h->dims.n + (long)W::MLAM * N * W::NS + (long)W::npoints(N) * W::NS + 15) / 16 * 16;
       const size_t head = ((size_t)nboards * sizeof(myriad::NodeBoard) + 128 + 127) / 128 * 128;
@@ -707,7 +709,15 @@ template <class Sys, int SCHEME>
 static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
                            int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                            int32_t* iters, double* kkt) {
-  if constexpr (NodeTraits<Sys>::mlp) {     // network dynamics: four wavefronts share a trajectory and the 40 KB of weights in LDS
+  if constexpr (NodeTraits<Sys>::mlp) {
+    // network dynamics.  Up to one trajectory per CU: four wavefronts share a trajectory (the LATENCY form: a launch is one solve long, idle CUs attach as
+    // helpers).  Beyond: two wavefronts per trajectory, two trajectories per CU (the THROUGHPUT form: one trajectory's sequential sweep and interval
+    // passes overlap the other's matrix-core passes on the CU's other two SIMDs; bound multipliers in global scratch so that two workgroups fit the LDS).
+    // MYRIAD_FUSED_WAVES=2|4 overrides.
+    int waves = (B > device_cus(h)) ? 2 : 4;
+    if (h->fused_waves == 2 || h->fused_waves == 4) waves = h->fused_waves;
+    if (waves == 2 && pstride == 0 && 2 * HsFused<Sys, 2, 0>::lds_bytes(h->d.intervals) <= 160 * 1024)
+      return launch_hs_fused_w<Sys, 2, 0>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     return launch_hs_fused_w<Sys, 4, 0>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   } else {
     // W = 2: two wavefronts per trajectory for batches of at most two trajectories per CU (a launch then lasts as long as one solve,

@@ -166,3 +166,31 @@ def test_node_helper_workgroups_return_the_bits_of_the_launch_without(monkeypatc
   for key, r in out.items():
     for k in ref:
       assert np.array_equal(r[k], ref[k]), (key, k)
+
+
+@pytest.mark.parametrize("N,B", [(20, 12), (100, 300)])
+def test_node_two_wavefront_throughput_form_returns_the_bits_of_the_four_wavefront_form(monkeypatch, N, B):
+  """Round 5: beyond one trajectory per CU the network kernel runs two wavefronts per trajectory and two trajectories per CU (bound multipliers in the
+  global scratch slot so that two workgroups fit the LDS; one trajectory's sweep overlaps the other's matrix-core passes).  Tiles, scans and sums are the
+  four-wavefront form's: identical bits -- with and without helper workgroups, under LDS / scratch poison and under the register / stack fill."""
+  x0 = np.clip(0.1 * np.random.default_rng(7 * N + B).standard_normal((B, 4)), -2, 2)
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  out = {}
+  for name, env in (("W4", {"MYRIAD_FUSED_WAVES": "4"}), ("W2", {"MYRIAD_FUSED_WAVES": "2"}), ("W2 no helpers", {"MYRIAD_FUSED_WAVES": "2", "MYRIAD_NODE_HELPERS": "0"}),
+                    ("W2 poison", {"MYRIAD_FUSED_WAVES": "2", "MYRIAD_POISON": "random"}),
+                    ("W2 fill", {"MYRIAD_FUSED_WAVES": "2", "MYRIAD_REG_FILL": "nan", "MYRIAD_STACK_FILL": "nan"})):
+    for k in ("MYRIAD_FUSED_WAVES", "MYRIAD_NODE_HELPERS", "MYRIAD_POISON", "MYRIAD_REG_FILL", "MYRIAD_STACK_FILL"):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    hp, node, opt = _setup(N)
+    r = opt.solve_batch(x0s=x0, params=opt.system.device_params())
+    if name.startswith("W2"):
+      assert opt.engine.solve_plan()["waves_per_trajectory"] == 2
+    out[name] = {k: np.array(r[k]) for k in ("status", "iters", "cost", "xs_and_us", "lambda")}
+    opt.engine.close()
+  ref = out["W4"]
+  assert (ref["status"] == 0).all()
+  for name, r in out.items():
+    for k in ref:
+      assert np.array_equal(r[k], ref[k]), (name, k)
