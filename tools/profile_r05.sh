@@ -22,7 +22,7 @@ pmc_passes bench_n1 python bench.py --cpu-budget 0 --no-other-configs --steps 3 
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt3 -o kt -- python tools/dev/cfg3.py 8192 > $OUT/config3.log 2>&1
 cp $(find $OUT/kt3 -name "*kernel_stats.csv" | head -1) $OUT/config3_kernel_stats.csv 2>/dev/null
 pmc_passes config3_shoot python tools/dev/cfg3.py 8192
-python tools/dev/node_bench.py 128 256 512 1024 2048 2>/dev/null | grep config > $OUT/config5_1gpu.jsonl
+python tools/dev/node_bench.py 128 256 300 512 1024 2048 2>/dev/null | grep config > $OUT/config5_1gpu.jsonl
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt5 -o kt -- python tools/dev/node_bench.py 128 1024 > $OUT/config5.log 2>&1
 cp $(find $OUT/kt5 -name "*kernel_stats.csv" | head -1) $OUT/config5_kernel_stats.csv 2>/dev/null
 pmc_passes config5_node python tools/dev/node_bench.py 1024
