@@ -167,3 +167,30 @@ def test_solve_batch_fan_out_over_two_handles_of_one_device_matches_one_handle()
 def _lib_device_count():
   from myriad_amd import _lib
   return max(1, _lib.device_count())
+
+
+def test_solve_plan_reports_the_launch_form_and_an_explicit_park_iter_selects_the_one_wavefront_form():
+  """myr_solve_plan (round 5): the library says how it launched the last solve -- what bench.py quotes instead of restating the library's rules.  A small
+  batch of a closed-form collocation problem runs two wavefronts per trajectory as whole solves; an explicit myr_solve_opts.park_iter > 0 selects the
+  one-wavefront form with its two-phase launch (include/myriad_hip.h: park_iter) and returns the same bits; single shooting reports its own kernel."""
+  from myriad_amd import _lib
+  from myriad_amd.trajectory_optimizers import get_optimizer
+  from myriad_amd.config import NLPSolverType
+  hp = _hp(20, nlpsolver=NLPSolverType.SQP)
+  opt = get_optimizer(hp, CFG, hp.system())
+  x0 = np.clip(0.1 * np.random.default_rng(3).standard_normal((40, 4)), -2, 2)
+  z0, lb, ub = opt.batch_inputs(x0)
+  eng = opt.engine
+  a = eng.solve(z0, lb, ub)
+  p = eng.solve_plan()
+  assert p["form"] == "fused" and p["waves_per_trajectory"] == 2 and p["park_iter"] == 0 and p["launches_per_solve"] == 1 and p["slots"] == 40
+  o = eng.default_opts(); o.park_iter = 5
+  b = eng.solve(z0, lb, ub, opts=o)
+  p = eng.solve_plan()
+  assert p["waves_per_trajectory"] == 1 and p["park_iter"] == 5 and p["launches_per_solve"] == 2
+  assert (a["status"] == 0).all() and np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"])
+  np.testing.assert_allclose(a["z"], b["z"], rtol=0, atol=1e-9)       # (W = 1 and W = 2 differ in the order of their merit sums only)
+  hs = HParams(system=SystemType.VANDERPOL, optimizer=OptimizerType.SHOOTING, intervals=1, controls_per_interval=20, nlpsolver=NLPSolverType.SQP)
+  os_ = get_optimizer(hs, CFG, hs.system())
+  os_.solve_batch(x0s=np.tile(os_.system.x_0, (3, 1)))
+  assert os_.engine.solve_plan()["form"] == "shooting_wave"
