@@ -45,7 +45,10 @@ def main():
   out = {}
   log = []
   rng = np.random.default_rng(5)
-  for st in SystemType:
+  # `--solve-only NAME`: only the reference's solve() runs, into tests/golden/NAME.npz -- used with /opt/conda/bin/python3.9 (SciPy 1.7.1: the
+  # reference pins scipy==1.7.0, requirements.txt) beside the default interpreter's SciPy 1.15
+  solve_only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "--solve-only" else None
+  for st in ([] if solve_only else SystemType):
     if st.name in SKIP:
       continue
     for tr, method, N, cpi in CASES:
@@ -105,9 +108,11 @@ def main():
     out[key + "/x"] = np.asarray(res["x"], dtype=np.float64); out[key + "/u"] = np.asarray(res["u"], dtype=np.float64)
     c = np.asarray(opt.constraints(np.asarray(res["xs_and_us"])), dtype=np.float64)
     log.append(f"{key}: cost={float(np.real(res['cost'])):.12g} |c|max={np.abs(c).max():.3g}")
-  path = os.path.join(HERE, "reference_callbacks.npz")
+  import scipy
+  out["scipy_version"] = np.array(scipy.__version__); out["numpy_version"] = np.array(np.__version__)
+  path = os.path.join(HERE, (solve_only or "reference_callbacks") + ".npz")
   np.savez_compressed(path, **out)
-  open(os.path.join(HERE, "reference_callbacks.log"), "w").write("\n".join(log) + "\n")
+  open(os.path.join(HERE, (solve_only or "reference_callbacks") + ".log"), "w").write("\n".join(log) + "\n")
   print("\n".join(log[-12:]))
   print(f"{len([k for k in out if k.endswith('/objective')])} cases -> {path} ({os.path.getsize(path)} bytes)")
 

@@ -108,3 +108,23 @@ def test_oracle_solve_path_reproduces_the_reference_solve(key):
   assert float(again["cost"]) <= float(FIX[key + "/cost"]) + 2e-6 * abs(float(FIX[key + "/cost"])) + 1e-9, key
   if "VANDERPOL" not in key:
     assert float(again["cost"]) == pytest.approx(float(FIX[key + "/cost"]), rel=2e-6, abs=1e-9), key
+
+
+FIX171 = np.load(os.path.join(HERE, "golden", "reference_solve_scipy171.npz"))
+
+
+@pytest.mark.parametrize("key", SOLVE_KEYS)
+def test_reference_solve_under_the_scipy_version_it_pins(key):
+  """the reference pins scipy==1.7.0 (requirements.txt); the image's default interpreter has SciPy 1.15, /opt/conda's python3.9
+  has 1.7.1.  The generator ran the reference's solve() under both (`--solve-only reference_solve_scipy171` with the conda interpreter): the SLSQP end points
+  agree -- to the last printed digit for four of the five problems, to SLSQP's own tolerance for the long-horizon single shooting of VANDERPOL -- so the
+  goldens do not hang on the SciPy version, and the oracle's path (SciPy 1.15) ends where the reference's pinned one does."""
+  assert str(FIX171["scipy_version"]) == "1.7.1" and key + "/cost" in FIX171.files
+  c171, c115 = float(FIX171[key + "/cost"]), float(FIX[key + "/cost"])
+  shooting_vdp = "VANDERPOL" in key
+  assert c171 == pytest.approx(c115, rel=1e-5 if shooting_vdp else 1e-10, abs=1e-12), key
+  if not shooting_vdp:
+    assert np.abs(FIX171[key + "/xs_and_us"] - FIX[key + "/xs_and_us"]).max() <= 1e-6 * max(1.0, np.abs(FIX[key + "/xs_and_us"]).max()), key
+  system, t = _solve_case(key)
+  res = O.solve(t, "SLSQP", max_iter=1000)
+  assert float(res["cost"]) == pytest.approx(c171, rel=1e-4 if "/SHOOTING/" in key else 1e-7, abs=1e-9), key
