@@ -108,6 +108,37 @@ def main():
     out[key + "/x"] = np.asarray(res["x"], dtype=np.float64); out[key + "/u"] = np.asarray(res["u"], dtype=np.float64)
     c = np.asarray(opt.constraints(np.asarray(res["xs_and_us"])), dtype=np.float64)
     log.append(f"{key}: cost={float(np.real(res['cost'])):.12g} |c|max={np.abs(c).max():.3g}")
+  # ---- the reference's Forward-Backward Sweep (trajectory_optimizers/forward_backward_sweep.py:88-116 over utils.py:138-197), every indirect system
+  # without a terminal state condition (and the discrete INVASIVEPLANT), fbsm_intervals = 200, capped at 40 sweeps through the stopping rule
+  if not solve_only:
+    from myriad.trajectory_optimizers.forward_backward_sweep import FBSM
+    for st in SystemType:
+      try:
+        hp = HParams(system=st, optimizer=OptimizerType.FBSM, fbsm_intervals=200)
+        system = hp.system()
+        if not hasattr(system, "adj_ODE"):
+          continue
+        opt = FBSM(hp, CFG, system)
+      except Exception as e:
+        log.append(f"fbsm/{st.name}: {type(e).__name__} at construction: {str(e)[:80]}")
+        continue
+      if opt.terminal_cdtion:
+        continue            # (PREDATORPREY: the secant sequence solver -- a loop over the sweeps recorded here)
+      count = {"n": 0}
+      stop0 = opt.stopping_criterion
+      def capped(xi, ui, ai, delta=0.001, _stop0=stop0, _count=count):
+        _count["n"] += 1
+        return bool(_stop0(xi, ui, ai, delta)) and _count["n"] < 40
+      opt.stopping_criterion = capped
+      try:
+        sol = opt.solve()
+      except Exception as e:
+        log.append(f"fbsm/{st.name}: {type(e).__name__} in solve: {str(e)[:80]}")
+        continue
+      key = f"fbsm/{st.name}"
+      out[key + "/x"] = np.asarray(sol["x"], dtype=np.float64); out[key + "/u"] = np.asarray(sol["u"], dtype=np.float64)
+      out[key + "/adj"] = np.asarray(sol["adj"], dtype=np.float64); out[key + "/sweeps"] = np.array(count["n"])
+      log.append(f"{key}: {count['n']} sweeps, u[0]={float(np.asarray(sol['u']).ravel()[0]):.10g} x[-1]={np.asarray(sol['x'])[-1].tolist()}")
   import scipy
   out["scipy_version"] = np.array(scipy.__version__); out["numpy_version"] = np.array(np.__version__)
   path = os.path.join(HERE, (solve_only or "reference_callbacks") + ".npz")

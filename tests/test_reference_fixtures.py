@@ -128,3 +128,23 @@ def test_reference_solve_under_the_scipy_version_it_pins(key):
   system, t = _solve_case(key)
   res = O.solve(t, "SLSQP", max_iter=1000)
   assert float(res["cost"]) == pytest.approx(c171, rel=1e-4 if "/SHOOTING/" in key else 1e-7, abs=1e-9), key
+
+
+FBSM_KEYS = sorted({k.rsplit("/", 1)[0] for k in FIX.files if k.startswith("fbsm/") and k.endswith("/sweeps")})
+
+
+def test_fbsm_fixture_covers_the_indirect_systems():
+  assert len(FBSM_KEYS) == 13 and "fbsm/INVASIVEPLANT" in FBSM_KEYS and "fbsm/BEARPOPULATIONS" in FBSM_KEYS, FBSM_KEYS
+
+
+@pytest.mark.parametrize("key", FBSM_KEYS)
+def test_oracle_fbsm_reproduces_the_reference_sweeps(key):
+  """trajectory_optimizers/forward_backward_sweep.py:88-116 executed by the generator (fbsm_intervals = 200, at most 40 sweeps through the reference's own
+  stopping rule): the oracle's restatement stops after the same number of sweeps with the same state, control and adjoint trajectories -- the discrete
+  INVASIVEPLANT and the two-control BEARPOPULATIONS included.  (The batched device kernel `myr_fbsm` is tested against this restatement, tests/test_gpu_fbsm.py.)"""
+  name = key.split("/")[1]
+  system = O.InvasivePlant() if name == "INVASIVEPLANT" else O.SYSTEMS[name]()
+  r = O.fbsm(system, N=200, max_sweeps=40)
+  assert r["sweeps"] == int(FIX[key + "/sweeps"]), (key, r["sweeps"], int(FIX[key + "/sweeps"]))
+  for f in ("x", "u", "adj"):
+    _close(r[f], FIX[key + "/" + f], key + " " + f, rtol=1e-12)
