@@ -139,6 +139,22 @@ def main():
       out[key + "/x"] = np.asarray(sol["x"], dtype=np.float64); out[key + "/u"] = np.asarray(sol["u"], dtype=np.float64)
       out[key + "/adj"] = np.asarray(sol["adj"], dtype=np.float64); out[key + "/sweeps"] = np.array(count["n"])
       log.append(f"{key}: {count['n']} sweeps, u[0]={float(np.asarray(sol['u']).ravel()[0]):.10g} x[-1]={np.asarray(sol['x'])[-1].tolist()}")
+  # ---- the reference's extragradient iteration (nlp_solvers/extra_gradient.py:10-84; jax.grad of its Lagrangian by complex-step derivatives), 25 steps
+  if not solve_only:
+    from myriad.nlp_solvers.extra_gradient import extra_gradient
+    EXGD = [("CARTPOLE", dict(optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.TRAPEZOIDAL, intervals=6)),
+            ("VANDERPOL", dict(optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON, intervals=5)),
+            ("SIMPLECASE", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=2, controls_per_interval=5)),
+            ("MOULDFUNGICIDE", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.EULER, intervals=1, controls_per_interval=8))]
+    for name, kw in EXGD:
+      hp = HParams(system=SystemType[name], **kw)
+      opt = get_optimizer(hp, CFG, hp.system())
+      res = extra_gradient(fun=opt.objective, x0=np.asarray(opt.guess, dtype=np.float64), method="exgd", constraints={"fun": opt.constraints},
+                           bounds=np.asarray(opt.bounds, dtype=np.float64), jac=None, options={"maxiter": 25, "eta_x": 1e-2, "eta_v": 1e-3})
+      key = "exgd/%s/%s/%s/%dx%d" % (name, kw["optimizer"].name, (kw.get("quadrature_rule") or kw.get("integration_method")).name, hp.intervals, hp.controls_per_interval)
+      out[key + "/x"] = np.real(np.asarray(res["x"])).astype(np.float64); out[key + "/v"] = np.real(np.asarray(res["v"])).astype(np.float64)
+      out[key + "/fun"] = np.array(float(np.real(res["fun"])))
+      log.append(f"{key}: 25 steps, fun={float(np.real(res['fun'])):.12g} |v|max={np.abs(np.real(np.asarray(res['v']))).max():.6g}")
   import scipy
   out["scipy_version"] = np.array(scipy.__version__); out["numpy_version"] = np.array(np.__version__)
   path = os.path.join(HERE, (solve_only or "reference_callbacks") + ".npz")

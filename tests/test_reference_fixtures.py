@@ -148,3 +148,27 @@ def test_oracle_fbsm_reproduces_the_reference_sweeps(key):
   assert r["sweeps"] == int(FIX[key + "/sweeps"]), (key, r["sweeps"], int(FIX[key + "/sweeps"]))
   for f in ("x", "u", "adj"):
     _close(r[f], FIX[key + "/" + f], key + " " + f, rtol=1e-12)
+
+
+EXGD_KEYS = sorted({k.rsplit("/", 1)[0] for k in FIX.files if k.startswith("exgd/") and k.endswith("/fun")})
+
+
+@pytest.mark.parametrize("key", EXGD_KEYS)
+def test_oracle_extragradient_step_reproduces_the_reference_iteration(key):
+  """nlp_solvers/extra_gradient.py:10-84 executed by the generator for 25 steps (eta_x 1e-2, eta_v 1e-3, the step decay at iteration 0 included; jax.grad of
+  the reference's Lagrangian by complex-step derivatives): the oracle's `Lagrangian.step` (what the device kernels `myr_vjp` / `myr_exgd` are tested against)
+  walks the same 25 steps."""
+  _, name, optimizer, rule, shape = key.split("/")
+  N, cpi = (int(v) for v in shape.split("x"))
+  system = O.SYSTEMS[name]()
+  t = O.make_transcription(system, "SHOOTING", N, cpi, integration_method=rule) if optimizer == "SHOOTING" else O.make_transcription(system, "COLLOCATION", N, 1, quadrature_rule=rule)
+  L = O.Lagrangian(t)
+  x = np.array(t.guess, dtype=np.float64); lam = np.ones(O.Callbacks(t).cons(x).size)
+  eta_x, eta_v = 1e-2, 1e-3
+  for i in range(25):
+    if i % 1000 == 0:                      # extra_gradient.py:56-59 (the convergence test at i = 0 cannot fire: x_old = x + 20)
+      eta_x *= 0.999; eta_v *= 0.999
+    x, lam = L.step(x, lam, eta_x, eta_v)
+  _close(x, FIX[key + "/x"], key + " x", rtol=1e-12)
+  _close(lam, FIX[key + "/v"], key + " lambda", rtol=1e-12)
+  assert O.Callbacks(t).fun(x) == pytest.approx(float(FIX[key + "/fun"]), rel=1e-11, abs=1e-13)
