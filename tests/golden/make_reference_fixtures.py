@@ -48,10 +48,13 @@ def main():
   # `--solve-only NAME`: only the reference's solve() runs, into tests/golden/NAME.npz -- used with /opt/conda/bin/python3.9 (SciPy 1.7.1: the
   # reference pins scipy==1.7.0, requirements.txt) beside the default interpreter's SciPy 1.15
   solve_only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "--solve-only" else None
+  # the BASELINE configurations at their full sizes (BASELINE.json configs 1-4 and README.md:83's literal; config 5's network needs haiku)
+  FULL = {"CARTPOLE": [("HERMITE_SIMPSON", None, 100, 1), ("TRAPEZOIDAL", None, 100, 1)], "VANDERPOL": [("SHOOTING", "HEUN", 1, 50)],
+          "CANCERTREATMENT": [("SHOOTING", "HEUN", 1, 100)], "SIMPLECASE": [("SHOOTING", "HEUN", 10, 100)]}
   for st in ([] if solve_only else SystemType):
     if st.name in SKIP:
       continue
-    for tr, method, N, cpi in CASES:
+    for tr, method, N, cpi in CASES + FULL.get(st.name, []):
       key = f"{st.name}/{tr}/{method or '-'}/{N}x{cpi}"
       try:
         kw = dict(system=st, intervals=N, controls_per_interval=cpi)
