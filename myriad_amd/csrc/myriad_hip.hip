@@ -727,8 +727,11 @@ static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, con
     int waves = (B <= 2 * device_cus(h)) ? 2 : 1;
     if (so.park_iter > 0) waves = 1;                  // an explicit two-phase launch: only the one-wavefront form parks (include/myriad_hip.h: park_iter)
     if (h->fused_waves > 0) waves = h->fused_waves;
-    if (waves == 2 && HsFused<Sys, 2, SCHEME>::lds_bytes(h->d.intervals) <= 160 * 1024)
-      return launch_hs_fused_w<Sys, 2, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    // (the wider systems -- two controls, six states, the small elastic twins: riccati_mfma_gen -- are built in the one-wavefront form only)
+    if constexpr (!HsFused<Sys, 1, SCHEME>::GEN) {
+      if (waves == 2 && HsFused<Sys, 2, SCHEME>::lds_bytes(h->d.intervals) <= 160 * 1024)
+        return launch_hs_fused_w<Sys, 2, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    }
     return launch_hs_fused_w<Sys, 1, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
 }
@@ -1684,6 +1687,9 @@ static int solve_restored(myr_handle h, int B, double* z, const double* lb, cons
       slack_prev = slack_last;
       HIPCHK(hipMemcpy(slack_last.data(), dslack, (size_t)nf * 8, hipMemcpyDeviceToHost));
       for (int r = 0; r < nf; ++r) { it_acc[r] += it2[r]; twin_stat[r] = st2[r]; }
+      if (getenv("MYRIAD_DEBUG_ELASTIC"))
+        for (int r = 0; r < nf && r < 8; ++r)
+          fprintf(stderr, "[myriad] elastic phase: instance %d, rho %g: twin status %d after %d iterations, slack %.3e\n", (int)fail_[r], rhos[k], (int)st2[r], (int)it2[r], slack_last[r]);
     }
     if (twin_ok) {
       hipLaunchKernelGGL(twin_narrow_kernel, dim3(grid_for((long)nf * n)), dim3(256), 0, h->stream, (long)nf * n, nx, nu, ns, zt, zf, n, nt);

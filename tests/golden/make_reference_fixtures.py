@@ -101,7 +101,11 @@ def main():
             ("CARTPOLE", dict(optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.TRAPEZOIDAL, intervals=8)),
             ("VANDERPOL", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=1, controls_per_interval=20)),
             ("CANCERTREATMENT", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=1, controls_per_interval=20)),
-            ("SIMPLECASE", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=2, controls_per_interval=10))]
+            ("SIMPLECASE", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=2, controls_per_interval=10)),
+            # BASELINE configs 3, 4 and 1 at their full shapes (SURVEY.md App. C measured the same three with its own probe: 2.8731963348, 20.5735535185, -1.3543305221)
+            ("VANDERPOL", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=1, controls_per_interval=50)),
+            ("CANCERTREATMENT", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=1, controls_per_interval=100, max_iter=500)),
+            ("SIMPLECASE", dict(optimizer=OptimizerType.SHOOTING, integration_method=IntegrationMethod.HEUN, intervals=10, controls_per_interval=100))]
   for name, kw in SOLVES:
     hp = HParams(system=SystemType[name], nlpsolver=NLPSolverType.SLSQP, **kw)
     opt = get_optimizer(hp, CFG, hp.system())

@@ -85,7 +85,8 @@ def test_hip_sqp_reaches_the_optimum_of_the_reference_solve(key):
   tol = 2e-5 if "VANDERPOL" in key else 1e-5
   assert float(r["cost"][0]) <= c_ref + tol * max(1.0, abs(c_ref)), (key, float(r["cost"][0]), c_ref)
   if "VANDERPOL" not in key:       # (the reference's own VANDERPOL run stops far from a minimiser: tests/test_reference_fixtures.py)
-    assert float(r["cost"][0]) == pytest.approx(c_ref, rel=1e-5, abs=1e-7), (key, float(r["cost"][0]), c_ref)
+    # (BASELINE config 1 at full size, 1012 variables: SLSQP's ftol 1e-6 stops it 2.5e-5 above the KKT point the device SQP reaches, -1.3543637)
+    assert float(r["cost"][0]) == pytest.approx(c_ref, rel=5e-5 if shape == "10x100" else 1e-5, abs=1e-7), (key, float(r["cost"][0]), c_ref)
 
 
 FBSM_KEYS = sorted({k.rsplit("/", 1)[0] for k in FIX.files if k.startswith("fbsm/") and k.endswith("/sweeps")})

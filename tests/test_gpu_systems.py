@@ -424,3 +424,47 @@ def test_pendulum_swing_up_converges_under_every_transcription(kw):
   assert r['status'][0] == 0
   assert np.abs(opt.constraints(r['xs_and_us'][0])).max() <= 1e-8
   assert 25.3 < r['cost'][0] < 25.8
+
+
+@pytest.mark.parametrize("rule", ["HERMITE_SIMPSON", "TRAPEZOIDAL"])
+@pytest.mark.parametrize("name,N,lim", [("BEARPOPULATIONS", 30, 300), ("BEARPOPULATIONS", 7, 300), ("ROCKETLANDING", 20, 12), ("ROCKETLANDING", 9, 6),
+                                       ("PENDULUM_ELASTIC", 20, 8), ("VANDERPOL_ELASTIC", 20, 300), ("MOUNTAINCAR_ELASTIC", 9, 8)])
+def test_wider_systems_run_on_the_fused_matrix_core_kernel(monkeypatch, name, N, lim, rule):
+  """Round 5: two controls (BEARPOPULATIONS), six states (ROCKETLANDING: its right-hand sides need a second column tile, and its pinned
+  terminal states exercise the bookkeeping rows there) and the three-control elastic twins of the two-state systems run on the fused-phase
+  kernel with the block form of the matrix-core sweep (hs_solver_fused.h: riccati_mfma_gen) instead of round 2's wavefront kernel and its
+  column-per-lane vector sweep.  The library says so (myr_solve_plan), and both kernels walk the same path: same status and iteration
+  count, iterates that agree -- to convergence where there is an optimum, over a fixed number of iterations where there is none
+  (ROCKETLANDING, and the twins that stop at a cap)."""
+  from myriad_amd import _lib
+  from oracle import myriad_oracle as O
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  twin = name.endswith("_ELASTIC")
+  s = O.Elastic(O.SYSTEMS[name[:-8]](), 1.0) if twin else O.SYSTEMS[name]()
+  tr = O.hermite_simpson(s, N) if rule == "HERMITE_SIMPSON" else O.trapezoidal(s, N)
+  if twin and rule == "TRAPEZOIDAL": lim = min(lim, 8)      # (the trapezoidal twins stop at their cap on this problem in every kernel: compare the path)
+  rng = np.random.default_rng(11)
+  B = 6
+  z0 = np.tile(tr.guess, (B, 1))
+  lb, ub = np.tile(tr.bounds[:, 0], (B, 1)), np.tile(tr.bounds[:, 1], (B, 1))
+  x0 = z0[:, :s.ns] * (1.0 + 0.02 * rng.standard_normal((B, s.ns)))     # perturbed start states (pinned through their bounds)
+  z0[:, :s.ns] = x0; lb[:, :s.ns] = x0; ub[:, :s.ns] = x0
+  res = {}
+  for mode in ("wave", "wave1"):
+    monkeypatch.setenv("MYRIAD_SOLVE_MODE", mode)
+    eng = _lib.Engine(name, rule, N, s.T)
+    o = eng.default_opts(); o.restoration = 0; o.max_iter = lim
+    res[mode] = eng.solve(z0, lb, ub, params=s.params() if twin else None, opts=o)
+    res[mode]["plan"] = eng.solve_plan()
+    eng.close()
+  f, w = res["wave"], res["wave1"]
+  if not twin:      # (a twin's solves are the restoration's, not "the" solve of a handle: no plan is recorded for them)
+    assert f["plan"]["form"] == "fused" and f["plan"]["waves_per_trajectory"] == 1 and w["plan"]["form"] == "wave"
+  assert np.array_equal(f["status"], w["status"]) and np.array_equal(f["iters"], w["iters"]), (f["status"], w["status"], f["iters"], w["iters"])
+  if lim == 300:
+    assert (f["status"] == 0).all(), (f["status"], f["iters"])
+  fin = np.isfinite(w["z"])
+  assert np.array_equal(np.isfinite(f["z"]), fin)
+  d = np.abs(f["z"] - w["z"])[fin] / np.maximum(1.0, np.abs(w["z"])[fin])
+  assert d.max(initial=0.0) <= 1e-6, d.max()
+  np.testing.assert_allclose(f["cost"], w["cost"], rtol=1e-8, atol=1e-12)
