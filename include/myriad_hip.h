@@ -60,8 +60,8 @@ enum { MYR_SYS_CARTPOLE = 0, MYR_SYS_VANDERPOL = 1, MYR_SYS_CANCERTREATMENT = 2,
        /* ELASTIC twins (100 + id; no counterpart in the reference -- the feasibility-restoration device of the solver, DESIGN.md
           "Elastic mode"): x' = f(x,u) + s with NS slack controls s appended to u and the running cost g + rho/2 |s|^2, rho the
           LAST model parameter.  All entry points work on them like on any system (NU = nu + ns controls), except myr_solve under
-          MYR_TR_SHOOTING (every twin) and under MYR_TR_TRAPEZOIDAL for twins with more than 9 variables per point
-          (ROCKETLANDING's): MYR_E_UNSUPPORTED, "... not built".  Every system with pinned terminal states has one (round 4). */
+          MYR_TR_SHOOTING (every twin): MYR_E_UNSUPPORTED, "... built for the collocation transcriptions".  (Up to round 4 ROCKETLANDING's
+          twin had no trapezoidal solver either.)  Every system with pinned terminal states has one (round 4). */
        MYR_SYS_CARTPOLE_ELASTIC = 100, MYR_SYS_VANDERPOL_ELASTIC = 101, MYR_SYS_PENDULUM_ELASTIC = 113, MYR_SYS_MOUNTAINCAR_ELASTIC = 114,
        MYR_SYS_ROCKETLANDING_ELASTIC = 115,
        /* lenhart/invasive_plant.py: DISCRETE-time (five foci, five controls).  Only myr_fbsm (its discrete recurrences)

@@ -128,7 +128,6 @@ struct HsFused {
   static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = TRAP ? NS + 2 * NU : D::NY, NQ = TRAP ? NU : D::NQ, NC = D::NC, NY1 = NY + 1;
   static constexpr int QE = NQ - NU;
   static constexpr int MLAM = TRAP ? 1 : 2;        // multiplier blocks (NS each) per interval
-  static constexpr bool SUPPORTED = (NU == 1 && NS <= 4) || (NS + NU <= 8 && (TRAP ? 1 : 2) * NU <= 6 && 16 - (NS + NU) - (TRAP ? 1 : 2) * NU >= 2);      // riccati_mfma / riccati_mfma_gen
   // Network dynamics (config 5, node_system.h): f, A, B of ALL points come from the matrix-core pass of node_mfma.h (MODE 1, every
   // wavefront of the workgroup takes every W-th tile of 16 points) into a global record the backward pass reads instead of calling
   // Sys::lin; MODE 2 delivers the multiplier-contracted second derivatives for the hessian pass, MODE 0 the values for the trials
@@ -1286,35 +1285,46 @@ struct HsFused {
     wave_sync<true>();
     return riccati_first_point(c, o, delta, nreg);
   }
-  // ---- The sweep for WIDER stages on the matrix pipe (round 5): two controls (BEARPOPULATIONS, ROCKETLANDING: six states) and the elastic twins of
-  // the two-state systems (three controls).  riccati_mfma above lives on one hand-placed 16x16 tile (NS <= 4, one control, the selector rows of G^
-  // done by lane shifts); here a stage is a small block algebra over 16x16 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64 (element (i,j)
-  // of a tile in lane 16 (i%4) + j, register i/4), built on two facts about that layout:
+  // ---- The sweep for WIDER stages on the matrix pipe (round 5): two controls (BEARPOPULATIONS, ROCKETLANDING: six states) and the elastic twins
+  // (nu + ns controls).  riccati_mfma above lives on one hand-placed 16x16 tile (NS <= 4, one control, the selector rows of G^ done by lane
+  // shifts); here a stage is a small block algebra over 16x16 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64 (element (i,j) of a tile
+  // in lane 16 (i%4) + j, register i/4), built on two facts about that layout:
   //   * register r of a tile M IS the B operand "rows 4r..4r+3 of M" and ALSO the A operand "columns 4r..4r+3 of M^T": for two tiles in this layout
   //     M^T Y = sum_r mfma(M[r], Y[r]) -- both products of a stage (R~ = P'^T [G^|g^] + [0|pc'],  [Q|qc] = [Qm|qcm] + G^^T R~) chain without moving
   //     a value between lanes (P' is symmetric), and so does the Schur step [P|pc] = Q - Qq^T K with A = the q rows of Q itself;
-  //   * rows and columns share ONE slot map: w = (dx_s, du_s) in slots 0..NW-1, the eliminated controls q = (du_m, du_e) in slots 8..8+NQ-1 (a
-  //     register of their own: ONE three-swap all-gather over the four lane groups hands every lane its column's q entries for the per-lane
-  //     L D L^T solve, pivots by v_readlane), the right-hand sides ("1", mu, nu_1..nu_NS) in the slots left over, spilling into a second column
-  //     tile when there are more than 16 (ROCKETLANDING: 8 + 4 + 8 = 20).  As in riccati_mfma the dual bookkeeping rows (g^T pc' in row "1",
-  //     -qc_q^T kc in rows nu_i) fall out of the same products as rows that are otherwise unused, and ride along in the accumulator.
-  // Same stage algebra, pivot rule and outputs (gains K | kc per stage; P, pc, Tnu for the first point) as HsWave::riccati, whose general
-  // column-per-lane vector form these systems ran on up to round 4.  Per stage (Hermite-Simpson): BEARPOPULATIONS 9 matrix instructions,
+  //   * rows and columns share ONE slot map: w = (dx_s, du_s) in slots 0..NW-1; the eliminated controls q = (du_m, du_e) in registers of their own
+  //     -- slots 8.. of the first tile while w and q fit eight slots each, else a tile of their own (the twins of CARTPOLE and ROCKETLANDING: 10 and
+  //     16 of them) -- so that ONE three-swap all-gather over the four lane groups hands every lane the four q entries of its column that a
+  //     register holds; the right-hand sides ("1", mu, nu_1..nu_NS) in the slots left over, spilling into a further column tile if need be.
+  // The q are eliminated FOUR AT A TIME (one register of q rows): gather, 4x4 pivot block by v_readlane, per-lane L D L^T solve, Schur update of
+  // every row that is still alive -- w, the later q, the bookkeeping rows -- by one matrix instruction per tile; the gains of a block then refer
+  // to the later q as well, which a back-substitution over the blocks removes (v_readlane of the 4x4 coupling blocks, per-lane products).  No
+  // factor of the whole NQ x NQ block is ever held (136 + 16 doubles per lane for ROCKETLANDING's twin in the vector form).  As in riccati_mfma
+  // the dual bookkeeping rows (g^T pc' in row "1", -qc_q^T kc in rows nu_i) fall out of the same products as rows that are otherwise unused.
+  // Same stage algebra, pivot order and rule, and outputs (gains K | kc per stage; P, pc, Tnu for the first point) as HsWave::riccati, whose
+  // column-per-lane vector form these systems ran on up to round 4.  Matrix instructions per Hermite-Simpson stage: BEARPOPULATIONS 9,
   // ROCKETLANDING 18; no LDS, no barrier.
   static constexpr bool GEN = !(NU == 1 && NS <= 4);
-  static constexpr int G_NB = (NW + 3) / 4, G_NQB = (NQ + 3) / 4, G_QB = 8;
-  static constexpr int G_FREE_LO = NW <= 8 ? 8 - NW : 0, G_FREE_HI = NQ <= 8 ? 8 - NQ : 0;
-  static constexpr int G_CT = (NC > G_FREE_LO + G_FREE_HI) ? 2 : 1;
-  static constexpr bool GEN_OK = NW <= 8 && NQ <= 8 && G_FREE_LO + G_FREE_HI >= 2 && NC - G_FREE_LO - G_FREE_HI <= 16;
+  static constexpr bool G_BIG = NW > 8 || NQ > 8;
+  static constexpr int G_QT = G_BIG ? 1 : 0;                  // column / row tile of the q slots
+  static constexpr int G_QS = G_BIG ? 16 : 8;                 // first q slot (w: slots 0 .. NW-1 in front of it)
+  static constexpr int G_NB = (NW + 3) / 4, G_NQB = (NQ + 3) / 4, G_NYT = G_QT + 1;
+  static constexpr int G_FREE_LO = G_QS - NW, G_FREE_HI = 16 * (G_QT + 1) - G_QS - NQ;
+  static constexpr int G_REST = NC - G_FREE_LO - G_FREE_HI;   // right-hand sides in a tile behind the q
+  static constexpr int G_CT = G_QT + 1 + (G_REST > 0 ? 1 : 0);
+  static constexpr bool GEN_OK = NW <= 14 && NQ <= 16 && (G_BIG ? G_FREE_LO : G_FREE_LO + G_FREE_HI) >= 2 && G_FREE_HI >= 0 && G_REST <= 16;
+  static constexpr bool SUPPORTED = !GEN || GEN_OK;      // riccati_mfma / riccati_mfma_trap / riccati_mfma_gen
   __host__ __device__ static constexpr int g_rhs_slot(int cc) {
-    return cc < G_FREE_LO ? NW + cc : (cc - G_FREE_LO < G_FREE_HI ? G_QB + NQ + (cc - G_FREE_LO) : 16 + (cc - G_FREE_LO - G_FREE_HI));
+    return cc < G_FREE_LO ? NW + cc : (cc - G_FREE_LO < G_FREE_HI ? G_QS + NQ + (cc - G_FREE_LO) : 16 * (G_QT + 1) + (cc - G_FREE_LO - G_FREE_HI));
   }
   __host__ __device__ static constexpr int g_slot_cc(int slot) {
-    if (slot < NW) return -1;
-    if (slot < 8) return slot - NW < NC ? slot - NW : -1;
-    if (slot < G_QB + NQ) return -1;
-    if (slot < 16) return G_FREE_LO + (slot - G_QB - NQ) < NC ? G_FREE_LO + (slot - G_QB - NQ) : -1;
-    return G_FREE_LO + G_FREE_HI + (slot - 16) < NC ? G_FREE_LO + G_FREE_HI + (slot - 16) : -1;
+    int cc = -1;
+    if (slot < NW) cc = -1;
+    else if (slot < G_QS) cc = slot - NW;
+    else if (slot < G_QS + NQ) cc = -1;
+    else if (slot < 16 * (G_QT + 1)) cc = G_FREE_LO + (slot - G_QS - NQ);
+    else cc = G_FREE_LO + G_FREE_HI + (slot - 16 * (G_QT + 1));
+    return cc < NC ? cc : -1;
   }
   // every lane group <- the values of lane groups 0..3 (same lane within the group): v_permlane32_swap, then v_permlane16_swap twice
   __device__ static inline void gather4(double x, double* o) {
@@ -1331,29 +1341,34 @@ struct HsFused {
   }
   __device__ static int riccati_mfma_gen(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
     using namespace detail;
-    static_assert(GEN_OK, "slot map: w in 0..7, q in 8..15, '1' and mu in the first column tile");
-    constexpr int NB = G_NB, NQB = G_NQB, CT = G_CT, QB = G_QB;
-    constexpr int NL = (TRAP ? 2 : 4) * NB;           // loads per lane and stage: H_e, G_e (, H_m, G_m), NB registers each
-    constexpr int L_HE = 0, L_GE = NB, L_HM = 2 * NB, L_GM = 3 * NB;
+    static_assert(GEN_OK, "slot map: w in front of the q, '1' and mu in the first column tile");
+    constexpr int NB = G_NB, NQB = G_NQB, CT = G_CT, QT = G_QT, NYT = G_NYT;
+    constexpr int QL = G_QS & 15;                     // first q lane / row inside its tile
+    constexpr int QR = QL / 4;                        // ... and its first register
+    constexpr int PFG = G_BIG ? 2 : PF;               // prefetch depth (<= PF: the padding in front of hr / st covers it)
+    constexpr int NL1 = NB * (1 + NYT);               // loads per lane and stage half: H (first tile), G (every y tile), NB registers each
+    constexpr int NL = (TRAP ? 1 : 2) * NL1;
+    constexpr int L_HE = 0, L_GE = NB, L_HM = NL1, L_GM = NL1 + NB;
     constexpr long H_STEP = TRAP ? (long)HR_N : 2L * HR_N;
     const int lane = c.lane, N = c.N;
     const int g = lane >> 4, j = lane & 15;
     // this lane's column in column tile C: a w component, an eliminated control, a right-hand side, or nothing
-    int wc[CT], qc[CT], rc[CT];
+    int wc[CT], qc[CT], rc[CT], yc[NYT];
 #pragma unroll
     for (int C = 0; C < CT; ++C) {
       const int slot = 16 * C + j;
       wc[C] = slot < NW ? slot : -1;
-      qc[C] = (slot >= QB && slot < QB + NQ) ? slot - QB : -1;
+      qc[C] = (slot >= G_QS && slot < G_QS + NQ) ? slot - G_QS : -1;
       rc[C] = g_slot_cc(slot);
     }
-    const int yc = wc[0] >= 0 ? wc[0] : (qc[0] >= 0 ? NW + qc[0] : -1);      // component of y (first column tile holds all of y)
+#pragma unroll
+    for (int C = 0; C < NYT; ++C) yc[C] = wc[C] >= 0 ? wc[C] : (qc[C] >= 0 ? NW + qc[C] : -1);      // component of y
     const double* he = c.hr + (TRAP ? (long)N * HR_N : (long)(2 * (N - 1) + 2) * HR_N);
     const double* hm = he - HR_N;
     const double* st = c.st + (long)(N - 1) * SG_N;
     const double* ptr[NL];
     long stp[NL];
-    double gce[NB], gcm[NB], mWrow[NB], dv[NB];
+    double gce[NYT][NB], gcm[NYT][NB], mWrow[NB], dv[NB];
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
       const int row = 4 * r + g;
@@ -1364,34 +1379,38 @@ struct HsFused {
         if (rc[0] == 1) return rec + HR_G1 + row;
         return c.zr;
       };
-      auto gsel = [&](int off) -> const double* {
+      auto gsel = [&](int off, int C) -> const double* {
         if (row >= NS) return c.zr;
-        if (yc >= 0) return st + off + row * NY1 + yc;
-        if (rc[0] == 0) return st + off + row * NY1 + NY;
+        if (yc[C] >= 0) return st + off + row * NY1 + yc[C];
+        if (rc[C] == 0) return st + off + row * NY1 + NY;
         return c.zr;
       };
       ptr[L_HE + r] = hsel(he);
-      ptr[L_GE + r] = gsel(SG_GE);
-      if constexpr (!TRAP) { ptr[L_HM + r] = hsel(hm); ptr[L_GM + r] = gsel(SG_GM); }
+      if constexpr (!TRAP) ptr[L_HM + r] = hsel(hm);
       // selector rows of G^ (row NS + a picks du_e[a]) and of G^m (picks du_m[a]): constants
       const int a = row - NS;
-      gce[r] = (a >= 0 && a < NU && qc[0] == (TRAP ? a : NU + a)) ? 1.0 : 0.0;
-      gcm[r] = (a >= 0 && a < NU && qc[0] == a) ? 1.0 : 0.0;
+#pragma unroll
+      for (int C = 0; C < NYT; ++C) {
+        ptr[L_GE + C * NB + r] = gsel(SG_GE, C);
+        if constexpr (!TRAP) ptr[L_GM + C * NB + r] = gsel(SG_GM, C);
+        gce[C][r] = (a >= 0 && a < NU && qc[C] == (TRAP ? a : NU + a)) ? 1.0 : 0.0;
+        gcm[C][r] = (a >= 0 && a < NU && qc[C] == a) ? 1.0 : 0.0;
+      }
       mWrow[r] = row < NW ? 1.0 : 0.0;
       dv[r] = (row < NW && wc[0] == row) ? delta : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < NL; ++q) stp[q] = (ptr[q] == c.zr) ? 0 : (((q / NB) & 1) ? (long)SG_N : H_STEP);
+    for (int q = 0; q < NL; ++q) stp[q] = (ptr[q] == c.zr) ? 0 : (((q % NL1) < NB) ? H_STEP : (long)SG_N);
     const double mWcol = wc[0] >= 0 ? 1.0 : 0.0;
-    double mRhs[CT], mA3[CT], mTrow[4];
+    double mRhs[CT], mA3[CT], mTrow[CT][4];
 #pragma unroll
     for (int C = 0; C < CT; ++C) {
       mRhs[C] = rc[C] >= 0 ? 1.0 : 0.0;
-      mA3[C] = (wc[C] >= 0 || rc[C] >= 2) ? -1.0 : 0.0;       // output rows of the Schur step: w, and the nu rows of the bookkeeping
-    }
+      mA3[C] = (wc[C] >= 0 || rc[C] >= 2) ? -1.0 : 0.0;       // output rows of a Schur step: w, the nu rows of the bookkeeping (and the later q: below)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int cc = g_slot_cc(4 * r + g); mTrow[r] = (cc == 0 || cc >= 2) ? 1.0 : 0.0; }
-    // gains: lane group g stores rows g, g + 4 of its column
+      for (int r = 0; r < 4; ++r) { const int cc = g_slot_cc(16 * C + 4 * r + g); mTrow[C][r] = (cc == 0 || cc >= 2) ? 1.0 : 0.0; }
+    }
+    // gains: lane group g stores rows g, g + 4, .. of its column
     double* kp[CT][NQB];
     long kstep[CT][NQB];
 #pragma unroll
@@ -1406,113 +1425,158 @@ struct HsFused {
     double reg_floor = o.reg_floor;
     asm volatile("" : "+v"(reg_floor));
     int nreg = 0;
-    mfma_d4 D3[CT][CT];
+    mfma_d4 Q[CT][CT];          // the stage's matrix; between stages: [P | pc] in the w rows, the bookkeeping in its rows
 #pragma unroll
     for (int R = 0; R < CT; ++R)
 #pragma unroll
-      for (int C = 0; C < CT; ++C) D3[R][C] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+      for (int C = 0; C < CT; ++C) Q[R][C] = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int C = 0; C < CT; ++C)
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
         const int row = 4 * r + g;
         const bool pin = row < NS && c.term_pinned[row < NS ? row : 0];
-        D3[0][C][r] = (pin && wc[C] == row) ? o.rho_term - delta : ((pin && rc[C] == 2 + row) ? 1.0 : 0.0);
+        Q[0][C][r] = (pin && wc[C] == row) ? o.rho_term - delta : ((pin && rc[C] == 2 + row) ? 1.0 : 0.0);
       }
-    double in[PF][NL];
+    double in[PFG][NL];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
+    for (int u = 0; u < PFG; ++u) {
 #pragma unroll
       for (int q = 0; q < NL; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
     }
-    // midpoint part of a stage: [Qm | qcm] = G^m^T ((H_m + delta I) [G^m | g^m] + [0 | g0_m g1_m]) -- first column tile only
-    auto mid_part = [&](const double* v) -> mfma_d4 {
-      mfma_d4 R = {0.0, 0.0, 0.0, 0.0};
-      double X[NB];
+    // midpoint part of a stage: [Qm | qcm] = G^m^T ((H_m + delta I) [G^m | g^m] + [0 | g0_m g1_m]) -- the y tiles only
+    struct MidT { mfma_d4 t[NYT][NYT]; };
+    auto mid_part = [&](const double* v) -> MidT {
+      MidT M;
+      mfma_d4 R[NYT];
+      double X[NB], Gm[NYT][NB];
 #pragma unroll
-      for (int r = 0; r < NB; ++r) { X[r] = v[L_HM + r] + dv[r]; R[r] = X[r] * mRhs[0]; }
+      for (int r = 0; r < NB; ++r) X[r] = v[L_HM + r] + dv[r];
 #pragma unroll
-      for (int r = 0; r < NB; ++r) R = __builtin_amdgcn_mfma_f64_16x16x4f64(X[r] * mWcol, v[L_GM + r] + gcm[r], R, 0, 0, 0);
-      mfma_d4 Q = {0.0, 0.0, 0.0, 0.0};
+      for (int C = 0; C < NYT; ++C) {
+        R[C] = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int r = 0; r < NB; ++r) Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v[L_GM + r] + gcm[r], R[r], Q, 0, 0, 0);
-      return Q;
+        for (int r = 0; r < NB; ++r) { Gm[C][r] = v[L_GM + C * NB + r] + gcm[C][r]; if (C == 0) R[C][r] = X[r] * mRhs[0]; }
+#pragma unroll
+        for (int r = 0; r < NB; ++r) R[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[r] * mWcol, Gm[C][r], R[C], 0, 0, 0);
+      }
+#pragma unroll
+      for (int Rr = 0; Rr < NYT; ++Rr)
+#pragma unroll
+        for (int C = 0; C < NYT; ++C) {
+          M.t[Rr][C] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int r = 0; r < NB; ++r) M.t[Rr][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gm[Rr][r], R[C][r], M.t[Rr][C], 0, 0, 0);
+        }
+      return M;
     };
-    mfma_d4 Qm = {0.0, 0.0, 0.0, 0.0};
+    MidT Qm{};
     if constexpr (!TRAP) Qm = mid_part(in[0]);
-    for (int kb = N - 1; kb >= 0; kb -= PF) {
+    for (int kb = N - 1; kb >= 0; kb -= PFG) {
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
+      for (int u = 0; u < PFG; ++u) {
         const int k = kb - u;
         if (k < 0) break;
-        double X[CT][NB], G[NB], nmid[NL];
+        double X[CT][NB], G[NYT][NB], nmid[NL];
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-          X[0][r] = fma(D3[0][0][r], mWrow[r], in[u][L_HE + r] + dv[r]);
-          if constexpr (CT > 1) X[CT - 1][r] = D3[0][CT - 1][r] * mWrow[r];
-          G[r] = in[u][L_GE + r] + gce[r];
+          X[0][r] = fma(Q[0][0][r], mWrow[r], in[u][L_HE + r] + dv[r]);
+#pragma unroll
+          for (int C = 1; C < CT; ++C) X[C][r] = Q[0][C][r] * mWrow[r];
+#pragma unroll
+          for (int C = 0; C < NYT; ++C) G[C][r] = in[u][L_GE + C * NB + r] + gce[C][r];
         }
         if constexpr (!TRAP) {
 #pragma unroll
-          for (int q = 0; q < NL; ++q) nmid[q] = in[(u + 1) % PF][q];
+          for (int q = 0; q < NL; ++q) nmid[q] = in[(u + 1) % PFG][q];
         }
 #pragma unroll
         for (int q = 0; q < NL; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
-        // R~ = P'^T [G^ | g^] + [0 | pc']: rows w; the second column tile holds right-hand sides only (G^ has no column there)
+        // R~ = P'^T [G^ | g^] + [0 | pc']: rows w; a column tile behind the y tiles holds right-hand sides only (G^ has no column there)
         mfma_d4 Rt[CT];
 #pragma unroll
         for (int C = 0; C < CT; ++C) {
           Rt[C] = mfma_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int r = 0; r < NB; ++r) Rt[C][r] = X[C][r] * mRhs[C];
+          if (C < NYT) {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) Rt[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[0][r] * mWcol, G[C < NYT ? C : 0][r], Rt[C], 0, 0, 0);
+          }
         }
+        // [Q | qc] = [Qm | qcm] + G^^T R~, on top of the bookkeeping rows carried from the stage above (a row tile behind the y tiles: those only)
 #pragma unroll
-        for (int r = 0; r < NB; ++r) Rt[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[0][r] * mWcol, G[r], Rt[0], 0, 0, 0);
-        // [Q | qc] = [Qm | qcm] + G^^T R~, on top of the bookkeeping rows carried from the stage above
-        mfma_d4 Q[CT][CT];
+        for (int R = 0; R < NYT; ++R)
 #pragma unroll
-        for (int C = 0; C < CT; ++C) {
+          for (int C = 0; C < CT; ++C) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Q[0][C][r] = (C == 0) ? fma(D3[0][C][r], mTrow[r], Qm[r]) : D3[0][C][r] * mTrow[r];
+            for (int r = 0; r < 4; ++r) Q[R][C][r] = (!TRAP && C < NYT) ? fma(Q[R][C][r], mTrow[R][r], Qm.t[R][C < NYT ? C : 0][r]) : Q[R][C][r] * mTrow[R][r];
 #pragma unroll
-          for (int r = 0; r < NB; ++r) Q[0][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(G[r], Rt[C][r], Q[0][C], 0, 0, 0);
-          if constexpr (CT > 1) Q[CT - 1][C] = D3[CT - 1][C];
-        }
+            for (int r = 0; r < NB; ++r) Q[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(G[R][r], Rt[C][r], Q[R][C], 0, 0, 0);
+          }
         // the midpoint part of stage k - 1 does not depend on the recursion: issued here, it runs while the vector pipe solves for the gains
         if constexpr (!TRAP) Qm = mid_part(nmid);
-        // every lane <- the q entries of its column(s); pivot block by v_readlane (column 8 + u sits in lanes 8 + u of the first tile)
+        // eliminate the q four at a time
         double kk[CT][4 * NQB];
+#pragma unroll
+        for (int b = 0; b < NQB; ++b) {
+          const int nbq = (NQ - 4 * b) < 4 ? (NQ - 4 * b) : 4;      // (compile-time after unrolling)
+#pragma unroll
+          for (int C = 0; C < CT; ++C) gather4(Q[QT][C][QR + b], &kk[C][4 * b]);
+          double Lq[16], dinv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q <= r; ++q) Lq[r * 4 + q] = (r < nbq) ? W0::rdlane(kk[QT][4 * b + r], QL + 4 * b + q) : (r == q ? 1.0 : 0.0);
+          nreg += ldl_reg<4>(Lq, dinv, reg_floor);
+          if (nreg > 0 && abort_on_reg) return nreg;
+          const double mQ = (qc[QT] >= 4 * (b + 1)) ? -1.0 : 0.0;       // ... and the q rows that are still alive
+#pragma unroll
+          for (int C = 0; C < CT; ++C) {
+#pragma unroll
+            for (int e = nbq; e < 4; ++e) kk[C][4 * b + e] = 0.0;
+            ldl_solve<4>(Lq, dinv, &kk[C][4 * b]);
+            double B3 = 0.0;                      // row 4 b + g of this block's gains (rows past NQ: zero)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < nbq) B3 = (g == e) ? kk[C][4 * b + e] : B3;
+#pragma unroll
+            for (int R = 0; R < CT; ++R) {
+              if (R == QT && b == NQB - 1 && G_FREE_HI == 0 && QT > 0) continue;      // a tile of q rows only, none of them alive
+              const double A3 = Q[QT][R][QR + b] * (R == QT ? (mA3[R] + mQ) : mA3[R]);
+              Q[R][C] = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, B3, Q[R][C], 0, 0, 0);
+            }
+          }
+        }
+        // the gains of block b refer to the q of the blocks behind it: substitute those (final ones) -- K_b <- K_b - K_b[:, q_b'] K_b'
+#pragma unroll
+        for (int b = NQB - 2; b >= 0; --b) {
+          double m[4][4 * NQB];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 4 * (b + 1); e < NQ; ++e) m[t][e] = W0::rdlane(kk[QT][4 * b + t], QL + e);
+#pragma unroll
+          for (int C = 0; C < CT; ++C)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              double s = kk[C][4 * b + t];
+#pragma unroll
+              for (int e = 4 * (b + 1); e < NQ; ++e) s = fma(-m[t][e], kk[C][e], s);
+              kk[C][4 * b + t] = s;
+            }
+        }
 #pragma unroll
         for (int C = 0; C < CT; ++C)
 #pragma unroll
-          for (int b = 0; b < NQB; ++b) gather4(Q[0][C][2 + b], &kk[C][4 * b]);
-        double Lq[NQ * NQ], dinv[NQ];
-#pragma unroll
-        for (int r = 0; r < NQ; ++r)
-#pragma unroll
-          for (int q = 0; q <= r; ++q) Lq[r * NQ + q] = W0::rdlane(kk[0][r], QB + q);
-        nreg += ldl_reg<NQ>(Lq, dinv, reg_floor);
-        if (nreg > 0 && abort_on_reg) return nreg;
-#pragma unroll
-        for (int C = 0; C < CT; ++C) {
-          ldl_solve<NQ>(Lq, dinv, kk[C]);
-          mfma_d4 acc[CT];
-#pragma unroll
-          for (int R = 0; R < CT; ++R) acc[R] = Q[R][C];
-#pragma unroll
           for (int b = 0; b < NQB; ++b) {
-            double B3 = 0.0;                      // row 4 b + g of the gains (rows past NQ: zero)
+            double v = 0.0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (4 * b + e < NQ) B3 = (g == e) ? kk[C][4 * b + e] : B3;
-            kp[C][b][0] = B3;
+              if (4 * b + e < NQ) v = (g == e) ? kk[C][4 * b + e] : v;
+            kp[C][b][0] = v;
             kp[C][b] -= kstep[C][b];
-#pragma unroll
-            for (int R = 0; R < CT; ++R) acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(Q[0][R][2 + b] * mA3[R], B3, acc[R], 0, 0, 0);
           }
-#pragma unroll
-          for (int R = 0; R < CT; ++R) D3[R][C] = acc[R];
-        }
       }
     }
     // P, pc, Tnu -> LDS for the first point
@@ -1521,15 +1585,15 @@ struct HsFused {
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
         const int row = 4 * r + g;
-        if (row < NW && wc[C] >= 0) c.sP[row * NW + wc[C]] = D3[0][C][r];
-        if (row < NW && rc[C] >= 0) c.sPc[row * NC + rc[C]] = D3[0][C][r];
+        if (row < NW && wc[C] >= 0) c.sP[row * NW + wc[C]] = Q[0][C][r];
+        if (row < NW && rc[C] >= 0) c.sPc[row * NC + rc[C]] = Q[0][C][r];
       }
 #pragma unroll
       for (int R = 0; R < CT; ++R)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int cc = g_slot_cc(16 * R + 4 * r + g);
-          if (cc >= 2 && rc[C] >= 0) c.sTnu[(cc - 2) * NC + rc[C]] = D3[R][C][r];
+          if (cc >= 2 && rc[C] >= 0) c.sTnu[(cc - 2) * NC + rc[C]] = Q[R][C][r];
         }
     }
     wave_sync<true>();
@@ -1538,7 +1602,7 @@ struct HsFused {
       static_assert(s1 < 16, "row '1' in the first tile");
 #pragma unroll
       for (int C = 0; C < CT; ++C)
-        if (g == (s1 & 3) && rc[C] >= 2) c.sTnu[(rc[C] - 2) * NC + 0] += D3[0][C][s1 >> 2];
+        if (g == (s1 & 3) && rc[C] >= 2) c.sTnu[(rc[C] - 2) * NC + 0] += Q[0][C][s1 >> 2];
     }
     wave_sync<true>();
     return riccati_first_point(c, o, delta, nreg);

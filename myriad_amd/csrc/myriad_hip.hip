@@ -744,7 +744,7 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   const myr_dims& dm = h->dims;
   // one trajectory per wavefront while its LDS working set fits a CU (N <= ~480 for CARTPOLE); beyond that the
   // lane-per-trajectory form, which keeps everything in global scratch, takes over
-  if constexpr (HsFused<Sys>::SUPPORTED && !(SCHEME == 1 && NodeTraits<Sys>::mlp)) {
+  if constexpr (HsFused<Sys, 1, SCHEME>::SUPPORTED && !(SCHEME == 1 && NodeTraits<Sys>::mlp)) {
     if (h->solve_mode == 1 && h->solve_fused && HsFused<Sys, (NodeTraits<Sys>::mlp ? 4 : 1), SCHEME>::lds_bytes(N) <= 160 * 1024)
       return launch_hs_fused<Sys, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
@@ -753,6 +753,10 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
   // ended in NaN.  Fixed in HsWave::riccati (H_PTS); MYRIAD_TRAP_GENERAL_WAVE=0 sends those systems to the lane form again.)
   static const bool trap_general_wave = [] { const char* e = getenv("MYRIAD_TRAP_GENERAL_WAVE"); return !(e && atoi(e) == 0); }();
   const bool wave_ok = !(SCHEME == 1 && !(Sys::NU == 1 && Sys::NS <= 4)) || trap_general_wave;
+  // (ROCKETLANDING's twin, 14 variables per point: round 2's kernel -- minutes of build time, a 16 x 16 factor per lane and stage -- is not built any more
+  //  now that the fused kernel serves it; beyond the fused kernel's LDS limit it runs on the lane kernel)
+  constexpr bool round2_built = !(Sys::ID >= 100 && Sys::NW > 9 && HsFused<Sys, 1, SCHEME>::SUPPORTED);
+  if constexpr (round2_built)
   if (wave_ok)
   if (h->solve_mode == 1 && HsWave<Sys, SCHEME>::lds_bytes(N) <= 160 * 1024) {
     using W = HsWave<Sys, SCHEME>;
@@ -935,8 +939,8 @@ int solve_for_system(myr_handle h, int B, double* z, const double* lb, const dou
     case MYR_TR_HERMITE_SIMPSON:
       return launch_hs_solve<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     case MYR_TR_TRAPEZOIDAL:     // wavefront form (falls back to the lane form for MYRIAD_SOLVE_MODE=lane / very large N)
-      // (the twin of ROCKETLANDING -- 14 variables per point -- costs minutes of build time per solver: its trapezoidal one is not built)
-      if constexpr (Sys::ID >= 100 && Sys::NW > 9) return fail(MYR_E_UNSUPPORTED, "myr_solve: the trapezoidal solver of this elastic twin is not built");
+      // (a twin too wide for the fused kernel's block sweep would cost minutes of build time per solver on round 2's kernel: refused; no twin is, since round 5)
+      if constexpr (Sys::ID >= 100 && Sys::NW > 9 && !HsFused<Sys, 1, 1>::SUPPORTED) return fail(MYR_E_UNSUPPORTED, "myr_solve: the trapezoidal solver of this elastic twin is not built");
       else return launch_hs_solve<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     case MYR_TR_SHOOTING:
       // elastic twins (id >= 100) exist for the collocation solvers, whose restoration device they are; their shooting solver is not built

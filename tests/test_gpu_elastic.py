@@ -176,13 +176,14 @@ def test_rocketlanding_converges_or_is_reported_infeasible():
     assert np.abs(opt.constraints(r["xs_and_us"][0])).max() <= 1e-6
 
 
-def test_twin_without_a_trapezoidal_solver_is_skipped_not_raised():
-  """ROCKETLANDING's twin (14 variables per point) has no trapezoidal solver in the library (myr_solve: UNSUPPORTED, "not built");
-  the elastic phase is then skipped for that optimizer and the second starts take over -- nothing is raised."""
-  hp, opt = _opt("ROCKETLANDING", rule="TRAPEZOIDAL", N=20, max_iter=100)
+def test_rocketlanding_trapezoidal_goes_through_the_elastic_phase_too():
+  """ROCKETLANDING's twin (14 variables per point, 8 eliminated controls per trapezoidal stage) had no trapezoidal solver up to round 4 -- minutes of
+  build time on round 2's kernel -- and the phase was skipped for that optimizer.  On the fused kernel's block sweep it is built: the phase runs (three
+  twin solves and the problem itself again), and the outcome is a verdict as under Hermite-Simpson."""
+  hp, opt = _opt("ROCKETLANDING", rule="TRAPEZOIDAL", N=20, max_iter=300)
   r = opt.solve_batch()
-  assert r["restored"][0] == 0 and r["status"][0] in (0, 1, 2, 3)
-  assert r["attempts"][0] == 1 + 3 and np.isfinite(r["xs_and_us"]).all()
+  assert r["attempts"][0] >= 1 + 4 and np.isfinite(r["xs_and_us"]).all(), (r["attempts"], r["status"])
+  assert r["status"][0] in (0, 1, _lib.STATUS_INFEASIBLE), (r["status"], r["iters"], r["kkt"])
   eng = _lib.Engine("ROCKETLANDING_ELASTIC", "TRAPEZOIDAL", 20, 16.0)
-  with pytest.raises(NotImplementedError, match="not built"):
-    eng.solve(np.zeros((1, eng.n)), -np.ones((1, eng.n)), np.ones((1, eng.n)))
+  out = eng.solve(np.zeros((1, eng.n)), -np.ones((1, eng.n)), np.ones((1, eng.n)))
+  assert np.isfinite(out["z"]).all()

@@ -428,7 +428,8 @@ def test_pendulum_swing_up_converges_under_every_transcription(kw):
 
 @pytest.mark.parametrize("rule", ["HERMITE_SIMPSON", "TRAPEZOIDAL"])
 @pytest.mark.parametrize("name,N,lim", [("BEARPOPULATIONS", 30, 300), ("BEARPOPULATIONS", 7, 300), ("ROCKETLANDING", 20, 12), ("ROCKETLANDING", 9, 6),
-                                       ("PENDULUM_ELASTIC", 20, 8), ("VANDERPOL_ELASTIC", 20, 300), ("MOUNTAINCAR_ELASTIC", 9, 8)])
+                                       ("PENDULUM_ELASTIC", 20, 8), ("VANDERPOL_ELASTIC", 20, 300), ("MOUNTAINCAR_ELASTIC", 9, 8),
+                                       ("CARTPOLE_ELASTIC", 20, 300), ("CARTPOLE_ELASTIC", 7, 6)])
 def test_wider_systems_run_on_the_fused_matrix_core_kernel(monkeypatch, name, N, lim, rule):
   """Round 5: two controls (BEARPOPULATIONS), six states (ROCKETLANDING: its right-hand sides need a second column tile, and its pinned
   terminal states exercise the bookkeeping rows there) and the three-control elastic twins of the two-state systems run on the fused-phase

@@ -35,5 +35,9 @@ if __name__ == "__main__":
   for name, rule, N, B, lim in (("BEARPOPULATIONS", "HERMITE_SIMPSON", 100, 4096, 300), ("BEARPOPULATIONS", "TRAPEZOIDAL", 100, 4096, 300),
                                 ("ROCKETLANDING", "HERMITE_SIMPSON", 100, 4096, 30), ("ROCKETLANDING", "TRAPEZOIDAL", 100, 4096, 30),
                                 ("PENDULUM_ELASTIC", "HERMITE_SIMPSON", 100, 4096, 60), ("VANDERPOL_ELASTIC", "HERMITE_SIMPSON", 100, 4096, 300),
+                                ("CARTPOLE_ELASTIC", "HERMITE_SIMPSON", 100, 4096, 60), ("CARTPOLE_ELASTIC", "TRAPEZOIDAL", 100, 4096, 60),
                                 ("BEARPOPULATIONS", "HERMITE_SIMPSON", 100, 256, 300)):
     run(name, rule, N, B, lim)
+  # ROCKETLANDING's twin: round 2's kernel is not built for it any more (MYRIAD_SOLVE_MODE=wave1 ends on the lane kernel)
+  run("ROCKETLANDING_ELASTIC", "HERMITE_SIMPSON", 100, 1024, 30)
+  run("ROCKETLANDING_ELASTIC", "TRAPEZOIDAL", 100, 1024, 30)
