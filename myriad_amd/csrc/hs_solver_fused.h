@@ -1326,6 +1326,11 @@ struct HsFused {
     else cc = G_FREE_LO + G_FREE_HI + (slot - 16 * (G_QT + 1));
     return cc < NC ? cc : -1;
   }
+  __host__ __device__ static constexpr bool g_map_ok() {      // every right-hand side has a slot of its own, "1" and mu in the first tile, all inside the tiles
+    for (int cc = 0; cc < NC; ++cc)
+      if (g_slot_cc(g_rhs_slot(cc)) != cc || g_rhs_slot(cc) >= 16 * G_CT) return false;
+    return g_rhs_slot(0) < 16 && g_rhs_slot(1) < 16;
+  }
   // every lane group <- the values of lane groups 0..3 (same lane within the group): v_permlane32_swap, then v_permlane16_swap twice
   __device__ static inline void gather4(double x, double* o) {
     const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
@@ -1341,7 +1346,7 @@ struct HsFused {
   }
   __device__ static int riccati_mfma_gen(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg) {
     using namespace detail;
-    static_assert(GEN_OK, "slot map: w in front of the q, '1' and mu in the first column tile");
+    static_assert(GEN_OK && g_map_ok(), "slot map: w in front of the q, '1' and mu in the first column tile");
     constexpr int NB = G_NB, NQB = G_NQB, CT = G_CT, QT = G_QT, NYT = G_NYT;
     constexpr int QL = G_QS & 15;                     // first q lane / row inside its tile
     constexpr int QR = QL / 4;                        // ... and its first register

@@ -524,6 +524,20 @@ template <class Core, class Sys>
 static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const double* lb, const double* ub, const double* params,
                              int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
                              int32_t* iters, double* kkt);
+#define MYR_SOLVE_ARGS myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params, int pstride, const myr_solve_opts& so, \
+                       double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt
+#define MYR_SOLVE_ARG_TYPES myr_handle, int, double*, const double*, const double*, const double*, int, const myr_solve_opts&, double*, double*, int32_t*, int32_t*, double*
+// the lane kernels of the collocation solvers as an entry point of their own (objects of their own in a split build: MYR_TU_PART 5, 6)
+template <class Sys, int SCHEME>
+int solve_lane_colloc_for_system(MYR_SOLVE_ARGS);
+#if defined(MYR_TU_SYSTEM) && defined(MYR_TU_PART)
+#if MYR_TU_PART != 5
+extern template int solve_lane_colloc_for_system<myriad::MYR_TU_SYSTEM, 0>(MYR_SOLVE_ARG_TYPES);
+#endif
+#if MYR_TU_PART != 6
+extern template int solve_lane_colloc_for_system<myriad::MYR_TU_SYSTEM, 1>(MYR_SOLVE_ARG_TYPES);
+#endif
+#endif
 
 // Resume order of a two-phase launch: parked trajectories by DESCENDING key (the geometric mean of the stationarity and the complementarity
 // residual at the parking point: rank correlation 0.9 with the iterations still to go), bucketed by half powers of two.  Three small launches.
@@ -825,11 +839,7 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     kt.launches += 1;
     return MYR_OK;
   }
-  if constexpr (SCHEME == 1)
-    return launch_lane_solve<TrapCore<Sys>, Sys>(h, B, TrapCore<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-  else {
-    return launch_lane_solve<HsSolver<Sys>, Sys>(h, B, HsSol<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-  }
+  return solve_lane_colloc_for_system<Sys, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
 }
 
 // lane-per-trajectory path, any sweep core (Hermite-Simpson, trapezoidal, shooting)
@@ -925,31 +935,56 @@ static int launch_shoot_solve(myr_handle h, int B, double* z, const double* lb, 
   return MYR_OK;
 }
 
-template <class Sys>
-int solve_for_system(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params,
-                            int pstride, const myr_solve_opts& so, double* lam, double* cost, int32_t* status,
-                            int32_t* iters, double* kkt) {
-  const int N = h->d.intervals, cpi = h->d.controls_per_interval;
-  if constexpr (Sys::PARAMS_BY_POINTER) {
-    (void)N; (void)cpi;
-    if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "myr_solve: NODE systems are built for HERMITE_SIMPSON");
-    return launch_hs_solve<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+// One function template per transcription, so that the build can give each its own object (MYR_TU_PART below: the solver kernels of a wide system
+// are minutes of compile time per scheme).
+template <class Sys, int SCHEME>
+int solve_lane_colloc_for_system(MYR_SOLVE_ARGS) {
+  const int N = h->d.intervals;
+  if constexpr (SCHEME == 1) {
+    if constexpr (Sys::PARAMS_BY_POINTER) return fail(MYR_E_UNSUPPORTED, "myr_solve: NODE systems are built for HERMITE_SIMPSON");
+    else return launch_lane_solve<TrapCore<Sys>, Sys>(h, B, TrapCore<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   } else
+    return launch_lane_solve<HsSolver<Sys>, Sys>(h, B, HsSol<Sys>::stage_doubles(N), z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+}
+template <class Sys>
+int solve_hs_for_system(MYR_SOLVE_ARGS) {
+  return launch_hs_solve<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+}
+template <class Sys>
+int solve_trap_for_system(MYR_SOLVE_ARGS) {      // wavefront form (falls back to the lane form for MYRIAD_SOLVE_MODE=lane / very large N)
+  if constexpr (Sys::PARAMS_BY_POINTER) return fail(MYR_E_UNSUPPORTED, "myr_solve: NODE systems are built for HERMITE_SIMPSON");
+  // (a twin too wide for the fused kernel's block sweep would cost minutes of build time per solver on round 2's kernel: refused; no twin is, since round 5)
+  else if constexpr (Sys::ID >= 100 && Sys::NW > 9 && !HsFused<Sys, 1, 1>::SUPPORTED) return fail(MYR_E_UNSUPPORTED, "myr_solve: the trapezoidal solver of this elastic twin is not built");
+  else return launch_hs_solve<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+}
+template <class Sys>
+int solve_shoot_for_system(MYR_SOLVE_ARGS) {
+  if constexpr (Sys::PARAMS_BY_POINTER) return fail(MYR_E_UNSUPPORTED, "myr_solve: NODE systems are built for HERMITE_SIMPSON");
+  // elastic twins (id >= 100) exist for the collocation solvers, whose restoration device they are; their shooting solver is not built
+  else if constexpr (Sys::ID >= 100) return fail(MYR_E_UNSUPPORTED, "myr_solve: elastic twins are built for the collocation transcriptions");
+  else {
+    if (h->d.integration_method == MYR_INT_RK4)
+      return launch_shoot_solve<Sys, 2>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    return launch_shoot_solve<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+  }
+}
+#if defined(MYR_TU_SYSTEM) && defined(MYR_TU_PART)      // the scheme solvers this object does not hold: no implicit instantiation
+#if MYR_TU_PART != 1
+extern template int solve_hs_for_system<myriad::MYR_TU_SYSTEM>(MYR_SOLVE_ARG_TYPES);
+#endif
+#if MYR_TU_PART != 3
+extern template int solve_trap_for_system<myriad::MYR_TU_SYSTEM>(MYR_SOLVE_ARG_TYPES);
+#endif
+#if MYR_TU_PART != 4
+extern template int solve_shoot_for_system<myriad::MYR_TU_SYSTEM>(MYR_SOLVE_ARG_TYPES);
+#endif
+#endif
+template <class Sys>
+int solve_for_system(MYR_SOLVE_ARGS) {
   switch (h->d.transcription) {
-    case MYR_TR_HERMITE_SIMPSON:
-      return launch_hs_solve<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-    case MYR_TR_TRAPEZOIDAL:     // wavefront form (falls back to the lane form for MYRIAD_SOLVE_MODE=lane / very large N)
-      // (a twin too wide for the fused kernel's block sweep would cost minutes of build time per solver on round 2's kernel: refused; no twin is, since round 5)
-      if constexpr (Sys::ID >= 100 && Sys::NW > 9 && !HsFused<Sys, 1, 1>::SUPPORTED) return fail(MYR_E_UNSUPPORTED, "myr_solve: the trapezoidal solver of this elastic twin is not built");
-      else return launch_hs_solve<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-    case MYR_TR_SHOOTING:
-      // elastic twins (id >= 100) exist for the collocation solvers, whose restoration device they are; their shooting solver is not built
-      if constexpr (Sys::ID >= 100) return fail(MYR_E_UNSUPPORTED, "myr_solve: elastic twins are built for the collocation transcriptions");
-      else {
-        if (h->d.integration_method == MYR_INT_RK4)
-          return launch_shoot_solve<Sys, 2>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-        return launch_shoot_solve<Sys, 1>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
-      }
+    case MYR_TR_HERMITE_SIMPSON: return solve_hs_for_system<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_TR_TRAPEZOIDAL: return solve_trap_for_system<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    case MYR_TR_SHOOTING: return solve_shoot_for_system<Sys>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   }
   return fail(MYR_E_ARG, "solve: unknown transcription");
 }
@@ -1014,7 +1049,30 @@ int rollout_for_system(myr_handle h, int B, int num_steps, int u_rows, const dou
   LINK template int rollout_for_system<S>(myr_handle, int, int, int, const double*, const double*, const double*, int, double*, double*); \
   LINK template int launch_fbsm<S>(myr_handle, int, long, int, const double*, const double*, const double*, int, const VarScale&,  \
                                    const VarScale&, double, double, int, double*, double*, double*, int32_t*);
-#if defined(MYR_TU_SYSTEM)
+#if defined(MYR_TU_SYSTEM) && defined(MYR_TU_PART)
+// a system's object in parts (the build splits the slow ones): -DMYR_TU_PART=1 the Hermite-Simpson wavefront solvers and the dispatch, 3 the trapezoidal
+// wavefront solvers, 4 the shooting solvers, 5 / 6 the lane kernels of the two collocation solvers, 2 everything else
+#if MYR_TU_PART == 1
+template int solve_hs_for_system<myriad::MYR_TU_SYSTEM>(MYR_SOLVE_ARG_TYPES);
+template int solve_for_system<myriad::MYR_TU_SYSTEM>(MYR_SOLVE_ARG_TYPES);
+#elif MYR_TU_PART == 3
+template int solve_trap_for_system<myriad::MYR_TU_SYSTEM>(MYR_SOLVE_ARG_TYPES);
+#elif MYR_TU_PART == 4
+template int solve_shoot_for_system<myriad::MYR_TU_SYSTEM>(MYR_SOLVE_ARG_TYPES);
+#elif MYR_TU_PART == 5
+template int solve_lane_colloc_for_system<myriad::MYR_TU_SYSTEM, 0>(MYR_SOLVE_ARG_TYPES);
+#elif MYR_TU_PART == 6
+template int solve_lane_colloc_for_system<myriad::MYR_TU_SYSTEM, 1>(MYR_SOLVE_ARG_TYPES);
+#else
+#define MYR_SYSTEM_ENTRY_POINTS_REST(S)                                                                                            \
+  template int eval_for_system<S>(myr_handle, int, const double*, const double*, int, double*, double*, double*, double*);         \
+  template int products_for_system<S>(myr_handle, const ProdArgs&);                                                                \
+  template int rollout_for_system<S>(myr_handle, int, int, int, const double*, const double*, const double*, int, double*, double*); \
+  template int launch_fbsm<S>(myr_handle, int, long, int, const double*, const double*, const double*, int, const VarScale&,        \
+                              const VarScale&, double, double, int, double*, double*, double*, int32_t*);
+MYR_SYSTEM_ENTRY_POINTS_REST(myriad::MYR_TU_SYSTEM)
+#endif
+#elif defined(MYR_TU_SYSTEM)
 MYR_SYSTEM_ENTRY_POINTS(, myriad::MYR_TU_SYSTEM)
 #elif defined(MYR_TU_MAIN)
 #define X(N) MYR_SYSTEM_ENTRY_POINTS(extern, Sys##N)
