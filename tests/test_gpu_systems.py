@@ -469,3 +469,42 @@ def test_wider_systems_run_on_the_fused_matrix_core_kernel(monkeypatch, name, N,
   d = np.abs(f["z"] - w["z"])[fin] / np.maximum(1.0, np.abs(w["z"])[fin])
   assert d.max(initial=0.0) <= 1e-6, d.max()
   np.testing.assert_allclose(f["cost"], w["cost"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("rule", ["HERMITE_SIMPSON", "TRAPEZOIDAL"])
+@pytest.mark.parametrize("name", ["BEARPOPULATIONS", "ROCKETLANDING", "PENDULUM_ELASTIC", "CARTPOLE_ELASTIC", "ROCKETLANDING_ELASTIC"])
+def test_block_sweep_on_short_horizons(monkeypatch, name, rule):
+  """The block sweep prefetches two to four stages ahead and runs its midpoint product one stage early: horizons shorter than the prefetch depth, of
+  odd length, of one and two intervals -- the fused kernel against the lane kernel (which shares none of that machinery), three iterations from
+  perturbed start states, both schemes.  (Trapezoidal: the reference pins row -nu of the state block, trapezoidal.py:71, so N + 1 > nu.  One interval
+  is run for the systems of moderate scale only: on ROCKETLANDING at N = 1 -- states of 1e3, inertia corrections from the first iteration -- the three
+  kernels differ by 3e-5 after ONE iteration, the fused one and round 2's together against the lane kernel, tools/dev/exp/exp70.py.)"""
+  from myriad_amd import _lib
+  from oracle import myriad_oracle as O
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  twin = name.endswith("_ELASTIC")
+  s = O.Elastic(O.SYSTEMS[name[:-8]](), 1.0) if twin else O.SYSTEMS[name]()
+  for N in (1, 2, 3, 4, 5, 8, 11):
+    if (rule == "TRAPEZOIDAL" and N + 1 <= s.nu) or (N == 1 and "ROCKETLANDING" in name):
+      continue
+    tr = O.hermite_simpson(s, N) if rule == "HERMITE_SIMPSON" else O.trapezoidal(s, N)
+    rng = np.random.default_rng(100 + N)
+    B = 3
+    z0 = np.tile(tr.guess, (B, 1))
+    lb, ub = np.tile(tr.bounds[:, 0], (B, 1)), np.tile(tr.bounds[:, 1], (B, 1))
+    x0 = z0[:, :s.ns] * (1.0 + 0.02 * rng.standard_normal((B, s.ns)))
+    z0[:, :s.ns] = x0; lb[:, :s.ns] = x0; ub[:, :s.ns] = x0
+    res = {}
+    for mode in ("wave", "lane"):
+      monkeypatch.setenv("MYRIAD_SOLVE_MODE", mode)
+      eng = _lib.Engine(name, rule, N, s.T)
+      o = eng.default_opts(); o.restoration = 0; o.max_iter = 3
+      res[mode] = eng.solve(z0, lb, ub, params=s.params() if twin else None, opts=o)
+      eng.close()
+    f, l = res["wave"], res["lane"]
+    assert np.array_equal(f["status"], l["status"]) and np.array_equal(f["iters"], l["iters"]), (N, f["status"], l["status"], f["iters"], l["iters"])
+    fin = np.isfinite(l["z"])
+    assert np.array_equal(np.isfinite(f["z"]), fin), N
+    d = np.abs(f["z"] - l["z"])[fin] / np.maximum(1.0, np.abs(l["z"])[fin])
+    assert d.max(initial=0.0) <= 2e-6, (N, d.max())
+    np.testing.assert_allclose(f["cost"], l["cost"], rtol=2e-8, atol=1e-12)
