@@ -296,3 +296,49 @@ def test_headline_batch_is_bit_reproducible(monkeypatch):
     bits = hashlib.sha1(b"".join(np.ascontiguousarray(r[k]).tobytes() for k in ("z", "lam", "cost", "kkt", "status", "iters"))).hexdigest()
     ref = ref or bits
     assert bits == ref, env
+
+
+@pytest.mark.parametrize("rule", ["HERMITE_SIMPSON", "TRAPEZOIDAL"])
+@pytest.mark.parametrize("base", ["PENDULUM", "VANDERPOL", "MOUNTAINCAR", "CARTPOLE", "ROCKETLANDING"])
+def test_twin_kernels_do_not_compute_with_inherited_state(monkeypatch, base, rule):
+  """The elastic twins on the fused kernel (round 5: block sweep; up to 14 variables per point, the largest unrolled blocks of the library): the gates
+  of the systems above -- poison in LDS and the scratch slots, patterns in every register and in private memory, fresh handles -- on the phase's own
+  first problem (the base system's guess and bounds widened by free slacks), a few iterations and a whole twin solve; the lane kernel under the
+  register / stack fill as well."""
+  from myriad_amd import _lib
+  from oracle import myriad_oracle as O
+  b = O.SYSTEMS[base]()
+  s = O.Elastic(b, 1.0)
+  mk = O.hermite_simpson if rule == "HERMITE_SIMPSON" else O.trapezoidal
+  for N, lim in ((6 if rule == "HERMITE_SIMPSON" else 9, 4), (20, 40)):
+    trb, tr = mk(b, N), mk(s, N)
+    u_rows = (tr.guess.size - trb.guess.size) // s.ns
+    nx = trb.guess.size - u_rows * b.nu
+    def widen(v, fill):
+      return np.concatenate([v[:nx], np.hstack([v[nx:].reshape(u_rows, b.nu), np.full((u_rows, s.ns), fill)]).ravel()])
+    B = 3
+    z0 = np.tile(widen(trb.guess, 0.0), (B, 1)); lb = np.tile(widen(trb.bounds[:, 0], -np.inf), (B, 1)); ub = np.tile(widen(trb.bounds[:, 1], np.inf), (B, 1))
+    x0 = z0[:, :b.ns] * (1.0 + 0.01 * np.arange(B)[:, None])
+    z0[:, :b.ns] = x0; lb[:, :b.ns] = x0; ub[:, :b.ns] = x0
+
+    def run(env):
+      for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+      for k, v in env.items():
+        monkeypatch.setenv(k, v)
+      eng = _lib.Engine(base + "_ELASTIC", rule, N, s.T)
+      o = eng.default_opts(); o.restoration = 0; o.max_iter = lim
+      r = eng.solve(z0, lb, ub, params=s.params(), opts=o)
+      eng.close()
+      return hashlib.sha1(b"".join(np.ascontiguousarray(r[k]).tobytes() for k in ("z", "lam", "cost", "kkt", "status", "iters"))).hexdigest(), r
+
+    for form in ({}, {"MYRIAD_SOLVE_MODE": "lane"}):
+      ref, r0 = run(dict(form, MYRIAD_REG_FILL="zero", MYRIAD_STACK_FILL="zero"))
+      for pat in ("nan", "random"):
+        got, r1 = run(dict(form, MYRIAD_REG_FILL=pat, MYRIAD_STACK_FILL=pat))
+        assert got == ref, (form, N, lim, "registers / stack " + pat, r0["status"], r1["status"], r0["iters"], r1["iters"], r0["cost"], r1["cost"])
+    ref, r0 = run({})
+    for pz in ("nan", "big", "random"):
+      got, r1 = run({"MYRIAD_POISON": pz})
+      assert got == ref, (N, lim, "poison " + pz, r0["status"], r1["status"], r0["iters"], r1["iters"])
+    assert run({})[0] == ref
