@@ -457,7 +457,7 @@ def run(a, rank, world, dev, make_engine):
   prof = {}
   fused = os.environ.get("MYRIAD_SOLVE_MODE", "wave") == "wave"
   skey = "hs_solve_fused_kernel" if fused else "hs_solve_wave_kernel"
-  for rnd in ("r04", "r03", "r02", "r01"):
+  for rnd in ("r05", "r04", "r03", "r02", "r01"):
     sp = os.path.join(ROOT, "profiles", rnd, "pmc_bench_n1.json")
     if "eval" not in prof and os.path.exists(sp) and B == 4096 and N == 100:     # the newest round's PMC passes carry the roofline kernel too
       try:
@@ -471,6 +471,11 @@ def run(a, rank, world, dev, make_engine):
         prof["solver"] = (float(d["fetch_x2"]) + float(d["write"]), os.path.relpath(sp, ROOT))
       except Exception:
         pass
+    if "mfma" not in prof and os.path.exists(sp) and B == 4096 and N == 100:      # matrix instructions of the solver kernel, per dispatch (same file)
+      try:
+        prof["mfma"] = (float(json.load(open(sp))[skey]["per_dispatch_avg"]["SQ_INSTS_MFMA"]), os.path.relpath(sp, ROOT))
+      except Exception:
+        pass
     tp = os.path.join(ROOT, "profiles", rnd, "hs_eval_traffic.json")
     if "eval" not in prof and os.path.exists(tp) and B == 4096 and N == 100:
       prof["eval"] = (json.load(open(tp)).get("traffic_bytes_per_launch"), os.path.relpath(tp, ROOT))
@@ -481,6 +486,9 @@ def run(a, rank, world, dev, make_engine):
   park_k1 = plan["park_iter"]
   traffic, traffic_src = prof.get("eval", (None, None))
   sol_bytes, sol_src = prof.get("solver", (None, None))
+  mfma_n, mfma_src = prof.get("mfma", (None, None))
+  FP64_MFMA_PEAK_TFLOPS = 78.6          # MI355X_MICROARCH.md: dense fp64 matrix peak (= the vector peak on this part)
+  mfma_tf = (lps * mfma_n * 2048.0 / (sv_ms * 1e-3) / 1e12) if (mfma_n and sv_ms) else None      # v_mfma_f64_16x16x4_f64: 16 x 16 x 4 x 2 flop
   out = {
     "metric": "converged trajopt solves/sec (batched), CARTPOLE collocation N=100",
     "value": nconv_all / dt, "unit": "solves/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -527,7 +535,11 @@ def run(a, rank, world, dev, make_engine):
                       "launches_per_solve": lps, "plan": plan,
                       "hbm_bytes_per_launch_from_profile": sol_bytes, "hbm_profile": sol_src,       # (per KERNEL launch: the profile averages over both phases)
                       "hbm_GBps": (lps * sol_bytes / (sv_ms * 1e-3) / 1e9) if (sol_bytes and sv_ms) else None,
-                      "hbm_over_alg": (lps * sol_bytes / (B * 8 * (3 * (2 * N + 1) * 5 + (2 * N + 1) * 5 + 2 * N * 4))) if sol_bytes else None},
+                      "hbm_over_alg": (lps * sol_bytes / (B * 8 * (3 * (2 * N + 1) * 5 + (2 * N + 1) * 5 + 2 * N * 4))) if sol_bytes else None,
+                      # the matrix-pipe view of the same kernel: instruction count from the committed counter pass, duration measured in this run
+                      "mfma": {"bound": "mfma", "insts_per_launch_from_profile": mfma_n, "profile": mfma_src, "achieved": mfma_tf, "peak": FP64_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": (mfma_tf / FP64_MFMA_PEAK_TFLOPS) if mfma_tf else None,
+                               "note": "the Riccati sweep is a chain of dependent 16x16x4 products, one wavefront per SIMD: low by construction (SURVEY.md 8(d))"}},
   }
   if world == 1 and a.cpu_budget > 0 and cuda:
     try:
