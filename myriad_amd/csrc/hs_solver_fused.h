@@ -1302,8 +1302,8 @@ struct HsFused {
   // factor of the whole NQ x NQ block is ever held (136 + 16 doubles per lane for ROCKETLANDING's twin in the vector form).  As in riccati_mfma
   // the dual bookkeeping rows (g^T pc' in row "1", -qc_q^T kc in rows nu_i) fall out of the same products as rows that are otherwise unused.
   // Same stage algebra, pivot order and rule, and outputs (gains K | kc per stage; P, pc, Tnu for the first point) as HsWave::riccati, whose
-  // column-per-lane vector form these systems ran on up to round 4.  Matrix instructions per Hermite-Simpson stage: BEARPOPULATIONS 9,
-  // ROCKETLANDING 18; no LDS, no barrier.
+  // column-per-lane vector form these systems ran on up to round 4.  Matrix instructions per Hermite-Simpson stage (counted in the listings):
+  // BEARPOPULATIONS 9, ROCKETLANDING 14, CARTPOLE's twin 57, ROCKETLANDING's twin 85; no LDS, no barrier.
   static constexpr bool GEN = !(NU == 1 && NS <= 4);
   static constexpr bool G_BIG = NW > 8 || NQ > 8;
   static constexpr int G_QT = G_BIG ? 1 : 0;                  // column / row tile of the q slots
