@@ -741,8 +741,7 @@ static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, con
     int waves = (B <= 2 * device_cus(h)) ? 2 : 1;
     if (so.park_iter > 0) waves = 1;                  // an explicit two-phase launch: only the one-wavefront form parks (include/myriad_hip.h: park_iter)
     if (h->fused_waves > 0) waves = h->fused_waves;
-    // (the wider systems -- two controls, six states, the small elastic twins: riccati_mfma_gen -- are built in the one-wavefront form only)
-    if constexpr (!HsFused<Sys, 1, SCHEME>::GEN) {
+    {
       if (waves == 2 && HsFused<Sys, 2, SCHEME>::lds_bytes(h->d.intervals) <= 160 * 1024)
         return launch_hs_fused_w<Sys, 2, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
     }

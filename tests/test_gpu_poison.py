@@ -301,7 +301,8 @@ def test_headline_batch_is_bit_reproducible(monkeypatch):
 @pytest.mark.parametrize("rule", ["HERMITE_SIMPSON", "TRAPEZOIDAL"])
 @pytest.mark.parametrize("base", ["PENDULUM", "VANDERPOL", "MOUNTAINCAR", "CARTPOLE", "ROCKETLANDING"])
 def test_twin_kernels_do_not_compute_with_inherited_state(monkeypatch, base, rule):
-  """The elastic twins on the fused kernel (round 5: block sweep; up to 14 variables per point, the largest unrolled blocks of the library): the gates
+  """The elastic twins on the fused kernel (round 5: block sweep, both wavefront forms; up to 14 variables per point, the largest unrolled blocks of the
+  library): the gates
   of the systems above -- poison in LDS and the scratch slots, patterns in every register and in private memory, fresh handles -- on the phase's own
   first problem (the base system's guess and bounds widened by free slacks), a few iterations and a whole twin solve; the lane kernel under the
   register / stack fill as well."""
@@ -332,13 +333,19 @@ def test_twin_kernels_do_not_compute_with_inherited_state(monkeypatch, base, rul
       eng.close()
       return hashlib.sha1(b"".join(np.ascontiguousarray(r[k]).tobytes() for k in ("z", "lam", "cost", "kkt", "status", "iters"))).hexdigest(), r
 
-    for form in ({}, {"MYRIAD_SOLVE_MODE": "lane"}):
+    for form in ({"MYRIAD_FUSED_WAVES": "1"}, {"MYRIAD_FUSED_WAVES": "2"}, {"MYRIAD_SOLVE_MODE": "lane"}):
       ref, r0 = run(dict(form, MYRIAD_REG_FILL="zero", MYRIAD_STACK_FILL="zero"))
       for pat in ("nan", "random"):
         got, r1 = run(dict(form, MYRIAD_REG_FILL=pat, MYRIAD_STACK_FILL=pat))
         assert got == ref, (form, N, lim, "registers / stack " + pat, r0["status"], r1["status"], r0["iters"], r1["iters"], r0["cost"], r1["cost"])
-    ref, r0 = run({})
-    for pz in ("nan", "big", "random"):
-      got, r1 = run({"MYRIAD_POISON": pz})
-      assert got == ref, (N, lim, "poison " + pz, r0["status"], r1["status"], r0["iters"], r1["iters"])
-    assert run({})[0] == ref
+    for form in ({"MYRIAD_FUSED_WAVES": "1"}, {"MYRIAD_FUSED_WAVES": "2"}):
+      ref, r0 = run(form)
+      for pz in ("nan", "big", "random"):
+        got, r1 = run(dict(form, MYRIAD_POISON=pz))
+        assert got == ref, (form, N, lim, "poison " + pz, r0["status"], r1["status"], r0["iters"], r1["iters"])
+      assert run(form)[0] == ref
+    w1, w2 = run({"MYRIAD_FUSED_WAVES": "1"})[1], run({"MYRIAD_FUSED_WAVES": "2"})[1]      # the two forms: the same steps, merit sums in another order
+    assert np.array_equal(w1["status"], w2["status"]) and (lim > 10 or np.array_equal(w1["iters"], w2["iters"]))
+    if lim <= 10:
+      fin = np.isfinite(w1["z"])
+      assert (np.abs(w1["z"] - w2["z"])[fin] / np.maximum(1.0, np.abs(w1["z"])[fin])).max(initial=0.0) <= 1e-7

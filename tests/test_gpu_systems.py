@@ -460,7 +460,7 @@ def test_wider_systems_run_on_the_fused_matrix_core_kernel(monkeypatch, name, N,
     eng.close()
   f, w = res["wave"], res["wave1"]
   if not twin:      # (a twin's solves are the restoration's, not "the" solve of a handle: no plan is recorded for them)
-    assert f["plan"]["form"] == "fused" and f["plan"]["waves_per_trajectory"] == 1 and w["plan"]["form"] == "wave"
+    assert f["plan"]["form"] == "fused" and f["plan"]["waves_per_trajectory"] == 2 and w["plan"]["form"] == "wave"      # (a small batch: two wavefronts per trajectory)
   assert np.array_equal(f["status"], w["status"]) and np.array_equal(f["iters"], w["iters"]), (f["status"], w["status"], f["iters"], w["iters"])
   if lim == 300:
     assert (f["status"] == 0).all(), (f["status"], f["iters"])
