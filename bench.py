@@ -393,6 +393,25 @@ def run(a, rank, world, dev, make_engine):
       dist.barrier()
     sync()
 
+  # The asynchronous-copy path pays a ONE-TIME host stall of 5-10 ms inside one enqueue, 0.3-0.4 s after the process's first downloads -- at step 14..27
+  # of a run, whatever the warm-up count, and EARLIER in step count the more copies ran before the steps: a matter of elapsed time under traffic, not of
+  # a count (tools/dev/exp/exp73.sh).  Initialisation, like the first import: the download path is exercised for `prime_ms` before the steps -- the same
+  # three pinned-buffer copies a step queues, on the stream the steps use; the longest enqueue seen is reported in the line.  (MYRIAD_BENCH_PRIME_MS=0: off.)
+  prime_ms = float(os.environ.get("MYRIAD_BENCH_PRIME_MS", "700"))
+  prime_info = None
+  if cuda and rank == 0 and prime_ms > 0:
+    tp0 = time.perf_counter(); worst = 0.0; ncp = 0
+    with torch.cuda.stream(copy_streams[0]):
+      while 1e3 * (time.perf_counter() - tp0) < prime_ms:
+        for k, t in (("status", stats[0]), ("cost", costs[0]), ("z", zs[0])):
+          te = time.perf_counter()
+          host[ncp & 1][k][:B].copy_(t, non_blocking=True)
+          worst = max(worst, time.perf_counter() - te)
+        ncp += 1
+        if ncp % 4 == 0:
+          copy_streams[0].synchronize()
+    sync()
+    prime_info = {"ms": prime_ms, "rounds_of_three_copies": ncp, "longest_enqueue_ms": 1e3 * worst}
   for _ in range(a.warmup):
     step()        # the same work as a timed step, including the count read-back
   eng.timer_reset()
@@ -507,7 +526,8 @@ def run(a, rank, world, dev, make_engine):
     "converged_fraction": nconv_all / (a.steps * total),
     "download": {"what": "z*, cost, status of all instances -> pinned host buffers on rank 0, inside every timed step (side stream, double-buffered: "
                          "overlaps the next step's solve); SURVEY.md 8(d): the metric ends on host rank 0",
-                 "bytes_per_step": d2h_bytes, "value_without_download": nconv_all / dt_nodl, "ms_per_step_without_download": 1e3 * dt_nodl / a.steps},
+                 "bytes_per_step": d2h_bytes, "value_without_download": nconv_all / dt_nodl, "ms_per_step_without_download": 1e3 * dt_nodl / a.steps,
+                 "primed_before_the_steps": prime_info},
     "solver_options": ({"mu_init": mu_used, "library_default_mu_init": mu_lib,
                         "why": "initial barrier parameter of the interior-point iteration (public field of myr_solve_opts, IPOPT's mu_init): 0.003 "
                                "saves about two iterations per solve on this workload, same tolerances, same converged fraction; it is NOT the "
