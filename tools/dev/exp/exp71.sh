@@ -9,4 +9,4 @@ print('B=$B waves=$w', round(d['value']), 'solves/s', 'solver kernel', round(d['
   done
 done
 # Result (one MI355X, solver kernel ms, waves 1 / 2): B=768 3.65 / 4.81, B=1024 4.79 / 5.81, B=1536 6.26 / 7.81, B=2048 6.82 / 9.98 -- the switch at two
-# trajectories per CU stays.  (B=768 and B=1024 are ONE round of the one-wavefront form: their time is the longest solve of the draw, 33 and 43 iterations.)
+# trajectories per CU stays.  (B=768 and B=1024 are ONE round of the one-wavefront form: their time is the longest solve of the draw -- 34 iterations at B=1024.)
