@@ -78,10 +78,10 @@ constexpr int MYR_STATUS_PARKED_ = 5;     // internal: never leaves myr_solve
 // are gone.  All workgroups of the launch are resident (one per CU, grid <= #CU), so the waits cannot deadlock; every wait is bounded all the same and
 // raises `abort` instead of hanging the device.
 struct NodeBoard {
-  unsigned long long cmd;       // (sequence number << 32) | (helpers taking part << 12) | (activations valid << 8) | mode; mode 15: the solve is over
+  unsigned long long cmd;       // (sequence number << 32) | (generation << 16) | (helpers taking part << 12) | (activations valid << 8) | mode; mode 15: the solve is over
   unsigned int done;            // passes finished by helpers, cumulative: the owner waits for the sum of the helper counts it posted
   unsigned int xcc;             // 1 + the owner's XCD
-  unsigned int att;             // bit 31: a solve is running here; low bits: helpers attached to it
+  unsigned int att;             // bit 31: a solve is running here; bits 16..30: its generation (one per trajectory of this owner); low 16 bits: helpers attached to it
   unsigned int pad_[27];        // 128 B apart
 };
 struct CoopArgs {
@@ -93,9 +93,16 @@ struct CoopArgs {
 };
 constexpr unsigned int MYR_COOP_RUNNING = 0x80000000u;
 constexpr int MYR_COOP_EXIT = 15;
+// The generation closes an ABA window of the attach (round 6): a helper reads att = RUNNING | k, then the command sequence, then raises the count by a
+// compare-and-swap.  Without it an owner that finished its trajectory and started the next one in between (att back to RUNNING | 0 ... k) let the swap
+// succeed against the NEW trajectory; the helper then took the OLD trajectory's EXIT for its own and left, still counted in, and the owner waited into its
+// bound.  With the generation in the word the swap fails across trajectories; with it in every command a helper of an earlier trajectory that has not
+// seen its EXIT yet (the command word is overwritten by the next trajectory's first command) leaves instead of serving under a helper index that a new
+// helper holds.  The owner orders its three stores -- att <- 0, EXIT, att <- RUNNING | generation -- by waiting for each to leave the CU.
+constexpr unsigned int MYR_COOP_GEN_MASK = 0x7fffu;
 // Visibility between an owner and its helpers WITHOUT agent-scope fences: those write the whole L2 back (buffer_wbl2) -- measured with 256 workgroups on
-// the device, B = 128 with one helper each: 14.0 ms against 9.4 ms without helpers (tools/dev/exp/exp54.sh).  Owner and helpers sit on the SAME XCD (the
-// dispatcher deals workgroup ids round robin over the 8 XCDs and B is a multiple of 8; checked at run time through HW_REG_XCC_ID, a mismatch aborts),
+// the device, B = 128 with one helper each: 14.0 ms against 9.4 ms without helpers (tools/dev/exp/exp54.sh).  Owner and helpers sit on the SAME XCD (a
+// helper reads its XCD from HW_REG_XCC_ID and only attaches to owners whose board names the same one),
 // i.e. behind the same L2: the producer only has to wait until its stores have left the CU (the vector L1 is write-through: s_waitcnt vmcnt(0)), the
 // consumer only has to drop its L1 (buffer_inv sc1: no write-back); the flag words are relaxed atomics, executed at the L2.
 __device__ inline void coop_release() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
@@ -127,6 +134,15 @@ struct HsFused {
   using D = HsSol<Sys>;
   static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = TRAP ? NS + 2 * NU : D::NY, NQ = TRAP ? NU : D::NQ, NC = D::NC, NY1 = NY + 1;
   static constexpr int QE = NQ - NU;
+  // Two-level sweep (round 6; -DMYR_TWO_LEVEL=0: round 5's form): the W wavefronts a trajectory owns each condense a CHUNK of N / W stages in parallel
+  // (riccati_chunk), a small interface recursion joins the chunks (tl_join), see there.  Hermite-Simpson, the hand-placed tile (one control, NS <= 4).
+#ifndef MYR_TWO_LEVEL
+#define MYR_TWO_LEVEL 1
+#endif
+#ifndef MYR_TL_FLOOR
+#define MYR_TL_FLOOR 1e-10      // smallest pivot accepted in an interface's C = I + L^T M L (its eigenvalues lie in (0, ~1] when the reduced Hessian is positive definite)
+#endif
+  static constexpr bool TL = (MYR_TWO_LEVEL != 0) && W > 1 && !TRAP && (D::NU == 1 && D::NS <= 4);
   static constexpr int MLAM = TRAP ? 1 : 2;        // multiplier blocks (NS each) per interval
   // Network dynamics (config 5, node_system.h): f, A, B of ALL points come from the matrix-core pass of node_mfma.h (MODE 1, every
   // wavefront of the workgroup takes every W-th tile of 16 points) into a global record the backward pass reads instead of calling
@@ -177,7 +193,11 @@ struct HsFused {
   // exchange between blocks / wavefronts (double-buffered by round): neighbour record, block total of a scan, trial knot; partial sums
   static constexpr int NTOT = NW * NW + NW, NRED = 12;
   static constexpr int XCH = 2 * W * NREC + 2 * W * NTOT + 2 * W * 2 * NS + W * NRED + 8;
-  __host__ __device__ static int lds_solver_doubles(int N) { return (ZLU_GLOBAL ? 2 : 4) * npoints(N) * NW + MLAM * N * NS + 6 * NW + XCH + (W > 1 ? 2 : 1) * EXCH + 8; }
+  // sweep outputs in LDS: one block (P | pc | Tnu | Ku) per set; two-level form: one per chunk, the multiplier vector theta of every chunk (+ the chunks'
+  // pivot counts), and per interface the four NW x NW maps of the join's forward pass
+  static constexpr int NXB = TL ? W : (W > 1 ? 2 : 1);
+  static constexpr int TL_TH = TL ? W * NC + W + 2 : 0, TL_JN = TL ? (W - 1) * 4 * NW * NW : 0;
+  __host__ __device__ static int lds_solver_doubles(int N) { return (ZLU_GLOBAL ? 2 : 4) * npoints(N) * NW + MLAM * N * NS + 6 * NW + XCH + NXB * EXCH + TL_TH + TL_JN + 8; }
   __host__ __device__ static int lds_doubles(int N) { return lds_solver_doubles(N) + (MLP ? npoints(N) * NS + NodeTraits<Sys>::lds_doubles : 0); }
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
   static constexpr int NSCAL = 48;      // scalars of the solve loop in a parked trajectory's record
@@ -189,9 +209,11 @@ struct HsFused {
     double *z, *zL, *zU, *dz;             // the iterate and the step (LDS)
     double *hr, *st, *kg, *zr;            // global scratch of this wavefront
     double *kgA, *kgB, *xA, *xB;          // W = 2: the two sets of sweep outputs (gains in global scratch, first-point exchange in LDS)
+    double *sTh, *sJn;                    // two-level sweep: theta per chunk | pivot counts; the interfaces' maps (LDS)
     double *pt, *sF, *wl;                 // network systems: point records (global), trial values and weights (LDS)
     double *hb, *mb;                      //   stored activations / tangents (global, per tile and lane)
     int nh, hidx;                         //   helper workgroups of this trajectory, this workgroup's index among them (0: the owner)
+    unsigned int gen;                     //   generation of the trajectory (owner: its own count; helper: the one it attached under)
     NodeBoard* board; int* coop_abort;    //   the owner's board
     double *pubx, *publam, *pubf;         //   what the owner publishes for a pass / the helpers' trial values (global)
     bool h_valid;                         //   hb holds the activations of the iterate (the last trial point was accepted)
@@ -277,7 +299,7 @@ struct HsFused {
         COOP_TR(1, seq); COOP_TR(9, 2); COOP_TR(3, MODE);
         coop_target(c) += (unsigned int)c.nh;
         if (seq < 6) COOP_DBG(2, "[wg %d] owner: post seq %u mode %d nh %d target %u\n", (int)blockIdx.x, seq, MODE, c.nh, coop_target(c));
-        __hip_atomic_store(&c.board->cmd, ((unsigned long long)seq << 32) | ((unsigned long long)c.nh << 12) | (c.h_valid ? 256ull : 0ull) | (unsigned long long)MODE,
+        __hip_atomic_store(&c.board->cmd, ((unsigned long long)seq << 32) | ((unsigned long long)(c.gen & MYR_COOP_GEN_MASK) << 16) | ((unsigned long long)c.nh << 12) | (c.h_valid ? 256ull : 0ull) | (unsigned long long)MODE,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else { (void)c; (void)alpha; }
@@ -342,6 +364,7 @@ struct HsFused {
         COOP_TR(7, seq);
         finished_pass = false;
         if (mode == MYR_COOP_EXIT) break;
+        if ((unsigned int)((v >> 16) & MYR_COOP_GEN_MASK) != (c.gen & MYR_COOP_GEN_MASK)) break;      // a command of the owner's NEXT trajectory: this one's EXIT was overwritten
         expect = seq + 1;
         if (nh < c.hidx) continue;           // the owner has not counted this workgroup in yet (it looks once per iteration)
         coop_acquire();
@@ -389,27 +412,29 @@ struct HsFused {
       c.z = ha.z; c.sLam = ha.sLam; c.sF = ha.sF; c.wl = ha.wl; c.sMisc = ha.sMisc; c.coop_abort = ha.co.abort;
       c.nh = 0; c.hidx = 0; c.board = nullptr; c.h_valid = false;
       const CoopArgs co = ha.co; double* const scratch = ha.scratch; const long scratch_stride = ha.scratch_stride; const int B = ha.B, nboards = ha.nboards;
-      int* info = reinterpret_cast<int*>(c.sMisc) + 12;      // sMisc[6], sMisc[7]: owner, helper index, commands seen, quit
+      int* info = reinterpret_cast<int*>(c.sMisc) + 12;      // sMisc[6], sMisc[7]: owner, helper index, commands seen, quit | generation << 1
       for (;;) {
         if (c.tid == 0) {
           const unsigned int myx = 1u + coop_xcc_id();
-          int found = -1, hid = 0, quit = 0; unsigned int seen = 0, spins = 0;
+          int found = -1, hid = 0, quit = 0; unsigned int seen = 0, spins = 0, gen = 0;
           COOP_TR(8, 0);
           for (;;) {
-            int best = -1; unsigned int bestk = 0xffffu;
+            int best = -1; unsigned int bestk = 0xffffu, besta = 0;
             for (int sl = (int)(blockIdx.x & 7u); sl < nboards; sl += 8) {        // (workgroup ids are dealt round robin over the 8 XCDs; the board says where its owner really is)
               if (sl == (int)blockIdx.x) continue;
               const unsigned int a = __hip_atomic_load(&co.boards[sl].att, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               const unsigned int k = a & 0xffffu;
               if ((a & MYR_COOP_RUNNING) && k < (unsigned int)co.maxh && k < bestk &&
-                  __hip_atomic_load(&co.boards[sl].xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == myx) { best = sl; bestk = k; }
+                  __hip_atomic_load(&co.boards[sl].xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == myx) { best = sl; bestk = k; besta = a; }
             }
             if (best >= 0) {
-              // (the commands seen BEFORE attaching: every command that counts this workgroup in is posted after the attach)
+              // (the commands seen BEFORE attaching: every command that counts this workgroup in is posted after the attach.  The attach word carries the
+              //  trajectory's generation: the swap fails when the owner has gone on to its next trajectory since the word was read.)
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               seen = (unsigned int)(__hip_atomic_load(&co.boards[best].cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
-              unsigned int expected = MYR_COOP_RUNNING | bestk;
-              if (__hip_atomic_compare_exchange_strong(&co.boards[best].att, &expected, MYR_COOP_RUNNING | (bestk + 1u), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                found = best; hid = (int)bestk + 1; COOP_DBG(16, "[wg %d] attached to %d as helper %d (seen %u)\n", (int)blockIdx.x, best, hid, seen); break;
+              unsigned int expected = besta;
+              if (__hip_atomic_compare_exchange_strong(&co.boards[best].att, &expected, besta + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                found = best; hid = (int)bestk + 1; gen = (besta >> 16) & MYR_COOP_GEN_MASK; COOP_DBG(16, "[wg %d] attached to %d as helper %d (seen %u)\n", (int)blockIdx.x, best, hid, seen); break;
               }
               continue;
             }
@@ -417,15 +442,17 @@ struct HsFused {
             __builtin_amdgcn_s_sleep(64);
             if (coop_bounded(c, spins)) { quit = 1; break; }
           }
-          info[0] = found; info[1] = hid; info[2] = (int)seen; info[3] = quit;
+          info[0] = found; info[1] = hid; info[2] = (int)seen; info[3] = quit | (int)(gen << 1);
           COOP_TR(5, found); COOP_TR(6, hid); COOP_TR(10, quit ? 999 : 0);
         }
         __syncthreads();
         const int found = __builtin_amdgcn_readfirstlane(info[0]), hid = __builtin_amdgcn_readfirstlane(info[1]);
         const unsigned int seen = (unsigned int)__builtin_amdgcn_readfirstlane(info[2]);
-        const int quit = __builtin_amdgcn_readfirstlane(info[3]);
+        const int quit_gen = __builtin_amdgcn_readfirstlane(info[3]);
+        const int quit = quit_gen & 1;
         __syncthreads();
         if (quit) break;
+        c.gen = (unsigned int)(quit_gen >> 1);
         double* so = scratch + (long)found * scratch_stride;
         c.pt = so + off_pt(c.N); c.hb = so + off_hb(c.N); c.mb = so + off_mb(c.N);
         c.board = co.boards + found; c.hidx = hid;
@@ -486,7 +513,7 @@ struct HsFused {
       const double l = bl[q], u = bu[q], zv = c.z[i], d = c.dz[i], zl = c.zL[i], zu = c.zU[i];
       const bool fr = l < u;
       const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
-      const double zn = fr ? zv + st.ap * d : zv;
+      const double zn = fr ? fma(st.ap, d, zv) : zv;      // (an explicit fma: the network passes evaluate the trial point as fma(alpha, dz, z), and the stored activations must belong to THIS point)
       const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
       const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
       double vl = zl + st.ad * (-zl + (st.mu - zl * d) * detail::rcp_(sl));
@@ -519,7 +546,7 @@ struct HsFused {
         const double l = V.l[q], u = V.u[q], zv = V.z[q], d = dv[q], zl = V.zl[q], zu = V.zu[q];
         const bool fr = l < u;
         const bool hl = fr && (l > -INFINITY), hu = fr && (u < INFINITY);
-        const double zn = fr ? zv + st.ap * d : zv;
+        const double zn = fr ? fma(st.ap, d, zv) : zv;      // (an explicit fma: the network passes evaluate the trial point as fma(alpha, dz, z), and the stored activations must belong to THIS point)
         const double sl = hl ? zv - l : 1.0, su = hu ? u - zv : 1.0;
         const double snl = hl ? zn - l : 1.0, snu = hu ? u - zn : 1.0;
         double vl = zl + st.ad * (-zl + (st.mu - zl * d) * detail::rcp_(sl));
@@ -1189,6 +1216,167 @@ struct HsFused {
     return riccati_first_point(c, o, delta, nreg);
   }
 
+  // ---- Two-level sweep, level 1: the stages [k_lo, k_hi) of ONE chunk on the tile of riccati_mfma -----------------------------------------
+  // The recursion over the stages is sequential and, in one wavefront, issue-bound (profiles/r05/sweep_issue_bound.md); the W wavefronts a
+  // trajectory owns at small batch sizes can only share it if every wavefront starts somewhere.  Chunk c < W - 1 therefore starts at its end knot
+  // e from the terminal form  rho/2 |w_e|^2 + nu^T w_e  with the NW multipliers nu of the continuity condition w_e = w_a(chunk c + 1) as
+  // right-hand-side COLUMNS -- exactly what the tile already does for the pinned terminal states of the last stage (the nu_T columns; here every
+  // row is "pinned", and the control row's multiplier takes the slot of the mu column: the barrier parameter is known before the sweep, so the
+  // caller folds g0 + mu g1 into the "1" column -- tl_fold).  The last chunk is the plain sweep down to its first stage.  A chunk returns the
+  // symmetric form over (w_a ; theta_c), theta_c = (1, nu_u, nu_x):  P | pc | T  -- T row m = d/d nu_m of the chunk's value = the end knot w_e as an
+  // affine function of theta_c (riccati_mfma's terminal-multiplier bookkeeping, with the control's row 7 kept as well) -- in ONE exchange block
+  // (the layout of sP | sPc | sTnu | sKu, the control's T row where sKu is); tl_join eliminates the multipliers.  Gains K | kc as before (kc column
+  // 1 now multiplies nu_u).  Same pivot rule; no first point.
+  __device__ static int riccati_chunk(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg, int k_lo, int k_hi, bool last, double* xo) {
+    using namespace detail;
+    static_assert(!TL || (NC == NS + 2 && NU == 1), "slot 7 takes the control's multiplier");
+    const int lane = c.lane;
+    const int g = lane >> 4, j = lane & 15;
+    const int scol = j < 4 ? (j < NS ? j : -1) : (j < 6 ? NS : -1);
+    const int ycol = scol >= 0 ? scol : ((j == 12 || j == 13) ? NS + 1 : ((j == 8 || j == 9) ? NS + 2 : -1));
+    const int cc = j == 6 ? 0 : (j == 7 ? 1 : (j == 10 ? 2 : (j == 11 ? 3 : (j == 14 ? 4 : (j == 15 ? 5 : -1)))));
+    const int rcc = (cc >= 0 && cc < NC) ? cc : -1;
+    const bool rowx = g < NS;
+    const double* he = c.hr + (long)(2 * (k_hi - 1) + 2) * HR_N;
+    const double* hm = he - HR_N;
+    const double* st = c.st + (long)(k_hi - 1) * SG_N;
+    auto hsel = [&](const double* rec, int row, bool on) -> const double* {
+      if (!on) return c.zr;
+      if (scol >= 0) return rec + HR_H + (scol <= row ? scol * NW - scol * (scol - 1) / 2 + (row - scol) : row * NW - row * (row - 1) / 2 + (scol - row));
+      if (rcc == 0) return rec + HR_G0 + row;      // (g0 + mu g1: folded by the caller)
+      return c.zr;
+    };
+    auto gsel = [&](int off) -> const double* {
+      if (!rowx) return c.zr;
+      if (ycol >= 0) return st + off + g * NY1 + ycol;
+      if (rcc == 0) return st + off + g * NY1 + NY;
+      return c.zr;
+    };
+    const double* ptr[6] = {hsel(he, g, rowx), hsel(he, NS, g < 2), gsel(SG_GE), hsel(hm, g, rowx), hsel(hm, NS, g < 2), gsel(SG_GM)};
+    long stp[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) stp[q] = (ptr[q] == c.zr) ? 0 : ((q == 2 || q == 5) ? (long)SG_N : 2L * HR_N);
+    const bool pinr = rowx && (!last || c.term_pinned[rowx ? g : 0]);
+    // (a pinned terminal state takes no inertia correction: rho - delta, the stage adds delta back; an interface knot is an ordinary point whose
+    // Hessian record -- with its delta -- is added by the chunk's last stage on top of the terminal form rho)
+    const double rho0 = last ? o.rho_term - delta : o.rho_term;
+    double X0 = (pinr && scol == g) ? rho0 : ((pinr && rcc == 2 + g) ? 1.0 : 0.0);
+    double X1 = (!last && g < 2) ? (scol == NS ? rho0 : (rcc == 1 ? 1.0 : 0.0)) : 0.0;
+    const double dv0 = (rowx && scol == g) ? delta : 0.0, dv1 = (g < 2 && scol == NS) ? delta : 0.0;
+    const double f_a1 = j < 6 ? 1.0 : 0.0;
+    const double f_keep = rcc >= 0 ? 1.0 : 0.0;
+    const double f_she = (j == 8 || j == 9) ? 1.0 : 0.0, f_shm = (j == 12 || j == 13) ? 1.0 : 0.0;
+    const double f_x1 = g < 2 ? 1.0 : 0.0, f_t1 = g >= 2 ? 1.0 : 0.0, f_t23 = g >= 2 ? 1.0 : 0.0;      // (row 7 -- the control's multiplier -- is carried like row 6)
+    const bool a3_on = g < 2 && (j < 6 || j == 7 || j == 10 || j == 11 || j == 14 || j == 15);          // ... and takes the rank-2 update like the rows nu_x
+    const double f_a3m = (a3_on && g == 0) ? -1.0 : 0.0, f_a3e = (a3_on && g == 1) ? -1.0 : 0.0;
+    const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
+    const int k_str = k_off < 0 ? 1 : ((scol >= 0) ? NW : NC);
+    double* k_ptr = k_off >= 0 ? c.kg + (long)(k_hi - 1) * KSTR + k_off : c.zr + ZR - 2;
+    const long k_step = k_off >= 0 ? KSTR : 0;
+    double reg_floor = o.reg_floor;
+    asm volatile("" : "+v"(reg_floor));
+    int nreg = 0;
+    const bool abort_u = uniform_if<true>(abort_on_reg);
+    double in[PF][6];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
+    }
+    auto mid_part = [&](double n0, double n1, double Gm) -> mfma_d4 {
+      n0 += dv0; n1 += dv1;
+      const double s0 = W0::dpp_row_shr8(n0), s1 = W0::dpp_row_shr8(n1);
+      mfma_d4 C;
+      C[0] = fma(s0, f_shm, n0 * f_keep);
+      C[1] = fma(s1, f_shm, n1 * f_keep);
+      C[2] = 0.0; C[3] = 0.0;
+      const mfma_d4 R = __builtin_amdgcn_mfma_f64_16x16x4f64(n0 * f_a1, Gm, C, 0, 0, 0);
+      mfma_d4 C2;
+      C2[0] = 0.0; C2[1] = 0.0; C2[2] = 0.0; C2[3] = R[1];
+      return __builtin_amdgcn_mfma_f64_16x16x4f64(Gm, R[0], C2, 0, 0, 0);
+    };
+    mfma_d4 Qm = mid_part(in[0][3], in[0][4], in[0][5]);
+    mfma_d4 D3 = {X0, X1, 0.0, 0.0};
+    for (int kb = k_hi - 1; kb >= k_lo; kb -= PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int k = kb - u;
+        if (k < k_lo) break;
+        X0 = D3[0] + (in[u][0] + dv0); X1 = fma(D3[1], f_x1, in[u][1] + dv1);
+        const double G = in[u][2];
+        const double nn0 = in[(u + 1) % PF][3], nn1 = in[(u + 1) % PF][4], nGm = in[(u + 1) % PF][5];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
+        const double sh0 = W0::dpp_row_shr4(X0), sh1 = W0::dpp_row_shr4(X1);
+        mfma_d4 C1;
+        C1[0] = fma(sh0, f_she, X0 * f_keep);
+        C1[1] = fma(sh1, f_she, X1 * f_keep);
+        C1[2] = 0.0; C1[3] = 0.0;
+        const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X0 * f_a1, G, C1, 0, 0, 0);
+        mfma_d4 C2;
+        C2[0] = Qm[0]; C2[1] = fma(D3[1], f_t1, Qm[1]); C2[2] = fma(D3[2], f_t23, Qm[2]) + D1[1]; C2[3] = fma(D3[3], f_t23, Qm[3]);
+        const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
+        double m0 = nn0 + dv0, m1 = nn1 + dv1;
+        const double ms0 = W0::dpp_row_shr8(m0), ms1 = W0::dpp_row_shr8(m1);
+        mfma_d4 Cm;
+        Cm[0] = fma(ms0, f_shm, m0 * f_keep);
+        Cm[1] = fma(ms1, f_shm, m1 * f_keep);
+        Cm[2] = 0.0; Cm[3] = 0.0;
+        const mfma_d4 Rm = __builtin_amdgcn_mfma_f64_16x16x4f64(m0 * f_a1, nGm, Cm, 0, 0, 0);
+        mfma_d4 Cq;
+        Cq[0] = 0.0; Cq[1] = 0.0; Cq[2] = 0.0; Cq[3] = Rm[1];
+        Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(nGm, Rm[0], Cq, 0, 0, 0);
+        const double q00 = W0::rdlane(D2[3], 12), q10 = W0::rdlane(D2[2], 12), q11 = W0::rdlane(D2[2], 8);
+        const double det = fma(q00, q11, -(q10 * q10));
+        const double rdet = fast_rcp(det);
+        const double b0 = D2[3], b1 = D2[2];
+        double kk0 = fma(q11, b0, -(q10 * b1)) * rdet;
+        double kk1 = fma(q00, b1, -(q10 * b0)) * rdet;
+        const bool rare_ = !(q00 > reg_floor) || !(det > reg_floor * q00);
+        if (uniform_if<true>(rare_)) {                                       // rare; a scalar branch (no matrix instruction inside an EXEC-masked region)
+          const double u00 = q00, u10 = q10, u11 = q11;
+          double d0 = u00;
+          if (!(d0 > reg_floor)) { d0 = dmax(fabs(d0), reg_floor); ++nreg; }
+          const double i0 = fast_rcp(d0);
+          const double l10 = u10 * i0;
+          double d1 = u11 - l10 * l10 * d0;
+          if (!(d1 > reg_floor)) { d1 = dmax(fabs(d1), reg_floor); ++nreg; }
+          if (uniform_if<true>(nreg > 0) && abort_u) return nreg;
+          const double i1 = fast_rcp(d1);
+          kk0 = b0; kk1 = b1;
+          kk1 -= l10 * kk0;
+          kk0 *= i0; kk1 *= i1;
+          kk0 -= l10 * kk1;
+        }
+        k_ptr[0] = kk0; k_ptr[k_str] = kk1;
+        k_ptr -= k_step;
+        const double A3 = fma(D2[3], f_a3m, D2[2] * f_a3e);
+        const double B3 = g == 0 ? kk0 : (g == 1 ? kk1 : 0.0);
+        D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, B3, D2, 0, 0, 0);
+      }
+    }
+    X0 = D3[0]; X1 = D3[1];
+    const double T1 = D3[1], T2 = D3[2], T3 = D3[3];
+    double* xP = xo; double* xPc = xo + NW * NW; double* xT = xPc + NW * NC;      // T: rows nu_x (NS), then the row of nu_u
+    if (scol >= 0 && j != 5) {
+      if (rowx) xP[g * NW + scol] = X0;
+      if (g == 0) xP[NS * NW + scol] = X1;
+    }
+    if (rcc >= 0) {
+      if (rowx) xPc[g * NC + rcc] = X0;
+      if (g == 0) xPc[NS * NC + rcc] = X1;
+      if (g >= 2 && g - 2 < NS) xT[(g - 2) * NC + rcc] = T2;
+      if (g >= 2 && g < NS) xT[g * NC + rcc] = T3;
+      if (g == 3) xT[NS * NC + rcc] = T1;
+    }
+    wave_sync<true>();
+    // the part of T[nu_m]["1"] that the products leave in row "1" (g^T pc', riccati_mfma)
+    if (g == 2 && rcc >= 2) xT[(rcc - 2) * NC + 0] += T1;
+    if (g == 2 && rcc == 1) xT[NS * NC + 0] += T1;
+    wave_sync<true>();
+    return nreg;
+  }
+
   // The same sweep for the trapezoidal scheme (HsWave::riccati_mfma_trap): y = (dx_s, du_s, du_e), ONE eliminated control per stage, no
   // midpoint part -- three matrix instructions per stage, the single pivot Q[du_e][du_e] read from lane 8 of register 2; the end point
   // of stage k is point k + 1.
@@ -1678,6 +1866,230 @@ struct HsFused {
 #endif
   }
 
+  // ---- Two-level sweep: wrappers and level 2 ---------------------------------------------------------------------------------------------------
+  __host__ __device__ static inline int tl_edge(int N, int ci) { return (int)(((long)ci * N) / W); }      // chunk ci = stages [tl_edge(ci), tl_edge(ci + 1))
+  __host__ __device__ static inline int tl_chunk(int N, int k) {
+    int ci = 0;
+#pragma unroll
+    for (int w = 1; w < W; ++w) ci += (k >= tl_edge(N, w)) ? 1 : 0;
+    return ci;
+  }
+  struct SwArgsC { nd_glb *hr, *st, *zr, *kg; nd_lds* xo; int lane, pinned, abort, k_lo, k_hi, last; double reg_floor, rho_term, delta; };
+  __device__ __attribute__((noinline)) static int chunk_call(SwArgsC a) {
+    Ctx c;
+    c.lane = a.lane; c.hr = (double*)a.hr; c.st = (double*)a.st; c.zr = (double*)a.zr; c.kg = (double*)a.kg;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) c.term_pinned[q] = ((a.pinned >> q) & 1) != 0;
+    HsSolveOpts o;
+    o.reg_floor = a.reg_floor; o.rho_term = a.rho_term;
+    if constexpr (TL) return riccati_chunk(c, o, a.delta, a.abort != 0, a.k_lo, a.k_hi, a.last != 0, (double*)a.xo);
+    else return 0;
+  }
+  __device__ static inline int sweep_chunk(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg, int ci) {
+    SwArgsC a;
+    a.hr = (nd_glb*)c.hr; a.st = (nd_glb*)c.st; a.zr = (nd_glb*)c.zr; a.kg = (nd_glb*)c.kg; a.xo = (nd_lds*)(c.xA + ci * EXCH);
+    a.lane = c.lane; a.abort = abort_on_reg ? 1 : 0;
+    a.pinned = 0;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) a.pinned |= c.term_pinned[q] ? (1 << q) : 0;
+    a.k_lo = tl_edge(c.N, ci); a.k_hi = tl_edge(c.N, ci + 1); a.last = (ci == W - 1) ? 1 : 0;
+    a.reg_floor = o.reg_floor; a.rho_term = o.rho_term; a.delta = delta;
+    return chunk_call(a);
+  }
+  // g0 + mu g1 -> the "1" column of every point record (the mu column's slot carries the control's continuity multiplier in riccati_chunk)
+  __device__ static inline void tl_fold(Ctx& c, double mu) {
+    // (uniform trip count, `live` gates the stores: a divergent loop ends in a join block, and this compiler has put spills in front of such a block's
+    // EXEC restore -- DESIGN.md section 8.1; the first form of this loop was caught by tools/dev/scan_exec_prologue.py)
+    for (int j0 = 0; j0 < c.K; j0 += NT) {
+      const bool live = j0 + c.tid < c.K;
+      double* hr = c.hr + (long)(live ? j0 + c.tid : c.K - 1) * HR_N;
+      double v[NW];
+#pragma unroll
+      for (int r = 0; r < NW; ++r) v[r] = fma(mu, hr[HR_G1 + r], hr[HR_G0 + r]);
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < NW; ++r) hr[HR_G0 + r] = v[r];
+      }
+    }
+  }
+  // Level 2: the interfaces, last first (one wavefront; lane l < 2 NW owns COLUMN l of every product -- the coefficient of w_a[l], resp. of
+  // theta_g[l - NW], theta_g = (1, nu_T) --, the NW x NW factors are computed by every lane alike).  Behind interface ci the TRUE value form of the
+  // rest of the horizon  1/2 w^T Pt w + w^T pt theta_g + ...  is known (block tb, block layout: nu_T in the columns 2.., column 1 zero).  Chunk ci
+  // delivered P, pc = [pc1 | E], T = [t1 | Tnn] for its own multipliers nu: w_e = E^T w_a + t1 + Tnn nu, and nu has to equal the gradient of the
+  // true form less the terminal form it was swept with:  nu = M w_e + pt theta_g,  M = Pt - rho I.  With S = -Tnn = L L^T (positive
+  // semidefinite: the chunk's pivots were positive) and C = I + L^T M L:
+  //     (I - Tnn M)^-1 v = v - L C^-1 L^T M v         (no inverse of S: unreachable directions of w_e stay where they are)
+  //     w_e = We [w_a ; theta_g],  nu = Nu [w_a ; theta_g]         (stored for tl_theta)
+  //     Pt' = P + E Nu_w,   pt' = [pc1 | 0] + E Nu_t,   Tt'[i] = Tt[i] + pt[:, nu_T i]^T We_t
+  // and the reduced Hessian of the whole horizon is positive definite iff the chunks' pivots are positive AND every C is: its Cholesky pivots are
+  // counted like the stages' (inertia correction).  tools/dev/twolevel/model.py is this algebra in numpy against the plain recursion.
+  struct JnArgs { nd_lds *xb, *jn; int N, lane; double rho, floor_c; };
+  __device__ __attribute__((noinline)) static int tl_join(JnArgs a) {
+    using namespace detail;
+    constexpr int NG = NS + 1, NCOL = NW + NG;
+    static_assert(NCOL == 2 * NW, "stash layout");
+    const int lane = a.lane;
+    const int col = lane < NCOL ? lane : 0;
+    const bool isw = col < NW;
+    const int gi = isw ? 0 : col - NW;
+    const int gcc = gi == 0 ? 0 : gi + 1;                 // block column of theta_g[gi]
+    auto mcc = [](int m) { return m < NS ? 2 + m : 1; };  // block column of the multiplier of w component m
+    int nreg = 0, tb = W - 1;
+#pragma unroll 1
+    for (int ci = W - 2; ci >= 0; --ci) {
+      if (tl_edge(a.N, ci + 1) <= tl_edge(a.N, ci)) continue;      // an empty chunk (N < W)
+      const nd_lds* Tb = a.xb + tb * EXCH; nd_lds* Bb = a.xb + ci * EXCH; nd_lds* J = a.jn + ci * 4 * NW * NW;
+      const nd_lds* Tpc = Tb + NW * NW; const nd_lds* TT = Tpc + NW * NC;
+      nd_lds* Bpc = Bb + NW * NW; nd_lds* BT = Bpc + NW * NC;
+      double M[NW * NW], L[NW * NW], LtM[NW * NW], C[NW * NW];
+      double smax = 0.0;
+#pragma unroll
+      for (int r = 0; r < NW; ++r)
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+          M[r * NW + q] = 0.5 * (Tb[r * NW + q] + Tb[q * NW + r]) - ((r == q) ? a.rho : 0.0);
+          L[r * NW + q] = -0.5 * (BT[r * NC + mcc(q)] + BT[q * NC + mcc(r)]);
+          if (r == q) smax = dmax(smax, fabs(L[r * NW + q]));
+        }
+      (void)chol_reg<NW>(L, 1e-14 * dmax(smax, 1e-300));
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+          double v = 0.0;
+#pragma unroll
+          for (int r = i; r < NW; ++r) v += L[r * NW + i] * M[r * NW + q];
+          LtM[i * NW + q] = v;
+        }
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+#pragma unroll
+        for (int jj = 0; jj <= i; ++jj) {
+          double v = (i == jj) ? 1.0 : 0.0;
+#pragma unroll
+          for (int q = jj; q < NW; ++q) v += LtM[i * NW + q] * L[q * NW + jj];
+          C[i * NW + jj] = v;
+        }
+      nreg += chol_reg<NW>(C, a.floor_c);
+      // this lane's column
+      double v[NW], y[NW], we[NW], nu[NW];
+#pragma unroll
+      for (int m = 0; m < NW; ++m) {
+        double e = Bpc[col * NC + mcc(m)];          // (w column: E[col][m]; read by every lane, used by the first NW)
+        double t = (gi == 0) ? BT[m * NC + 0] : 0.0;
+#pragma unroll
+        for (int r = 0; r < NW; ++r) t += BT[m * NC + mcc(r)] * Tpc[r * NC + gcc];
+        v[m] = isw ? e : t;
+      }
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) t += LtM[i * NW + q] * v[q];
+        y[i] = t;
+      }
+      chol_solve<NW, 1>(C, y);
+#pragma unroll
+      for (int m = 0; m < NW; ++m) {
+        double t = v[m];
+#pragma unroll
+        for (int i = 0; i <= m; ++i) t -= L[m * NW + i] * y[i];
+        we[m] = t;
+      }
+#pragma unroll
+      for (int m = 0; m < NW; ++m) {
+        double t = isw ? 0.0 : Tpc[m * NC + gcc];
+#pragma unroll
+        for (int r = 0; r < NW; ++r) t += M[m * NW + r] * we[r];
+        nu[m] = t;
+      }
+      // the new true form's column
+      double cn[NW], tn[NS];
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+        double t = isw ? Bb[r * NW + col] : ((gi == 0) ? Bpc[r * NC + 0] : 0.0);
+#pragma unroll
+        for (int m = 0; m < NW; ++m) t += Bpc[r * NC + mcc(m)] * nu[m];
+        cn[r] = t;
+      }
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        double t = TT[i * NC + gcc];
+#pragma unroll
+        for (int r = 0; r < NW; ++r) t += Tpc[r * NC + 2 + i] * we[r];
+        tn[i] = t;
+      }
+      wave_sync<true>();                 // every lane has read what it needs of the two blocks
+      if (lane < NCOL) {
+#pragma unroll
+        for (int m = 0; m < NW; ++m) { J[m * NCOL + col] = we[m]; J[NW * NCOL + m * NCOL + col] = nu[m]; }
+        if (isw) {
+#pragma unroll
+          for (int r = 0; r < NW; ++r) Bb[r * NW + col] = cn[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < NW; ++r) Bpc[r * NC + gcc] = cn[r];
+#pragma unroll
+          for (int i = 0; i < NS; ++i) BT[i * NC + gcc] = tn[i];
+        }
+      } else if (lane == NCOL) {
+#pragma unroll
+        for (int r = 0; r < NW; ++r) Bpc[r * NC + 1] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) BT[i * NC + 1] = 0.0;
+      }
+      wave_sync<true>();
+      tb = ci;
+    }
+    if (tb != 0) {                        // (N < W: chunk 0 is empty) the first point reads block 0
+      constexpr int NCP = NW * NW + NW * NC + NS * NC;
+      for (int i0 = 0; i0 < NCP; i0 += 64) {      // (uniform trip count)
+        const int i = i0 + lane < NCP ? i0 + lane : NCP - 1;
+        a.xb[i] = a.xb[tb * EXCH + i];
+      }
+      wave_sync<true>();
+    }
+    return nreg;
+  }
+  // the multipliers of every chunk from the first point's control step and nu_T: forward over the interfaces (one wavefront, every lane alike)
+  __device__ static void tl_theta(Ctx& c, const double* thg) {      // thg = (1, 0, nu_T): the last chunk's theta
+    constexpr int NCOL = 2 * NW;
+    double wa[NW], tg[NS + 1];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) wa[q] = 0.0;
+    { double v = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) v -= c.sKu[cc] * thg[cc];
+      wa[NS] = v; }
+    tg[0] = 1.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) tg[1 + i] = thg[2 + i];
+#pragma unroll 1
+    for (int ci = 0; ci < W - 1; ++ci) {
+      if (tl_edge(c.N, ci + 1) <= tl_edge(c.N, ci)) continue;
+      const nd_lds* J = (const nd_lds*)c.sJn + ci * 4 * NW * NW;
+      double we[NW], nu[NW];
+#pragma unroll
+      for (int m = 0; m < NW; ++m) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { a += J[m * NCOL + i] * wa[i]; b += J[NW * NCOL + m * NCOL + i] * wa[i]; }
+#pragma unroll
+        for (int g = 0; g <= NS; ++g) { a += J[m * NCOL + NW + g] * tg[g]; b += J[NW * NCOL + m * NCOL + NW + g] * tg[g]; }
+        we[m] = a; nu[m] = b;
+      }
+      double* th = c.sTh + ci * NC;
+      th[0] = 1.0; th[1] = nu[NS];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
+#pragma unroll
+      for (int m = 0; m < NW; ++m) wa[m] = we[m];
+    }
+    double* th = c.sTh + (W - 1) * NC;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) th[cc] = thg[cc];
+  }
+
   // ---- FORWARD phase: closed-loop maps -> wave scan -> step of the stage's midpoint and end knot -> their step limits ----------
   __device__ static void forward(Ctx& c, const HsSolveOpts& o, double mu, const double* th, typename S::FwdOut& fo) {
     const int N = c.N, K = c.K, lane = c.lane;
@@ -1723,11 +2135,19 @@ struct HsFused {
       double Kk[NQ * NW], kq[NQ], Ge[NS * NY1], Gm[TRAP ? 1 : NS * NY1];
 #pragma unroll
       for (int q = 0; q < NQ * NW; ++q) Kk[q] = Kst[q];
+      double thk[NC];                           // two-level sweep: the multipliers of the stage's chunk
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) thk[cc] = th[cc];
+      if constexpr (TL) {
+        const double* tc = c.sTh + tl_chunk(N, k) * NC;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) thk[cc] = tc[cc];
+      }
 #pragma unroll
       for (int t = 0; t < NQ; ++t) {
         double v = 0.0;
 #pragma unroll
-        for (int cc = 0; cc < NC; ++cc) v += Kst[NQ * NW + t * NC + cc] * th[cc];
+        for (int cc = 0; cc < NC; ++cc) v += Kst[NQ * NW + t * NC + cc] * thk[cc];
         kq[t] = v;
       }
 #pragma unroll
@@ -2073,14 +2493,77 @@ struct HsFused {
       auto next_delta = [&](double d) {       // the inertia-correction ladder (IPOPT's: first 1e-4 or a third of the last one, then x 100 / x 8)
         return d == 0.0 ? ((delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4) : d * ((delta_last > 0.0) ? 8.0 : 100.0);
       };
-      // (Speculative second rung, -DMYR_FUSED_SPEC: measured +3.5 % at B=512, and bit-identical to the plain ladder on CARTPOLE -- but
-      // TIMBERHARVEST N=6 takes another path in the build WITHOUT debug output and the right one with it, the outputs of the
-      // speculative sweep being provably those of a repeated one; not understood, so it stays off.)
+      // (Two-level sweep: the barrier parameter is folded into the sweep's "1" column, so the tests and the barrier update come BEFORE the sweep -- they
+      // depend on the two passes above only; the other forms keep round 5's order, in which the last iteration's sweep is run and dropped.)
+      if constexpr (TL) {
+        const int nm = MLAM * c.N * NS + p1.nm;
+        const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
+        const double stat = stat_raw / sd, comp = p1.cmax / sd;
+        res.cost = p1.f; res.feas = cinf; res.stat = stat; res.compl_ = comp;
+        if (__builtin_amdgcn_readfirstlane((int)!(finite_(p1.f) && finite_(cinf) && finite_(stat_raw)))) { res.status = 2; res.iters = it; return; }
+        if (__builtin_amdgcn_readfirstlane((int)(cinf <= o.tol_feas && stat <= o.tol_stat && comp <= o.tol_compl))) { res.status = 0; res.iters = it; return; }
+        if (it == o.max_iter) break;
+        for (int guard = 0; guard < 8; ++guard) {
+          const double cerr = (p1.cmin <= p1.cmax) ? dmax(fabs(p1.cmax - mu), fabs(p1.cmin - mu)) : 0.0;
+          const double emu = dmax(dmax(stat, cinf), cerr / sd);
+          if (emu <= o.kappa_eps * mu && mu > mu_min) {
+            const double nmu = dmax(mu_min, dmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+            mu = nmu;
+          } else break;
+        }
+      }
+      // (Speculative second rung, -DMYR_FUSED_SPEC -- the W > 1 forms without a two-level sweep: trapezoidal, the block sweep of the wider systems.
+      // Round 4 saw TIMBERHARVEST N = 6 take another path from handle to handle in this form; round 5 traced it to a spill the compiler placed in front of
+      // a join block's EXEC restore, removed the two sites, and holds every build with tools/dev/scan_exec_prologue.py -- per-unit
+      // fallback to -DMYR_FUSED_SPEC=0 -- and the register-fill gate of tests/test_gpu_poison.py.)
 #if !defined(MYR_FUSED_SPEC) || MYR_FUSED_SPEC
       constexpr bool SPEC = W > 1;          // (on since round 5: the build guard tools/dev/scan_exec_prologue.py and the register-fill gate hold it; -DMYR_FUSED_SPEC=0 switches it off)
 #else
       constexpr bool SPEC = false;
 #endif
+      if constexpr (TL) {
+        // Two-level sweep: every wavefront condenses its chunk of the horizon (riccati_chunk), wavefront 0 joins the chunks at their interfaces
+        // (tl_join) and eliminates the first point.  One rung of the inertia ladder = W chunk sweeps side by side + the join; a rung fails when a
+        // stage pivot of any chunk, a pivot of an interface or the first point's is not positive.  (The speculative second rung of round 5 is gone:
+        // wavefront 1 has its own chunk to sweep.)
+        tl_fold(c, mu);
+        wsync();
+        double* cnt = c.sTh + W * NC;         // pivot counts: the chunks', the join's
+        for (int tr_ = 0; tr_ < 12; ++tr_) {
+          const bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
+          int nr = 0;
+          if (tl_edge(c.N, c.wave + 1) > tl_edge(c.N, c.wave)) nr = sweep_chunk(c, o, delta, abort_on_reg, c.wave);
+          cnt[c.wave] = (double)nr;             // (every lane: the count is wave-uniform)
+          wsync();
+          int ns = 0;
+#pragma unroll
+          for (int w = 0; w < W; ++w) ns += (int)cnt[w];
+          ns = __builtin_amdgcn_readfirstlane(ns);
+          if (ns == 0 || !abort_on_reg) {       // (the same in every wavefront)
+            if (c.wave == 0) {
+              JnArgs ja;
+              ja.xb = (nd_lds*)c.xA; ja.jn = (nd_lds*)c.sJn; ja.N = c.N; ja.lane = c.lane; ja.rho = o.rho_term; ja.floor_c = MYR_TL_FLOOR;
+              int nj = tl_join(ja);
+              nj = riccati_first_point(c, o, delta, nj);
+              cnt[W] = (double)nj;
+            }
+            wsync();
+            ns += (int)cnt[W];
+          }
+          nreg = __builtin_amdgcn_readfirstlane(ns);
+#ifdef MYR_TRACE
+          if (c.tid == 0 && c.traj < MYR_TRACE) {
+            printf("L b%d it%d rung %d delta=%.9g chunks", c.traj, it, tr_, delta);
+            for (int w = 0; w < W; ++w) printf(" %d", (int)cnt[w]);
+            printf(" join+first %d\n", (ns == nreg && ((int)cnt[0] + (W > 1 ? (int)cnt[1] : 0)) == 0) ? (int)cnt[W] : -1);
+          }
+#endif
+          wsync();
+          MYR_PH(6)
+          if (nreg == 0 || !abort_on_reg) break;
+          delta = next_delta(delta);
+        }
+      } else
       if constexpr (SPEC) {
         // Two rungs of the ladder at a time: wavefront 0 sweeps with delta, wavefront 1 -- idle otherwise -- with the NEXT candidate
         // into a second set of outputs.  A failed first sweep costs a whole sweep (the bad pivot shows up near stage 0: 5 of 22
@@ -2137,20 +2620,22 @@ struct HsFused {
         printf("T b%d w%d it%d f=%.17g c1=%.17g cinf=%.17g stat=%.17g sm=%.17g lg=%.17g nreg=%d delta=%.9g mu=%.9g pen=%.9g\n", c.traj, c.wave, it,
                p1.f, p1.c1, p1.cinf, stat_raw, p1.sum_mult, p1.lg, nreg, delta, mu, pen);
 #endif
-      const int nm = MLAM * c.N * NS + p1.nm;
-      const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
-      const double stat = stat_raw / sd, comp = p1.cmax / sd;
-      res.cost = p1.f; res.feas = cinf; res.stat = stat; res.compl_ = comp;
-      if (!(finite_(p1.f) && finite_(cinf) && finite_(stat_raw))) { res.status = 2; res.iters = it; return; }
-      if (cinf <= o.tol_feas && stat <= o.tol_stat && comp <= o.tol_compl) { res.status = 0; res.iters = it; return; }
-      if (it == o.max_iter) break;
-      for (int guard = 0; guard < 8; ++guard) {
-        const double cerr = (p1.cmin <= p1.cmax) ? dmax(fabs(p1.cmax - mu), fabs(p1.cmin - mu)) : 0.0;
-        const double emu = dmax(dmax(stat, cinf), cerr / sd);
-        if (emu <= o.kappa_eps * mu && mu > mu_min) {
-          const double nmu = dmax(mu_min, dmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-          mu = nmu;
-        } else break;
+      if constexpr (!TL) {
+        const int nm = MLAM * c.N * NS + p1.nm;
+        const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
+        const double stat = stat_raw / sd, comp = p1.cmax / sd;
+        res.cost = p1.f; res.feas = cinf; res.stat = stat; res.compl_ = comp;
+        if (!(finite_(p1.f) && finite_(cinf) && finite_(stat_raw))) { res.status = 2; res.iters = it; return; }
+        if (cinf <= o.tol_feas && stat <= o.tol_stat && comp <= o.tol_compl) { res.status = 0; res.iters = it; return; }
+        if (it == o.max_iter) break;
+        for (int guard = 0; guard < 8; ++guard) {
+          const double cerr = (p1.cmin <= p1.cmax) ? dmax(fabs(p1.cmax - mu), fabs(p1.cmin - mu)) : 0.0;
+          const double emu = dmax(dmax(stat, cinf), cerr / sd);
+          if (emu <= o.kappa_eps * mu && mu > mu_min) {
+            const double nmu = dmax(mu_min, dmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+            mu = nmu;
+          } else break;
+        }
       }
       typename S::SweepOut so;
 #pragma unroll
@@ -2158,11 +2643,15 @@ struct HsFused {
 #pragma unroll
       for (int i = 0; i < NS; ++i) so.term_pinned[i] = c.term_pinned[i];
       double nu[NS];
-      S::solve_nu(so, mu, nu);
+      S::solve_nu(so, TL ? 0.0 : mu, nu);      // (two-level sweep: mu is folded into the "1" column)
       double th[NC];
-      th[0] = 1.0; th[1] = mu;
+      th[0] = 1.0; th[1] = TL ? 0.0 : mu;
 #pragma unroll
       for (int i = 0; i < NS; ++i) th[2 + i] = nu[i];
+      if constexpr (TL) {
+        if (c.wave == 0) tl_theta(c, th);
+        wsync();
+      }
       MYR_PH(7)
       typename S::FwdOut fo;
       { ThT th_; for (int q = 0; q < NC; ++q) th_.v[q] = th[q]; fo = forward_pass(c, o, mu, th_); }
@@ -2269,6 +2758,7 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   c.sRed = l; l += NWAVES * W::NRED;
   c.sMisc = l; l += 8;
   c.xA = l; c.xB = l + W::EXCH;
+  c.sTh = l + W::NXB * W::EXCH; c.sJn = c.sTh + W::TL_TH;
   W::use_set(c, c.kgA, c.xA);
   c.sF = reinterpret_cast<double*>(smem_fused) + W::lds_solver_doubles(c.N);
   c.wl = c.sF + c.K * W::NS;
@@ -2290,6 +2780,7 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     }
   }
   bool took = false;
+  c.gen = 0;
   for (;;) {
     int t = 0;
     if (c.tid == 0) t = fixed ? ((can_own && !took) ? (int)blockIdx.x : B) : atomicAdd(ticket, 1);
@@ -2341,7 +2832,10 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
 #endif
     if constexpr (W::MLP) {
       c.nh = 0;
-      if (coop && c.tid == 0) __hip_atomic_store(&c.board->att, MYR_COOP_RUNNING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // helpers may attach from here on
+      c.gen = (c.gen + 1u) & MYR_COOP_GEN_MASK;
+      if (coop && c.tid == 0) {      // helpers may attach from here on (the previous trajectory's EXIT has left the CU: see below)
+        __hip_atomic_store(&c.board->att, MYR_COOP_RUNNING | (c.gen << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if constexpr (NWAVES == 1 || W::MLP) W::solve(c, o, zg, r, pk.mode, pk.k1, pk.state + b * pk.stride);      // (W = 2 serves batches of one round only)
     else W::solve(c, o, zg, r);
@@ -2370,8 +2864,10 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
       if (coop) {        // no more attaching; release the helpers; one more trajectory finished
         if (c.tid == 0) {
           (void)__hip_atomic_exchange(&c.board->att, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          coop_release();            // (the exchange has been performed at the L2 before the EXIT is issued, the EXIT before the next trajectory's attach word)
           const unsigned int seq = ++W::coop_seq(c);
-          __hip_atomic_store(&c.board->cmd, ((unsigned long long)seq << 32) | (unsigned long long)MYR_COOP_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&c.board->cmd, ((unsigned long long)seq << 32) | ((unsigned long long)c.gen << 16) | (unsigned long long)MYR_COOP_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          coop_release();
           (void)__hip_atomic_fetch_add(co.abort + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         c.nh = 0;

@@ -122,6 +122,7 @@ struct myr_handle_s {
   void* coop_buf = nullptr; size_t coop_bytes = 0;
   int node_helpers = -1;      // MYRIAD_NODE_HELPERS: helper workgroups per trajectory (-1 = by batch size)
   int32_t plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // myr_solve_plan: how the last first-attempt solve was launched
+  bool plan_frozen = false;                     //   (second starts re-launch on this handle: they leave the first attempt's record alone)
   int reg_fill = 0;                    // MYRIAD_REG_FILL (tests): pattern left in every VGPR / AGPR of every SIMD before every solver launch (1 nan, 2 finite, 3 big, 4 zero)
   unsigned long long stack_fill = 0;   // MYRIAD_STACK_FILL (tests / experiments): bit pattern left in the queue's private-segment memory before every solver launch
 };
@@ -694,7 +695,7 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
     }).detach();
   }
 #endif
-  if (h->d.system_id < 100) { const int32_t pl[8] = {1, NWAVES, k1, k1 > 0 ? 2 : 1, slots, co.maxh, 0, 0}; memcpy(h->plan, pl, sizeof(pl)); }      // (twins: the restoration's solves are not "the" solve)
+  { const int32_t pl[8] = {1, NWAVES, k1, k1 > 0 ? 2 : 1, slots, co.maxh, 0, 0}; if (!h->plan_frozen) memcpy(h->plan, pl, sizeof(pl)); }      // (the plan of THIS handle's last launch; a restoration twin is a handle of its own)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVES), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
                      params, pstride, cost, status, iters, kkt, h->poison, pk, co);
   HIPCHK(hipGetLastError());
@@ -703,8 +704,7 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
   if (co.maxh > 0) {
     int ab = 0;
     HIPCHK(hipMemcpy(&ab, co.abort, sizeof(int), hipMemcpyDeviceToHost));
-    if (ab) return fail(MYR_E_HIP, ab == 2 ? "network kernel: a helper workgroup runs on another XCD than its owner (MYRIAD_NODE_HELPERS=0 runs without helper workgroups)"
-                                           : "network kernel: a wait between a trajectory's workgroups ran into its bound (MYRIAD_NODE_HELPERS=0 runs without helper workgroups)");
+    if (ab) return fail(MYR_E_HIP, "network kernel: a wait between a trajectory's workgroups ran into its bound (MYRIAD_NODE_HELPERS=0 runs without helper workgroups)");
   }
   if (k1 > 0) {
     if (const char* path = getenv("MYRIAD_PARK_DUMP")) {      // developer knob: the loop scalars of every record as parked ([B][NSCAL] doubles), for the study of resume orders
@@ -826,7 +826,7 @@ static int launch_hs_solve(myr_handle h, int B, double* z, const double* lb, con
     if (int rc_fill = stack_fill(h)) return rc_fill;
     HIPCHK(hipEventRecord(kt.a, h->stream));
     h->last_solve_form = 1;
-    if (h->d.system_id < 100) { const int32_t pl[8] = {2, coop ? wpb : 1, 0, 1, slots, 0, 0, 0}; memcpy(h->plan, pl, sizeof(pl)); }
+    { const int32_t pl[8] = {2, coop ? wpb : 1, 0, 1, slots, 0, 0, 0}; if (!h->plan_frozen) memcpy(h->plan, pl, sizeof(pl)); }
     hipLaunchKernelGGL(kern, dim3((unsigned)(slots / lwaves)), dim3(64 * wpb), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, (double*)h->sbuf, stride,
                        params, pstride, cost, status, iters, kkt, coop, h->poison);
     HIPCHK(hipGetLastError());
@@ -879,7 +879,7 @@ static int launch_lane_solve(myr_handle h, int B, long nst, double* z, const dou
   HIPCHK(hipEventRecord(kt.a, h->stream));
   const int lpw = h->solve_lpw;
   h->last_solve_form = 0;
-  if (h->d.system_id < 100) { const int32_t pl[8] = {0, 0, 0, 1, B, 0, 0, 0}; memcpy(h->plan, pl, sizeof(pl)); }
+  { const int32_t pl[8] = {0, 0, 0, 1, B, 0, 0, 0}; if (!h->plan_frozen) memcpy(h->plan, pl, sizeof(pl)); }
   hipLaunchKernelGGL((lane_solve_kernel<Core, Sys>), dim3((unsigned)((B + lpw - 1) / lpw)), dim3(64), 0, h->stream, B, Bp, lpw, o, h->vscale, sz, slb, sub, szL,
                      szU, slam, sdz, sst, params, pstride, cost, status, iters, kkt);
   HIPCHK(hipGetLastError());
@@ -921,7 +921,7 @@ static int launch_shoot_solve(myr_handle h, int B, double* z, const double* lb, 
   if (int rc_fill = stack_fill(h)) return rc_fill;
   HIPCHK(hipEventRecord(kt.a, h->stream));
   h->last_solve_form = 1;
-  if (h->d.system_id < 100) { const int32_t pl[8] = {3, 1, 0, 1, slots, 0, 0, 0}; memcpy(h->plan, pl, sizeof(pl)); }
+  { const int32_t pl[8] = {3, 1, 0, 1, slots, 0, 0, 0}; if (!h->plan_frozen) memcpy(h->plan, pl, sizeof(pl)); }
   hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, params, pstride,
                      cost, status, iters, kkt, h->poison);
   HIPCHK(hipGetLastError());
@@ -1612,6 +1612,8 @@ static myr_handle twin_of(myr_handle h) {
 static int solve_restored(myr_handle h, int B, double* z, const double* lb, const double* ub, const double* params, int pstride,
                           const myr_solve_opts& so, double* lam, double* cost, int32_t* status, int32_t* iters, double* kkt) {
   h->info_start.assign(B, 0); h->info_attempts.assign(B, 1); h->info_restored.assign(B, 0);
+  h->plan_frozen = false;
+  struct Thaw { myr_handle h; ~Thaw() { h->plan_frozen = false; } } thaw{h};
   const RestoreCfg cfg = restore_cfg(so);
   if (!cfg.elastic && !cfg.starts) return dispatch_solve_scaled(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
   const myr_dims& dm = h->dims;
@@ -1624,6 +1626,7 @@ static int solve_restored(myr_handle h, int B, double* z, const double* lb, cons
   int32_t* dit = iters ? iters : (int32_t*)(z0c + al((size_t)B * n) + al((size_t)B));
   HIPCHK(hipMemcpyAsync(z0c, z, (size_t)B * n * 8, hipMemcpyDeviceToDevice, h->stream));
   if (int rc = dispatch_solve_scaled(h, B, z, lb, ub, params, pstride, so, lam, cost, dstat, dit, kkt)) return rc;
+  h->plan_frozen = true;
   if (!h->nfail_host) HIPCHK(hipHostMalloc((void**)&h->nfail_host, 64, hipHostMallocDefault));
   if (!h->nfail_dev) HIPCHK(hipMalloc((void**)&h->nfail_dev, 64));
   *h->nfail_host = -1;
