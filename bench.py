@@ -101,7 +101,7 @@ def cpu_baseline(N, budget_s):
   dt, nit, done, _ = timed_solve(N, budget_s)
   its_per_s = nit / dt
   full_its, measured = 110, None
-  for rnd in ("r05", "r04", "r03"):          # a whole solve measured on a GPU-box host by `bench.py --cpu-full` (committed)
+  for rnd in ("r06", "r05", "r04", "r03"):          # a whole solve measured on a GPU-box host by `bench.py --cpu-full` (committed)
     fp = os.path.join(ROOT, "profiles", rnd, "cpu_baseline_full.json")
     if N == 100 and os.path.exists(fp):
       try:
@@ -476,7 +476,7 @@ def run(a, rank, world, dev, make_engine):
   prof = {}
   fused = os.environ.get("MYRIAD_SOLVE_MODE", "wave") == "wave"
   skey = "hs_solve_fused_kernel" if fused else "hs_solve_wave_kernel"
-  for rnd in ("r05", "r04", "r03", "r02", "r01"):
+  for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
     sp = os.path.join(ROOT, "profiles", rnd, "pmc_bench_n1.json")
     if "eval" not in prof and os.path.exists(sp) and B == 4096 and N == 100:     # the newest round's PMC passes carry the roofline kernel too
       try:
@@ -645,8 +645,8 @@ def both_scalings(a, rank, world, dev, make_engine):
       out["other_scaling"]["global_batch"] = o2["config"]["global_batch"]; out["other_scaling"]["per_gpu_batch"] = o2["config"]["per_gpu_batch"]
       out["other_scaling"]["solver_kernel_avg_ms"] = o2["solver_kernel"]["avg_ms"]
   if rank == 0 and out is not None:
-    pj = os.path.join(ROOT, "profiles", "r05", "projected_scaling.json")
-    if os.path.exists(pj):
+    pj = next((q for q in (os.path.join(ROOT, "profiles", r, "projected_scaling.json") for r in ("r06", "r05")) if os.path.exists(q)), None)
+    if pj:
       try:
         out["projected_scaling"] = {"file": os.path.relpath(pj, ROOT), "config2": json.load(open(pj)).get("config2")}
       except Exception:

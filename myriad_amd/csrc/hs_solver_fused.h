@@ -135,14 +135,15 @@ struct HsFused {
   static constexpr int NS = D::NS, NU = D::NU, NW = D::NW, NY = TRAP ? NS + 2 * NU : D::NY, NQ = TRAP ? NU : D::NQ, NC = D::NC, NY1 = NY + 1;
   static constexpr int QE = NQ - NU;
   // Two-level sweep (round 6; -DMYR_TWO_LEVEL=0: round 5's form): the W wavefronts a trajectory owns each condense a CHUNK of N / W stages in parallel
-  // (riccati_chunk), a small interface recursion joins the chunks (tl_join), see there.  Hermite-Simpson, the hand-placed tile (one control, NS <= 4).
+  // (riccati_chunk / riccati_chunk_trap), a small interface recursion joins the chunks (tl_join), see there.  Both collocation schemes on the hand-placed
+  // tile (one control, NS <= 4).
 #ifndef MYR_TWO_LEVEL
 #define MYR_TWO_LEVEL 1
 #endif
 #ifndef MYR_TL_FLOOR
 #define MYR_TL_FLOOR 1e-10      // smallest pivot accepted in an interface's C = I + L^T M L (its eigenvalues lie in (0, ~1] when the reduced Hessian is positive definite)
 #endif
-  static constexpr bool TL = (MYR_TWO_LEVEL != 0) && W > 1 && !TRAP && (D::NU == 1 && D::NS <= 4);
+  static constexpr bool TL = (MYR_TWO_LEVEL != 0) && W > 1 && (D::NU == 1 && D::NS <= 4);
   static constexpr int MLAM = TRAP ? 1 : 2;        // multiplier blocks (NS each) per interval
   // Network dynamics (config 5, node_system.h): f, A, B of ALL points come from the matrix-core pass of node_mfma.h (MODE 1, every
   // wavefront of the workgroup takes every W-th tile of 16 points) into a global record the backward pass reads instead of calling
@@ -932,7 +933,7 @@ struct HsFused {
   }
 
   // ---- HESSIAN phase: lanes over points -- Lagrangian Hessian, gradient columns, control-row stationarity ----------------------
-  __device__ static void hessian(Ctx& c, double& stat) {
+  __device__ static void hessian(Ctx& c, double& stat, double mu_fold = 0.0) {      // (two-level sweep: the "1" column is written as g0 + mu_fold g1)
     const int N = c.N, K = c.K;
     const double h6 = c.h6, h8 = c.h8;
     double st_ = 0;
@@ -1019,7 +1020,7 @@ struct HsFused {
           const bool zq = last && q < NS && c.term_pinned[q < NS ? q : 0];
           hr[HR_H + symidx(r, q)] = (zr || zq) ? 0.0 : (Wh[r * NW + q] + ((r == q) ? sig[r] : 0.0));
         }
-        hr[HR_G0 + r] = zr ? 0.0 : wj * P.gw[r];
+        hr[HR_G0 + r] = zr ? 0.0 : (TL ? fma(mu_fold, g1v[r], wj * P.gw[r]) : wj * P.gw[r]);
         hr[HR_G1 + r] = zr ? 0.0 : g1v[r];
       }
       }
@@ -1866,6 +1867,104 @@ struct HsFused {
 #endif
   }
 
+  // The same for the trapezoidal scheme: riccati_mfma_trap over the stages [k_lo, k_hi) of one chunk (stage k ends at point k + 1; one eliminated control).
+  __device__ static int riccati_chunk_trap(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg, int k_lo, int k_hi, bool last, double* xo) {
+    using namespace detail;
+    const int lane = c.lane;
+    const int g = lane >> 4, j = lane & 15;
+    const int scol = j < 4 ? (j < NS ? j : -1) : (j < 6 ? NS : -1);
+    const int ycol = scol >= 0 ? scol : ((j == 8 || j == 9) ? NW : -1);
+    const int cc = j == 6 ? 0 : (j == 7 ? 1 : (j == 10 ? 2 : (j == 11 ? 3 : (j == 14 ? 4 : (j == 15 ? 5 : -1)))));
+    const int rcc = (cc >= 0 && cc < NC) ? cc : -1;
+    const bool rowx = g < NS;
+    const double* he = c.hr + (long)k_hi * HR_N;
+    const double* st = c.st + (long)(k_hi - 1) * SG_N;
+    auto hsel = [&](int row, bool on) -> const double* {
+      if (!on) return c.zr;
+      if (scol >= 0) return he + HR_H + (scol <= row ? scol * NW - scol * (scol - 1) / 2 + (row - scol) : row * NW - row * (row - 1) / 2 + (scol - row));
+      if (rcc == 0) return he + HR_G0 + row;      // (g0 + mu g1: folded by the hessian pass / tl_fold)
+      return c.zr;
+    };
+    const double* ptr[3] = {hsel(g, rowx), hsel(NS, g < 2),
+                            !rowx ? c.zr : (ycol >= 0 ? st + SG_GE + g * NY1 + ycol : (rcc == 0 ? st + SG_GE + g * NY1 + NY : c.zr))};
+    long stp[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) stp[q] = (ptr[q] == c.zr) ? 0 : (q == 2 ? (long)SG_N : (long)HR_N);
+    const bool pinr = rowx && (!last || c.term_pinned[rowx ? g : 0]);
+    const double rho0 = last ? o.rho_term - delta : o.rho_term;      // (see riccati_chunk)
+    const double X0i = (pinr && scol == g) ? rho0 : ((pinr && rcc == 2 + g) ? 1.0 : 0.0);
+    const double X1i = (!last && g < 2) ? (scol == NS ? rho0 : (rcc == 1 ? 1.0 : 0.0)) : 0.0;
+    const double dv0 = (rowx && scol == g) ? delta : 0.0, dv1 = (g < 2 && scol == NS) ? delta : 0.0;
+    const double f_a1 = j < 6 ? 1.0 : 0.0, f_keep = rcc >= 0 ? 1.0 : 0.0, f_she = (j == 8 || j == 9) ? 1.0 : 0.0;
+    const double f_x1 = g < 2 ? 1.0 : 0.0, f_t1 = g >= 2 ? 1.0 : 0.0, f_t23 = g >= 2 ? 1.0 : 0.0;
+    const double f_a3 = (g == 0 && (j < 6 || j == 7 || j == 10 || j == 11 || j == 14 || j == 15)) ? -1.0 : 0.0;
+    const int k_off = (g == 0 && scol >= 0 && j != 5) ? scol : ((g == 0 && rcc >= 0) ? NQ * NW + rcc : -1);
+    double* k_ptr = k_off >= 0 ? c.kg + (long)(k_hi - 1) * KSTR + k_off : c.zr + ZR - 2;
+    const long k_step = k_off >= 0 ? KSTR : 0;
+    double reg_floor = o.reg_floor;
+    asm volatile("" : "+v"(reg_floor));
+    int nreg = 0;
+    const bool abort_u = uniform_if<true>(abort_on_reg);
+    double in[PF][3];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
+    }
+    mfma_d4 D3 = {X0i, X1i, 0.0, 0.0};
+    for (int kb = k_hi - 1; kb >= k_lo; kb -= PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int k = kb - u;
+        if (k < k_lo) break;
+        const double X0 = D3[0] + (in[u][0] + dv0), X1 = fma(D3[1], f_x1, in[u][1] + dv1);
+        const double G = in[u][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
+        const double sh0 = W0::dpp_row_shr4(X0), sh1 = W0::dpp_row_shr4(X1);
+        mfma_d4 C1;
+        C1[0] = fma(sh0, f_she, X0 * f_keep);
+        C1[1] = fma(sh1, f_she, X1 * f_keep);
+        C1[2] = 0.0; C1[3] = 0.0;
+        const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X0 * f_a1, G, C1, 0, 0, 0);
+        mfma_d4 C2;
+        C2[0] = 0.0; C2[1] = D3[1] * f_t1; C2[2] = fma(D3[2], f_t23, D1[1]); C2[3] = D3[3] * f_t23;
+        const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
+        const double q11 = W0::rdlane(D2[2], 8);
+        double d = q11;
+        const bool rare_ = !(d > reg_floor);
+        if (uniform_if<true>(rare_)) {
+          d = dmax(fabs(d), reg_floor); ++nreg;
+          if (abort_u) return nreg;
+        }
+        const double kk = D2[2] * fast_rcp(d);
+        k_ptr[0] = kk;
+        k_ptr -= k_step;
+        const double A3 = D2[2] * f_a3;
+        const double B3 = g == 0 ? kk : 0.0;
+        D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(A3, B3, D2, 0, 0, 0);
+      }
+    }
+    const double X0 = D3[0], X1 = D3[1], T1 = D3[1], T2 = D3[2], T3 = D3[3];
+    double* xP = xo; double* xPc = xo + NW * NW; double* xT = xPc + NW * NC;
+    if (scol >= 0 && j != 5) {
+      if (rowx) xP[g * NW + scol] = X0;
+      if (g == 0) xP[NS * NW + scol] = X1;
+    }
+    if (rcc >= 0) {
+      if (rowx) xPc[g * NC + rcc] = X0;
+      if (g == 0) xPc[NS * NC + rcc] = X1;
+      if (g >= 2 && g - 2 < NS) xT[(g - 2) * NC + rcc] = T2;
+      if (g >= 2 && g < NS) xT[g * NC + rcc] = T3;
+      if (g == 3) xT[NS * NC + rcc] = T1;
+    }
+    wave_sync<true>();
+    if (g == 2 && rcc >= 2) xT[(rcc - 2) * NC + 0] += T1;
+    if (g == 2 && rcc == 1) xT[NS * NC + 0] += T1;
+    wave_sync<true>();
+    return nreg;
+  }
+
   // ---- Two-level sweep: wrappers and level 2 ---------------------------------------------------------------------------------------------------
   __host__ __device__ static inline int tl_edge(int N, int ci) { return (int)(((long)ci * N) / W); }      // chunk ci = stages [tl_edge(ci), tl_edge(ci + 1))
   __host__ __device__ static inline int tl_chunk(int N, int k) {
@@ -1882,7 +1981,8 @@ struct HsFused {
     for (int q = 0; q < NS; ++q) c.term_pinned[q] = ((a.pinned >> q) & 1) != 0;
     HsSolveOpts o;
     o.reg_floor = a.reg_floor; o.rho_term = a.rho_term;
-    if constexpr (TL) return riccati_chunk(c, o, a.delta, a.abort != 0, a.k_lo, a.k_hi, a.last != 0, (double*)a.xo);
+    if constexpr (TL && TRAP) return riccati_chunk_trap(c, o, a.delta, a.abort != 0, a.k_lo, a.k_hi, a.last != 0, (double*)a.xo);
+    else if constexpr (TL) return riccati_chunk(c, o, a.delta, a.abort != 0, a.k_lo, a.k_hi, a.last != 0, (double*)a.xo);
     else return 0;
   }
   __device__ static inline int sweep_chunk(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg, int ci) {
@@ -1896,7 +1996,8 @@ struct HsFused {
     a.reg_floor = o.reg_floor; a.rho_term = o.rho_term; a.delta = delta;
     return chunk_call(a);
   }
-  // g0 + mu g1 -> the "1" column of every point record (the mu column's slot carries the control's continuity multiplier in riccati_chunk)
+  // g0 + mu g1 -> the "1" column of every point record (the mu column's slot carries the control's continuity multiplier in riccati_chunk).  The
+  // hessian pass writes it with the barrier parameter it knows; this pass adds dmu g1 in the iterations that change the parameter afterwards.
   __device__ static inline void tl_fold(Ctx& c, double mu) {
     // (uniform trip count, `live` gates the stores: a divergent loop ends in a join block, and this compiler has put spills in front of such a block's
     // EXEC restore -- DESIGN.md section 8.1; the first form of this loop was caught by tools/dev/scan_exec_prologue.py)
@@ -1926,56 +2027,71 @@ struct HsFused {
   struct JnArgs { nd_lds *xb, *jn; int N, lane; double rho, floor_c; };
   __device__ __attribute__((noinline)) static int tl_join(JnArgs a) {
     using namespace detail;
-    constexpr int NG = NS + 1, NCOL = NW + NG;
-    static_assert(NCOL == 2 * NW, "stash layout");
+    constexpr int NG = NS + 1, NCOL = NW + NG, NN = NW * NW;
+    static_assert(NCOL == 2 * NW && NN <= 64, "stash layout; one element of an NW x NW product per lane");
     const int lane = a.lane;
     const int col = lane < NCOL ? lane : 0;
     const bool isw = col < NW;
     const int gi = isw ? 0 : col - NW;
     const int gcc = gi == 0 ? 0 : gi + 1;                 // block column of theta_g[gi]
     auto mcc = [](int m) { return m < NS ? 2 + m : 1; };  // block column of the multiplier of w component m
+    const int el = lane < NN ? lane : 0, er = el / NW, eq = el - er * NW;      // this lane's element of the NW x NW products
     int nreg = 0, tb = W - 1;
 #pragma unroll 1
     for (int ci = W - 2; ci >= 0; --ci) {
       if (tl_edge(a.N, ci + 1) <= tl_edge(a.N, ci)) continue;      // an empty chunk (N < W)
-      const nd_lds* Tb = a.xb + tb * EXCH; nd_lds* Bb = a.xb + ci * EXCH; nd_lds* J = a.jn + ci * 4 * NW * NW;
-      const nd_lds* Tpc = Tb + NW * NW; const nd_lds* TT = Tpc + NW * NC;
-      nd_lds* Bpc = Bb + NW * NW; nd_lds* BT = Bpc + NW * NC;
-      double M[NW * NW], L[NW * NW], LtM[NW * NW], C[NW * NW];
-      double smax = 0.0;
+      const nd_lds* Tb = a.xb + tb * EXCH; nd_lds* Bb = a.xb + ci * EXCH; nd_lds* J = a.jn + ci * 4 * NN;
+      const nd_lds* Tpc = Tb + NN; const nd_lds* TT = Tpc + NW * NC;
+      nd_lds* Bpc = Bb + NN; nd_lds* BT = Bpc + NW * NC;
+      nd_lds *sM = J, *sL = J + NN, *sG = J + 2 * NN, *sC = J + 3 * NN;      // (the interface's stash serves as the work space until We | Nu are written)
+      // M = sym(Pt) - rho I and S = -sym(Tnn), one element per lane
+      {
+        const double m = 0.5 * (Tb[er * NW + eq] + Tb[eq * NW + er]) - ((er == eq) ? a.rho : 0.0);
+        const double sv = -0.5 * (BT[er * NC + mcc(eq)] + BT[eq * NC + mcc(er)]);
+        sM[el] = m; sL[el] = sv;            // (lanes >= NN repeat element 0)
+      }
+      wave_sync<true>();
+      // S = L L^T by every lane alike (the factor is needed whole by every lane; pivots of unreachable directions are floored, their columns then vanish)
+      double L[NN];
+      {
+        double smax = 0.0;
+#pragma unroll
+        for (int r = 0; r < NW; ++r)
+#pragma unroll
+          for (int q = 0; q <= r; ++q) { L[r * NW + q] = sL[r * NW + q]; if (r == q) smax = dmax(smax, fabs(L[r * NW + q])); }
+        (void)chol_reg<NW>(L, 1e-14 * dmax(smax, 1e-300));
+      }
+      wave_sync<true>();                  // (every lane has read S)
 #pragma unroll
       for (int r = 0; r < NW; ++r)
 #pragma unroll
-        for (int q = 0; q < NW; ++q) {
-          M[r * NW + q] = 0.5 * (Tb[r * NW + q] + Tb[q * NW + r]) - ((r == q) ? a.rho : 0.0);
-          L[r * NW + q] = -0.5 * (BT[r * NC + mcc(q)] + BT[q * NC + mcc(r)]);
-          if (r == q) smax = dmax(smax, fabs(L[r * NW + q]));
-        }
-      (void)chol_reg<NW>(L, 1e-14 * dmax(smax, 1e-300));
+        for (int q = 0; q < NW; ++q) sL[r * NW + q] = (q <= r) ? L[r * NW + q] : 0.0;      // (every lane stores the same values: no lane-0 region)
+      wave_sync<true>();
+      {                                   // G = L^T M
+        double g = 0.0;
 #pragma unroll
-      for (int i = 0; i < NW; ++i)
+        for (int r = 0; r < NW; ++r) g += sL[r * NW + er] * sM[r * NW + eq];
+        sG[el] = g;
+      }
+      wave_sync<true>();
+      {                                   // C = I + G L
+        double cv = (er == eq) ? 1.0 : 0.0;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) {
-          double v = 0.0;
+        for (int q = 0; q < NW; ++q) cv += sG[er * NW + q] * sL[q * NW + eq];
+        sC[el] = cv;
+      }
+      wave_sync<true>();
+      double C[NN], dinv[NW];
 #pragma unroll
-          for (int r = i; r < NW; ++r) v += L[r * NW + i] * M[r * NW + q];
-          LtM[i * NW + q] = v;
-        }
+      for (int r = 0; r < NW; ++r)
 #pragma unroll
-      for (int i = 0; i < NW; ++i)
-#pragma unroll
-        for (int jj = 0; jj <= i; ++jj) {
-          double v = (i == jj) ? 1.0 : 0.0;
-#pragma unroll
-          for (int q = jj; q < NW; ++q) v += LtM[i * NW + q] * L[q * NW + jj];
-          C[i * NW + jj] = v;
-        }
-      nreg += chol_reg<NW>(C, a.floor_c);
+        for (int q = 0; q <= r; ++q) C[r * NW + q] = 0.5 * (sC[r * NW + q] + sC[q * NW + r]);
+      nreg += ldl_reg<NW>(C, dinv, a.floor_c);
       // this lane's column
       double v[NW], y[NW], we[NW], nu[NW];
 #pragma unroll
       for (int m = 0; m < NW; ++m) {
-        double e = Bpc[col * NC + mcc(m)];          // (w column: E[col][m]; read by every lane, used by the first NW)
+        const double e = Bpc[col * NC + mcc(m)];          // (w column: E[col][m]; read by every lane, used by the first NW)
         double t = (gi == 0) ? BT[m * NC + 0] : 0.0;
 #pragma unroll
         for (int r = 0; r < NW; ++r) t += BT[m * NC + mcc(r)] * Tpc[r * NC + gcc];
@@ -1985,10 +2101,10 @@ struct HsFused {
       for (int i = 0; i < NW; ++i) {
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) t += LtM[i * NW + q] * v[q];
+        for (int q = 0; q < NW; ++q) t += sG[i * NW + q] * v[q];
         y[i] = t;
       }
-      chol_solve<NW, 1>(C, y);
+      ldl_solve<NW>(C, dinv, y);
 #pragma unroll
       for (int m = 0; m < NW; ++m) {
         double t = v[m];
@@ -2000,7 +2116,7 @@ struct HsFused {
       for (int m = 0; m < NW; ++m) {
         double t = isw ? 0.0 : Tpc[m * NC + gcc];
 #pragma unroll
-        for (int r = 0; r < NW; ++r) t += M[m * NW + r] * we[r];
+        for (int r = 0; r < NW; ++r) t += sM[m * NW + r] * we[r];
         nu[m] = t;
       }
       // the new true form's column
@@ -2019,7 +2135,7 @@ struct HsFused {
         for (int r = 0; r < NW; ++r) t += Tpc[r * NC + 2 + i] * we[r];
         tn[i] = t;
       }
-      wave_sync<true>();                 // every lane has read what it needs of the two blocks
+      wave_sync<true>();                 // every lane has read what it needs of the two blocks and of the work space
       if (lane < NCOL) {
 #pragma unroll
         for (int m = 0; m < NW; ++m) { J[m * NCOL + col] = we[m]; J[NW * NCOL + m * NCOL + col] = nu[m]; }
@@ -2042,7 +2158,7 @@ struct HsFused {
       tb = ci;
     }
     if (tb != 0) {                        // (N < W: chunk 0 is empty) the first point reads block 0
-      constexpr int NCP = NW * NW + NW * NC + NS * NC;
+      constexpr int NCP = NN + NW * NC + NS * NC;
       for (int i0 = 0; i0 < NCP; i0 += 64) {      // (uniform trip count)
         const int i = i0 + lane < NCP ? i0 + lane : NCP - 1;
         a.xb[i] = a.xb[tb * EXCH + i];
@@ -2367,7 +2483,7 @@ struct HsFused {
 #endif
   struct NuT { double v[NS]; };
   __device__ MYR_PASS_ATTR static BOut backward_pass(Ctx c, Step stp, NuT nu) { BOut o; backward(c, stp, nu.v, o); return o; }
-  __device__ MYR_PASS_ATTR static double hessian_pass(Ctx c) { double st; hessian(c, st); return st; }
+  __device__ MYR_PASS_ATTR static double hessian_pass(Ctx c, double mu_fold) { double st; hessian(c, st, mu_fold); return st; }
   struct ThT { double v[NC]; };
   __device__ MYR_PASS_ATTR static typename S::FwdOut forward_pass(Ctx c, HsSolveOpts o, double mu, ThT th) { typename S::FwdOut fo; forward(c, o, mu, th.v, fo); return fo; }
   struct TrialOut { double f, bar, c1; bool ok; };
@@ -2483,7 +2599,8 @@ struct HsFused {
       wsync();
       MYR_PH(0)
       double stat_raw;
-      stat_raw = hessian_pass(c);
+      const double mu_hess = mu;              // (two-level sweep: the records' "1" column holds g0 + mu_hess g1)
+      stat_raw = hessian_pass(c, mu);
       wsync();
       MYR_PH(4)
       const double c1 = p1.c1, cinf = p1.cinf, sum_mult = p1.sum_mult;
@@ -2526,15 +2643,20 @@ struct HsFused {
         // (tl_join) and eliminates the first point.  One rung of the inertia ladder = W chunk sweeps side by side + the join; a rung fails when a
         // stage pivot of any chunk, a pivot of an interface or the first point's is not positive.  (The speculative second rung of round 5 is gone:
         // wavefront 1 has its own chunk to sweep.)
-        tl_fold(c, mu);
-        wsync();
+        if (__builtin_amdgcn_readfirstlane((int)(mu != mu_hess))) {      // the barrier parameter moved after the hessian pass wrote g0 + mu g1: add the difference
+          tl_fold(c, mu - mu_hess);
+          wsync();
+        }
+        MYR_PH(3)
         double* cnt = c.sTh + W * NC;         // pivot counts: the chunks', the join's
         for (int tr_ = 0; tr_ < 12; ++tr_) {
           const bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
           int nr = 0;
           if (tl_edge(c.N, c.wave + 1) > tl_edge(c.N, c.wave)) nr = sweep_chunk(c, o, delta, abort_on_reg, c.wave);
           cnt[c.wave] = (double)nr;             // (every lane: the count is wave-uniform)
+          MYR_PH(13)
           wsync();
+          MYR_PH(5)
           int ns = 0;
 #pragma unroll
           for (int w = 0; w < W; ++w) ns += (int)cnt[w];
@@ -2544,8 +2666,10 @@ struct HsFused {
               JnArgs ja;
               ja.xb = (nd_lds*)c.xA; ja.jn = (nd_lds*)c.sJn; ja.N = c.N; ja.lane = c.lane; ja.rho = o.rho_term; ja.floor_c = MYR_TL_FLOOR;
               int nj = tl_join(ja);
+              MYR_PH(9)
               nj = riccati_first_point(c, o, delta, nj);
               cnt[W] = (double)nj;
+              MYR_PH(10)
             }
             wsync();
             ns += (int)cnt[W];
@@ -2845,8 +2969,8 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     }
 #ifdef MYR_PHASE_TIMING
     if (c.lane == 0 && b < 4) {
-      printf("traj %ld it %d: backward %lld hess %lld ricc %lld nu %lld forward %lld ls %lld\n",
-             b, r.iters, c.tph[0], c.tph[4], c.tph[6], c.tph[7], c.tph[8], c.tph[11]);
+      printf("traj %ld wave %d it %d: backward %lld hess %lld fold %lld chunk %lld wait %lld join %lld first %lld ricc %lld nu %lld forward %lld ls %lld\n",
+             b, c.wave, r.iters, c.tph[0], c.tph[4], c.tph[3], c.tph[13], c.tph[5], c.tph[9], c.tph[10], c.tph[6], c.tph[7], c.tph[8], c.tph[11]);
     }
     if (W::MLP && c.tid == 0 && blockIdx.x == 0) {
       printf("  workgroup 0, traj %ld it %d: network passes of wavefront 0 (cycles): MODE0 %lld MODE3 %lld MODE4 %lld\n", b, r.iters, node_tph_[0], node_tph_[3], node_tph_[4]);

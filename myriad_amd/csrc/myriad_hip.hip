@@ -302,8 +302,10 @@ static int launch_shoot_eval(myr_handle h, int B, const double* z, const double*
 template <class Sys>
 int eval_for_system(myr_handle h, int B, const double* z, const double* params, int pstride,
                            double* f, double* g, double* c, double* j) {
-  if constexpr (Sys::PARAMS_BY_POINTER) {   // neural-ODE systems: built for the Hermite-Simpson transcription (config 5)
-    if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "myr_eval: NODE systems are built for HERMITE_SIMPSON");
+  if constexpr (Sys::PARAMS_BY_POINTER) {   // neural-ODE systems: Hermite-Simpson (config 5) and shooting (the reference's default route for a NodeSystem,
+                                            // config.py:66 + shooting.py:144-167, 212-228); its parametrised trapezoid is dead code (trapezoidal.py:204-206, quirk Q8)
+    if (h->d.transcription == MYR_TR_SHOOTING) return launch_shoot_eval<Sys>(h, B, z, params, pstride, f, g, c, j);
+    if (h->d.transcription != MYR_TR_HERMITE_SIMPSON) return fail(MYR_E_UNSUPPORTED, "myr_eval: NODE systems are built for HERMITE_SIMPSON and SHOOTING");
     return launch_hs_eval<Sys, EVAL_HS>(h, B, z, params, pstride, f, g, c, j);
   } else {
     switch (h->d.transcription) {
@@ -739,8 +741,12 @@ static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, con
     // results that differed from launch to launch; round 4 found the form of the sweep that does it
     // (hs_solver_fused.h: sweep) and gates every build with tests/test_gpu_poison.py.  MYRIAD_FUSED_WAVES=1|2 overrides the choice.
     int waves = (B <= 2 * device_cus(h)) ? 2 : 1;
+    // (Four wavefronts per trajectory for batches of at most one trajectory per CU -- chunks of N / 4 stages -- were built and measured in round 6,
+    // tools/dev/exp/exp84.sh: same iterates, and NO gain over two wavefronts -- B = 128 50.6 k against 50.4 k solves/s, B = 256 97.5 k against 96.6 k: what the
+    // shorter chunks save, the three interface joins, one after the other on wavefront 0, cost.  Not instantiated: 160 KB of code per system.)
     if (so.park_iter > 0) waves = 1;                  // an explicit two-phase launch: only the one-wavefront form parks (include/myriad_hip.h: park_iter)
     if (h->fused_waves > 0) waves = h->fused_waves;
+    if (waves > 2) waves = 2;
     {
       if (waves == 2 && HsFused<Sys, 2, SCHEME>::lds_bytes(h->d.intervals) <= 160 * 1024)
         return launch_hs_fused_w<Sys, 2, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
@@ -958,9 +964,8 @@ int solve_trap_for_system(MYR_SOLVE_ARGS) {      // wavefront form (falls back t
 }
 template <class Sys>
 int solve_shoot_for_system(MYR_SOLVE_ARGS) {
-  if constexpr (Sys::PARAMS_BY_POINTER) return fail(MYR_E_UNSUPPORTED, "myr_solve: NODE systems are built for HERMITE_SIMPSON");
   // elastic twins (id >= 100) exist for the collocation solvers, whose restoration device they are; their shooting solver is not built
-  else if constexpr (Sys::ID >= 100) return fail(MYR_E_UNSUPPORTED, "myr_solve: elastic twins are built for the collocation transcriptions");
+  if constexpr (Sys::ID >= 100) return fail(MYR_E_UNSUPPORTED, "myr_solve: elastic twins are built for the collocation transcriptions");
   else {
     if (h->d.integration_method == MYR_INT_RK4)
       return launch_shoot_solve<Sys, 2>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);

@@ -209,7 +209,7 @@ struct ShootWave {
   // the FULL step Hessian Hs | gy as the C operand of the second product (where Hermite-Simpson feeds its midpoint terms).
   // Own (bound) terms are diagonal here: sigma + delta of the control row of every point, of the state rows at nodes only.
   static constexpr bool MFMA_RICCATI = (M == 1 && NU == 1 && NS <= 4);
-  using HW = HsWave<Sys, 1>;
+  using HW = HsWave<Sys, NodeTraits<Sys>::mlp ? 0 : 1>;      // (only its lane-movement helpers are used; the trapezoidal form of HsWave is not built for network dynamics)
   typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 #ifndef MYR_SHOOT_RICCATI_PF
 #define MYR_SHOOT_RICCATI_PF 2

@@ -169,10 +169,12 @@ def test_node_helper_workgroups_return_the_bits_of_the_launch_without(monkeypatc
 
 
 @pytest.mark.parametrize("N,B", [(20, 12), (100, 300)])
-def test_node_two_wavefront_throughput_form_returns_the_bits_of_the_four_wavefront_form(monkeypatch, N, B):
+def test_node_two_wavefront_throughput_form_walks_the_path_of_the_four_wavefront_form(monkeypatch, N, B):
   """Round 5: beyond one trajectory per CU the network kernel runs two wavefronts per trajectory and two trajectories per CU (bound multipliers in the
   global scratch slot so that two workgroups fit the LDS; one trajectory's sweep overlaps the other's matrix-core passes).  Tiles, scans and sums are the
-  four-wavefront form's: identical bits -- with and without helper workgroups, under LDS / scratch poison and under the register / stack fill."""
+  four-wavefront form's.  Round 6: the sweep is the two-level one, and the two forms cut the horizon into two resp. four chunks -- the same Newton steps in
+  another order of operations: same statuses, same iteration counts, optima within 1e-9 (bit-identical up to round 5).  Within the two-wavefront form the
+  bits do not depend on helper workgroups, LDS / scratch poison or the register / stack fill."""
   x0 = np.clip(0.1 * np.random.default_rng(7 * N + B).standard_normal((B, 4)), -2, 2)
   monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
   out = {}
@@ -189,8 +191,69 @@ def test_node_two_wavefront_throughput_form_returns_the_bits_of_the_four_wavefro
       assert opt.engine.solve_plan()["waves_per_trajectory"] == 2
     out[name] = {k: np.array(r[k]) for k in ("status", "iters", "cost", "xs_and_us", "lambda")}
     opt.engine.close()
-  ref = out["W4"]
+  ref = out["W2"]
   assert (ref["status"] == 0).all()
   for name, r in out.items():
+    if name == "W4":
+      assert np.array_equal(r["status"], ref["status"]) and np.array_equal(r["iters"], ref["iters"]), (name, r["iters"], ref["iters"])
+      np.testing.assert_allclose(r["cost"], ref["cost"], rtol=1e-11, atol=0.0)
+      assert np.abs(r["xs_and_us"] - ref["xs_and_us"]).max() <= 1e-9 and np.abs(r["lambda"] - ref["lambda"]).max() <= 1e-7 * max(1.0, np.abs(ref["lambda"]).max())
+      continue
     for k in ref:
       assert np.array_equal(r[k], ref[k]), (name, k)
+
+
+# ---- NodeSystem under SHOOTING: the reference's DEFAULT route for a NodeSystem (config.py:66 optimizer = SHOOTING; solve_with_params goes through
+# ---- parametrized_objective / parametrized_constraints of the shooting transcription, shooting.py:144-167, 212-228; useful_scripts.py:79-89) --------------
+
+def _setup_shooting(intervals, cpi, method):
+  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.SHOOTING, integration_method=method, intervals=intervals, controls_per_interval=cpi,
+               hidden_layers=(64, 64), nlpsolver=NLPSolverType.SQP)
+  node = NeuralODE.load_fitted_cartpole()
+  return hp, node, get_optimizer(hp, CFG, NodeSystem(node, hp.system()))
+
+
+@pytest.mark.parametrize("method", [IntegrationMethod.HEUN, IntegrationMethod.RK4, IntegrationMethod.EULER, IntegrationMethod.MIDPOINT])
+@pytest.mark.parametrize("intervals,cpi", [(4, 3), (1, 10)])
+def test_node_shooting_eval_matches_oracle_autodiff(method, intervals, cpi):
+  """myr_eval of the shooting transcription with the network as the dynamics: objective, constraints and both derivatives against the oracle's autodiff
+  of its restatement of shooting.py:144-167 (parametrized_objective) and :212-228 (parametrized_constraints)."""
+  from oracle import myriad_oracle as O
+  hp, node, opt = _setup_shooting(intervals, cpi, method)
+  tr = O.shooting(O.NodeCartPole(node.params), intervals, cpi, method.name)
+  cb = O.Callbacks(tr)
+  rng = np.random.default_rng(1)
+  z = tr.guess + 0.2 * rng.standard_normal(tr.guess.size)
+  np.testing.assert_allclose(opt.parametrized_constraints(node.params, z), cb.cons(z), rtol=1e-11, atol=1e-11)
+  assert opt.parametrized_objective(node.params, z) == pytest.approx(cb.fun(z), rel=1e-11)
+  np.testing.assert_allclose(opt.constraints_jac(z, params=node.params), cb.jac(z), rtol=1e-9, atol=1e-10)
+  np.testing.assert_allclose(opt.objective_grad(z, params=node.params), cb.grad(z), rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("method", [IntegrationMethod.HEUN, IntegrationMethod.RK4])
+def test_node_shooting_solve_with_params_is_kkt_point(method):
+  """run_node_trajectory_opt with the reference's default flags (useful_scripts.py:79-89): multiple shooting through the network."""
+  from oracle import myriad_oracle as O
+  intervals, cpi = 20, 2
+  hp, node, opt = _setup_shooting(intervals, cpi, method)
+  sol = opt.solve_with_params(node.params)
+  z = sol['xs_and_us']
+  cb = O.Callbacks(O.shooting(O.NodeCartPole(node.params), intervals, cpi, method.name))
+  assert np.abs(cb.cons(z)).max() <= 1e-8
+  assert cb.fun(z) == pytest.approx(sol['cost'], rel=1e-10)
+  lb, ub = opt.bounds[:, 0], opt.bounds[:, 1]
+  r = cb.grad(z) + cb.jac(z).T @ sol['lambda']
+  inact = (lb < ub) & (z - lb > 1e-3) & (ub - z > 1e-3)
+  assert np.abs(r[inact]).max() < 1e-5
+  assert 40.0 < sol['cost'] < 200.0
+
+
+def test_node_shooting_batch():
+  """A batch of multiple-shooting problems through the network (20 intervals x 5 controls, random x0, one shared weight set): every instance converges."""
+  from oracle import myriad_oracle as O
+  hp, node, opt = _setup_shooting(20, 5, IntegrationMethod.HEUN)
+  x0 = O.random_x0(O.CartPole(), 256, seed=2019)
+  res = opt.solve_batch(x0s=x0, params=opt.system.device_params())
+  assert (res['status'] == 0).all(), np.bincount(res['status'])
+  ev = opt.engine.eval(res['xs_and_us'], params=opt.system.device_params(), want=("c",))
+  assert np.abs(ev["c"]).max() <= 1e-8

@@ -7,6 +7,17 @@ import numpy as np
 NW, NQ = 5, 2
 rng = np.random.default_rng(0)
 
+def chol_floor(A, floor):
+  """detail::chol_reg of hs_solver.h: a pivot that is not above `floor` is replaced by max(|pivot|, floor) (unreachable directions of a short chunk)"""
+  n = A.shape[0]; L = np.zeros_like(A)
+  for j in range(n):
+    d = A[j, j] - L[j, :j] @ L[j, :j]
+    if not d > floor: d = max(abs(d), floor)
+    L[j, j] = np.sqrt(d)
+    for i in range(j + 1, n):
+      L[i, j] = (A[i, j] - L[i, :j] @ L[j, :j]) / L[j, j]
+  return L
+
 def stage_step(Z, Q, l, F, f, nth):
   """Z over (w+; theta) -> Z over (w; theta) and the gains K | kc (q = -K w - kc theta)."""
   ny = NW + NQ
@@ -90,7 +101,7 @@ def two_level(stages, pinned, rho_t, rho, W):
     M = Pp - rho * np.eye(NW)
     A = np.eye(NW) - Tnn @ M
     S = -Tnn
-    L = np.linalg.cholesky(S + 1e-300 * np.eye(NW))
+    L = chol_floor(S, 1e-14 * max(np.abs(np.diag(S)).max(), 1e-300))
     C = np.eye(NW) + L.T @ M @ L
     pmin_if = min(pmin_if, np.linalg.eigvalsh(C).min())
     Ai = np.linalg.inv(A)
@@ -111,10 +122,10 @@ def two_level(stages, pinned, rho_t, rho, W):
     Ztrue = Zn
   return out, join, Ztrue, edges, pmin_if
 
-def main():
-  N, W = 24, 4
-  pinned = [0, 1, 3]
-  for convex in (True, False):
+def compare(N=24, W=4, pinned=(0, 1, 3), convex=True, verbose=False):
+  """two-level against the plain recursion on one random staged QP: largest differences of the value form, nu_T, the states w and the controls q"""
+  pinned = list(pinned)
+  if True:
     st = make(N, convex)
     Zt, nth = terminal(pinned, 1e4)
     Z, G, pmin = sweep(st, Zt, nth)
@@ -134,8 +145,15 @@ def main():
       c = max(i for i in range(W) if edges[i] <= k)
       return ths[c]
     ws2, qs2 = rollout(st, G2, w02, th_of)
-    print("convex" if convex else "indefinite", "min pivot sequential %.3g | chunks %s interface %.3g" % (min(pmin, p0), ["%.3g" % o[2] for o in out], pmin_if))
-    print("  Z(P,pc) diff %.3e  nuT diff %.3e  w diff %.3e  q diff %.3e  pinned terminal %.2e" % (
-      np.abs(Ztrue[:NW, :] - Z[:NW, :]).max(), np.abs(th - th2).max(), np.abs(ws - ws2).max(), np.abs(qs - qs2).max(), np.abs(ws2[-1][pinned]).max()))
+    if verbose:
+      print("convex" if convex else "indefinite", "min pivot sequential %.3g | chunks %s interface %.3g" % (min(pmin, p0), ["%.3g" % o[2] for o in out], pmin_if))
+      print("  Z(P,pc) diff %.3e  nuT diff %.3e  w diff %.3e  q diff %.3e  pinned terminal %.2e" % (
+        np.abs(Ztrue[:NW, :] - Z[:NW, :]).max(), np.abs(th - th2).max(), np.abs(ws - ws2).max(), np.abs(qs - qs2).max(), np.abs(ws2[-1][pinned]).max()))
+    return dict(dZ=np.abs(Ztrue[:NW, :] - Z[:NW, :]).max(), dnu=np.abs(th - th2).max(), dw=np.abs(ws - ws2).max(), dq=np.abs(qs - qs2).max(),
+                pinned=np.abs(ws2[-1][pinned]).max() if pinned else 0.0, pmin_seq=min(pmin, p0), pmin_chunks=min(o[2] for o in out), pmin_if=pmin_if,
+                scale=max(1.0, np.abs(ws).max(), np.abs(qs).max()))
 
-main()
+
+if __name__ == "__main__":
+  for convex in (True, False):
+    compare(convex=convex, verbose=True)

@@ -2,7 +2,7 @@
 """What the single-GPU kernels predict for the strong split of every BASELINE config (ONE batch partitioned over G GPUs): the measured
 single-GPU rate at B / G instances, times G, for G in {1, 2, 4, 8} -- the expectation the first real SCALE run has to agree with.
 No xGMI byte enters: the only collective is the final gather (8-33 MB, < 0.1 ms on any link); what bounds the strong split is that a launch of B / G
-instances is one solve long, so the per-GPU rate at that size is what counts.  -> profiles/r05/projected_scaling.json
+instances is one solve long, so the per-GPU rate at that size is what counts.  -> profiles/r06/projected_scaling.json
   usage (GPU box): python tools/projected_scaling.py out.json"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
