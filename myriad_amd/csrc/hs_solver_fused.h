@@ -137,6 +137,9 @@ struct HsFused {
   // Two-level sweep (round 6; -DMYR_TWO_LEVEL=0: round 5's form): the W wavefronts a trajectory owns each condense a CHUNK of N / W stages in parallel
   // (riccati_chunk / riccati_chunk_trap), a small interface recursion joins the chunks (tl_join), see there.  Both collocation schemes on the hand-placed
   // tile (one control, NS <= 4).
+#ifndef MYR_SWEEP_CARRY
+#define MYR_SWEEP_CARRY 0      // experiment (round 6): C operands whose upper half is zero inherit it from the previous result instead of a zero fill
+#endif
 #ifndef MYR_TWO_LEVEL
 #define MYR_TWO_LEVEL 1
 #endif
@@ -1134,8 +1137,28 @@ struct HsFused {
       C2[0] = 0.0; C2[1] = 0.0; C2[2] = 0.0; C2[3] = R[1];
       return __builtin_amdgcn_mfma_f64_16x16x4f64(Gm, R[0], C2, 0, 0, 0);
     };
+#if MYR_SWEEP_CARRY >= 2
+    double QmU = 0.0;
+    mfma_d4 Qm;
+    {
+      double n0 = in[0][3] + dv0, n1 = in[0][4] + dv1;
+      const double s0 = W0::dpp_row_shr8(n0), s1 = W0::dpp_row_shr8(n1);
+      mfma_d4 C;
+      C[0] = fma(s0, f_shm, n0 * f_keep);
+      C[1] = fma(s1, f_shm, n1 * f_keep);
+      C[2] = 0.0; C[3] = 0.0;
+      const mfma_d4 R = __builtin_amdgcn_mfma_f64_16x16x4f64(n0 * f_a1, in[0][5], C, 0, 0, 0);
+      Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(in[0][5], R[0], mfma_d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+      QmU = R[1];
+    }
+#else
     mfma_d4 Qm = mid_part(in[0][3], in[0][4], in[0][5]);
+#endif
     mfma_d4 D3 = {X0, X1, 0.0, 0.0};
+#if MYR_SWEEP_CARRY
+    mfma_d4 D1c = {0.0, 0.0, 0.0, 0.0}, Rmc = {0.0, 0.0, 0.0, 0.0};
+
+#endif
     for (int kb = N - 1; kb >= 0; kb -= PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -1147,26 +1170,53 @@ struct HsFused {
 #pragma unroll
         for (int q = 0; q < 6; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
         const double sh0 = W0::dpp_row_shr4(X0), sh1 = W0::dpp_row_shr4(X1);
+#if MYR_SWEEP_CARRY
+        // (rows 8..15 of R~ are zero -- the A operand has no such rows -- and stay zero from stage to stage: the previous result IS the next C operand's
+        //  upper half, no zero fill)
+        mfma_d4 C1 = D1c;
+        C1[0] = fma(sh0, f_she, X0 * f_keep);
+        C1[1] = fma(sh1, f_she, X1 * f_keep);
+        const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X0 * f_a1, G, C1, 0, 0, 0);
+        D1c = D1;
+#else
         mfma_d4 C1;
         C1[0] = fma(sh0, f_she, X0 * f_keep);
         C1[1] = fma(sh1, f_she, X1 * f_keep);
         C1[2] = 0.0; C1[3] = 0.0;
         const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X0 * f_a1, G, C1, 0, 0, 0);
+#endif
         mfma_d4 C2;
         C2[0] = Qm[0]; C2[1] = fma(D3[1], f_t1, Qm[1]); C2[2] = fma(D3[2], f_t23, Qm[2]) + D1[1]; C2[3] = fma(D3[3], f_t23, Qm[3]);
+#if MYR_SWEEP_CARRY >= 2
+        C2[3] += QmU;
+#endif
         const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
         // midpoint part of stage k-1 (independent of the recursion): issued HERE, so that its two dependent products run on
         // the matrix pipe while the vector pipe waits for D2 and computes the gains -- behind D3 they delayed the next stage's D1
         double m0 = nn0 + dv0, m1 = nn1 + dv1;
         const double ms0 = W0::dpp_row_shr8(m0), ms1 = W0::dpp_row_shr8(m1);
+#if MYR_SWEEP_CARRY
+        mfma_d4 Cm = Rmc;
+        Cm[0] = fma(ms0, f_shm, m0 * f_keep);
+        Cm[1] = fma(ms1, f_shm, m1 * f_keep);
+        const mfma_d4 Rm = __builtin_amdgcn_mfma_f64_16x16x4f64(m0 * f_a1, nGm, Cm, 0, 0, 0);
+        Rmc = Rm;
+#else
         mfma_d4 Cm;
         Cm[0] = fma(ms0, f_shm, m0 * f_keep);
         Cm[1] = fma(ms1, f_shm, m1 * f_keep);
         Cm[2] = 0.0; Cm[3] = 0.0;
         const mfma_d4 Rm = __builtin_amdgcn_mfma_f64_16x16x4f64(m0 * f_a1, nGm, Cm, 0, 0, 0);
+#endif
+#if MYR_SWEEP_CARRY >= 2
+        // (the control rows of R enter rows 12..15 of Q: added where Q is consumed -- QmU -- instead of through a C operand that is zero but for them)
+        Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(nGm, Rm[0], mfma_d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        QmU = Rm[1];
+#else
         mfma_d4 Cq;
         Cq[0] = 0.0; Cq[1] = 0.0; Cq[2] = 0.0; Cq[3] = Rm[1];
         Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(nGm, Rm[0], Cq, 0, 0, 0);
+#endif
         const double q00 = W0::rdlane(D2[3], 12), q10 = W0::rdlane(D2[2], 12), q11 = W0::rdlane(D2[2], 8);
         const double det = fma(q00, q11, -(q10 * q10));
         const double rdet = fast_rcp(det);

@@ -46,3 +46,38 @@ def test_smoke(sysname, approach):
   ns = system.x_0.shape[0]
   assert x.ndim == 2 and x.shape[1] == ns and u.shape[0] >= 1
   assert np.isfinite(x).all() and np.isfinite(u).all()
+
+
+# ---- the shooting rows again, this time asserting the outcome (round 6) --------------------------------------------------------------
+# The reference's IPOPT call carries a restoration phase for every transcription (nlp_solvers/__init__.py:57-58).  The device path has TWO stand-ins:
+# the elastic twin problems for the collocation transcriptions, and SECOND STARTS -- excitation guesses, myriad_hip.hip: solve_restored -- for all three.
+# For shooting the second starts are the whole restoration.  This test is the statement that nothing is lost by that: of the 60 shooting cases of the
+# reference's smoke matrix (20 systems x single / multiple shooting 30 x 3 / 90 x 1) 52 converge from the reference's guess, 5 more from a second start
+# (CARTPOLE single shooting; PENDULUM and PREDATORPREY multiple shooting), and the remaining three are ROCKETLANDING, whose problem as posed has no
+# feasible point (its collocation runs end INFEASIBLE after the elastic phase) -- no restoration phase could converge them.
+# (tools/dev/shoot_matrix.py prints the table with and without second starts.)
+SHOOTING = {k: v for k, v in APPROACHES.items() if v["optimizer"] == OptimizerType.SHOOTING}
+NEEDS_SECOND_START = {("CARTPOLE", "single_shooting"), ("PENDULUM", "multiple_shooting_3_controls"), ("PENDULUM", "multiple_shooting_1_control"),
+                      ("PREDATORPREY", "multiple_shooting_3_controls"), ("PREDATORPREY", "multiple_shooting_1_control")}
+
+
+@pytest.mark.parametrize("approach", list(SHOOTING))
+@pytest.mark.parametrize("sysname", SYSTEMS)
+def test_shooting_needs_no_elastic_phase(monkeypatch, sysname, approach):
+  monkeypatch.delenv("MYRIAD_SECOND_STARTS", raising=False)
+  hp = HParams(system=SystemType[sysname], **SHOOTING[approach])
+  if sysname == "ROCKETLANDING":
+    hp.max_iter = 150
+  opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+  res = opt.solve_batch(x0s=np.asarray(opt.system.x_0, dtype=np.float64)[None])
+  status, attempts = int(res["status"][0]), int(res["attempts"][0])
+  if sysname == "ROCKETLANDING":
+    assert status != 0 and attempts > 1, (status, attempts)          # every start is tried; none can succeed
+    return
+  assert status == 0, (sysname, approach, status, attempts, res["start"])
+  z = res["xs_and_us"][0]
+  assert np.abs(opt.constraints(z)).max() <= 1e-8 * max(1.0, np.abs(z).max()), (sysname, approach, np.abs(opt.constraints(z)).max())      # (SEIR's states are populations of 1e3)
+  if (sysname, approach) in NEEDS_SECOND_START:
+    assert attempts > 1 and int(res["start"][0]) > 0
+  else:
+    assert attempts == 1

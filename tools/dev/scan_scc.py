@@ -15,7 +15,8 @@ Usage: hipcc -S --cuda-device-only ... -o x.s ; python tools/dev/scan_scc.py x.s
 import re
 import sys
 
-_W = re.compile(r'^\s*s_(add|sub|addc|subb|min|max|and|or|xor|andn2|orn2|nand|nor|xnor|lshl|lshr|ashr|bfe|absdiff|abs|not|wqm|bcnt|cmp|bitcmp|quadmask|addk|cmpk|mulk)\w*\s')
+# (s_mulk_i32 is NOT in the list: it leaves SCC alone -- round 6: a legitimate `s_cmp_gt_i32 .. ; s_mulk_i32 .. ; <vector code> ; s_cselect_b64` was flagged)
+_W = re.compile(r'^\s*s_(add|sub|addc|subb|min|max|and|or|xor|andn2|orn2|nand|nor|xnor|lshl|lshr|ashr|bfe|absdiff|abs|not|wqm|bcnt|cmp|bitcmp|quadmask|addk|cmpk)\w*\s')
 
 
 _VCC_SRC = re.compile(r'(,\s*vcc\b)|(s_cbranch_vcc)')

@@ -19,7 +19,8 @@ for st in SystemType:
       if st.name == "ROCKETLANDING": hp.max_iter = 150
       t0 = time.time()
       try:
-        res = get_optimizer(hp, Config(verbose=False, plot=False), hp.system()).solve()
+        opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+        res = opt.solve_batch(x0s=np.asarray(opt.system.x_0, dtype=np.float64)[None])
         row[ss] = dict(status=int(np.asarray(res["status"]).ravel()[0]), attempts=int(np.asarray(res.get("attempts", 1)).ravel()[0]), start=int(np.asarray(res.get("start", 0)).ravel()[0]),
                        cost=float(np.asarray(res["cost"]).ravel()[0]), s=round(time.time() - t0, 2))
       except Exception as e:
