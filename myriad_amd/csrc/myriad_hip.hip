@@ -923,13 +923,25 @@ static int launch_shoot_solve(myr_handle h, int B, double* z, const double* lb, 
   if (!h->ticket) HIPCHK(hipMalloc(&h->ticket, sizeof(int)));
   HIPCHK(hipMemsetAsync(h->ticket, 0, sizeof(int), h->stream));
   HsSolveOpts o = make_opts(h, so);
+  // network systems: records, activations and tangents of the matrix-core passes, per resident workgroup (shoot_solver_wave.h: mlp_scratch_doubles)
+  long sstride = (W::mlp_scratch_doubles(N, cpi) + 31) / 32 * 32;
+  if (sstride > 0) {
+    if (((sstride / 32) & 1) == 0) sstride += 32;
+    const size_t need = (size_t)slots * (size_t)sstride * 8;
+    if (need > h->sbuf_bytes) {
+      if (h->sbuf) HIPCHK(hipFree(h->sbuf));
+      h->sbuf = nullptr; h->sbuf_bytes = 0;
+      HIPCHK(hipMalloc(&h->sbuf, need));
+      h->sbuf_bytes = need;
+    }
+  }
   KTimer& kt = h->kt[MYR_K_SOLVE];
   if (int rc_fill = stack_fill(h)) return rc_fill;
   HIPCHK(hipEventRecord(kt.a, h->stream));
   h->last_solve_form = 1;
   { const int32_t pl[8] = {3, 1, 0, 1, slots, 0, 0, 0}; if (!h->plan_frozen) memcpy(h->plan, pl, sizeof(pl)); }
   hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(64), lds, h->stream, B, h->ticket, o, h->vscale, z, lb, ub, lam, params, pstride,
-                     cost, status, iters, kkt, h->poison);
+                     cost, status, iters, kkt, h->poison, sstride > 0 ? (double*)h->sbuf : (double*)nullptr, sstride);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(kt.b, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

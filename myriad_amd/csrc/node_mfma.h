@@ -163,6 +163,8 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
     nd_glb* hb = nullptr;                                   // hidden activations of tile t: hb[(t * 32 + f) * 64 + lane], f = 4 mt + s (h1), 16 + 4 mt + s (h2)
     nd_glb* mb = nullptr;                                   // MODE 3 -> MODE 4: tangents m_c of tile t: mb[(t * 80 + c * 16 + 4 mt + s) * 64 + lane]
     int h_valid = 0;                                        // MODE 3: hb holds the activations of this iterate (the last trial was accepted)
+    const ZT* avec = nullptr;                               // MODE 4: the contraction vector of point j given directly, avec[j * NS + r] (shooting: stage weights
+                                                            //   of the step's costate, os_solver.h: step_lin / rk4_lin) instead of the Hermite-Simpson combination of `lam`
   };
   static constexpr int HB_TILE = 32 * 64, MB_TILE = NW * 16 * 64;
   __host__ __device__ static constexpr int ntiles(int K) { return (K + 15) / 16; }
@@ -300,7 +302,8 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
       }
       if (MODE == 4) {
         double ar;
-        if (j & 1) ar = -4.0 * a.h6 * a.lam[(long)((j - 1) >> 1) * NS + g];
+        if (a.avec) ar = a.avec[(long)j * NS + g];
+        else if (j & 1) ar = -4.0 * a.h6 * a.lam[(long)((j - 1) >> 1) * NS + g];
         else {
           const int kL = (j >> 1) - 1, kR = j >> 1;
           ar = 0.0;

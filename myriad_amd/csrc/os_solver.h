@@ -494,6 +494,15 @@ struct ShootCore {
   MYR_HD static void update(const HsWork& w, int n, double ap, double ad, double mu, double ksig) { H::update(w, n, ap, ad, mu, ksig); }
   MYR_HD static void solve_nu(const SweepOut& so, double mu, double* nu) { H::solve_nu(so, mu, nu); }
 
+  // What a step linearisation asks of the system at its stage points: value + first derivatives + cost terms of stage j (`lin`), and the second
+  // derivatives contracted with the stage weights (`hess`).  SysEval evaluates the system in place (closed-form systems, and the per-lane form of
+  // the network); the wavefront kernel of the network system (shoot_solver_wave.h) passes an evaluator that reads what matrix-core passes over all
+  // stage points of the horizon have left in records.
+  struct SysEval {
+    MYR_HD inline void lin(int, HsPoint<Sys>& P, const double* p) const { Sys::lin_d2(P.x, P.u, p, P.f, P.A, P.B, &P.g, P.gw, P.D2); }
+    MYR_HD inline void hess(int, const HsPoint<Sys>& P, const double* p, const double* mu, double w, double* W) const { Sys::hessian(P.x, P.u, p, P.D2, mu, w, W); }
+  };
+
   // one integration step of [x; integral of g]  (utils.py:41-44 Heun, :52-54 Euler), plain values
   // t0: time at the start of the step (cost functions with explicit time, shooting.py:196-203 integrates with the global
   // step times); last: the final step of the final interval, whose end state carries the terminal cost (shooting.py:206-208)
@@ -539,8 +548,9 @@ struct ShootCore {
   // Hs = d2 (dc + pin^T x_next) / dy2
   // A (linear) terminal cost on x_next is folded into the last step: its gradient joins the costate for the Hessian term
   // and is pulled back through Fy into gy.
+  template <class EV = SysEval>
   MYR_HD static inline void step_lin(int method, double h, const double* x, const double* u, const double* un, const double* p,
-                                     const double* pin_in, double* Fy, double* gy, double* Hs, double t0 = 0.0, bool last = false) {
+                                     const double* pin_in, double* Fy, double* gy, double* Hs, double t0 = 0.0, bool last = false, const EV& ev = EV()) {
     double pin[NS], tg[NW];
 #pragma unroll
     for (int c = 0; c < NW; ++c) tg[c] = 0.0;
@@ -568,14 +578,14 @@ struct ShootCore {
 #pragma unroll
     for (int a = 0; a < NU; ++a) P1.u[a] = u[a];
     set_time<Sys>(p, t0);
-    Sys::lin_d2(P1.x, P1.u, p, P1.f, P1.A, P1.B, &P1.g, P1.gw, P1.D2);
+    ev.lin(0, P1, p);
 #pragma unroll
     for (int i = 0; i < NY * NY; ++i) Hs[i] = 0.0;
     if (method == 0) {
       double W1[NW * NW], mu1[NS];
 #pragma unroll
       for (int c = 0; c < NS; ++c) mu1[c] = h * pin[c];
-      Sys::hessian(P1.x, P1.u, p, P1.D2, mu1, h, W1);
+      ev.hess(0, P1, p, mu1, h, W1);
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
 #pragma unroll
@@ -607,7 +617,7 @@ struct ShootCore {
 #pragma unroll
     for (int a = 0; a < NU; ++a) P2.u[a] = cu * u[a] + cun * un[a];
     set_time<Sys>(p, t0 + (mid ? 0.5 * h : h));
-    Sys::lin_d2(P2.x, P2.u, p, P2.f, P2.A, P2.B, &P2.g, P2.gw, P2.D2);
+    ev.lin(1, P2, p);
     // J2 = d w2 / dy (NW x NY): x~ rows [I + h A1, h B1, 0], u2 rows [0, cu I, cun I]
     double J2[NW * NY];
 #pragma unroll
@@ -651,8 +661,8 @@ struct ShootCore {
       mu1[c] = h1 * pin[c] + h * h2 * s;
       mu2[c] = h2 * pin[c];
     }
-    Sys::hessian(P1.x, P1.u, p, P1.D2, mu1, h1, W1);
-    Sys::hessian(P2.x, P2.u, p, P2.D2, mu2, h2, W2);
+    ev.hess(0, P1, p, mu1, h1, W1);
+    ev.hess(1, P2, p, mu2, h2, W2);
     double T[NW * NY];
 #pragma unroll
     for (int r = 0; r < NW; ++r)
@@ -702,8 +712,9 @@ struct ShootCore {
   // Fy (NS x NY) = d x_next / dy, gy = d dc / dy, Hs = d2 (dc + pin^T x_next) / dy2 -- exact, by forward Jacobians J_j = dW_j/dy
   // and a reverse pass for the stage weights: kappa_4 = h b_4 pin, xi_j = A_j^T kappa_j + h b_j dg/dx_j,
   // kappa_{j-1} = h b_{j-1} pin + h a_j xi_j;  Hs = sum_j J_j^T [sum_i kappa_j,i d2 f_i + h b_j d2 g](W_j) J_j
+  template <class EV = SysEval>
   MYR_HD static inline void rk4_lin(double h, const double* x, const double* u1, const double* u2, const double* u3, const double* p,
-                                    const double* pin_in, double* Fy, double* gy, double* Hs, double t0, bool last) {
+                                    const double* pin_in, double* Fy, double* gy, double* Hs, double t0, bool last, const EV& ev = EV()) {
     static_assert(M == 2, "RK4 stages carry three control rows");
     const double* U[4] = {u1, u2, u2, u3};
     const int usel[4] = {0, 1, 1, 2};
@@ -737,7 +748,7 @@ struct ShootCore {
 #pragma unroll
         for (int c = 0; c < NY; ++c) J[j][(NS + a) * NY + c] = (c == NS + usel[j] * NU + a) ? 1.0 : 0.0;
       set_time<Sys>(p, t0 + aj[j] * h);
-      Sys::lin_d2(P[j].x, P[j].u, p, P[j].f, P[j].A, P[j].B, &P[j].g, P[j].gw, P[j].D2);
+      ev.lin(j, P[j], p);
       // dk_j = [A_j B_j] J_j ; accumulate Fy, gy
 #pragma unroll
       for (int r = 0; r < NS; ++r)
@@ -770,7 +781,7 @@ struct ShootCore {
 #pragma unroll
     for (int c = 0; c < NS; ++c) kap[c] = h * bj[3] * pin[c];
     for (int j = 3; j >= 0; --j) {
-      Sys::hessian(P[j].x, P[j].u, p, P[j].D2, kap, h * bj[j], W);
+      ev.hess(j, P[j], p, kap, h * bj[j], W);
 #pragma unroll
       for (int r = 0; r < NW; ++r)
 #pragma unroll
@@ -823,10 +834,11 @@ struct ShootCore {
     if constexpr (M == 2) rk4_val(h, x, uc, uc + NU, uc + 2 * NU, p, xn, dc, t0, last);
     else step_val(method, h, x, uc, uc + NU, p, xn, dc, t0, last);
   }
+  template <class EV = SysEval>
   MYR_HD static inline void slin(int method, double h, const double* x, const double* uc, const double* p, const double* pin,
-                                 double* Fy, double* gy, double* Hs, double t0, bool last) {
-    if constexpr (M == 2) rk4_lin(h, x, uc, uc + NU, uc + 2 * NU, p, pin, Fy, gy, Hs, t0, last);
-    else step_lin(method, h, x, uc, uc + NU, p, pin, Fy, gy, Hs, t0, last);
+                                 double* Fy, double* gy, double* Hs, double t0, bool last, const EV& ev = EV()) {
+    if constexpr (M == 2) rk4_lin(h, x, uc, uc + NU, uc + 2 * NU, p, pin, Fy, gy, Hs, t0, last, ev);
+    else step_lin(method, h, x, uc, uc + NU, p, pin, Fy, gy, Hs, t0, last, ev);
   }
 
   // own (bound) terms of one decision variable

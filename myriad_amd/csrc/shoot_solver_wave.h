@@ -65,7 +65,31 @@ struct ShootWave {
                        // the last trial point: step length, objective, defect norms; 1 if its rollout is the current iterate's;
                        // problem dimensions for the phases that are not handed the options (update)
                        X_TA = X_PC + NW * NC, X_TF = X_TA + 1, X_TC1 = X_TF + 1, X_TCINF = X_TC1 + 1, X_ROLL = X_TCINF + 1,
-                       X_DN = X_ROLL + 1, X_DCPI = X_DN + 1, X_N = (X_DCPI + 1 + 7) / 8 * 8;
+                       X_DN = X_ROLL + 1, X_DCPI = X_DN + 1, X_SCR = X_DCPI + 1 /* network systems: this slot's global scratch (a pointer) */,
+                       X_N = (X_SCR + 1 + 7) / 8 * 8;
+
+  // ---- network dynamics (node_system.h) on the matrix-core passes of node_mfma.h (round 6) --------------------------------------------------
+  // The per-lane form of the network (SysNODE::f / lin / hessian: every lane walks the 64 x 64 layers of ITS point with the hidden vectors in
+  // private memory) made a shooting solve of the network system thousands of times slower than a collocation solve.  Here the evaluations of a
+  // phase are gathered into point lists and run as tiles of 16 points, as in the collocation kernel:
+  //   * rollouts: the steps of an interval are sequential, the intervals are not -- per step and stage ONE value pass (MODE 0) over the stage
+  //     points of all intervals (lane k = interval k);
+  //   * linearisation: after the rollout every step's first stage point is known; per stage one MODE 3 pass over the S steps (value, A, B into
+  //     global records; the hidden activations and tangents stay in the slot's scratch for MODE 4), the next stage's points follow from the
+  //     records; the step algebra (os_solver.h: step_lin / rk4_lin) then reads the records through an evaluator instead of calling the system;
+  //   * second derivatives: a dry run of the step algebra with the costates records the stage weights (the contraction vectors), one MODE 4
+  //     pass per stage contracts the network's second derivatives with them, a last run of the step algebra assembles the step Hessians.
+  static constexpr bool MLP = NodeTraits<Sys>::mlp;
+  static constexpr int NSTM = (M == 2) ? 4 : 2;                    // stage points per step at most
+  static constexpr int PT_F = 0, PT_A = PT_F + NS, PT_B = PT_A + NS * NS, PT_D2 = PT_B + NS * NU, PT_N = PT_D2 + NW * (NW + 1) / 2;
+  __host__ __device__ static long mlp_kmax(long S) { return S > 64 ? S : 64; }
+  __host__ __device__ static long mlp_lds_doubles(long S) {       // weights | point list | values (one rollout pass) | costates per step | stage weights
+    return MLP ? (long)NodeTraits<Sys>::lds_doubles + NW * mlp_kmax(S) + NS * 64 + S * NS + (long)NSTM * S * NS : 0;
+  }
+  __host__ __device__ static long mlp_scratch_doubles(int I, int cpi) {      // per resident workgroup (global): records, activations, tangents of every stage
+    const long S = (long)I * cpi, nt = (S + 15) / 16;
+    return MLP ? (long)NSTM * (PT_N * S + nt * (NodeMfma64::HB_TILE + NodeMfma64::MB_TILE)) : 0;
+  }
 
   __host__ __device__ static inline int steps(const HsSolveOpts& o) { return o.N * o.cpi; }
   __host__ __device__ static inline int nvars(const HsSolveOpts& o) { return (o.N + 1) * NS + (M * steps(o) + 1) * NU; }
@@ -75,7 +99,7 @@ struct ShootWave {
   __host__ __device__ static long tmp_doubles(long S, long n) { return 2 * (S + 1) * NS + n; }
   __host__ __device__ static long lds_doubles(int I, int cpi) {
     const long S = (long)I * cpi, n = (long)(I + 1) * NS + (M * S + 1) * NU;
-    return X_N + 9 * n + tmp_doubles(S, n) + S * (REC + KG) + NU * NC + 2 * (long)I * NS;
+    return X_N + 9 * n + tmp_doubles(S, n) + S * (REC + KG) + NU * NC + 2 * (long)I * NS + mlp_lds_doubles(S);
   }
   __host__ __device__ static size_t lds_bytes(int I, int cpi) { return (size_t)lds_doubles(I, cpi) * 8; }
 
@@ -85,6 +109,7 @@ struct ShootWave {
     sw_lds *zlu;             // = dz  (bound-multiplier difference, dead before the step is written)
     sw_lds *xs, *xt, *zt;    // rollout states of the iterate / of the last trial point, the trial point
     sw_lds *ct;              // continuity defects of the last trial point
+    sw_lds *wl, *pts, *sF, *pinS, *avec;      // network systems: weights, point list, values of a rollout pass, costates per step, stage weights
   };
   __device__ static inline sw_lds* lds_base() {
     extern __shared__ __attribute__((aligned(16))) char smem_wave[];
@@ -99,7 +124,8 @@ struct ShootWave {
     l.sig = s; s += n; l.g1 = s; s += n; l.z0 = s; s += n;
     l.zlu = l.dz;
     l.xs = s; l.xt = s + (S + 1) * NS; l.zt = s + 2 * (S + 1) * NS; s += tmp_doubles(S, n);
-    l.rec = s; s += S * REC; l.kg = s; s += S * KG; l.ku = s; s += NU * NC; l.lam = s; s += steps(o) / o.cpi * NS; l.ct = s;
+    l.rec = s; s += S * REC; l.kg = s; s += S * KG; l.ku = s; s += NU * NC; l.lam = s; s += steps(o) / o.cpi * NS; l.ct = s; s += steps(o) / o.cpi * NS;
+    l.wl = s; s += NodeTraits<Sys>::lds_doubles; l.pts = s; s += NW * mlp_kmax(S); l.sF = s; s += NS * 64; l.pinS = s; s += S * NS; l.avec = s;
     return l;
   }
 #ifdef MYR_SW_TIMING
@@ -200,6 +226,221 @@ struct ShootWave {
 #pragma unroll
       for (int c = 0; c < NS; ++c) x[c] = xn[c];
     }
+  }
+
+  // ---- network systems: the phases on the matrix-core passes ------------------------------------------------------------------------------
+  struct MlpScr { nd_glb *pt, *hb, *mb; long nt; };
+  __device__ static inline MlpScr mlp_scr(const Lds& l, long S) {
+    MlpScr m;
+    nd_glb* g = (nd_glb*)(double*)__builtin_bit_cast(unsigned long long, (double)l.ex[X_SCR]);
+    m.nt = (S + 15) / 16;
+    m.pt = g; m.hb = g + (long)NSTM * PT_N * S; m.mb = m.hb + (long)NSTM * m.nt * NodeMfma64::HB_TILE;
+    return m;
+  }
+  // f at the K points of the list l.pts (states [K][NS], then the controls [K]) -> l.sF[k * NS + r]
+  __device__ static inline void mlp_values(const Lds& l, int K) {
+    if constexpr (MLP) {
+      NodeMfma64::ArgsT<nd_lds> a;
+      a.z = (const nd_lds*)l.pts; a.dz = (const nd_lds*)l.pts; a.lam = nullptr; a.pt = nullptr; a.sF = (nd_lds*)l.sF;
+      a.alpha = 0.0; a.h6 = 0.0; a.h8 = 0.0; a.K = K; a.N = 0; a.pf_f = 0; a.pf_a = 0; a.pf_b = 0; a.pf_d2 = 0;
+      a.t0 = 0; a.ts = 1; a.hb = nullptr; a.mb = nullptr; a.h_valid = 0;
+      __syncthreads();
+      NodeMfma64::pass<0, nd_lds>((const nd_lds*)l.wl, a, (int)threadIdx.x);
+      __syncthreads();
+    } else { (void)l; (void)K; }
+  }
+  // Rollouts of ALL intervals from the variables in `v`: step states -> xs, continuity defects -> dfc, objective and defect norms summed.  Lane k
+  // rolls interval k out; the network is evaluated for the stage points of all lanes together (mlp_values).  The step formulas are step_val's /
+  // rk4_val's (os_solver.h; utils.py:31-54).
+  __device__ static void roll_all_mlp(const HsSolveOpts& o, const double* p, const Lds& l, const sw_lds* v, sw_lds* xs, sw_lds* dfc, double& f, double& c1, double& cinf) {
+    if constexpr (MLP) {
+      const int I = o.N, cpi = o.cpi, lane = threadIdx.x;
+      const double h = SC::hstep(o);
+      for (int kb = 0; kb < I; kb += 64) {
+        const int K = (I - kb) < 64 ? (I - kb) : 64;
+        const bool on = lane < K;
+        const int k = on ? kb + lane : kb;
+        double x[NS];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) x[c] = v[xi(k, c)];
+        auto F = [&](const double* X, const double* U, double* out) {      // (every lane calls it: the pass is the whole wavefront's)
+          if (on) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) l.pts[lane * NS + c] = X[c];
+            l.pts[K * NS + lane] = U[0];
+          }
+          mlp_values(l, K);
+#pragma unroll
+          for (int c = 0; c < NS; ++c) out[c] = l.sF[(on ? lane : 0) * NS + c];
+        };
+        for (int s2 = 0; s2 < cpi; ++s2) {
+          const int i = k * cpi + s2;
+          double uc[(M + 1) * NU];
+#pragma unroll
+          for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = v[ui(o, M * i, a)];
+          if (on) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) xs[(long)i * NS + c] = x[c];
+          }
+          double xn[NS], dc;
+          if constexpr (M == 2) {
+            const double* U[4] = {uc, uc + NU, uc + NU, uc + 2 * NU};
+            const double aj[4] = {0.0, 0.5, 0.5, 1.0}, bj[4] = {1.0 / 6.0, 2.0 / 6.0, 2.0 / 6.0, 1.0 / 6.0};
+            double kk[NS], X[NS], acc[NS], g = 0.0;
+#pragma unroll
+            for (int c = 0; c < NS; ++c) { acc[c] = 0.0; kk[c] = 0.0; }
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+              for (int c = 0; c < NS; ++c) X[c] = x[c] + aj[j] * h * kk[c];
+              F(X, U[j], kk);
+              g += bj[j] * Sys::g(X, U[j], p);
+#pragma unroll
+              for (int c = 0; c < NS; ++c) acc[c] += bj[j] * kk[c];
+            }
+#pragma unroll
+            for (int c = 0; c < NS; ++c) xn[c] = x[c] + h * acc[c];
+            dc = h * g;
+          } else {
+            const double* u = uc; const double* un = uc + NU;
+            double f1[NS];
+            F(x, u, f1);
+            const double g1 = Sys::g(x, u, p);
+            if (o.method == 0) {          // (wave-uniform)
+#pragma unroll
+              for (int c = 0; c < NS; ++c) xn[c] = x[c] + h * f1[c];
+              dc = h * g1;
+            } else {
+              double xt[NS], f2[NS], u2[NU];
+#pragma unroll
+              for (int c = 0; c < NS; ++c) xt[c] = x[c] + h * f1[c];
+              const bool mid = (o.method == 2);
+#pragma unroll
+              for (int a = 0; a < NU; ++a) u2[a] = mid ? 0.5 * (u[a] + un[a]) : un[a];
+              F(xt, u2, f2);
+              const double g2 = Sys::g(xt, u2, p);
+              if (mid) {
+#pragma unroll
+                for (int c = 0; c < NS; ++c) xn[c] = x[c] + h * f2[c];
+                dc = h * g2;
+              } else {
+#pragma unroll
+                for (int c = 0; c < NS; ++c) xn[c] = x[c] + 0.5 * h * (f1[c] + f2[c]);
+                dc = 0.5 * h * (g1 + g2);
+              }
+            }
+          }
+          if (on) f += dc;
+#pragma unroll
+          for (int c = 0; c < NS; ++c) x[c] = xn[c];
+        }
+        if (on) {
+#pragma unroll
+          for (int c = 0; c < NS; ++c) {
+            const double ck = x[c] - v[xi(k + 1, c)];                          // shooting.py:239-241
+            dfc[(long)k * NS + c] = ck;
+            c1 += fabs(ck);
+            cinf = detail::dmax(cinf, fabs(ck));
+          }
+        }
+      }
+    } else { (void)o; (void)p; (void)l; (void)v; (void)xs; (void)dfc; (void)f; (void)c1; (void)cinf; }
+  }
+  // what the step algebra reads instead of calling the system (os_solver.h: SysEval): stage j of step i from the records of the passes
+  struct RecEval {
+    const nd_glb* pt; sw_lds* avec; long S; int i, mode;      // mode 0: first derivatives; 1: + record the stage weights; 2: + second derivatives from the records
+    __device__ inline void lin(int j, HsPoint<Sys>& P, const double* p) const {
+      const nd_glb* r = pt + (long)j * PT_N * S + i;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) P.f[c] = r[(long)(PT_F + c) * S];
+#pragma unroll
+      for (int q = 0; q < NS * NS; ++q) P.A[q] = r[(long)(PT_A + q) * S];
+#pragma unroll
+      for (int q = 0; q < NS * NU; ++q) P.B[q] = r[(long)(PT_B + q) * S];
+      Sys::cost_grad(P.x, P.u, p, &P.g, P.gw);
+    }
+    __device__ inline void hess(int j, const HsPoint<Sys>& P, const double* p, const double* mu, double w, double* W) const {
+      (void)p;
+      if (mode == 1) {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) avec[((long)j * S + i) * NS + c] = mu[c];
+      }
+      if (mode == 2) {
+        double Wm[NW * (NW + 1) / 2];
+        const nd_glb* r = pt + (long)j * PT_N * S + i;
+#pragma unroll
+        for (int e = 0; e < NW * (NW + 1) / 2; ++e) Wm[e] = r[(long)(PT_D2 + e) * S];
+        Sys::hessian_packed(P.x, P.u, Wm, w, W);
+      } else {
+#pragma unroll
+        for (int q = 0; q < NW * NW; ++q) W[q] = 0.0;
+      }
+    }
+  };
+  __device__ static inline int mlp_stages(const HsSolveOpts& o) { return M == 2 ? 4 : (o.method == 0 ? 1 : 2); }
+  // value + first derivatives at every stage point of every step (the iterate's rollout states are in l.xs): one MODE 3 pass per stage
+  __device__ static void mlp_lin_passes(const HsSolveOpts& o, const Lds& l) {
+    if constexpr (MLP) {
+      const int S = steps(o), lane = threadIdx.x;
+      const double h = SC::hstep(o);
+      const MlpScr m = mlp_scr(l, S);
+      const int nst = mlp_stages(o);
+      for (int j = 0; j < nst; ++j) {
+        for (int i0 = 0; i0 < S; i0 += 64) {
+          const int i = i0 + lane < S ? i0 + lane : S - 1;
+          double X[NS], U[NU];
+#pragma unroll
+          for (int c = 0; c < NS; ++c) X[c] = l.xs[(long)i * NS + c];
+          if (j > 0) {       // X_j = x + a_j h k_{j-1}  (rk4_lin) / x + h f_1 (step_lin), with k from the previous stage's records
+            const double aj = (M == 2) ? (j == 3 ? 1.0 : 0.5) : 1.0;
+            const nd_glb* r = m.pt + (long)(j - 1) * PT_N * S + i;
+#pragma unroll
+            for (int c = 0; c < NS; ++c) X[c] = X[c] + aj * h * r[(long)(PT_F + c) * S];
+          }
+          if constexpr (M == 2) {
+            const int row = (j == 0) ? 0 : (j == 3 ? 2 : 1);
+#pragma unroll
+            for (int a = 0; a < NU; ++a) U[a] = l.z[ui(o, M * i + row, a)];
+          } else {
+            const bool mid = (o.method == 2);
+            const double cu = (j == 0) ? 1.0 : (mid ? 0.5 : 0.0), cun = (j == 0) ? 0.0 : (mid ? 0.5 : 1.0);
+#pragma unroll
+            for (int a = 0; a < NU; ++a) U[a] = cu * l.z[ui(o, i, a)] + cun * l.z[ui(o, i + 1, a)];
+          }
+          if (i0 + lane < S) {
+#pragma unroll
+            for (int c = 0; c < NS; ++c) l.pts[(long)i * NS + c] = X[c];
+            l.pts[(long)S * NS + i] = U[0];
+          }
+        }
+        __syncthreads();
+        NodeMfma64::ArgsT<nd_lds> a;
+        a.z = (const nd_lds*)l.pts; a.dz = (const nd_lds*)l.pts; a.lam = nullptr; a.pt = m.pt + (long)j * PT_N * S; a.sF = (nd_lds*)l.sF;
+        a.alpha = 0.0; a.h6 = 0.0; a.h8 = 0.0; a.K = S; a.N = 0; a.pf_f = PT_F; a.pf_a = PT_A; a.pf_b = PT_B; a.pf_d2 = PT_D2;
+        a.t0 = 0; a.ts = 1; a.hb = m.hb + (long)j * m.nt * NodeMfma64::HB_TILE; a.mb = m.mb + (long)j * m.nt * NodeMfma64::MB_TILE; a.h_valid = 0;
+        NodeMfma64::pass<3, nd_lds>((const nd_lds*)l.wl, a, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+      }
+    } else { (void)o; (void)l; }
+  }
+  // the network's second derivatives contracted with the stage weights in l.avec: one MODE 4 pass per stage
+  __device__ static void mlp_hess_passes(const HsSolveOpts& o, const Lds& l) {
+    if constexpr (MLP) {
+      const int S = steps(o), lane = threadIdx.x;
+      const MlpScr m = mlp_scr(l, S);
+      const int nst = mlp_stages(o);
+      __syncthreads();
+      for (int j = 0; j < nst; ++j) {
+        NodeMfma64::ArgsT<nd_lds> a;
+        a.z = (const nd_lds*)l.pts; a.dz = (const nd_lds*)l.pts; a.lam = nullptr; a.pt = m.pt + (long)j * PT_N * S; a.sF = (nd_lds*)l.sF;
+        a.alpha = 0.0; a.h6 = 0.0; a.h8 = 0.0; a.K = S; a.N = 0; a.pf_f = PT_F; a.pf_a = PT_A; a.pf_b = PT_B; a.pf_d2 = PT_D2;
+        a.t0 = 0; a.ts = 1; a.hb = m.hb + (long)j * m.nt * NodeMfma64::HB_TILE; a.mb = m.mb + (long)j * m.nt * NodeMfma64::MB_TILE; a.h_valid = 1;
+        a.avec = (const nd_lds*)(l.avec + (long)j * S * NS);
+        NodeMfma64::pass<4, nd_lds>((const nd_lds*)l.wl, a, lane);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+    } else { (void)o; (void)l; }
   }
 
   // ---- Riccati recursion on the matrix cores (one control, NS <= 4, one control row per step) --------------------------
@@ -342,6 +583,10 @@ struct ShootWave {
       double f = 0, c1 = 0, cinf = 0;
       const bool have_roll = l.ex[X_ROLL] != 0.0;
       if (!have_roll) {
+        if constexpr (MLP) {
+          __syncthreads();
+          roll_all_mlp(o, p, l, l.z, l.xs, l.lam, f, c1, cinf);
+        } else
         for (int k = lane; k < I; k += 64) {
           double x[NS], xe[NS];
 #pragma unroll
@@ -360,6 +605,7 @@ struct ShootWave {
       if (have_roll) { f = l.ex[X_TF]; c1 = l.ex[X_TC1]; cinf = l.ex[X_TCINF]; }
       __syncthreads();
       MYR_SWT(0)
+      if constexpr (MLP) mlp_lin_passes(o, l);      // network systems: f, A, B at every stage point of every step -> records
       // Step linearisations, costates, step Hessians in ONE pass, lanes over steps (64 steps at a time, from the end).
       // The costate recursion pi_i = Fx_i^T pi_{i+1} + gx_i (+ own terms of a node state) is affine: a suffix scan of map
       // compositions over the wave (6 rounds) gives every lane the costate behind its step, with which it evaluates its
@@ -394,7 +640,11 @@ struct ShootWave {
             double caff[NS];
 #pragma unroll
             for (int t = 0; t < NS; ++t) caff[t] = node_next ? l.lam[(long)k * NS + t] : 0.0;
-            SC::slin(o.method, h, x, uc, p, zero, Fy, gy, Hs, h * i, i == S - 1);
+            if constexpr (MLP) {
+              const RecEval ev{mlp_scr(l, S).pt, l.avec, (long)S, i, 0};
+              SC::slin(o.method, h, x, uc, p, zero, Fy, gy, Hs, h * i, i == S - 1, ev);
+            } else
+              SC::slin(o.method, h, x, uc, p, zero, Fy, gy, Hs, h * i, i == S - 1);
             sw_lds* r = l.rec + (long)i * REC;
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
@@ -462,17 +712,45 @@ struct ShootWave {
               }
             }
             // step Hessian of the Lagrangian with the costate of the step's end state
+            if constexpr (MLP) {
+              // (network systems: this run of the step algebra only records the stage weights; the Hessians follow behind the loop, after the MODE 4 passes)
+              const RecEval ev{mlp_scr(l, S).pt, l.avec, (long)S, i, 1};
+              SC::slin(o.method, h, x, uc, p, pin, Fy, gy, Hs, h * i, i == S - 1, ev);
+#pragma unroll
+              for (int c = 0; c < NS; ++c) l.pinS[(long)i * NS + c] = pin[c];
+            } else {
             SC::slin(o.method, h, x, uc, p, pin, Fy, gy, Hs, h * i, i == S - 1);
             sw_lds* r = l.rec + (long)i * REC;
 #pragma unroll
             for (int a = 0; a < NY; ++a)
 #pragma unroll
               for (int b2 = 0; b2 <= a; ++b2) r[R_HS + hsp(a, b2)] = Hs[a * NY + b2];
+            }
           }
 #pragma unroll
           for (int c = 0; c < NS; ++c) piS[c] = __shfl(pi_i[c], 0, 64);
 #pragma unroll
           for (int a = 0; a < NU; ++a) ruS[a] = __shfl(ru[a], 0, 64);
+        }
+        if constexpr (MLP) {
+          mlp_hess_passes(o, l);
+          for (int i0 = 0; i0 < S; i0 += 64) {
+            const int i = i0 + lane < S ? i0 + lane : S - 1;
+            double x[NS], uc[(M + 1) * NU], pin[NS], Fy[NS * NY], gy[NY], Hs[NY * NY];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) { x[c] = l.xs[(long)i * NS + c]; pin[c] = l.pinS[(long)i * NS + c]; }
+#pragma unroll
+            for (int a = 0; a < (M + 1) * NU; ++a) uc[a] = l.z[ui(o, M * i, a)];
+            const RecEval ev{mlp_scr(l, S).pt, l.avec, (long)S, i, 2};
+            SC::slin(o.method, h, x, uc, p, pin, Fy, gy, Hs, h * i, i == S - 1, ev);
+            if (i0 + lane < S) {
+              sw_lds* r = l.rec + (long)i * REC;
+#pragma unroll
+              for (int a = 0; a < NY; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 <= a; ++b2) r[R_HS + hsp(a, b2)] = Hs[a * NY + b2];
+            }
+          }
         }
 #pragma unroll
         for (int a = 0; a < NU; ++a) stat = dmax(stat, fabs(ruS[a]));          // first point
@@ -752,6 +1030,8 @@ struct ShootWave {
     } else {
       __syncthreads();
       double cm = 0;
+      if constexpr (MLP) roll_all_mlp(o, p, l, l.zt, l.xt, l.ct, fl, cl, cm);
+      else
       for (int k = lane; k < I; k += 64) {
         double x[NS], xe[NS];
 #pragma unroll
@@ -781,13 +1061,14 @@ struct ShootWave {
 // Persistent: grid = resident workgroups (one wavefront each); each pulls trajectories from `ticket`.  z / lb / ub / lam are
 // the caller's instance-major rows ([B][n], [B][I*NS]); the iterate is copied into LDS, solved there and copied back.
 template <class Sys, int M = 1>
-__global__ __launch_bounds__(64, MYR_SHOOT_MIN_WAVES)
+__global__ __launch_bounds__(64, NodeTraits<Sys>::mlp ? 1 : MYR_SHOOT_MIN_WAVES)      // (network systems: one workgroup per CU by LDS anyway -- the whole register file for the matrix-core passes)
 void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                              const double* __restrict__ ub, double* __restrict__ lam, const double* __restrict__ params, int params_stride,
-                             double* cost, int32_t* status, int32_t* iters, double* kkt, unsigned long long poison) {
+                             double* cost, int32_t* status, int32_t* iters, double* kkt, unsigned long long poison, double* scratch, long scratch_stride) {
   using W = ShootWave<Sys, M>;
   const typename W::Lds l = W::lds(o);
   const int n = W::nvars(o), m = o.N * W::NS;
+  (void)scratch; (void)scratch_stride;
   for (;;) {
     int t = 0;
     if (threadIdx.x == 0) t = atomicAdd(ticket, 1);
@@ -805,6 +1086,10 @@ void shoot_solve_wave_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, dou
     SysParams<Sys> pp;
     pp.load(params, b, params_stride);
     pp.set_scale(vs.s);
+    if constexpr (W::MLP) {      // network systems: the weights (matrix-core operand layout) and this workgroup's global scratch
+      NodeMfma64::load_weights(pp.get(), (double*)l.wl, (int)threadIdx.x, 64);
+      if (threadIdx.x == 0) l.ex[W::X_SCR] = __builtin_bit_cast(double, (unsigned long long)(scratch + (long)blockIdx.x * scratch_stride));
+    }
     __syncthreads();
     HsWork w{{(double*)l.z, 1}, {(double*)l.lb, 1}, {(double*)l.ub, 1}, {(double*)l.zL, 1}, {(double*)l.zU, 1}, {(double*)l.lam, 1}, {(double*)l.dz, 1},
              {(double*)l.rec, 1}};
