@@ -2075,7 +2075,14 @@ struct HsFused {
   // and the reduced Hessian of the whole horizon is positive definite iff the chunks' pivots are positive AND every C is: its Cholesky pivots are
   // counted like the stages' (inertia correction).  tools/dev/twolevel/model.py is this algebra in numpy against the plain recursion.
   struct JnArgs { nd_lds *xb, *jn; int N, lane; double rho, floor_c; };
+#ifndef MYR_TL_JOIN_INLINE
+#define MYR_TL_JOIN_INLINE 0      // (as a function of its own the join saves and restores 189 callee-saved registers around 700 instructions of work; inlined it measures the same -- tools/dev/exp/exp88.sh: B = 512 180.6 k against 182.2 k -- so the validated form stays)
+#endif
+#if MYR_TL_JOIN_INLINE
+  __device__ __attribute__((always_inline)) static int tl_join(JnArgs a) {
+#else
   __device__ __attribute__((noinline)) static int tl_join(JnArgs a) {
+#endif
     using namespace detail;
     constexpr int NG = NS + 1, NCOL = NW + NG, NN = NW * NW;
     static_assert(NCOL == 2 * NW && NN <= 64, "stash layout; one element of an NW x NW product per lane");
