@@ -137,8 +137,14 @@ struct HsFused {
   // Two-level sweep (round 6; -DMYR_TWO_LEVEL=0: round 5's form): the W wavefronts a trajectory owns each condense a CHUNK of N / W stages in parallel
   // (riccati_chunk / riccati_chunk_trap), a small interface recursion joins the chunks (tl_join), see there.  Both collocation schemes on the hand-placed
   // tile (one control, NS <= 4).
+#ifndef MYR_EARLY_EXIT
+#define MYR_EARLY_EXIT 1       // (round 6) convergence tests and barrier update in front of the sweep in every kernel form (HsFused::solve): the converged iteration returns
+                               // without its sweep -- bit-identical results, 12.61 -> 12.45 ms per headline solve (tools/dev/exp/exp87.sh); 0: round 5's order
+#endif
 #ifndef MYR_SWEEP_CARRY
-#define MYR_SWEEP_CARRY 0      // experiment (round 6): C operands whose upper half is zero inherit it from the previous result instead of a zero fill
+#define MYR_SWEEP_CARRY 2      // (round 6) fewer operand moves in a sweep stage: 1 = C operands whose upper half is zero inherit it from the previous result instead of a zero
+                               // fill (bit-identical); 2 = also no C tuple for the midpoint product, its control rows are added where Q is consumed (last-bit differences, same
+                               // iteration counts): 788 -> 703 instructions per four stages, with the early exit 12.61 -> 12.25 ms per headline solve; 0: round 5's code
 #endif
 #ifndef MYR_TWO_LEVEL
 #define MYR_TWO_LEVEL 1
@@ -1346,8 +1352,27 @@ struct HsFused {
       C2[0] = 0.0; C2[1] = 0.0; C2[2] = 0.0; C2[3] = R[1];
       return __builtin_amdgcn_mfma_f64_16x16x4f64(Gm, R[0], C2, 0, 0, 0);
     };
+#if MYR_SWEEP_CARRY >= 2
+    double QmU = 0.0;
+    mfma_d4 Qm;
+    {
+      double n0 = in[0][3] + dv0, n1 = in[0][4] + dv1;
+      const double s0 = W0::dpp_row_shr8(n0), s1 = W0::dpp_row_shr8(n1);
+      mfma_d4 C;
+      C[0] = fma(s0, f_shm, n0 * f_keep);
+      C[1] = fma(s1, f_shm, n1 * f_keep);
+      C[2] = 0.0; C[3] = 0.0;
+      const mfma_d4 R = __builtin_amdgcn_mfma_f64_16x16x4f64(n0 * f_a1, in[0][5], C, 0, 0, 0);
+      Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(in[0][5], R[0], mfma_d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+      QmU = R[1];
+    }
+#else
     mfma_d4 Qm = mid_part(in[0][3], in[0][4], in[0][5]);
+#endif
     mfma_d4 D3 = {X0, X1, 0.0, 0.0};
+#if MYR_SWEEP_CARRY
+    mfma_d4 D1c = {0.0, 0.0, 0.0, 0.0}, Rmc = {0.0, 0.0, 0.0, 0.0};
+#endif
     for (int kb = k_hi - 1; kb >= k_lo; kb -= PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -1359,24 +1384,48 @@ struct HsFused {
 #pragma unroll
         for (int q = 0; q < 6; ++q) { in[u][q] = *ptr[q]; ptr[q] -= stp[q]; }
         const double sh0 = W0::dpp_row_shr4(X0), sh1 = W0::dpp_row_shr4(X1);
+#if MYR_SWEEP_CARRY
+        mfma_d4 C1 = D1c;      // (riccati_mfma: the zero upper half is inherited)
+        C1[0] = fma(sh0, f_she, X0 * f_keep);
+        C1[1] = fma(sh1, f_she, X1 * f_keep);
+        const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X0 * f_a1, G, C1, 0, 0, 0);
+        D1c = D1;
+#else
         mfma_d4 C1;
         C1[0] = fma(sh0, f_she, X0 * f_keep);
         C1[1] = fma(sh1, f_she, X1 * f_keep);
         C1[2] = 0.0; C1[3] = 0.0;
         const mfma_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(X0 * f_a1, G, C1, 0, 0, 0);
+#endif
         mfma_d4 C2;
         C2[0] = Qm[0]; C2[1] = fma(D3[1], f_t1, Qm[1]); C2[2] = fma(D3[2], f_t23, Qm[2]) + D1[1]; C2[3] = fma(D3[3], f_t23, Qm[3]);
+#if MYR_SWEEP_CARRY >= 2
+        C2[3] += QmU;
+#endif
         const mfma_d4 D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(G, D1[0], C2, 0, 0, 0);
         double m0 = nn0 + dv0, m1 = nn1 + dv1;
         const double ms0 = W0::dpp_row_shr8(m0), ms1 = W0::dpp_row_shr8(m1);
+#if MYR_SWEEP_CARRY
+        mfma_d4 Cm = Rmc;
+        Cm[0] = fma(ms0, f_shm, m0 * f_keep);
+        Cm[1] = fma(ms1, f_shm, m1 * f_keep);
+        const mfma_d4 Rm = __builtin_amdgcn_mfma_f64_16x16x4f64(m0 * f_a1, nGm, Cm, 0, 0, 0);
+        Rmc = Rm;
+#else
         mfma_d4 Cm;
         Cm[0] = fma(ms0, f_shm, m0 * f_keep);
         Cm[1] = fma(ms1, f_shm, m1 * f_keep);
         Cm[2] = 0.0; Cm[3] = 0.0;
         const mfma_d4 Rm = __builtin_amdgcn_mfma_f64_16x16x4f64(m0 * f_a1, nGm, Cm, 0, 0, 0);
+#endif
+#if MYR_SWEEP_CARRY >= 2
+        Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(nGm, Rm[0], mfma_d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        QmU = Rm[1];
+#else
         mfma_d4 Cq;
         Cq[0] = 0.0; Cq[1] = 0.0; Cq[2] = 0.0; Cq[3] = Rm[1];
         Qm = __builtin_amdgcn_mfma_f64_16x16x4f64(nGm, Rm[0], Cq, 0, 0, 0);
+#endif
         const double q00 = W0::rdlane(D2[3], 12), q10 = W0::rdlane(D2[2], 12), q11 = W0::rdlane(D2[2], 8);
         const double det = fma(q00, q11, -(q10 * q10));
         const double rdet = fast_rcp(det);
@@ -2668,8 +2717,10 @@ struct HsFused {
         return d == 0.0 ? ((delta_last > 0.0) ? dmax(1e-8, delta_last / 3.0) : 1e-4) : d * ((delta_last > 0.0) ? 8.0 : 100.0);
       };
       // (Two-level sweep: the barrier parameter is folded into the sweep's "1" column, so the tests and the barrier update come BEFORE the sweep -- they
-      // depend on the two passes above only; the other forms keep round 5's order, in which the last iteration's sweep is run and dropped.)
-      if constexpr (TL) {
+      // depend on the two passes above only.  -DMYR_EARLY_EXIT=1 gives every form this order: the converged iteration then returns WITHOUT its sweep, one
+      // sweep in twenty-one of a headline solve, same bits.  Round 5's order -- the last iteration's sweep run and dropped -- is the default for the other forms.)
+      constexpr bool EARLY = TL || (MYR_EARLY_EXIT != 0);
+      if constexpr (EARLY) {
         const int nm = MLAM * c.N * NS + p1.nm;
         const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
         const double stat = stat_raw / sd, comp = p1.cmax / sd;
@@ -2801,7 +2852,7 @@ struct HsFused {
         printf("T b%d w%d it%d f=%.17g c1=%.17g cinf=%.17g stat=%.17g sm=%.17g lg=%.17g nreg=%d delta=%.9g mu=%.9g pen=%.9g\n", c.traj, c.wave, it,
                p1.f, p1.c1, p1.cinf, stat_raw, p1.sum_mult, p1.lg, nreg, delta, mu, pen);
 #endif
-      if constexpr (!TL) {
+      if constexpr (!EARLY) {
         const int nm = MLAM * c.N * NS + p1.nm;
         const double sd = nm > 0 ? dmax(1.0, (sum_mult + p1.sm) / nm / 100.0) : 1.0;
         const double stat = stat_raw / sd, comp = p1.cmax / sd;

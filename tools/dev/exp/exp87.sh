@@ -1,7 +1,7 @@
 #!/bin/bash
 # exp87: fewer operand moves in the sweep stage (MYR_SWEEP_CARRY 1: zero halves inherited; 2: + no C tuple for the midpoint product): headline rate, same results?
 O=gpurun_out/exp87; mkdir -p $O
-for v in default carry1 carry2; do
+for v in ${EXP87_VARIANTS:-default carry1 carry2}; do
   if [ $v = default ]; then unset MYRIAD_HIP_LIB; else export MYRIAD_HIP_LIB=$PWD/xv/lib$v.so; fi
   for rep in 1 2; do timeout 300 python bench.py --cpu-budget 0 --no-other-configs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value']), 'solves/s; solver kernel', d['solver_kernel']['avg_ms'], 'ms', d['iterations'], d['converged_fraction'])"; done
   MYRIAD_FUSED_WAVES=1 python - <<'PY'
