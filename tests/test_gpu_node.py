@@ -285,3 +285,28 @@ def test_node_shooting_wavefront_kernel_agrees_with_the_lane_kernel(monkeypatch,
   np.testing.assert_allclose(w["cost"][ok], l["cost"][ok], rtol=1e-8)
   same = ok & (w["iters"] == l["iters"])
   assert np.abs(w["xs_and_us"][same] - l["xs_and_us"][same]).max(initial=0.0) <= 1e-6
+
+
+@pytest.mark.parametrize("N", [2, 3, 5, 7])
+def test_two_level_sweep_with_fewer_stages_than_wavefronts(monkeypatch, N):
+  """The two-level sweep cuts the horizon into W chunks of N / W stages: with N = 2 or 3 and four wavefronts some chunks are EMPTY (the join skips
+  them, block 0 is filled from the first non-empty one), with N = 5 or 7 they have one or two stages (terminal weights of unreachable directions are
+  floored).  Both multi-wavefront forms of the network kernel against round 2's kernel, whose sweep is the plain recursion: same statuses and iteration
+  counts, optima within 1e-10."""
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  x0 = np.clip(0.1 * np.random.default_rng(N).standard_normal((4, 4)), -2, 2)
+  out = {}
+  for tag, env in (("w4", {"MYRIAD_FUSED_WAVES": "4"}), ("w2", {"MYRIAD_FUSED_WAVES": "2"}), ("r2", {"MYRIAD_SOLVE_MODE": "wave1"})):
+    for k in ("MYRIAD_FUSED_WAVES", "MYRIAD_SOLVE_MODE"):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    hp, node, opt = _setup(N)
+    out[tag] = opt.solve_batch(x0s=x0, params=opt.system.device_params(), max_iter=200)
+    opt.engine.close()
+  ref = out["r2"]
+  assert (ref["status"] == 0).all()
+  for tag in ("w4", "w2"):
+    r = out[tag]
+    assert np.array_equal(r["status"], ref["status"]) and np.array_equal(r["iters"], ref["iters"]), (tag, r["status"], r["iters"], ref["iters"])
+    assert np.abs(r["xs_and_us"] - ref["xs_and_us"]).max() <= 1e-10 and np.abs(r["cost"] - ref["cost"]).max() <= 1e-10
