@@ -74,3 +74,33 @@ def run_trajectory_opt(hp: HParams, cfg: Config, save_as: str = None, params_pat
     except Exception as e:  # plotting is presentation only
       print("plot skipped:", e)
   return c, defect
+
+
+def run_node_trajectory_opt(hp: HParams, cfg: Config, save_as: str = None, params_path: str = None) -> Tuple[float, Optional[np.ndarray]]:
+  """useful_scripts.py:79-100: plan through a fitted network (NodeSystem over the true system; `solve_with_params(node.params)` on whatever optimizer
+  `hp` names -- SHOOTING by default, config.py:66), then roll the TRUE dynamics forward under the planned controls and return (integrated cost, terminal
+  defect).  `params_path`: a pickle of the Haiku-style mapping {'linear': {'w', 'b'}, 'linear_1': ..., 'linear_2': ...} (what the reference's
+  `NeuralODE.load_params` reads); None: the committed (64, 64) weight set fitted to the CARTPOLE field.  Training the network (create_node.py) is out of
+  scope: only fitted weights are used."""
+  from myriad_amd.systems.neural_ode import NeuralODE, NodeSystem
+  true_system = hp.system()
+  if params_path is not None:
+    import pickle as pkl
+    node = NeuralODE(pkl.load(open(params_path, 'rb')), hp.hidden_layers)
+  else:
+    node = NeuralODE.load_fitted_cartpole()
+  node_system = NodeSystem(node, true_system)
+  node_optimizer = get_optimizer(hp, cfg, node_system)
+  node_solution = node_optimizer.solve_with_params(node.params)
+  u = node_solution['u']
+  opt_x, c = get_state_trajectory_and_cost(hp, true_system, true_system.x_0, u)
+  defect = get_defect(true_system, opt_x)
+  if cfg.plot:
+    plot_path = f'plots/{hp.system.name}/node_trajectory_opt/'
+    Path(plot_path).mkdir(parents=True, exist_ok=True)
+    try:
+      from myriad_amd.plotting import plot
+      plot(hp, true_system, data={'x': opt_x, 'u': u, 'cost': c, 'defect': defect}, save_as=(plot_path + save_as) if save_as else None)
+    except Exception as e:  # plotting is presentation only (SURVEY.md section 2, row 20)
+      print("plot skipped:", e)
+  return c, defect

@@ -310,3 +310,16 @@ def test_two_level_sweep_with_fewer_stages_than_wavefronts(monkeypatch, N):
     r = out[tag]
     assert np.array_equal(r["status"], ref["status"]) and np.array_equal(r["iters"], ref["iters"]), (tag, r["status"], r["iters"], ref["iters"])
     assert np.abs(r["xs_and_us"] - ref["xs_and_us"]).max() <= 1e-10 and np.abs(r["cost"] - ref["cost"]).max() <= 1e-10
+
+
+def test_run_node_trajectory_opt_with_the_references_default_flags():
+  """useful_scripts.py:79-100 as a drop-in: HParams() names SHOOTING (config.py:66) -- here CARTPOLE, 20 intervals x 5 controls, Heun --, the plan comes from
+  `solve_with_params(node.params)` through the network, the returned cost and defect from rolling the TRUE dynamics forward under the planned controls."""
+  from myriad_amd.useful_scripts import run_node_trajectory_opt
+  hp = HParams(system=SystemType.CARTPOLE, intervals=20, controls_per_interval=5, hidden_layers=(64, 64))
+  assert hp.optimizer == OptimizerType.SHOOTING
+  c, defect = run_node_trajectory_opt(hp, CFG)
+  assert np.isfinite(c) and 40.0 < float(c) < 250.0
+  assert defect is not None and np.all(np.isfinite(defect))
+  # the network is a fit (R^2 = 0.997), not the true field: the true-dynamics rollout under its plan misses the target by a visible but bounded amount
+  assert np.abs(np.asarray(defect)).max() < 3.0
