@@ -149,6 +149,11 @@ struct HsFused {
 #ifndef MYR_TWO_LEVEL
 #define MYR_TWO_LEVEL 1
 #endif
+#ifndef MYR_TL_SPEC
+#define MYR_TL_SPEC 0           // 1: closed-form systems get a four-wavefront form for batches of at most one trajectory per CU -- two chunks x two rungs of the inertia
+                                // ladder at a time (HsFused::TLS).  Built and measured (tools/dev/exp/exp90.sh): the iterates of the two-wavefront form, bit for bit, and
+                                // B = 256 100.5 -> 103.7 k, B = 128 51.9 -> 53.3 k solves/s -- 3 % for 160 KB of code per system: off.
+#endif
 #ifndef MYR_TL_FLOOR
 #define MYR_TL_FLOOR 1e-10      // smallest pivot accepted in an interface's C = I + L^T M L (its eigenvalues lie in (0, ~1] when the reduced Hessian is positive definite)
 #endif
@@ -205,8 +210,16 @@ struct HsFused {
   static constexpr int XCH = 2 * W * NREC + 2 * W * NTOT + 2 * W * 2 * NS + W * NRED + 8;
   // sweep outputs in LDS: one block (P | pc | Tnu | Ku) per set; two-level form: one per chunk, the multiplier vector theta of every chunk (+ the chunks'
   // pivot counts), and per interface the four NW x NW maps of the join's forward pass
-  static constexpr int NXB = TL ? W : (W > 1 ? 2 : 1);
-  static constexpr int TL_TH = TL ? W * NC + W + 2 : 0, TL_JN = TL ? (W - 1) * 4 * NW * NW : 0;
+  // TLS (closed-form systems, W = 4: batches of at most one trajectory per CU): TWO chunks and TWO rungs of the inertia ladder at a time -- wavefronts 0, 1
+  // sweep the chunks with delta, wavefronts 2, 3 the same chunks with the NEXT candidate (round 5's speculative rung on top of the two-level sweep: a failed
+  // rung costs a whole sweep + join, its successor is then already there; same sequence of candidates, first success wins).  Four chunks instead were
+  // measured equal to two (three sequential joins, tools/dev/exp/exp84.sh).
+  static constexpr bool TLS = TL && W == 4 && !NodeTraits<Sys>::mlp && (MYR_TL_SPEC != 0);
+  static constexpr int NCH = TLS ? 2 : W;       // chunks of a sweep
+  static constexpr int NGR = TLS ? 2 : 1;       // rungs swept side by side
+  static constexpr int NXB = TL ? NCH * NGR : (W > 1 ? 2 : 1);
+  static constexpr int TL_TH1 = NCH * NC, TL_JN1 = (NCH - 1) * 4 * NW * NW;      // per rung group: theta table; the interfaces' maps
+  static constexpr int TL_TH = TL ? NGR * TL_TH1 + NGR * (NCH + 1) + 2 : 0, TL_JN = TL ? NGR * TL_JN1 : 0;
   __host__ __device__ static int lds_solver_doubles(int N) { return (ZLU_GLOBAL ? 2 : 4) * npoints(N) * NW + MLAM * N * NS + 6 * NW + XCH + NXB * EXCH + TL_TH + TL_JN + 8; }
   __host__ __device__ static int lds_doubles(int N) { return lds_solver_doubles(N) + (MLP ? npoints(N) * NS + NodeTraits<Sys>::lds_doubles : 0); }
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
@@ -2065,11 +2078,11 @@ struct HsFused {
   }
 
   // ---- Two-level sweep: wrappers and level 2 ---------------------------------------------------------------------------------------------------
-  __host__ __device__ static inline int tl_edge(int N, int ci) { return (int)(((long)ci * N) / W); }      // chunk ci = stages [tl_edge(ci), tl_edge(ci + 1))
+  __host__ __device__ static inline int tl_edge(int N, int ci) { return (int)(((long)ci * N) / NCH); }      // chunk ci = stages [tl_edge(ci), tl_edge(ci + 1))
   __host__ __device__ static inline int tl_chunk(int N, int k) {
     int ci = 0;
 #pragma unroll
-    for (int w = 1; w < W; ++w) ci += (k >= tl_edge(N, w)) ? 1 : 0;
+    for (int w = 1; w < NCH; ++w) ci += (k >= tl_edge(N, w)) ? 1 : 0;
     return ci;
   }
   struct SwArgsC { nd_glb *hr, *st, *zr, *kg; nd_lds* xo; int lane, pinned, abort, k_lo, k_hi, last; double reg_floor, rho_term, delta; };
@@ -2084,14 +2097,14 @@ struct HsFused {
     else if constexpr (TL) return riccati_chunk(c, o, a.delta, a.abort != 0, a.k_lo, a.k_hi, a.last != 0, (double*)a.xo);
     else return 0;
   }
-  __device__ static inline int sweep_chunk(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg, int ci) {
+  __device__ static inline int sweep_chunk(Ctx& c, const HsSolveOpts& o, double delta, bool abort_on_reg, int ci, int grp = 0) {
     SwArgsC a;
-    a.hr = (nd_glb*)c.hr; a.st = (nd_glb*)c.st; a.zr = (nd_glb*)c.zr; a.kg = (nd_glb*)c.kg; a.xo = (nd_lds*)(c.xA + ci * EXCH);
+    a.hr = (nd_glb*)c.hr; a.st = (nd_glb*)c.st; a.zr = (nd_glb*)c.zr; a.kg = (nd_glb*)(grp ? c.kgB : c.kgA); a.xo = (nd_lds*)(c.xA + (grp * NCH + ci) * EXCH);
     a.lane = c.lane; a.abort = abort_on_reg ? 1 : 0;
     a.pinned = 0;
 #pragma unroll
     for (int q = 0; q < NS; ++q) a.pinned |= c.term_pinned[q] ? (1 << q) : 0;
-    a.k_lo = tl_edge(c.N, ci); a.k_hi = tl_edge(c.N, ci + 1); a.last = (ci == W - 1) ? 1 : 0;
+    a.k_lo = tl_edge(c.N, ci); a.k_hi = tl_edge(c.N, ci + 1); a.last = (ci == NCH - 1) ? 1 : 0;
     a.reg_floor = o.reg_floor; a.rho_term = o.rho_term; a.delta = delta;
     return chunk_call(a);
   }
@@ -2142,9 +2155,9 @@ struct HsFused {
     const int gcc = gi == 0 ? 0 : gi + 1;                 // block column of theta_g[gi]
     auto mcc = [](int m) { return m < NS ? 2 + m : 1; };  // block column of the multiplier of w component m
     const int el = lane < NN ? lane : 0, er = el / NW, eq = el - er * NW;      // this lane's element of the NW x NW products
-    int nreg = 0, tb = W - 1;
+    int nreg = 0, tb = NCH - 1;
 #pragma unroll 1
-    for (int ci = W - 2; ci >= 0; --ci) {
+    for (int ci = NCH - 2; ci >= 0; --ci) {
       if (tl_edge(a.N, ci + 1) <= tl_edge(a.N, ci)) continue;      // an empty chunk (N < W)
       const nd_lds* Tb = a.xb + tb * EXCH; nd_lds* Bb = a.xb + ci * EXCH; nd_lds* J = a.jn + ci * 4 * NN;
       const nd_lds* Tpc = Tb + NN; const nd_lds* TT = Tpc + NW * NC;
@@ -2274,7 +2287,7 @@ struct HsFused {
     return nreg;
   }
   // the multipliers of every chunk from the first point's control step and nu_T: forward over the interfaces (one wavefront, every lane alike)
-  __device__ static void tl_theta(Ctx& c, const double* thg) {      // thg = (1, 0, nu_T): the last chunk's theta
+  __device__ static void tl_theta(Ctx& c, const double* thg) {      // thg = (1, 0, nu_T): the last chunk's theta (rung group 0's maps: the ladder leaves the standing rung there)
     constexpr int NCOL = 2 * NW;
     double wa[NW], tg[NS + 1];
 #pragma unroll
@@ -2287,7 +2300,7 @@ struct HsFused {
 #pragma unroll
     for (int i = 0; i < NS; ++i) tg[1 + i] = thg[2 + i];
 #pragma unroll 1
-    for (int ci = 0; ci < W - 1; ++ci) {
+    for (int ci = 0; ci < NCH - 1; ++ci) {
       if (tl_edge(c.N, ci + 1) <= tl_edge(c.N, ci)) continue;
       const nd_lds* J = (const nd_lds*)c.sJn + ci * 4 * NW * NW;
       double we[NW], nu[NW];
@@ -2307,7 +2320,7 @@ struct HsFused {
 #pragma unroll
       for (int m = 0; m < NW; ++m) wa[m] = we[m];
     }
-    double* th = c.sTh + (W - 1) * NC;
+    double* th = c.sTh + (NCH - 1) * NC;
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) th[cc] = thg[cc];
   }
@@ -2756,7 +2769,54 @@ struct HsFused {
           wsync();
         }
         MYR_PH(3)
-        double* cnt = c.sTh + W * NC;         // pivot counts: the chunks', the join's
+        if constexpr (TLS) {
+          // two chunks x two rungs: wavefront w sweeps chunk (w & 1) of rung group (w >> 1); wavefronts 0 and 2 join their group's chunks and eliminate the first point
+          for (int tr_ = 0; tr_ < 12; tr_ += 2) {
+            const double delta_b = next_delta(delta);
+            const bool abort_a = (tr_ < 11) && !(delta > 1e8), abort_b = (tr_ + 1 < 11) && !(delta_b > 1e8);
+            const int grp = c.wave >> 1, ci = c.wave & 1;
+            const double my_delta = grp ? delta_b : delta;
+            const bool my_abort = grp ? abort_b : abort_a;
+            double* cnt = c.sTh + NGR * TL_TH1 + grp * (NCH + 1);      // this group's pivot counts: the chunks', the join's
+            int nr = 0;
+            if (tl_edge(c.N, ci + 1) > tl_edge(c.N, ci)) nr = sweep_chunk(c, o, my_delta, my_abort, ci, grp);
+            cnt[ci] = (double)nr;
+            MYR_PH(13)
+            wsync();
+            MYR_PH(5)
+            const int nsg = __builtin_amdgcn_readfirstlane((int)cnt[0] + (int)cnt[1]);
+            if (ci == 0) {
+              int nj = 0;
+              if (nsg == 0 || !my_abort) {
+                Ctx cw = c;
+                use_set(cw, grp ? c.kgB : c.kgA, c.xA + grp * NCH * EXCH);
+                JnArgs ja;
+                ja.xb = (nd_lds*)(c.xA + grp * NCH * EXCH); ja.jn = (nd_lds*)(c.sJn + grp * TL_JN1); ja.N = c.N; ja.lane = c.lane; ja.rho = o.rho_term; ja.floor_c = MYR_TL_FLOOR;
+                nj = tl_join(ja);
+                nj = riccati_first_point(cw, o, my_delta, nj);
+              }
+              cnt[NCH] = (double)nj;
+            }
+            wsync();
+            const double* cn0 = c.sTh + NGR * TL_TH1;
+            const int na = __builtin_amdgcn_readfirstlane((int)cn0[0] + (int)cn0[1] + (int)cn0[NCH]);
+            const int nb = __builtin_amdgcn_readfirstlane((int)cn0[NCH + 1] + (int)cn0[NCH + 2] + (int)cn0[2 * NCH + 1]);
+            wsync();
+            MYR_PH(6)
+            nreg = na;
+            if (na == 0 || !abort_a) break;
+            delta = delta_b; nreg = nb;
+            if (nb == 0 || !abort_b) {        // the speculative rung stands: its gains, its first block and its interface maps become rung group 0's
+              for (int i = c.tid; i < c.N * KST; i += NT) c.kgA[i] = c.kgB[i];
+              for (int i = c.tid; i < EXCH; i += NT) c.xA[i] = c.xA[NCH * EXCH + i];
+              for (int i = c.tid; i < TL_JN1; i += NT) c.sJn[i] = c.sJn[TL_JN1 + i];
+              wsync();
+              break;
+            }
+            delta = next_delta(delta_b);
+          }
+        } else {
+        double* cnt = c.sTh + NGR * TL_TH1;         // pivot counts: the chunks', the join's
         for (int tr_ = 0; tr_ < 12; ++tr_) {
           const bool abort_on_reg = (tr_ < 11) && !(delta > 1e8);
           int nr = 0;
@@ -2794,6 +2854,7 @@ struct HsFused {
           MYR_PH(6)
           if (nreg == 0 || !abort_on_reg) break;
           delta = next_delta(delta);
+        }
         }
       } else
       if constexpr (SPEC) {

@@ -744,8 +744,15 @@ static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, con
     // (Four wavefronts per trajectory for batches of at most one trajectory per CU -- chunks of N / 4 stages -- were built and measured in round 6,
     // tools/dev/exp/exp84.sh: same iterates, and NO gain over two wavefronts -- B = 128 50.6 k against 50.4 k solves/s, B = 256 97.5 k against 96.6 k: what the
     // shorter chunks save, the three interface joins, one after the other on wavefront 0, cost.  Not instantiated: 160 KB of code per system.)
+    // With -DMYR_TL_SPEC=1 four wavefronts run two chunks and TWO RUNGS of the inertia ladder at a time (HsFused::TLS) for batches of at most one trajectory per
+    // CU: +3 % (exp90.sh), not built by default.
+    if (B <= device_cus(h) && HsFused<Sys, 4, SCHEME>::TLS) waves = 4;
     if (so.park_iter > 0) waves = 1;                  // an explicit two-phase launch: only the one-wavefront form parks (include/myriad_hip.h: park_iter)
     if (h->fused_waves > 0) waves = h->fused_waves;
+    if constexpr (HsFused<Sys, 4, SCHEME>::TLS) {
+      if (waves == 4 && HsFused<Sys, 4, SCHEME>::lds_bytes(h->d.intervals) <= 160 * 1024)
+        return launch_hs_fused_w<Sys, 4, SCHEME>(h, B, z, lb, ub, params, pstride, so, lam, cost, status, iters, kkt);
+    }
     if (waves > 2) waves = 2;
     {
       if (waves == 2 && HsFused<Sys, 2, SCHEME>::lds_bytes(h->d.intervals) <= 160 * 1024)
