@@ -180,7 +180,9 @@ def test_node_two_wavefront_throughput_form_walks_the_path_of_the_four_wavefront
   out = {}
   for name, env in (("W4", {"MYRIAD_FUSED_WAVES": "4"}), ("W2", {"MYRIAD_FUSED_WAVES": "2"}), ("W2 no helpers", {"MYRIAD_FUSED_WAVES": "2", "MYRIAD_NODE_HELPERS": "0"}),
                     ("W2 poison", {"MYRIAD_FUSED_WAVES": "2", "MYRIAD_POISON": "random"}),
-                    ("W2 fill", {"MYRIAD_FUSED_WAVES": "2", "MYRIAD_REG_FILL": "nan", "MYRIAD_STACK_FILL": "nan"})):
+                    ("W2 fill", {"MYRIAD_FUSED_WAVES": "2", "MYRIAD_REG_FILL": "nan", "MYRIAD_STACK_FILL": "nan"}),
+                    ("W4 fill", {"MYRIAD_FUSED_WAVES": "4", "MYRIAD_REG_FILL": "nan", "MYRIAD_STACK_FILL": "nan"}),
+                    ("W4 poison", {"MYRIAD_FUSED_WAVES": "4", "MYRIAD_POISON": "random"})):
     for k in ("MYRIAD_FUSED_WAVES", "MYRIAD_NODE_HELPERS", "MYRIAD_POISON", "MYRIAD_REG_FILL", "MYRIAD_STACK_FILL"):
       monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
@@ -194,6 +196,10 @@ def test_node_two_wavefront_throughput_form_walks_the_path_of_the_four_wavefront
   ref = out["W2"]
   assert (ref["status"] == 0).all()
   for name, r in out.items():
+    if name.startswith("W4") and name != "W4":       # the four-wavefront form under register / stack fill and poison: its own bits
+      for k in ref:
+        assert np.array_equal(r[k], out["W4"][k]), (name, k)
+      continue
     if name == "W4":
       assert np.array_equal(r["status"], ref["status"]) and np.array_equal(r["iters"], ref["iters"]), (name, r["iters"], ref["iters"])
       np.testing.assert_allclose(r["cost"], ref["cost"], rtol=1e-11, atol=0.0)
