@@ -154,6 +154,9 @@ struct HsFused {
                                 // ladder at a time (HsFused::TLS).  Built and measured (tools/dev/exp/exp90.sh): the iterates of the two-wavefront form, bit for bit, and
                                 // B = 256 100.5 -> 103.7 k, B = 128 51.9 -> 53.3 k solves/s -- 3 % for 160 KB of code per system: off.
 #endif
+#ifndef MYR_FWD_SEQ_NW
+#define MYR_FWD_SEQ_NW 7        // stages of at least this many knot variables run the forward phase's recursion sequentially (HsFused::FSEQ); 0: every system scans
+#endif
 #ifndef MYR_TL_FLOOR
 #define MYR_TL_FLOOR 1e-10      // smallest pivot accepted in an interface's C = I + L^T M L (its eigenvalues lie in (0, ~1] when the reduced Hessian is positive definite)
 #endif
@@ -201,7 +204,13 @@ struct HsFused {
   // scratch slot instead of LDS: two workgroups of 42.7 KB + 40.5 KB of weights do not fit a CU's 160 KB, two of 26.7 KB + 40.5 KB do.
   static constexpr bool ZLU_GLOBAL = MLP && W == 2;
   __host__ __device__ static long off_zlu(int N) { return off_mb(N) + (MLP ? (long)NodeMfma64::ntiles(npoints(N)) * NodeMfma64::MB_TILE : 0); }
-  __host__ __device__ static long scratch_doubles(int N) { return off_zlu(N) + (ZLU_GLOBAL ? 2L * npoints(N) * NW : 0); }
+  // Wide stages (round 6): the forward phase's closed-loop maps (NW x NW | NW per stage) go through global scratch to ONE sequential pass instead of a wave
+  // scan over affine maps held in registers -- three NW x NW matrices per lane are 216 doubles at NW = 8, 630 at NW = 14, against the 128 double registers a
+  // lane can address: the scan of ROCKETLANDING was 41 % of its iteration, most of it spill traffic (tools/dev/exp/exp92.sh, exp93.sh).
+  static constexpr bool FSEQ = (MYR_FWD_SEQ_NW > 0) && NW >= MYR_FWD_SEQ_NW && !MLP;
+  static constexpr int FWS = NW * NW + NW;
+  __host__ __device__ static long off_fw(int N) { return off_zlu(N) + (ZLU_GLOBAL ? 2L * npoints(N) * NW : 0); }
+  __host__ __device__ static long scratch_doubles(int N) { return off_fw(N) + (FSEQ ? (long)N * FWS : 0); }
   // LDS (doubles): z | zL | zU | dz | multipliers | bound table | neighbour stash | first-point exchange
   static constexpr int NREC = NS + NS + NS * NS + NS * NU + NS;   // x, f, A, B, own: what an interval takes from its end knot
   static constexpr int EXCH = NW * NW + NW * NC + NS * NC + NU * NC;
@@ -231,6 +240,7 @@ struct HsFused {
     double h, h6, h8;
     double *z, *zL, *zU, *dz;             // the iterate and the step (LDS)
     double *hr, *st, *kg, *zr;            // global scratch of this wavefront
+    double *fw;                           // wide stages: the forward phase's closed-loop maps (global scratch)
     double *kgA, *kgB, *xA, *xB;          // W = 2: the two sets of sweep outputs (gains in global scratch, first-point exchange in LDS)
     double *sTh, *sJn;                    // two-level sweep: theta per chunk | pivot counts; the interfaces' maps (LDS)
     double *pt, *sF, *wl;                 // network systems: point records (global), trial values and weights (LDS)
@@ -2325,6 +2335,48 @@ struct HsFused {
     for (int cc = 0; cc < NC; ++cc) th[cc] = thg[cc];
   }
 
+  __device__ static inline int knot(int k) { return TRAP ? k : 2 * k; }      // the point that starts stage k
+  // The forward recursion s_{k+1} = A_k s_k + b_k over stages k0 .. k1 - 1, one wavefront: lane r < NW owns row r (the lanes above repeat the last row), the
+  // state is broadcast from the lanes with v_readlane; the rows travel through a ring of FG stages (loaded FG stages ahead: they do not depend on the
+  // state).  In: c.dz at knot k0.  Out: c.dz at the knots k0 + 1 .. k1.  (The same treatment of the backward phase's adjoint recursion -- NS x NS maps, 126
+  // doubles in the scan at NS = 6 -- was measured SLOWER than its scan, 94.5 -> 97.5 ms per 4096 ROCKETLANDING solves, exp93.sh: not kept.)
+  __device__ static void fwd_seq(Ctx& c, int k0, int k1) {
+    constexpr int FG = 6;
+    const int row = c.lane < NW ? c.lane : NW - 1;
+    double x = c.dz[zi(c, knot(k0), row)];
+    double ring[FG][NW + 1];
+#pragma unroll
+    for (int g = 0; g < FG; ++g) {
+      const int k = (k0 + g < k1) ? k0 + g : k1 - 1;
+      const double* f = c.fw + (long)k * FWS;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) ring[g][j] = f[row * NW + j];
+      ring[g][NW] = f[NW * NW + row];
+    }
+#pragma unroll 1
+    for (int kb = k0; kb < k1; kb += FG) {
+#pragma unroll
+      for (int g = 0; g < FG; ++g) {
+        const int k = kb + g;
+        if (k < k1) {       // (wave-uniform)
+          double a0 = ring[g][NW], a1 = 0.0;
+#pragma unroll
+          for (int j = 0; j < NW; j += 2) {
+            a0 = fma(ring[g][j], W0::rdlane(x, j), a0);
+            if (j + 1 < NW) a1 = fma(ring[g][j + 1], W0::rdlane(x, j + 1), a1);
+          }
+          x = a0 + a1;
+          c.dz[zi(c, knot(k + 1), row)] = x;
+          const int kn = (k + FG < k1) ? k + FG : k1 - 1;
+          const double* f = c.fw + (long)kn * FWS;
+#pragma unroll
+          for (int j = 0; j < NW; ++j) ring[g][j] = f[row * NW + j];
+          ring[g][NW] = f[NW * NW + row];
+        }
+      }
+    }
+  }
+
   // ---- FORWARD phase: closed-loop maps -> wave scan -> step of the stage's midpoint and end knot -> their step limits ----------
   __device__ static void forward(Ctx& c, const HsSolveOpts& o, double mu, const double* th, typename S::FwdOut& fo) {
     const int N = c.N, K = c.K, lane = c.lane;
@@ -2410,6 +2462,23 @@ struct HsFused {
         for (int q = 0; q < NW; ++q) A[(NS + a) * NW + q] = on ? -Kk[(QE + a) * NW + q] : ((NS + a == q) ? 1.0 : 0.0);
         b[NS + a] = on ? -kq[QE + a] : 0.0;
       }
+      double sn[NW], y[NY];
+      if constexpr (FSEQ) {
+        // wide stages: the maps of the round go to global scratch, wavefront 0 runs the recursion over them (fwd_seq: one row per lane, the state broadcast
+        // with v_readlane) and leaves the knots' steps in c.dz; every lane then takes the states on either side of its stage from there
+        if (on) {
+          double* f = c.fw + (long)k * FWS;
+#pragma unroll
+          for (int q = 0; q < NW * NW; ++q) f[q] = A[q];
+#pragma unroll
+          for (int q = 0; q < NW; ++q) f[NW * NW + q] = b[q];
+        }
+        wsync();
+        if (c.wave == 0) fwd_seq(c, base0, base0 + NT < N ? base0 + NT : N);
+        wsync();
+#pragma unroll
+        for (int q = 0; q < NW; ++q) { y[q] = c.dz[zi(c, knot(k), q)]; sn[q] = c.dz[zi(c, knot(k + 1), q)]; }
+      } else {
       affine_prefix_scan_dpp<NW>(A, b);
       double sN[NW];                            // state behind the round, by every wavefront alike
 #pragma unroll
@@ -2443,7 +2512,6 @@ struct HsFused {
 #pragma unroll
         for (int q = 0; q < NW; ++q) s0[q] = sw[q];       // state in front of THIS wavefront's block
       }
-      double sn[NW], y[NY];
 #pragma unroll
       for (int r = 0; r < NW; ++r) {
         double v = b[r];
@@ -2458,6 +2526,7 @@ struct HsFused {
       }
 #pragma unroll
       for (int q = 0; q < NW; ++q) s0[q] = (W > 1) ? sN[q] : __shfl(sn[q], 63, 64);
+      }
 #pragma unroll
       for (int t = 0; t < NQ; ++t) {
         double v = -kq[t];
@@ -2469,7 +2538,7 @@ struct HsFused {
 #pragma unroll
       for (int r = 0; r < NS; ++r) de[r] = sn[r];                           // = Ge y + ge (0 on a pinned terminal state)
 #pragma unroll
-      for (int a = 0; a < NU; ++a) de[NS + a] = y[NW + QE + a];
+      for (int a = 0; a < NU; ++a) de[NS + a] = FSEQ ? sn[NS + a] : y[NW + QE + a];      // (FSEQ: the bits the recursion left in c.dz -- the next stage has read them from there)
       if constexpr (TRAP) {       // every point is a knot
         (void)dm;
         apply(k + 1, de, on);
@@ -3037,6 +3106,7 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
   c.zr = s; c.hr = s + W::off_hr(c.N); c.st = s + W::off_st(c.N); c.kg = s + W::off_kg(c.N);
   c.kgA = c.kg; c.kgB = s + W::off_kg2(c.N); c.pt = s + W::off_pt(c.N);
   c.hb = s + W::off_hb(c.N); c.mb = s + W::off_mb(c.N); c.h_valid = false;
+  c.fw = s + W::off_fw(c.N);
   double* const lam_own = s + W::off_lam(c.N);
   double* l = reinterpret_cast<double*>(smem_fused);
   c.z = l; l += c.n;
