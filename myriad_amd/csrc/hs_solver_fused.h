@@ -157,6 +157,9 @@ struct HsFused {
 #ifndef MYR_FWD_SEQ_NW
 #define MYR_FWD_SEQ_NW 7        // stages of at least this many knot variables run the forward phase's recursion sequentially (HsFused::FSEQ); 0: every system scans
 #endif
+#ifndef MYR_ZLU_GLOBAL_WIDE
+#define MYR_ZLU_GLOBAL_WIDE 1       // wide closed-form systems keep the bound multipliers in global scratch where that doubles the workgroups per CU (HsFused::ZLU_GLOBAL)
+#endif
 #ifndef MYR_TL_FLOOR
 #define MYR_TL_FLOOR 1e-10      // smallest pivot accepted in an interface's C = I + L^T M L (its eigenvalues lie in (0, ~1] when the reduced Hessian is positive definite)
 #endif
@@ -202,7 +205,6 @@ struct HsFused {
   // The two-wavefront form of the network kernel (round 5: the THROUGHPUT form for batches beyond one trajectory per CU -- two trajectories per CU, each on
   // two SIMDs, so that one trajectory's sequential sweep overlaps the other's matrix-core passes) keeps the bound multipliers zL, zU in its global
   // scratch slot instead of LDS: two workgroups of 42.7 KB + 40.5 KB of weights do not fit a CU's 160 KB, two of 26.7 KB + 40.5 KB do.
-  static constexpr bool ZLU_GLOBAL = MLP && W == 2;
   __host__ __device__ static long off_zlu(int N) { return off_mb(N) + (MLP ? (long)NodeMfma64::ntiles(npoints(N)) * NodeMfma64::MB_TILE : 0); }
   // Wide stages (round 6): the forward phase's closed-loop maps (NW x NW | NW per stage) go through global scratch to ONE sequential pass instead of a wave
   // scan over affine maps held in registers -- three NW x NW matrices per lane are 216 doubles at NW = 8, 630 at NW = 14, against the 128 double registers a
@@ -229,7 +231,14 @@ struct HsFused {
   static constexpr int NXB = TL ? NCH * NGR : (W > 1 ? 2 : 1);
   static constexpr int TL_TH1 = NCH * NC, TL_JN1 = (NCH - 1) * 4 * NW * NW;      // per rung group: theta table; the interfaces' maps
   static constexpr int TL_TH = TL ? NGR * TL_TH1 + NGR * (NCH + 1) + 2 : 0, TL_JN = TL ? NGR * TL_JN1 : 0;
-  __host__ __device__ static int lds_solver_doubles(int N) { return (ZLU_GLOBAL ? 2 : 4) * npoints(N) * NW + MLAM * N * NS + 6 * NW + XCH + NXB * EXCH + TL_TH + TL_JN + 8; }
+  __host__ __device__ static constexpr int lds_solver_doubles_z(int N, bool zlu_global) { return (zlu_global ? 2 : 4) * npoints(N) * NW + MLAM * N * NS + 6 * NW + XCH + NXB * EXCH + TL_TH + TL_JN + 8; }
+  // Round 6: the same for the wide closed-form systems (at least MYR_FWD_SEQ_NW knot variables) in the forms whose LDS, with the multipliers resident, would
+  // not let 4 / W workgroups onto a CU at the reference horizon of 100 intervals -- ROCKETLANDING's one-wavefront Hermite-Simpson form (65.6 -> 39.9 KB: four
+  // per CU instead of two, 94.5 -> 65.0 ms per 4096 solves of 30 iterations), CARTPOLE's twin (192 -> 111 ms), ROCKETLANDING's twin (one-wavefront form
+  // 109 -> 64 KB, two-wavefront form 118 -> 73 KB: two per CU instead of one, 397 -> 205 ms); tools/dev/exp/exp97.sh.  -DMYR_ZLU_GLOBAL_WIDE=0: resident.
+  static constexpr bool ZLU_GLOBAL = (MLP && W == 2) ||
+      ((MYR_ZLU_GLOBAL_WIDE != 0) && !MLP && (MYR_FWD_SEQ_NW > 0) && NW >= MYR_FWD_SEQ_NW && (long)lds_solver_doubles_z(100, false) * 8 > 40960L * W);
+  __host__ __device__ static int lds_solver_doubles(int N) { return lds_solver_doubles_z(N, ZLU_GLOBAL); }
   __host__ __device__ static int lds_doubles(int N) { return lds_solver_doubles(N) + (MLP ? npoints(N) * NS + NodeTraits<Sys>::lds_doubles : 0); }
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
   static constexpr int NSCAL = 48;      // scalars of the solve loop in a parked trajectory's record

@@ -747,6 +747,19 @@ static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, con
     // With -DMYR_TL_SPEC=1 four wavefronts run two chunks and TWO RUNGS of the inertia ladder at a time (HsFused::TLS) for batches of at most one trajectory per
     // CU: +3 % (exp90.sh), not built by default.
     if (B <= device_cus(h) && HsFused<Sys, 4, SCHEME>::TLS) waves = 4;
+    // Systems whose solver LDS lets at most two one-wavefront workgroups onto a CU (ROCKETLANDING's Hermite-Simpson form: 64 KB; the wider twins) leave two
+    // SIMDs of every CU idle in that form: when as many two-wavefront workgroups fit, those run at EVERY batch size (round 6, tools/dev/exp/exp96.sh, B = 4096:
+    // ROCKETLANDING 94.5 -> 70.4 ms, CARTPOLE's twin 192 -> 146 ms, ROCKETLANDING's twin 397 -> 311 ms; with four one-wavefront workgroups per CU the
+    // one-wavefront form wins as before -- BEARPOPULATIONS 9.6 against 14.9 ms).
+    if constexpr (HsFused<Sys, 2, SCHEME>::SUPPORTED && !HsFused<Sys, 2, SCHEME>::TL) {
+      const int N = h->d.intervals;
+      if (HsFused<Sys, 2, SCHEME>::lds_bytes(N) <= 160 * 1024) {
+        int pc1 = 0, pc2 = 0;
+        if (int rc = kernel_blocks_per_cu(h, reinterpret_cast<const void*>(hs_solve_fused_kernel<Sys, 1, SCHEME>), 64, HsFused<Sys, 1, SCHEME>::lds_bytes(N), &pc1)) return rc;
+        if (int rc = kernel_blocks_per_cu(h, reinterpret_cast<const void*>(hs_solve_fused_kernel<Sys, 2, SCHEME>), 128, HsFused<Sys, 2, SCHEME>::lds_bytes(N), &pc2)) return rc;
+        if (pc1 >= 1 && pc1 <= 2 && pc2 >= pc1) waves = 2;
+      }
+    }
     if (so.park_iter > 0) waves = 1;                  // an explicit two-phase launch: only the one-wavefront form parks (include/myriad_hip.h: park_iter)
     if (h->fused_waves > 0) waves = h->fused_waves;
     if constexpr (HsFused<Sys, 4, SCHEME>::TLS) {
