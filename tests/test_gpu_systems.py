@@ -508,3 +508,80 @@ def test_block_sweep_on_short_horizons(monkeypatch, name, rule):
     d = np.abs(f["z"] - l["z"])[fin] / np.maximum(1.0, np.abs(l["z"])[fin])
     assert d.max(initial=0.0) <= 2e-6, (N, d.max())
     np.testing.assert_allclose(f["cost"], l["cost"], rtol=2e-8, atol=1e-12)
+
+
+def _wide_problem(name, rule, N, B, seed):
+  from oracle import myriad_oracle as O
+  twin = name.endswith("_ELASTIC")
+  s = O.Elastic(O.SYSTEMS[name[:-8]](), 1.0) if twin else O.SYSTEMS[name]()
+  tr = O.hermite_simpson(s, N) if rule == "HERMITE_SIMPSON" else O.trapezoidal(s, N)
+  rng = np.random.default_rng(seed)
+  z0 = np.tile(tr.guess, (B, 1))
+  lb, ub = np.tile(tr.bounds[:, 0], (B, 1)), np.tile(tr.bounds[:, 1], (B, 1))
+  x0 = z0[:, :s.ns] * (1.0 + 0.02 * rng.standard_normal((B, s.ns)))
+  z0[:, :s.ns] = x0; lb[:, :s.ns] = x0; ub[:, :s.ns] = x0
+  return s, z0, lb, ub, (s.params() if twin else None)
+
+
+@pytest.mark.parametrize("rule", ["HERMITE_SIMPSON", "TRAPEZOIDAL"])
+@pytest.mark.parametrize("name", ["ROCKETLANDING", "CARTPOLE_ELASTIC", "ROCKETLANDING_ELASTIC"])
+def test_wide_stages_run_their_forward_recursion_over_stored_maps(monkeypatch, name, rule):
+  """Round 6: stages of seven or more knot variables (ROCKETLANDING: 8, CARTPOLE's twin: 9, ROCKETLANDING's twin: 14) run the forward phase's recursion
+  s_{k+1} = A_k s_k + b_k sequentially over maps stored in global scratch (hs_solver_fused.h: fwd_seq) instead of a wave scan over NW x NW affine maps in
+  registers.  Horizons on either side of the 64-stage block of a wavefront (one round, a round that ends on the block edge, two rounds, three for the
+  one-wavefront form), both wavefront forms, against the lane kernel, which shares none of that machinery: same statuses and iteration counts after three
+  iterations, iterates within 2e-6."""
+  from myriad_amd import _lib
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  for N in (63, 64, 65, 100, 130):
+    s, z0, lb, ub, prm = _wide_problem(name, rule, N, 3, 200 + N)
+    res = {}
+    for form, env in (("w1", {"MYRIAD_SOLVE_MODE": "wave", "MYRIAD_FUSED_WAVES": "1"}), ("w2", {"MYRIAD_SOLVE_MODE": "wave", "MYRIAD_FUSED_WAVES": "2"}),
+                      ("lane", {"MYRIAD_SOLVE_MODE": "lane", "MYRIAD_FUSED_WAVES": "0"})):
+      for k, v in env.items(): monkeypatch.setenv(k, v)
+      eng = _lib.Engine(name, rule, N, s.T)
+      o = eng.default_opts(); o.restoration = 0; o.max_iter = 3
+      res[form] = eng.solve(z0, lb, ub, params=prm, opts=o)
+      eng.close()
+    l = res["lane"]
+    fin = np.isfinite(l["z"])
+    for form in ("w1", "w2"):
+      f = res[form]
+      assert np.array_equal(f["status"], l["status"]) and np.array_equal(f["iters"], l["iters"]), (form, N, f["status"], l["status"], f["iters"], l["iters"])
+      assert np.array_equal(np.isfinite(f["z"]), fin), (form, N)
+      d = np.abs(f["z"] - l["z"])[fin] / np.maximum(1.0, np.abs(l["z"])[fin])
+      assert d.max(initial=0.0) <= 2e-6, (form, N, d.max())
+
+
+@pytest.mark.parametrize("name,rule,waves", [("ROCKETLANDING", "HERMITE_SIMPSON", 1), ("ROCKETLANDING_ELASTIC", "HERMITE_SIMPSON", 2),
+                                             ("ROCKETLANDING_ELASTIC", "TRAPEZOIDAL", 1), ("CARTPOLE_ELASTIC", "HERMITE_SIMPSON", 1)])
+def test_wide_systems_fill_the_cu_at_large_batch_sizes(monkeypatch, name, rule, waves):
+  """Round 6: the wide systems keep the bound multipliers in global scratch where the solver's LDS would otherwise let two workgroups onto a CU (four
+  one-wavefront workgroups then fit: ROCKETLANDING, CARTPOLE's twin, the trapezoidal form of ROCKETLANDING's twin), and where even then only two fit
+  (ROCKETLANDING's twin under Hermite-Simpson) two wavefronts share a trajectory at EVERY batch size.  A batch of more trajectories than slots -- every
+  slot takes several, one after the other, inheriting LDS and scratch -- of three distinct problems repeated: every copy returns the bits of the three
+  solved alone, with and without poison in what a trajectory inherits."""
+  from myriad_amd import _lib
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  monkeypatch.delenv("MYRIAD_FUSED_WAVES", raising=False); monkeypatch.delenv("MYRIAD_SOLVE_MODE", raising=False)
+  N, B = 100, 1100
+  s, z3, lb3, ub3, prm = _wide_problem(name, rule, N, 3, 77)
+  rep = np.arange(B) % 3
+  out = {}
+  for tag, poison, zz, ll, uu in (("alone", None, z3, lb3, ub3), ("batch", None, z3[rep], lb3[rep], ub3[rep]), ("poison", "nan", z3[rep], lb3[rep], ub3[rep])):
+    if poison: monkeypatch.setenv("MYRIAD_POISON", poison)
+    else: monkeypatch.delenv("MYRIAD_POISON", raising=False)
+    if tag == "alone": monkeypatch.setenv("MYRIAD_FUSED_WAVES", str(waves))      # (three trajectories would take the two-wavefront form: other sums, other bits)
+    else: monkeypatch.delenv("MYRIAD_FUSED_WAVES", raising=False)
+    eng = _lib.Engine(name, rule, N, s.T, max_batch=B)
+    o = eng.default_opts(); o.restoration = 0; o.max_iter = 4
+    out[tag] = eng.solve(zz, ll, uu, params=prm, opts=o)
+    out[tag]["plan"] = eng.solve_plan()
+    eng.close()
+  if not name.endswith("_ELASTIC"):
+    assert out["batch"]["plan"]["form"] == "fused" and out["batch"]["plan"]["waves_per_trajectory"] == waves, out["batch"]["plan"]
+  a = out["alone"]
+  for tag in ("batch", "poison"):
+    r = out[tag]
+    for k in ("z", "lam", "cost", "status", "iters"):
+      assert np.array_equal(np.asarray(r[k]), np.asarray(a[k])[rep], equal_nan=True) if np.asarray(r[k]).dtype.kind == "f" else np.array_equal(np.asarray(r[k]), np.asarray(a[k])[rep]), (tag, k)
