@@ -242,7 +242,7 @@ struct HsFused {
   __host__ __device__ static int lds_doubles(int N) { return lds_solver_doubles(N) + (MLP ? npoints(N) * NS + NodeTraits<Sys>::lds_doubles : 0); }
   __host__ __device__ static size_t lds_bytes(int N) { return (size_t)lds_doubles(N) * 8; }
   static constexpr int NSCAL = 48;      // scalars of the solve loop in a parked trajectory's record
-  __host__ __device__ static long park_doubles(int N) { return NSCAL + lds_solver_doubles(N); }
+  __host__ __device__ static long park_doubles(int N) { return NSCAL + lds_solver_doubles(N) + (ZLU_GLOBAL ? 2L * npoints(N) * NW : 0); }      // (+ the bound multipliers of the forms that keep them in the slot's scratch)
 
   struct Ctx {
     int N, K, n, lane, wave, tid;
@@ -2751,6 +2751,9 @@ struct HsFused {
       // resume a parked trajectory: the solver's LDS as it was at the top of iteration k1, the scalars of the loop, the slot's block of zeros
       const int nl = lds_solver_doubles(c.N);
       for (int i = c.tid; i < nl; i += NT) c.z[i] = __builtin_nontemporal_load(&sv[NSCAL + i]);     // (read once: keep it out of the caches the next kernels use)
+      if constexpr (ZLU_GLOBAL) {
+        for (int i = c.tid; i < 2 * c.n; i += NT) c.zL[i] = __builtin_nontemporal_load(&sv[NSCAL + nl + i]);      // (zU follows zL)
+      }
       if (c.tid < ZR) c.zr[c.tid] = 0.0;
       mu = sv[0]; pen = sv[1]; pen_over = (int)sv[2]; pen_cuts = (int)sv[3]; stall = (int)sv[4]; small_steps = (int)sv[5];
       delta_last = sv[6]; lm = sv[7]; nhist = (int)sv[8]; hpos = (int)sv[9]; hist_mu = sv[10]; hist_pen = sv[11];
@@ -2774,6 +2777,9 @@ struct HsFused {
         // park: everything the rest of the solve needs (the previous iteration ended with a workgroup barrier)
         const int nl = lds_solver_doubles(c.N);
         for (int i = c.tid; i < nl; i += NT) __builtin_nontemporal_store(c.z[i], &sv[NSCAL + i]);
+        if constexpr (ZLU_GLOBAL) {
+          for (int i = c.tid; i < 2 * c.n; i += NT) __builtin_nontemporal_store(c.zL[i], &sv[NSCAL + nl + i]);
+        }
         if (c.tid == 0) {
           sv[0] = mu; sv[1] = pen; sv[2] = (double)pen_over; sv[3] = (double)pen_cuts; sv[4] = (double)stall; sv[5] = (double)small_steps;
           sv[6] = delta_last; sv[7] = lm; sv[8] = (double)nhist; sv[9] = (double)hpos; sv[10] = hist_mu; sv[11] = hist_pen;

@@ -620,7 +620,8 @@ static int launch_hs_fused_w(myr_handle h, int B, double* z, const double* lb, c
                                                                                //  the network system's longest solves -- 75 iterations against a median of 24 -- have SMALL
                                                                                //  residuals at the parking point and would come last: 41 -> 52 ms at B = 1024, exp42 / exp43)
     if (k1 >= o.max_iter || !status || !kkt) k1 = 0;
-    if (W::ZLU_GLOBAL) k1 = 0;        // (the parked record is the solver's LDS: this form keeps part of the iterate in its scratch slot)
+    if (W::ZLU_GLOBAL && W::MLP) k1 = 0;        // (the network kernel's throughput form: its helper protocol and activation store are not part of a parked record;
+                                                //  the closed-form systems that keep the bound multipliers in the slot's scratch park them with the solver's LDS)
   }
   // Helper workgroups for the network passes (hs_solver_fused.h: NodeBoard): a batch of at most half the CUs (config 5's share of an 8-GPU node is 128
   // trajectories) gets nh = #CU / B - 1 <= 3 more workgroups per trajectory; whole solves with one shared weight set only.
@@ -751,7 +752,9 @@ static int launch_hs_fused(myr_handle h, int B, double* z, const double* lb, con
     // SIMDs of every CU idle in that form: when as many two-wavefront workgroups fit, those run at EVERY batch size (round 6, tools/dev/exp/exp96.sh, B = 4096:
     // ROCKETLANDING 94.5 -> 70.4 ms, CARTPOLE's twin 192 -> 146 ms, ROCKETLANDING's twin 397 -> 311 ms; with four one-wavefront workgroups per CU the
     // one-wavefront form wins as before -- BEARPOPULATIONS 9.6 against 14.9 ms).
-    if constexpr (HsFused<Sys, 2, SCHEME>::SUPPORTED && !HsFused<Sys, 2, SCHEME>::TL) {
+    // The same holds for every system once the horizon is long enough (exp100.sh, the headline system, B = 4096: N = 150 -- two workgroups per CU in either form --
+    // 34.1 -> 27.2 ms; N = 300 -- one -- 130.9 -> 88.2 ms; N = 200, where two one-wavefront workgroups fit but only one of two wavefronts, stays: 46.3 against 57.7 ms).
+    if constexpr (HsFused<Sys, 2, SCHEME>::SUPPORTED) {
       const int N = h->d.intervals;
       if (HsFused<Sys, 2, SCHEME>::lds_bytes(N) <= 160 * 1024) {
         int pc1 = 0, pc2 = 0;

@@ -585,3 +585,64 @@ def test_wide_systems_fill_the_cu_at_large_batch_sizes(monkeypatch, name, rule, 
     r = out[tag]
     for k in ("z", "lam", "cost", "status", "iters"):
       assert np.array_equal(np.asarray(r[k]), np.asarray(a[k])[rep], equal_nan=True) if np.asarray(r[k]).dtype.kind == "f" else np.array_equal(np.asarray(r[k]), np.asarray(a[k])[rep]), (tag, k)
+
+
+@pytest.mark.parametrize("N,waves", [(150, 2), (200, 1), (300, 2)])
+def test_long_horizons_take_two_wavefronts_per_trajectory_where_as_many_workgroups_fit(monkeypatch, N, waves):
+  """Round 6: the rule of the wide systems holds for every system once the horizon is long enough.  CARTPOLE, Hermite-Simpson: at N = 150 the solver's LDS lets
+  two one-wavefront workgroups onto a CU and two two-wavefront ones as well -- two wavefronts per trajectory at every batch size (B = 4096: 34.1 -> 27.2 ms);
+  at N = 200 two against one -- the one-wavefront form stays; at N = 300 one against one (130.9 -> 88.2 ms).  A batch beyond two trajectories per CU: the plan
+  says which form ran, every trajectory converges, and the copies of three problems return the bits of the three solved alone in the same form, with and
+  without poison in what a slot's next trajectory inherits (the two-wavefront form with the two-level sweep serves several trajectories per slot here)."""
+  from myriad_amd import _lib
+  from bench import build_workload
+  for k in ("MYRIAD_FUSED_WAVES", "MYRIAD_SOLVE_MODE", "MYRIAD_PARK_ITER"): monkeypatch.delenv(k, raising=False)
+  B = 600
+  x0, z3, lb3, ub3, T = build_workload(3, N, 5)
+  rep = np.arange(B) % 3
+  out = {}
+  for tag, poison, zz, ll, uu in (("alone", None, z3, lb3, ub3), ("batch", None, z3[rep], lb3[rep], ub3[rep]), ("poison", "random", z3[rep], lb3[rep], ub3[rep])):
+    if poison: monkeypatch.setenv("MYRIAD_POISON", poison)
+    else: monkeypatch.delenv("MYRIAD_POISON", raising=False)
+    if tag == "alone": monkeypatch.setenv("MYRIAD_FUSED_WAVES", str(waves)); monkeypatch.setenv("MYRIAD_PARK_ITER", "0")
+    else: monkeypatch.delenv("MYRIAD_FUSED_WAVES", raising=False); monkeypatch.delenv("MYRIAD_PARK_ITER", raising=False)
+    eng = _lib.Engine("CARTPOLE", "HERMITE_SIMPSON", N, T, max_batch=B)
+    out[tag] = eng.solve(zz, ll, uu)
+    out[tag]["plan"] = eng.solve_plan()
+    eng.close()
+  assert out["batch"]["plan"]["form"] == "fused" and out["batch"]["plan"]["waves_per_trajectory"] == waves, out["batch"]["plan"]
+  a = out["alone"]
+  assert (a["status"] == 0).all()
+  for tag in ("batch", "poison"):
+    r = out[tag]
+    for k in ("z", "lam", "cost"):
+      assert np.array_equal(np.asarray(r[k]), np.asarray(a[k])[rep]), (tag, k)
+    assert np.array_equal(r["status"], a["status"][rep]) and np.array_equal(r["iters"], a["iters"][rep]), tag
+
+
+@pytest.mark.parametrize("name,rule", [("ROCKETLANDING", "HERMITE_SIMPSON"), ("CARTPOLE_ELASTIC", "HERMITE_SIMPSON"), ("ROCKETLANDING_ELASTIC", "TRAPEZOIDAL")])
+def test_forms_with_the_bound_multipliers_in_scratch_park_and_resume(monkeypatch, name, rule):
+  """The two-phase launch of the one-wavefront forms that keep zL, zU in the slot's global scratch (round 6): the parked record carries them beside the
+  solver's LDS; parked after 1, 3 and 7 iterations, resumed in another slot, under poison, a trajectory returns the bits of a whole solve."""
+  from myriad_amd import _lib
+  monkeypatch.setenv("MYRIAD_SECOND_STARTS", "0"); monkeypatch.setenv("MYRIAD_ELASTIC", "0")
+  monkeypatch.setenv("MYRIAD_FUSED_WAVES", "1"); monkeypatch.delenv("MYRIAD_SOLVE_MODE", raising=False)
+  N, B = 20, 7
+  s, z0, lb, ub, prm = _wide_problem(name, rule, N, B, 31)
+  def run(park, poison):
+    monkeypatch.setenv("MYRIAD_PARK_ITER", str(park))
+    if poison: monkeypatch.setenv("MYRIAD_POISON", poison)
+    else: monkeypatch.delenv("MYRIAD_POISON", raising=False)
+    eng = _lib.Engine(name, rule, N, s.T)
+    o = eng.default_opts(); o.restoration = 0; o.max_iter = 12
+    r = eng.solve(z0, lb, ub, params=prm, opts=o)
+    r["plan"] = eng.solve_plan()
+    eng.close()
+    return r
+  ref = run(0, None)
+  for park, poison in ((1, None), (3, "nan"), (7, "random")):
+    r = run(park, poison)
+    if not name.endswith("_ELASTIC"):
+      assert r["plan"]["park_iter"] == park and r["plan"]["launches_per_solve"] == 2, r["plan"]
+    for k in ("z", "lam", "cost", "status", "iters"):
+      assert np.array_equal(np.asarray(r[k]), np.asarray(ref[k]), equal_nan=(np.asarray(r[k]).dtype.kind == "f")), (park, poison, k)
