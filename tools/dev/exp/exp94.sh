@@ -1,5 +1,6 @@
 #!/bin/bash
 # exp94: the sequential forward recursion (HsFused::FSEQ) on the elastic twins (CARTPOLE's: 9 knot variables, ROCKETLANDING's: 14), and whether the headline
+# (VOID for the headline-system part: xv/libfseq5.so linked the variant object of the whole system BEHIND the regular part objects, so the regular kernels ran; redone in exp101.sh)
 # system (5 knot variables) would gain from it (xv/libfseq5.so: SysCARTPOLE built with -DMYR_FWD_SEQ_NW=5)
 cd /root/repo; O=gpurun_out/exp94; mkdir -p $O
 for lib in myriad_amd/libmyriad_hip.so xv/libfseq.so; do
