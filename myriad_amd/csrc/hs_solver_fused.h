@@ -123,6 +123,10 @@ constexpr unsigned MYR_COOP_SPIN_MAX = 1u << 23;
 
 #ifdef MYR_PHASE_TIMING
 __device__ long long node_tph_[8];      // cycles of workgroup 0's network passes (MODE 0 / 1 / 2), wavefront 0
+__device__ long long bw_tph_[4];        // the backward pass of workgroup 0 in parts: linearisation | stage maps | adjoint scan + multipliers (the pass runs on a COPY of the context)
+#define MYR_BW_PH(i) { if (blockIdx.x == 0 && c.tid == 0) { const long long t1_ = clock64(); bw_tph_[i] += t1_ - bw_t0_; bw_t0_ = t1_; } }
+#else
+#define MYR_BW_PH(i)
 #endif
 
 template <class Sys, int W = 1, int SCHEME = 0>
@@ -668,6 +672,9 @@ struct HsFused {
     }
     // rounds of W blocks from the top: wavefront w takes block r0 - w of the round
     int round = 0;
+#ifdef MYR_PHASE_TIMING
+    long long bw_t0_ = clock64();
+#endif
     for (int r0 = N / 64; r0 >= 0; r0 -= W, ++round) {
       const int blk = r0 - c.wave;
       const int kr = blk >= 0 ? blk * 64 + 63 - lane : N + 1;
@@ -693,6 +700,7 @@ struct HsFused {
           re[q] = (lane == 0) ? theirs[q] : t;
         }
       }
+      MYR_BW_PH(0)     // (phase-timing builds: linearisation of the round's points + the neighbour exchange)
       double MA[NS * NS], Mb[NS], Ld[NS * NS], ld0[NS], Li[NS * NS], li0[NS];
       if constexpr (TRAP) {
         // trapezoidal scheme (TrapCore::backward, os_solver.h): c_k = h/2 (f_k + f_{k+1}) - (x_{k+1} - x_k);
@@ -903,6 +911,7 @@ struct HsFused {
         }
       }
       }
+      MYR_BW_PH(1)     // (... the stage's elimination maps and adjoint maps)
       affine_prefix_scan_dpp<NS>(MA, Mb);
       double piN[NS];                          // Pi below the round (the next round's carry), by every wavefront alike
 #pragma unroll
@@ -964,6 +973,7 @@ struct HsFused {
           smu += fabs(d) + fabs(i2);
         }
       }
+      MYR_BW_PH(2)     // (... the adjoint scan and the multipliers)
     }
     double v[10] = {wv_sum(acc.f), wv_max(acc.cmax), wv_min(acc.cmin), wv_sum(acc.sm), (double)wv_isum(acc.nm),
                     wv_sum(acc.lg), wv_sum(c1), wv_max(cinf), wv_max(li_), wv_sum(smu)};
@@ -3225,6 +3235,10 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     if (c.lane == 0 && b < 4) {
       printf("traj %ld wave %d it %d: backward %lld hess %lld fold %lld chunk %lld wait %lld join %lld first %lld ricc %lld nu %lld forward %lld ls %lld\n",
              b, c.wave, r.iters, c.tph[0], c.tph[4], c.tph[3], c.tph[13], c.tph[5], c.tph[9], c.tph[10], c.tph[6], c.tph[7], c.tph[8], c.tph[11]);
+    }
+    if (!W::MLP && c.tid == 0 && blockIdx.x == 0) {
+      printf("  workgroup 0, traj %ld it %d: backward pass in parts (cycles): linearisation %lld stage maps %lld scan + multipliers %lld\n", b, r.iters, bw_tph_[0], bw_tph_[1], bw_tph_[2]);
+      bw_tph_[0] = bw_tph_[1] = bw_tph_[2] = 0;
     }
     if (W::MLP && c.tid == 0 && blockIdx.x == 0) {
       printf("  workgroup 0, traj %ld it %d: network passes of wavefront 0 (cycles): MODE0 %lld MODE3 %lld MODE4 %lld\n", b, r.iters, node_tph_[0], node_tph_[3], node_tph_[4]);
