@@ -3243,6 +3243,11 @@ void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, doubl
     if (W::MLP && c.tid == 0 && blockIdx.x == 0) {
       printf("  workgroup 0, traj %ld it %d: network passes of wavefront 0 (cycles): MODE0 %lld MODE3 %lld MODE4 %lld\n", b, r.iters, node_tph_[0], node_tph_[3], node_tph_[4]);
       node_tph_[0] = node_tph_[3] = node_tph_[4] = 0;
+      for (int m = 0; m < 5; m += (m == 0 ? 3 : 1)) {
+        printf("    MODE %d segments: inputs %lld | layer 1 + sigmoids %lld | layer 2 %lld | sigmoids 2 %lld | activations stored / loaded %lld | last layer %lld | tangents / contraction %lld\n", m,
+               node_seg_[m][0], node_seg_[m][1], node_seg_[m][2], node_seg_[m][3], node_seg_[m][4], node_seg_[m][5], node_seg_[m][6]);
+        for (int q = 0; q < 8; ++q) node_seg_[m][q] = 0;
+      }
     }
 #endif
     if (c.tid == 0) {

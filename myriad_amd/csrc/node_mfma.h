@@ -31,6 +31,12 @@ typedef __attribute__((address_space(3))) double nd_lds;
 typedef __attribute__((address_space(1))) double nd_glb;
 typedef double nd4 __attribute__((ext_vector_type(4)));
 
+#ifdef MYR_PHASE_TIMING
+__device__ long long node_seg_[5][8];      // phase-timing builds: cycles of workgroup 0, wavefront 0 inside a pass, per MODE and segment (tools/dev/exp/exp104.sh)
+#define MYR_NSEG(k) { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t1_ = clock64(); node_seg_[MODE][k] += t1_ - tseg_; tseg_ = t1_; } }
+#else
+#define MYR_NSEG(k)
+#endif
 struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
   static constexpr int NS = 4, NU = 1, NW = 5, H = 64, LD2 = 65;
   // LDS block (doubles): W1 [8][64] (rows 5..7 zero) | W2 [64][65] (padded rows: column reads are conflict-free too) |
@@ -77,6 +83,13 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
   // (the "memory" barrier in front of every product keeps the compiler from holding the 64 weight values of one product in
   // registers for the next ones -- six products share W2 in MODE 2, and 128 registers of hoisted weights pushed that pass into
   // 4.4 KB of scratch per lane; an LDS read per matrix instruction is what the layout was made for)
+  // (Round 6: the weights of k-step ks + 1 are read BEFORE the four matrix instructions of k-step ks are issued, into registers of their own, and scheduling
+  // barriers keep it that way.  The compiler's own order -- one ds_read2_b64 into one register quad, s_waitcnt lgkmcnt(0), two matrix instructions, 32 times --
+  // exposed the LDS latency in front of every pair: a 64-instruction product took 9.6 k cycles for 4.1 k of matrix pipe, tools/dev/exp/exp104.sh.  Same
+  // operations in the same order: same bits.  -DMYR_NODE_PIPE=0: the old form.)
+#ifndef MYR_NODE_PIPE
+#define MYR_NODE_PIPE 1
+#endif
   template <bool BIAS>
   __device__ static inline void gemm_t(const nd_lds* wl, int g, int i, const nd4* in, nd4* out) {
     asm volatile("" ::: "memory");
@@ -85,6 +98,26 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc[mt][s] = BIAS ? wl[L_B2 + 16 * mt + 4 * s + g] : 0.0;
+#if MYR_NODE_PIPE
+    double w[2][4];
+    {
+      const nd_lds* row = wl + L_W2 + g * LD2 + i;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) w[0][mt] = row[16 * mt];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks + 1 < 16) {
+        const nd_lds* row = wl + L_W2 + (16 * ((ks + 1) >> 2) + 4 * ((ks + 1) & 3) + g) * LD2 + i;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) w[(ks + 1) & 1][mt] = row[16 * mt];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = mm(w[ks & 1][mt], in[ks >> 2][ks & 3], acc[mt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -93,6 +126,7 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = mm(row[16 * mt], in[t][s], acc[mt]);
       }
+#endif
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) out[mt] = acc[mt];
   }
@@ -102,6 +136,26 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
     nd4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = nd4{0.0, 0.0, 0.0, 0.0};
+#if MYR_NODE_PIPE
+    double w[2][4];
+    {
+      const nd_lds* col = wl + L_W2 + i * LD2 + g;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) w[0][nt] = col[16 * nt * LD2];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks + 1 < 16) {
+        const nd_lds* col = wl + L_W2 + i * LD2 + 16 * ((ks + 1) >> 2) + 4 * ((ks + 1) & 3) + g;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) w[(ks + 1) & 1][nt] = col[16 * nt * LD2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = mm(w[ks & 1][nt], in[ks >> 2][ks & 3], acc[nt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -110,6 +164,7 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = mm(col[16 * nt * LD2], in[t][s], acc[nt]);
       }
+#endif
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) out[nt] = acc[nt];
   }
@@ -190,6 +245,9 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
   template <int MODE, class ZT = nd_glb>
   __device__ __attribute__((noinline)) static void pass(const nd_lds* wl, ArgsT<ZT> a, int lane) {
     const int g = lane >> 4, i = lane & 15, K = a.K;
+#ifdef MYR_PHASE_TIMING
+    long long tseg_ = clock64();
+#endif
     for (int j0 = 16 * a.t0; j0 < K; j0 += 16 * a.ts) {
       const bool valid = j0 + i < K;
       const int j = valid ? j0 + i : K - 1;
@@ -201,6 +259,7 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
       }
       // (s'(A) = h (1 - h) and s''(A) = s'(A) (1 - 2 h) are formed where they are used: keeping them as arrays next to h1, h2
       // cost MODE 2 64 more live registers than it had)
+      MYR_NSEG(0)      // inputs
       nd4 h1[4], h2[4];
       nd_glb* const hbt = (MODE == 0 || MODE >= 3) && a.hb ? a.hb + (long)(j0 >> 4) * HB_TILE + lane : nullptr;
       const bool stored = (MODE == 4) || (MODE == 3 && a.h_valid);      // (wave-uniform)
@@ -216,20 +275,34 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int s = 0; s < 4; ++s) a1[mt][s] = wl[L_B1 + 16 * mt + 4 * s + g];
+#if MYR_NODE_PIPE
+          double wa[4], wb[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) { wa[mt] = wl[L_W1 + g * H + 16 * mt + i]; wb[mt] = wl[L_W1 + (4 + g) * H + 16 * mt + i]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) a1[mt] = mm(wa[mt], xg, a1[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) a1[mt] = mm(wb[mt], ug, a1[mt]);
+#else
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) a1[mt] = mm(wl[L_W1 + g * H + 16 * mt + i], xg, a1[mt]);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) a1[mt] = mm(wl[L_W1 + (4 + g) * H + 16 * mt + i], ug, a1[mt]);
+#endif
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int s = 0; s < 4; ++s) h1[mt][s] = sigm(a1[mt][s]);
         }
+        MYR_NSEG(1)    // layer 1 + sigmoids
         gemm_t<true>(wl, g, i, h1, h2);
+        MYR_NSEG(2)    // layer 2 product
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int s = 0; s < 4; ++s) h2[mt][s] = sigm(h2[mt][s]);
+        MYR_NSEG(3)    // sigmoids of layer 2
         if (hbt) {
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
@@ -237,11 +310,13 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
             for (int s = 0; s < 4; ++s) { nts(h1[mt][s], &hbt[(4 * mt + s) * 64]); nts(h2[mt][s], &hbt[(16 + 4 * mt + s) * 64]); }
         }
       }
+      MYR_NSEG(4)      // activations stored / loaded
       if (MODE == 0 || MODE == 1 || MODE == 3) {
         const double F = (MODE == 1) ? layer3<true>(wl, g, i, h2) : layer3_valu(wl, g, h2);
         if (MODE == 0) { if (valid) a.sF[j * NS + g] = F; }
         else if (valid) { if (a.use_rec) a.rec[j * a.rec_stride + a.rec_f + g] = F; else a.pt[(long)(a.pf_f + g) * K + j] = F; }
       }
+      MYR_NSEG(5)      // last layer + F stored
       if (MODE == 3) {
         // All five forward tangents through W2 in ONE k-loop: a k-step's weight reads feed ten independent matrix instructions
         // (5 tangents x 2 output tiles; the output tiles in two halves), the seeds s'(A1) W1[c, :] are formed on the fly.  The tangents
@@ -258,6 +333,36 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
           nd4 m[NW][2];
 #pragma unroll
           for (int c = 0; c < NW; ++c) { m[c][0] = nd4{0.0, 0.0, 0.0, 0.0}; m[c][1] = nd4{0.0, 0.0, 0.0, 0.0}; }
+#if MYR_NODE_PIPE
+          // (the k-step's seven LDS values -- two weights of W2, five of W1 -- read one k-step ahead, as in gemm_t)
+          double wq[2][2 + NW];
+          {
+            const nd_lds* row = wl + L_W2 + g * LD2 + 32 * half + i;
+            wq[0][0] = row[0]; wq[0][1] = row[16];
+#pragma unroll
+            for (int c = 0; c < NW; ++c) wq[0][2 + c] = wl[L_W1 + c * H + g];
+          }
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            if (ks + 1 < 16) {
+              const int k1 = 16 * ((ks + 1) >> 2) + 4 * ((ks + 1) & 3) + g;
+              const nd_lds* row = wl + L_W2 + k1 * LD2 + 32 * half + i;
+              wq[(ks + 1) & 1][0] = row[0]; wq[(ks + 1) & 1][1] = row[16];
+#pragma unroll
+              for (int c = 0; c < NW; ++c) wq[(ks + 1) & 1][2 + c] = wl[L_W1 + c * H + k1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const double hv1 = h1[ks >> 2][ks & 3];
+            const double sp = hv1 * (1.0 - hv1);
+#pragma unroll
+            for (int c = 0; c < NW; ++c) {
+              const double d = sp * wq[ks & 1][2 + c];
+              m[c][0] = mm(wq[ks & 1][0], d, m[c][0]);
+              m[c][1] = mm(wq[ks & 1][1], d, m[c][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#else
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -273,6 +378,7 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
                 m[c][1] = mm(w1, d, m[c][1]);
               }
             }
+#endif
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             const int mt = 2 * half + q;
@@ -347,6 +453,7 @@ struct NodeMfma64 {     // NS = 4, NU = 1, hidden (64, 64)
           if (valid && e0 + g < NPAIR) a.pt[(long)(a.pf_d2 + e0 + g) * K + j] = v;
         }
       }
+      MYR_NSEG(6)      // MODE 3: tangents + Jacobian; MODE 4: contraction
       if (MODE == 1) {
         // forward tangents: d A1 / d w_c = W1[c, :] (constant), so d H1 = s'(A1) * W1[c, :], then the two upper layers
 #pragma unroll
