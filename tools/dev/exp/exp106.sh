@@ -1,6 +1,8 @@
 #!/bin/bash
 # exp106: the network problem's line search started from GROW x the step length accepted last (-DMYR_LS_GROW_MLP=2 / 4, fused kernel only) instead of the
 # full step: kernel time, iteration distribution, convergence, optimum against the regular library (draws of config5_1gpu.jsonl)
+# (The experiment's code is NOT in the tree.  The patch, hs_solver_fused.h: solve(): a loop variable a_last = 1e301; in front of the line search
+#  `if (MLP && a_last < 1e300) a = min(a, GROW * a_last);`; behind it `a_last = ok ? a : 1e301;`.  Result: profiles/r06/README.md.)
 cd /root/repo; O=gpurun_out/exp106; mkdir -p $O
 for lib in myriad_amd/libmyriad_hip.so xv/libgrow2.so xv/libgrow4.so; do
   echo "== $lib"

@@ -1,6 +1,8 @@
 #!/bin/bash
 # exp107: the line search of the network problem backtracks to the minimiser of the quadratic through phi(0), phi'(0), phi(a) (clamped to [0.1 or 0.25, 0.5] a) instead of a / 2:
 # full step: kernel time, iteration distribution, convergence, optimum against the regular library (draws of config5_1gpu.jsonl)
+# (The experiment's code is NOT in the tree.  The patch, hs_solver_fused.h: solve(): a rejected, evaluable trial sets
+#  a = clamp(-Dphi a^2 / (2 (phi(a) - phi0 - Dphi a)), LO a, a / 2) instead of a / 2.  Result: profiles/r06/README.md.)
 cd /root/repo; O=gpurun_out/exp107; mkdir -p $O
 for lib in myriad_amd/libmyriad_hip.so xv/libinterp0.1.so xv/libinterp0.25.so; do
   echo "== $lib"
