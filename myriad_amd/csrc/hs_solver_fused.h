@@ -240,7 +240,10 @@ struct HsFused {
   // not let 4 / W workgroups onto a CU at the reference horizon of 100 intervals -- ROCKETLANDING's one-wavefront Hermite-Simpson form (65.6 -> 39.9 KB: four
   // per CU instead of two, 94.5 -> 65.0 ms per 4096 solves of 30 iterations), CARTPOLE's twin (192 -> 111 ms), ROCKETLANDING's twin (one-wavefront form
   // 109 -> 64 KB, two-wavefront form 118 -> 73 KB: two per CU instead of one, 397 -> 205 ms); tools/dev/exp/exp97.sh.  -DMYR_ZLU_GLOBAL_WIDE=0: resident.
-  static constexpr bool ZLU_GLOBAL = (MLP && W == 2) ||
+#ifndef MYR_ZLU_FORCE
+#define MYR_ZLU_FORCE 0         // experiment (tools/dev/exp/exp110.sh): 1 = every one-wavefront closed-form kernel keeps the bound multipliers in scratch
+#endif
+  static constexpr bool ZLU_GLOBAL = (MLP && W == 2) || ((MYR_ZLU_FORCE != 0) && !MLP && W == 1) ||
       ((MYR_ZLU_GLOBAL_WIDE != 0) && !MLP && (MYR_FWD_SEQ_NW > 0) && NW >= MYR_FWD_SEQ_NW && (long)lds_solver_doubles_z(100, false) * 8 > 40960L * W);
   __host__ __device__ static int lds_solver_doubles(int N) { return lds_solver_doubles_z(N, ZLU_GLOBAL); }
   __host__ __device__ static int lds_doubles(int N) { return lds_solver_doubles(N) + (MLP ? npoints(N) * NS + NodeTraits<Sys>::lds_doubles : 0); }
@@ -3102,8 +3105,11 @@ struct HsFused {
 
 // Persistent, one trajectory per wavefront (workgroup = one wavefront): every workgroup pulls trajectories from `ticket` until the
 // batch is done and owns ONE scratch block that it re-uses for all of them.
+#ifndef MYR_FUSED_OCC
+#define MYR_FUSED_OCC 1      // workgroups per SIMD the register allocation must allow (experiment, tools/dev/exp/exp109.sh: 2 = 256 registers per lane)
+#endif
 template <class Sys, int NWAVES = 1, int SCHEME = 0>
-__global__ __launch_bounds__(64 * NWAVES, 1)
+__global__ __launch_bounds__(64 * NWAVES, MYR_FUSED_OCC)
 void hs_solve_fused_kernel(int B, int* ticket, HsSolveOpts o, VarScale vs, double* __restrict__ z, const double* __restrict__ lb,
                            const double* __restrict__ ub, double* lam, double* scratch, long scratch_stride,
                            const double* __restrict__ params, int params_stride, double* cost, int32_t* status,
