@@ -17,3 +17,10 @@ pmc_passes wider_cartpole_twin_hs python tools/dev/wider_one.py CARTPOLE_ELASTIC
 pmc_passes wider_rocket_twin_hs python tools/dev/wider_one.py ROCKETLANDING_ELASTIC HERMITE_SIMPSON 4096 30 2
 bash tools/dev/exp/exp98.sh > /dev/null 2>&1; cp gpurun_out/exp98/times.txt $OUT/wider_systems_times.txt
 ls $OUT; head -c 1500 $OUT/pmc_wider_cartpole_twin_hs.json
+# kernel statistics (rocprofv3 --kernel-trace --stats) of the three wide systems' Hermite-Simpson solves, one file
+for sys in ROCKETLANDING CARTPOLE_ELASTIC ROCKETLANDING_ELASTIC; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$sys -o kt -- python tools/dev/wider_one.py $sys HERMITE_SIMPSON 4096 30 3 > $OUT/kt_$sys.log 2>&1
+  f=$(find $OUT/kt_$sys -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && { echo "# $sys HERMITE_SIMPSON N=100 B=4096, 30 iterations, 3 solves"; grep -E "Name|hs_solve" $f; } >> $OUT/wider_systems_kernel_stats.csv
+  rm -rf $OUT/kt_$sys
+done
