@@ -109,6 +109,11 @@ def main():
             # round 6 (VERDICT r5 next #6b): collocation solves larger than N = 8 computed by the reference's solve() -- the headline system at a quarter of its horizon
             ("CARTPOLE", dict(optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON, intervals=25)),
             ("CARTPOLE", dict(optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.TRAPEZOIDAL, intervals=25))]
+  if os.environ.get("MYRIAD_REF_FULL_SOLVE"):
+    # round 6, late: the HEADLINE problem at its full horizon (BASELINE config 2's shape, one trajectory from the reference's own start state) through the
+    # reference's solve() -- tens of minutes of SLSQP with complex-step Jacobians of 1005 variables; run as
+    #   MYRIAD_REF_FULL_SOLVE=1 python tests/golden/make_reference_fixtures.py --solve-only reference_solve_full
+    SOLVES = [("CARTPOLE", dict(optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON, intervals=100))]
   for name, kw in SOLVES:
     hp = HParams(system=SystemType[name], nlpsolver=NLPSolverType.SLSQP, **kw)
     opt = get_optimizer(hp, CFG, hp.system())

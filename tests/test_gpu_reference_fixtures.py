@@ -66,7 +66,12 @@ def test_hip_callbacks_reproduce_the_reference_lines(key):
     assert cr == pytest.approx(float(g("rollout_rk4_cost")), rel=1e-10, abs=1e-11), key
 
 
-SOLVE_KEYS = sorted({k.rsplit("/", 1)[0] for k in FIX.files if k.startswith("solve/") and k.endswith("/cost")})
+# (round 6: + tests/golden/reference_solve_full.npz -- the HEADLINE problem at its full horizon, CARTPOLE Hermite-Simpson N = 100 from the reference's own start state,
+#  through the reference's solve(): 44 minutes of SLSQP with complex-step Jacobians, MYRIAD_REF_FULL_SOLVE=1 in tests/golden/make_reference_fixtures.py)
+_FULL = np.load(os.path.join(HERE, "golden", "reference_solve_full.npz"))
+SOLVEFIX = {k: FIX[k] for k in FIX.files if k.startswith("solve/")}
+SOLVEFIX.update({k: _FULL[k] for k in _FULL.files})
+SOLVE_KEYS = sorted({k.rsplit("/", 1)[0] for k in SOLVEFIX if k.endswith("/cost")})
 
 
 @pytest.mark.parametrize("key", SOLVE_KEYS)
@@ -77,7 +82,7 @@ def test_hip_sqp_reaches_the_optimum_of_the_reference_solve(key):
   N, cpi = (int(v) for v in shape.split("x"))
   hp = _hp(name, "SHOOTING" if optimizer == "SHOOTING" else rule, rule, N, cpi, nlpsolver=NLPSolverType.SQP)
   opt = get_optimizer(hp, CFG, hp.system())
-  z_ref = FIX[key + "/xs_and_us"]; c_ref = float(FIX[key + "/cost"])
+  z_ref = SOLVEFIX[key + "/xs_and_us"]; c_ref = float(SOLVEFIX[key + "/cost"])
   assert float(opt.objective(z_ref)) == pytest.approx(c_ref, rel=1e-10, abs=1e-12), key
   r = opt.solve_batch(x0s=np.asarray(opt.system.x_0, dtype=np.float64)[None], guess=z_ref[None])
   assert r["status"][0] == 0, (key, r["status"], r["iters"])
@@ -99,7 +104,7 @@ def test_hip_sqp_from_the_reference_guess_reaches_the_reference_basin(key):
   N, cpi = (int(v) for v in shape.split("x"))
   hp = _hp(name, "SHOOTING" if optimizer == "SHOOTING" else rule, rule, N, cpi, nlpsolver=NLPSolverType.SQP)
   opt = get_optimizer(hp, CFG, hp.system())
-  c_ref = float(FIX[key + "/cost"])
+  c_ref = float(SOLVEFIX[key + "/cost"])
   eng = opt.engine
   o = eng.default_opts(); o.max_iter = hp.max_iter; o.restoration = 0
   z0, lb, ub = opt.batch_inputs(np.asarray(opt.system.x_0, dtype=np.float64)[None], opt.system.device_params())
@@ -117,7 +122,7 @@ def test_hip_sqp_from_the_reference_guess_reaches_the_reference_basin(key):
     assert cost == pytest.approx(c_ref, rel=5e-5 if shape == "10x100" else 1e-5, abs=1e-7), (key, cost, c_ref)
     # the same basin in the variables, at the accuracy SLSQP's stopping rule leaves (the objective is flat near the optimum: SURVEY.md App. C measured 1.4e-2
     # between SLSQP and trust-constr in the controls at N = 100)
-    z_ref = FIX[key + "/xs_and_us"]
+    z_ref = SOLVEFIX[key + "/xs_and_us"]
     if shape != "10x100":      # (BASELINE config 1: the end controls carry the quadrature weight h / 2 = 5e-4 and are left undetermined at SLSQP's tolerance -- SURVEY.md App. C)
       assert np.abs(z - z_ref).max() <= 5e-2 * max(1.0, np.abs(z_ref).max()), (key, np.abs(z - z_ref).max())
     else:

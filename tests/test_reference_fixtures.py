@@ -78,6 +78,25 @@ def test_oracle_reproduces_the_reference_lines(key):
 SOLVE_KEYS = sorted({k.rsplit("/", 1)[0] for k in FIX.files if k.startswith("solve/") and k.endswith("/cost")})
 
 
+def test_full_size_headline_solve_of_the_reference_is_the_oracles():
+  """tests/golden/reference_solve_full.npz (round 6): BASELINE config 2's problem -- CARTPOLE, Hermite-Simpson, N = 100, from the reference's own start state -- through the
+  reference's solve() (nlp_solvers/__init__.py:18-98, SLSQP branch; complex-step derivatives of the reference's callbacks; 44 minutes).  The oracle's restatement of that call was
+  run once for the CPU baseline (profiles/r05/cpu_baseline_full.json: 230 s, 110 iterations): the two end at the same cost to eleven digits, the reference's end point is feasible
+  for the oracle's constraints to 1e-8 and has the reference's cost under the oracle's objective.  (The oracle's 230-s solve is not repeated here.)"""
+  import json
+  full = np.load(os.path.join(HERE, "golden", "reference_solve_full.npz"))
+  key = "solve/CARTPOLE/COLLOCATION/HERMITE_SIMPSON/100x1"
+  z_ref, c_ref = full[key + "/xs_and_us"], float(full[key + "/cost"])
+  system = O.SYSTEMS["CARTPOLE"]()
+  t = O.make_transcription(system, "COLLOCATION", 100, 1, quadrature_rule="HERMITE_SIMPSON")
+  cb = O.Callbacks(t)
+  assert z_ref.shape == (1005,)
+  assert float(cb.fun(z_ref)) == pytest.approx(c_ref, rel=1e-12)
+  assert np.abs(cb.cons(z_ref)).max() < 1e-8
+  rec = json.load(open(os.path.join(os.path.dirname(HERE), "profiles", "r05", "cpu_baseline_full.json")))["slsqp_full_solve"]
+  assert rec["cost"] == pytest.approx(c_ref, rel=1e-10) and rec["converged"]
+
+
 def _solve_case(key):
   _, name, optimizer, rule, shape = key.split("/")
   N, cpi = (int(v) for v in shape.split("x"))

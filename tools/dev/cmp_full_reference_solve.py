@@ -1,0 +1,15 @@
+import os, sys, numpy as np
+sys.path.insert(0, "/root/repo")
+from myriad_amd.config import Config, HParams, NLPSolverType, OptimizerType, QuadratureRule
+from myriad_amd.systems import SystemType
+from myriad_amd.trajectory_optimizers import get_optimizer
+F = np.load("/root/repo/tests/golden/reference_solve_full.npz"); key = "solve/CARTPOLE/COLLOCATION/HERMITE_SIMPSON/100x1"
+hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule.HERMITE_SIMPSON, intervals=100, nlpsolver=NLPSolverType.SQP)
+opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+z_ref, c_ref = F[key + "/xs_and_us"], float(F[key + "/cost"])
+eng = opt.engine; o = eng.default_opts(); o.max_iter = hp.max_iter; o.restoration = 0
+z0, lb, ub = opt.batch_inputs(np.asarray(opt.system.x_0, dtype=np.float64)[None], opt.system.device_params())
+r = opt.device_solve(z0, lb, ub, opt.system.device_params(), o, second_starts=False)
+z = r["z"][0]
+print("device from the reference's guess: status", r["status"][0], "iterations", r["iters"][0], "cost %.12f" % r["cost"][0], "reference %.12f" % c_ref, "difference %.3e" % (r["cost"][0] - c_ref),
+      "max|c| %.2e" % np.abs(opt.constraints(z)).max(), "max|z - z_ref| %.3e" % np.abs(z - z_ref).max(), "states %.3e" % np.abs(z[:804] - z_ref[:804]).max())
