@@ -161,3 +161,35 @@ def test_hip_extragradient_reproduces_the_reference_iteration(key):
   x, lam = opt.extragradient_step(x, lam, 1e-2 * 0.999, 1e-3 * 0.999, nsteps=25)
   _close(x, FIX[key + "/x"], key + " x", 1e-10)
   _close(lam, FIX[key + "/v"], key + " lambda", 1e-10)
+
+
+_DRAWS = os.path.join(HERE, "golden", "reference_solve_draws.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(_DRAWS), reason="tests/golden/reference_solve_draws.npz not generated")
+def test_hip_sqp_solves_instances_of_the_headline_batch_to_the_reference_optimum():
+  """Round 6, late: instances of the HEADLINE WORKLOAD itself -- rows 0..2 of the batch bench.py draws, CARTPOLE Hermite-Simpson N = 100 -- and README.md:83's literal
+  (trapezoidal N = 100) solved by the reference's solve() (tests/golden/make_reference_full_draws.py, ~45 minutes of SLSQP each).  The device solves the same instances in ONE
+  batched call from the reference-shaped guess, restoration and second starts off: KKT points, feasible to 1e-8, cost within SLSQP's stopping tolerance of the reference's
+  and never above it, states within 5e-3 and all variables within 5 % of the reference's end point."""
+  d = np.load(_DRAWS)
+  for rule in ("HERMITE_SIMPSON", "TRAPEZOIDAL"):
+    keys = sorted(k.rsplit("/", 1)[0] for k in d.files if k.startswith(f"draw/{rule}/") and k.endswith("/cost"))
+    if not keys: continue
+    hp = _hp("CARTPOLE", rule, None, 100, 1, nlpsolver=NLPSolverType.SQP)
+    opt = get_optimizer(hp, CFG, hp.system())
+    x0 = np.stack([d[k + "/x0"] for k in keys])
+    eng = opt.engine
+    o = eng.default_opts(); o.max_iter = hp.max_iter; o.restoration = 0
+    z0, lb, ub = opt.batch_inputs(x0, opt.system.device_params())
+    r = opt.device_solve(z0, lb, ub, opt.system.device_params(), o, second_starts=False)
+    assert (r["status"] == 0).all(), (rule, r["status"], r["iters"])
+    for b, k in enumerate(keys):
+      z, z_ref, c_ref = r["z"][b], d[k + "/xs_and_us"], float(d[k + "/cost"])
+      cost = float(r["cost"][b])
+      assert r["kkt"][b, 0] <= 1e-8 and np.abs(opt.constraints(z)).max() <= 1e-8, (k, r["kkt"][b])      # (defects: the start state enters through the bounds)
+      assert cost <= c_ref + 1e-5 * max(1.0, abs(c_ref)), (k, cost, c_ref)
+      assert cost == pytest.approx(c_ref, rel=1e-5), (k, cost, c_ref)
+      nx = (opt.engine.n // 5) * 4
+      assert np.abs(z[:nx] - z_ref[:nx]).max() <= 5e-3 * max(1.0, np.abs(z_ref[:nx]).max()), (k, np.abs(z[:nx] - z_ref[:nx]).max())
+      assert np.abs(z - z_ref).max() <= 5e-2 * max(1.0, np.abs(z_ref).max()), (k, np.abs(z - z_ref).max())

@@ -191,3 +191,27 @@ def test_oracle_extragradient_step_reproduces_the_reference_iteration(key):
   _close(x, FIX[key + "/x"], key + " x", rtol=1e-12)
   _close(lam, FIX[key + "/v"], key + " lambda", rtol=1e-12)
   assert O.Callbacks(t).fun(x) == pytest.approx(float(FIX[key + "/fun"]), rel=1e-11, abs=1e-13)
+
+
+_DRAWS = os.path.join(HERE, "golden", "reference_solve_draws.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(_DRAWS), reason="tests/golden/reference_solve_draws.npz not generated")
+def test_reference_solves_of_the_headline_workloads_instances_are_feasible_for_the_oracle():
+  """tests/golden/reference_solve_draws.npz (round 6, tests/golden/make_reference_full_draws.py): rows 0..2 of the batch bench.py draws (x0 = clip(x_0 + 0.1 xi), seed 2019)
+  and README.md:83's literal, each through the reference's solve() at N = 100.  The start states are the bench's, the reference's end points are feasible for the oracle's
+  constraints of the same instance and have the reference's cost under the oracle's objective."""
+  from bench import build_workload
+  d = np.load(_DRAWS)
+  x0b = build_workload(4, 100, 2019)[0]
+  for key in sorted({k.rsplit("/", 1)[0] for k in d.files}):
+    _, rule, row = key.split("/")
+    x0, z_ref, c_ref = d[key + "/x0"], d[key + "/xs_and_us"], float(d[key + "/cost"])
+    if row != "x_0": np.testing.assert_array_equal(x0, x0b[int(row)])
+    system = O.SYSTEMS["CARTPOLE"]()
+    system.x_0 = np.asarray(x0, dtype=np.float64)
+    t = O.make_transcription(system, "COLLOCATION", 100, 1, quadrature_rule=rule)
+    cb = O.Callbacks(t)
+    assert float(cb.fun(z_ref)) == pytest.approx(c_ref, rel=1e-12), key
+    assert np.abs(cb.cons(z_ref)).max() < 1e-7, (key, np.abs(cb.cons(z_ref)).max())
+    np.testing.assert_allclose(z_ref[:4], x0, rtol=0, atol=1e-9)      # (the pinned first knot)

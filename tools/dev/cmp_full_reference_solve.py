@@ -13,3 +13,16 @@ r = opt.device_solve(z0, lb, ub, opt.system.device_params(), o, second_starts=Fa
 z = r["z"][0]
 print("device from the reference's guess: status", r["status"][0], "iterations", r["iters"][0], "cost %.12f" % r["cost"][0], "reference %.12f" % c_ref, "difference %.3e" % (r["cost"][0] - c_ref),
       "max|c| %.2e" % np.abs(opt.constraints(z)).max(), "max|z - z_ref| %.3e" % np.abs(z - z_ref).max(), "states %.3e" % np.abs(z[:804] - z_ref[:804]).max())
+# ... and the instances of the headline batch / README:83's literal (tests/golden/reference_solve_draws.npz)
+D = np.load("/root/repo/tests/golden/reference_solve_draws.npz")
+for rule in ("HERMITE_SIMPSON", "TRAPEZOIDAL"):
+  keys = sorted(k.rsplit("/", 1)[0] for k in D.files if k.startswith(f"draw/{rule}/") and k.endswith("/cost"))
+  hp = HParams(system=SystemType.CARTPOLE, optimizer=OptimizerType.COLLOCATION, quadrature_rule=QuadratureRule[rule], intervals=100, nlpsolver=NLPSolverType.SQP)
+  opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+  o = opt.engine.default_opts(); o.max_iter = hp.max_iter; o.restoration = 0
+  z0, lb, ub = opt.batch_inputs(np.stack([D[k + "/x0"] for k in keys]), opt.system.device_params())
+  r = opt.device_solve(z0, lb, ub, opt.system.device_params(), o, second_starts=False)
+  for b, k in enumerate(keys):
+    zr = D[k + "/xs_and_us"]; nx = (opt.engine.n // 5) * 4
+    print(k, "status", r["status"][b], "iterations", r["iters"][b], "cost %.10f" % r["cost"][b], "reference %.10f" % float(D[k + "/cost"]), "difference %.2e" % (r["cost"][b] - float(D[k + "/cost"])),
+          "feasibility %.1e" % r["kkt"][b, 0], "states %.2e" % np.abs(r["z"][b][:nx] - zr[:nx]).max(), "all %.2e" % np.abs(r["z"][b] - zr).max())
