@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE (round 6, late): the reference's own solve() on instances of the HEADLINE WORKLOAD -- CARTPOLE, Hermite-Simpson, N = 100, start states drawn as
-bench.py draws them (x0 = clip(x_0 + 0.1 xi), default_rng(2019), rows 0..2 of the batch) -- and on README.md:83's literal (trapezoidal, N = 100, the system's own start state).
+bench.py draws them (x0 = clip(x_0 + 0.1 xi), default_rng(2019), rows 0..10 of the batch) -- and on README.md:83's literal (trapezoidal, N = 100, the system's own start state).
 Same arrangement as make_reference_fixtures.py: /root/reference read in place through the JAX stand-in (tests/golden/refshim), SLSQP with complex-step derivatives of the
 reference's callbacks, ~45 minutes per Hermite-Simpson instance on one core; the cases are independent processes:
     for i in 0 1 2 3; do PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_reference_full_draws.py $i & done; wait
@@ -14,21 +14,26 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import numpy as np  # noqa: E402
 
-CASES = [("HERMITE_SIMPSON", 0), ("HERMITE_SIMPSON", 1), ("HERMITE_SIMPSON", 2), ("TRAPEZOIDAL", None)]
+CASES = [("HERMITE_SIMPSON", 0), ("HERMITE_SIMPSON", 1), ("HERMITE_SIMPSON", 2), ("TRAPEZOIDAL", None)] + [("HERMITE_SIMPSON", r) for r in range(3, 11)]      # (rows 3..10: a second run, merged in)
 
 
 def draws():
   """rows 0..2 of bench.build_workload(B, 100, 2019): the same generator, the same clip (bench.py:41-47)"""
   x_0 = np.array([0., 0., 0., 0.]); lo = np.array([-2., -np.pi, -np.inf, -np.inf]); hi = -lo      # CartPole: x_0 and the state box (cartpole.py:48-59)
   rng = np.random.default_rng(2019)
-  return np.clip(x_0[None] + 0.1 * rng.standard_normal((3, 4)), lo, hi)
+  return np.clip(x_0[None] + 0.1 * rng.standard_normal((11, 4)), lo, hi)
 
 
 def main():
   if sys.argv[1] == "merge":
     out = {}
+    have = os.path.join(HERE, "reference_solve_draws.npz")
+    if os.path.exists(have):      # (cases of an earlier run stay)
+      d = np.load(have); out.update({k: d[k] for k in d.files})
     for i in range(len(CASES)):
-      d = np.load(os.path.join(HERE, f"reference_solve_draw{i}.npz"))
+      f = os.path.join(HERE, f"reference_solve_draw{i}.npz")
+      if not os.path.exists(f): continue
+      d = np.load(f)
       out.update({k: d[k] for k in d.files})
     np.savez_compressed(os.path.join(HERE, "reference_solve_draws.npz"), **out)
     print(sorted(out))

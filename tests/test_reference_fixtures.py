@@ -198,12 +198,12 @@ _DRAWS = os.path.join(HERE, "golden", "reference_solve_draws.npz")
 
 @pytest.mark.skipif(not os.path.exists(_DRAWS), reason="tests/golden/reference_solve_draws.npz not generated")
 def test_reference_solves_of_the_headline_workloads_instances_are_feasible_for_the_oracle():
-  """tests/golden/reference_solve_draws.npz (round 6, tests/golden/make_reference_full_draws.py): rows 0..2 of the batch bench.py draws (x0 = clip(x_0 + 0.1 xi), seed 2019)
+  """tests/golden/reference_solve_draws.npz (round 6, tests/golden/make_reference_full_draws.py): rows of the batch bench.py draws (x0 = clip(x_0 + 0.1 xi), seed 2019; rows 0..2, later 0..10)
   and README.md:83's literal, each through the reference's solve() at N = 100.  The start states are the bench's, the reference's end points are feasible for the oracle's
   constraints of the same instance and have the reference's cost under the oracle's objective."""
   from bench import build_workload
   d = np.load(_DRAWS)
-  x0b = build_workload(4, 100, 2019)[0]
+  x0b = build_workload(16, 100, 2019)[0]
   for key in sorted({k.rsplit("/", 1)[0] for k in d.files}):
     _, rule, row = key.split("/")
     x0, z_ref, c_ref = d[key + "/x0"], d[key + "/xs_and_us"], float(d[key + "/cost"])
