@@ -193,3 +193,28 @@ def test_hip_sqp_solves_instances_of_the_headline_batch_to_the_reference_optimum
       nx = (opt.engine.n // 5) * 4
       assert np.abs(z[:nx] - z_ref[:nx]).max() <= 5e-3 * max(1.0, np.abs(z_ref[:nx]).max()), (k, np.abs(z[:nx] - z_ref[:nx]).max())
       assert np.abs(z - z_ref).max() <= 5e-2 * max(1.0, np.abs(z_ref).max()), (k, np.abs(z - z_ref).max())
+
+
+_SWEEP = os.path.join(HERE, "golden", "reference_solve_sweep.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(_SWEEP), reason="tests/golden/reference_solve_sweep.npz not generated")
+def test_hip_sqp_solves_instances_of_the_parameter_sweep_to_the_reference_optimum():
+  """Round 6, late: rows 0..3 of BASELINE config 4's batch (CANCERTREATMENT single shooting 1 x 100, per-instance r, a, delta and start state: the draws of
+  tools/bench_configs.py) solved by the reference's solve() (tests/golden/make_reference_sweep.py).  The device solves them in one batched call with a parameter row per instance:
+  KKT points, cost within SLSQP's stopping tolerance of the reference's and never above it, controls within 5 % of the reference's."""
+  d = np.load(_SWEEP)
+  keys = sorted({k.rsplit("/", 1)[0] for k in d.files})
+  hp = HParams(system=SystemType.CANCERTREATMENT, optimizer=OptimizerType.SHOOTING, max_iter=500, nlpsolver=NLPSolverType.SQP)
+  assert hp.intervals == 1 and hp.controls_per_interval == 100 and hp.integration_method == IntegrationMethod.HEUN      # (the reference's defaults: config 4's shape)
+  opt = get_optimizer(hp, CFG, hp.system())
+  params = np.stack([d[k + "/params"] for k in keys]); x0 = np.stack([d[k + "/x0"] for k in keys])
+  r = opt.solve_batch(x0s=x0, params=params)
+  assert (r["status"] == 0).all(), (r["status"], r["iters"])
+  for b, k in enumerate(keys):
+    c_ref, z_ref = float(d[k + "/cost"]), d[k + "/xs_and_us"]
+    cost = float(r["cost"][b])
+    assert cost <= c_ref + 1e-5 * max(1.0, abs(c_ref)), (k, cost, c_ref)
+    assert cost == pytest.approx(c_ref, rel=1e-5), (k, cost, c_ref)
+    z = r["xs_and_us"][b]
+    assert z.shape == z_ref.shape and np.abs(z - z_ref).max() <= 5e-2 * max(1.0, np.abs(z_ref).max()), (k, np.abs(z - z_ref).max())

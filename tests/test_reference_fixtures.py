@@ -215,3 +215,33 @@ def test_reference_solves_of_the_headline_workloads_instances_are_feasible_for_t
     assert float(cb.fun(z_ref)) == pytest.approx(c_ref, rel=1e-12), key
     assert np.abs(cb.cons(z_ref)).max() < 1e-7, (key, np.abs(cb.cons(z_ref)).max())
     np.testing.assert_allclose(z_ref[:4], x0, rtol=0, atol=1e-9)      # (the pinned first knot)
+
+
+_SWEEP = os.path.join(HERE, "golden", "reference_solve_sweep.npz")
+
+
+def _sweep_rows():
+  """tools/bench_configs.py: measure(), config 4 -- the generator calls in their order"""
+  rng = np.random.default_rng(2019)
+  rng.standard_normal((8192, 2))
+  B = 2048
+  params = np.stack([rng.uniform(0.1, 0.5, B), rng.uniform(1, 5, B), rng.uniform(0.2, 0.8, B)], axis=1)
+  return params, rng.uniform(0.5, 0.99, (B, 1))
+
+
+@pytest.mark.skipif(not os.path.exists(_SWEEP), reason="tests/golden/reference_solve_sweep.npz not generated")
+def test_reference_solves_of_the_parameter_sweeps_instances_match_the_oracle():
+  """tests/golden/reference_solve_sweep.npz (round 6, tests/golden/make_reference_sweep.py): rows 0..3 of BASELINE config 4's batch -- CANCERTREATMENT single shooting 1 x 100
+  with per-instance (r, a, delta) and start state -- through the reference's solve().  The instances are the bench's; the oracle's objective at the reference's end point is the
+  reference's cost, and the oracle's restatement of the SciPy call ends at the same cost (single shooting: 1e-4, as for the default-parameter fixtures)."""
+  d = np.load(_SWEEP)
+  params, x0 = _sweep_rows()
+  for key in sorted({k.rsplit("/", 1)[0] for k in d.files}):
+    i = int(key.split("/")[1])
+    np.testing.assert_array_equal(d[key + "/params"], params[i]); np.testing.assert_array_equal(d[key + "/x0"], x0[i])
+    system = O.SYSTEMS["CANCERTREATMENT"](r=float(params[i, 0]), a=float(params[i, 1]), delta=float(params[i, 2]), x_0=float(x0[i, 0]))
+    t = O.make_transcription(system, "SHOOTING", 1, 100, integration_method="HEUN")
+    z_ref, c_ref = d[key + "/xs_and_us"], float(d[key + "/cost"])
+    assert float(O.Callbacks(t).fun(z_ref)) == pytest.approx(c_ref, rel=1e-12), key
+    res = O.solve(t, "SLSQP", max_iter=500)
+    assert float(res["cost"]) == pytest.approx(c_ref, rel=1e-4), (key, float(res["cost"]), c_ref)

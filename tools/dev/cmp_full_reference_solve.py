@@ -26,3 +26,13 @@ for rule in ("HERMITE_SIMPSON", "TRAPEZOIDAL"):
     zr = D[k + "/xs_and_us"]; nx = (opt.engine.n // 5) * 4
     print(k, "status", r["status"][b], "iterations", r["iters"][b], "cost %.10f" % r["cost"][b], "reference %.10f" % float(D[k + "/cost"]), "difference %.2e" % (r["cost"][b] - float(D[k + "/cost"])),
           "feasibility %.1e" % r["kkt"][b, 0], "states %.2e" % np.abs(r["z"][b][:nx] - zr[:nx]).max(), "all %.2e" % np.abs(r["z"][b] - zr).max())
+# ... and rows 0..3 of config 4's parameter sweep (tests/golden/reference_solve_sweep.npz)
+from myriad_amd.config import IntegrationMethod
+S = np.load("/root/repo/tests/golden/reference_solve_sweep.npz")
+keys = sorted({k.rsplit("/", 1)[0] for k in S.files})
+hp = HParams(system=SystemType.CANCERTREATMENT, optimizer=OptimizerType.SHOOTING, max_iter=500, nlpsolver=NLPSolverType.SQP)
+opt = get_optimizer(hp, Config(verbose=False, plot=False), hp.system())
+r = opt.solve_batch(x0s=np.stack([S[k + "/x0"] for k in keys]), params=np.stack([S[k + "/params"] for k in keys]))
+for b, k in enumerate(keys):
+  print(k, "status", r["status"][b], "iterations", r["iters"][b], "cost %.10f" % r["cost"][b], "reference %.10f" % float(S[k + "/cost"]), "difference %.2e" % (r["cost"][b] - float(S[k + "/cost"])),
+        "all %.2e" % np.abs(r["xs_and_us"][b] - S[k + "/xs_and_us"]).max())
